@@ -1,0 +1,168 @@
+"""CPU checks of the oracle itself (no GPU): closed-form known answers, an independent
+implementation (HF transformers on torch-CPU) and explicit dequantise-then-matmul.
+
+The reference pins nothing for this path ("parity unpinned"), so these checks are what
+stands between the oracle and a typo; they mirror SURVEY.md 8c "What pins the build's results instead".
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pie_oracle as po
+
+RNG = np.random.default_rng(1234)
+
+
+@pytest.mark.parametrize("dt,tt", [("bfloat16", torch.bfloat16), ("float16", torch.float16)])
+def test_rounding_matches_torch_casts(dt, tt):
+    x = (RNG.standard_normal(200_000) * 10.0 ** RNG.integers(-9, 6, 200_000)).astype(np.float32)
+    x[:10] = [0, -0.0, 1e-40, 65504, 65520, 1e5, 6e-8, 5.96e-8, 3e-8, -2.98e-8]
+    ref = torch.from_numpy(x).to(tt)
+    assert np.array_equal(po.to_bits(x, dt), ref.view(torch.int16).numpy().view(np.uint16))
+    assert np.array_equal(po.round_T(x, dt).view(np.uint32), ref.float().numpy().view(np.uint32))
+    assert np.array_equal(po.from_bits(po.to_bits(x, dt), dt), po.round_T(x, dt))
+
+
+def test_quantize_known_answers():
+    # one group whose extremes must land exactly on codes 0 and 15: w = bias + scale*q
+    q = np.arange(64) % 16
+    w = (-1.125 + 0.125 * q).astype(np.float32)[None, :]         # |w_min| > |w_max| -> side: edge=w_min
+    wq, s, b = po.quantize(w, 64, 4, "float32")
+    codes = (wq.reshape(-1)[:, None] >> (4 * np.arange(8))[None, :]) & 0xF   # little-endian nibble order
+    assert np.array_equal(codes.reshape(-1), q)
+    assert np.allclose(po.dequantize(wq, s, b, 64, 4, "float32"), w, atol=1e-7)
+    # mirrored group: |w_max| > |w_min| -> scale negative, bias = w_max (scales can be negative)
+    wq2, s2, b2 = po.quantize(-w, 64, 4, "float32")
+    assert s2[0, 0] < 0 and b2[0, 0] == pytest.approx(1.125)
+    assert np.allclose(po.dequantize(wq2, s2, b2, 64, 4, "float32"), -w, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16", "float16"])
+def test_quantize_roundtrip_bound(dt):
+    w = po.round_T(RNG.standard_normal((48, 256)) * 0.02, dt)
+    wq, s, b = po.quantize(w, 64, 4, dt)
+    wh = po.dequantize(wq, s, b, 64, 4, dt)
+    scale = np.repeat(np.abs(po.from_bits(s, dt)), 64, axis=1)
+    # interior codes err <= scale/2; the far end of the range can clip at code 15 because scale is re-fitted
+    # to make the edge exact (scale = edge/q0, |edge/scale0| >= 7.5) -> <= 1.0*scale; plus storage rounding.
+    slack = {"float32": 1e-6, "bfloat16": 2 ** -8, "float16": 2 ** -11}[dt]
+    bound = 1.0 * scale + slack * (16 * scale + np.abs(w) + np.repeat(np.abs(po.from_bits(b, dt)), 64, axis=1))
+    assert np.all(np.abs(w - wh) <= bound + 1e-9)
+
+
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_quantized_matmul_vs_dequantize_then_matmul(dt):
+    N, K, M = 96, 512, 3
+    w = po.round_T(RNG.standard_normal((N, K)) * 0.05, dt)
+    wq, s, b = po.quantize(w, 64, 4, dt)
+    x = po.round_T(RNG.standard_normal((M, K)), dt)
+    y = po.quantized_matmul(x, wq, s, b, dtype=dt)
+    sf, bf = po.from_bits(s, dt).astype(np.float64), po.from_bits(b, dt).astype(np.float64)
+    codes = ((wq[:, :, None] >> (4 * np.arange(8))) & 0xF).reshape(N, K).astype(np.float64)
+    wd = np.repeat(sf, 64, 1) * codes + np.repeat(bf, 64, 1)      # un-rounded affine dequant, fp64
+    ref = x.astype(np.float64) @ wd.T
+    tol = 1e-4 if dt == "float32" else 2 ** -8 * np.abs(ref).max()
+    assert np.max(np.abs(y - ref)) <= tol
+    assert np.array_equal(y, po.round_T(y, dt))
+
+
+def test_rms_norm_rope_sdpa_closed_forms():
+    H = 128
+    w = po.to_bits(np.full(H, 2.0, np.float32), "float32")
+    y = po.rms_norm(np.full((1, H), 3.0, np.float32), w, 0.0, "float32")
+    assert np.allclose(y, 2.0)                                     # 3/sqrt(9) * 2
+    freqs = po.llama3_rope_freqs(64, 10000.0)
+    assert np.allclose(freqs, 10000.0 ** (np.arange(0, 64, 2) / 64), rtol=1e-6)
+    x = RNG.standard_normal((4, 1, 64)).astype(np.float32)
+    assert np.array_equal(po.rope(x, freqs, 0, "float32"), x)      # position 0 = identity
+    r = po.rope(x, freqs, 7, "float32")                            # rotation preserves pair norms
+    assert np.allclose(r[..., :32] ** 2 + r[..., 32:] ** 2, x[..., :32] ** 2 + x[..., 32:] ** 2, rtol=1e-5)
+    th = 7.0 / freqs[3]
+    assert r[0, 0, 3] == pytest.approx(x[0, 0, 3] * np.cos(th) - x[0, 0, 35] * np.sin(th), rel=1e-5)
+    k = np.zeros((2, 16, 64), np.float32)
+    v = RNG.standard_normal((2, 16, 64)).astype(np.float32)
+    q = RNG.standard_normal((4, 1, 64)).astype(np.float32)
+    o = po.sdpa(q, k, v, 0.125, None, "float32", T=10)             # equal scores -> mean of the first T rows of V
+    assert np.allclose(o[0, 0], v[0, :10].mean(0), atol=1e-6)
+    assert np.allclose(o[3, 0], v[1, :10].mean(0), atol=1e-6)      # GQA: q-head 3 -> kv-head 1
+
+
+def test_logprobs_argmax_first_max():
+    x = np.array([0.5, 2.0, 2.0, -1.0], np.float32)
+    tok, lp = po.logprobs_argmax(x)
+    assert tok == 1
+    assert np.exp(lp.astype(np.float64)).sum() == pytest.approx(1.0, rel=1e-6)
+
+
+def _hf_model(cfg, weights_f32):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    hc = LlamaConfig(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                     num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                     num_key_value_heads=cfg["num_key_value_heads"], vocab_size=cfg["vocab_size"],
+                     rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"],
+                     max_position_embeddings=cfg["max_position_embeddings"], tie_word_embeddings=False,
+                     attention_bias=False, mlp_bias=False)
+    hc._attn_implementation = "eager"
+    m = LlamaForCausalLM(hc).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_f32.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def test_llama_graph_vs_hf_transformers_fp32():
+    """Independent implementation check: same random fp32 weights, prefill 12 tokens then 3 decode steps."""
+    cfg = dict(po.TINY_CONFIG)
+    cfg.pop("quantization")
+    w = po.synth_checkpoint(cfg, seed=3, dtype="float32")
+    hf = _hf_model(cfg, w)
+    orc = po.OracleLlama(cfg, w, "float32")
+    cache = [po.OracleKVCache() for _ in orc.layers]
+    ids = RNG.integers(0, cfg["vocab_size"], 15)
+    with torch.no_grad():
+        ref_all = hf(torch.from_numpy(ids[None, :]).long()).logits[0].numpy()
+    got = orc.forward(ids[:12], cache)
+    assert np.max(np.abs(got - ref_all[:12])) <= 2e-5 * np.abs(ref_all).max() + 1e-5
+    for t in range(12, 15):                                        # L=1 path: no mask, offset = t
+        step = orc.forward(ids[t:t + 1], cache)
+        assert np.max(np.abs(step[0] - ref_all[t])) <= 2e-5 * np.abs(ref_all).max() + 1e-5
+    assert cache[0].offset == 15 and cache[0].keys.shape[2] == 256
+
+
+def test_llama_graph_bf16_close_to_fp32():
+    cfg = dict(po.TINY_CONFIG)
+    cfg.pop("quantization")
+    w32 = po.synth_checkpoint(cfg, seed=5, dtype="float32")
+    wbf = {k: po.to_bits(v, "bfloat16") for k, v in w32.items()}
+    w32r = {k: po.from_bits(v, "bfloat16") for k, v in wbf.items()}
+    ids = RNG.integers(0, cfg["vocab_size"], 10)
+    a = po.OracleLlama(cfg, w32r, "float32").forward(ids, [po.OracleKVCache() for _ in range(2)])
+    b = po.OracleLlama(cfg, wbf, "bfloat16").forward(ids, [po.OracleKVCache() for _ in range(2)])
+    assert np.max(np.abs(a - b)) <= 2e-2                           # bf16 activations, logits max-abs
+    u = po.OracleLlama(cfg, wbf, "bfloat16").forward(ids, [po.OracleKVCache() for _ in range(2)], sdpa_fused=False)
+    assert np.max(np.abs(u - b)) <= 2e-2                           # fused vs unfused-fallback attention contracts
+
+
+def test_kv_cache_growth_and_prefix_reuse():
+    c = po.OracleKVCache()
+    k = np.ones((1, 2, 128, 8), np.float32)
+    c.update_and_fetch(k, k)
+    assert (c.offset, c.keys.shape[2]) == (128, 256)               # ceil(128/256)*256
+    one = np.ones((1, 2, 1, 8), np.float32)
+    caps = []
+    for _ in range(1100):
+        c.update_and_fetch(one * 2, one * 2)
+        caps.append(c.keys.shape[2])
+    assert sorted(set(caps)) == [256, 512, 768, 1280]              # max(int(cap*1.5), need) rounded up to 256
+    assert c.offset == 1228 and np.all(c.keys[0, 0, :128] == 1) and np.all(c.keys[0, 0, 128:1228] == 2)
+    assert c.trim(28) == 28 and c.offset == 1200
+    pc = po.OraclePromptCache()
+    pc.cache = [po.OracleKVCache()]
+    pc.cache[0].update_and_fetch(k, k)
+    pc.update(np.arange(128))
+    rest = pc(np.arange(128))                                       # identical prompt: >= 1 token re-processed
+    assert rest.tolist() == [127] and pc.cache[0].offset == 127
+    rest = pc(np.concatenate([np.arange(50), np.arange(900, 1200)]))
+    assert len(rest) == 300 and pc.cache[0].offset == 50 and pc.cache[0].keys.shape[2] == 512
+    assert pc(np.array([999, 1, 2])).tolist() == [999, 1, 2]       # no common prefix: cache untouched
