@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- decode tokens/s of Llama-3-8B int4 g=64, batch 1, on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one decode step (one token) through InferenceEngine.generate_step: hipGraph replay of the fused
+HIP launch sequence, synthetic random-weight checkpoint (no network), weights and KV cache resident in HBM.
+Workload (config.workload): Llama-3-8B-shaped, int4 group 64, bf16 activations, 128-token prompt, greedy.
+N > 1: batch-1 decode has no independent units inside one sequence and the 8B model fits one card, so ranks are
+independent REPLICAS (one sequence each, no data-path collective): value = sum of tokens over ranks / max time.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus:
+  roofline     -- the dominant kernel (gate/up W4S GEMV): algorithmic bytes per launch / mean launch duration,
+                  measured here with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+                  `step` = the same fraction for the whole decode step (the north-star figure).
+  cpu_baseline -- the CPU oracle (oracle/pie_oracle.c, OpenMP) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=0, help="debug: override num_hidden_layers (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=3)
+    ap.add_argument("--kv-splits", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, weights_host, n_tokens):
+    """Oracle decode tokens/s on the host cores: 4-token prompt (last_only lm_head), then `n_tokens` timed steps."""
+    from oracle import pie_oracle as po
+
+    threads = len(os.sched_getaffinity(0))
+    po.set_threads(threads)
+    model = po.OracleLlama(cfg, weights_host, "bfloat16")
+    cache = [po.OracleKVCache() for _ in model.layers]
+    rng = np.random.default_rng(1)
+    model.forward(rng.integers(0, cfg["vocab_size"], 4), cache, last_only=True)
+    tok = 1
+    t0 = time.perf_counter()
+    for _ in range(n_tokens):
+        logits = model.forward(np.array([tok]), cache, last_only=True)
+        tok, _ = po.logprobs_argmax(logits)
+    dt = time.perf_counter() - t0
+    return {"value": n_tokens / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/pie_oracle.c (OpenMP, {threads} threads), same synthetic Llama-3-8B int4 weights, "
+                      f"{n_tokens} greedy decode steps at context 4..{4 + n_tokens} ({dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from proxy_inference_engine_amd import InferenceEngine
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, synthetic_checkpoint
+
+    cfg = dict(LLAMA3_8B)
+    if args.layers:
+        cfg["num_hidden_layers"] = args.layers
+    weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    weights_host = None
+    if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
+        weights_host = {k: (v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.view(torch.int16).cpu().numpy().view(np.uint16))
+                        for k, v in weights.items()}
+    model = Model(ModelArgs(**cfg), weights, kv_splits=args.kv_splits)
+    del weights
+    torch.cuda.empty_cache()
+
+    eng = InferenceEngine(model=model)
+    prompt = torch.randint(0, cfg["vocab_size"], (args.prompt,), generator=torch.Generator().manual_seed(1 + rank))
+    eng.prepare_engine(prompt, temp=0)
+    gen = eng.generate_step(prompt)
+    next(gen)  # prefill + first token
+    for _ in range(args.warmup):
+        next(gen)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next(gen)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    tokens_per_s = world * args.steps / elapsed
+    T_mid = args.prompt + 1 + args.warmup + args.steps // 2  # context length in the middle of the timed region
+    step_bytes = model.step_bytes(T_mid, True)
+    step_gbps = step_bytes * (args.steps / elapsed) / 1e9  # per GPU
+
+    # dominant kernel (gate/up GEMV: 38 % of the step's bytes), timed alone with HIP events on the launch stream,
+    # cycling through the layers so every launch streams weights that are not in the 256 MiB Infinity Cache.
+    reps = 4
+    n_l = cfg["num_hidden_layers"]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * n_l)]
+    for li in range(n_l):
+        model.launch_kernel("gate_up", li)
+    torch.cuda.synchronize()
+    i = 0
+    for _ in range(reps):
+        for li in range(n_l):
+            ev[i][0].record()
+            model.launch_kernel("gate_up", li)
+            ev[i][1].record()
+            i += 1
+    torch.cuda.synchronize()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k_bytes = model.kernel_bytes("gate_up", T_mid)
+    k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s",
+        "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 activations / fp32 accumulate over uint4 g=64 weights", "data": "synthetic",
+        "config": {"workload": f"Llama-3-8B-shaped (H4096 L{n_l} 32/8 heads I14336 V128256) int4 g=64 greedy decode, batch 1, "
+                               f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
+                   "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 2 + 6 * n_l + 1,
+                   "hipgraph": True},
+        "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": k_bytes,
+                     "ms_per_launch": k_ms,
+                     "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "bytes_per_step": step_bytes}},
+    }
+    if rank == 0:
+        if want_cpu:
+            del model, eng, gen
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, weights_host, args.cpu_tokens)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                                   "sample": "skipped (timed on rank 0 at N=1 only)"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+/*
+ * pie_hip.h -- C ABI of libpie_hip.so: the MI355X (gfx950) implementation of PIE's decode hot path.
+ *
+ * The reference (TheProxyCompany/proxy-inference-engine @ 2025-05-09) has no FFI for this path: its seam
+ * is the set of MLX op call sites inside `proxy_inference_engine` (all tensor math is `import mlx.core as
+ * mx`, engine/inference_engine.py:6) plus the one-symbol native module `pie_core` (hello(),
+ * src/pie_core/src/bindings.cpp:6-9).  Each entry point below replaces exactly one of those call sites (or a
+ * fused run of them) and cites it.  Paths are relative to /root/reference/src/proxy_inference_engine/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch/HIP C++ types in signatures (hipStream_t travels as void*).
+ *   - All data pointers are DEVICE pointers owned by the caller.  The library never allocates or frees
+ *     caller tensors and keeps no reference after return, except pie_decoder_* which records the weight /
+ *     KV pointers it is given (the caller keeps those alive until pie_decoder_destroy).
+ *   - Every launch is asynchronous on `stream`; nothing synchronises the device.
+ *   - Return value: 0 = PIE_OK, negative = PIE_E_*.  Nothing throws across the ABI.
+ *     pie_last_error() returns a thread-local description of the last failure on the calling thread.
+ *   - `dtype`: activation / parameter float type, PIE_BF16 or PIE_F16 (16-bit storage, fp32 accumulate).
+ *   - Threading: thread-compatible (no global mutable state besides the thread-local error string); one
+ *     host thread drives one decoder, like the reference's single non re-entrant InferenceEngine
+ *     (server/app.py:23,35).
+ */
+#ifndef PIE_HIP_H
+#define PIE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PIE_OK = 0, PIE_E_ARG = -1, PIE_E_SHAPE = -2, PIE_E_ALIGN = -3, PIE_E_HIP = -4, PIE_E_STATE = -5, PIE_E_ARCH = -6 };
+enum { PIE_BF16 = 1, PIE_F16 = 2 };
+
+/* pie_core.hello()  (src/pie_core/src/bindings.cpp:8; asserted by tests/python/test_basic.py:16). */
+const char *pie_hello(void);
+const char *pie_version(void);
+const char *pie_last_error(void);
+/* Fills name (<= name_len bytes, NUL-terminated gcnArchName), CU count, bytes of device memory. */
+int pie_device_info(char *name, int name_len, int *n_cus, size_t *hbm_bytes);
+
+/* ---------------------------------------------------------------- mx.quantize / mx.dequantize (K10)
+ * Call sites: cache/kv_cache/cache.py:144-147, quantized.py:91-96; defines the checkpoint triplet
+ * models/utils.py:96-111 consumes.  w [N,K] T -> codes uint32 [N,K/8], scales/biases T [N,K/64].
+ * Bit-exact with the published algorithm: integer codes, T-rounded affine params. */
+int pie_quantize_w4g64(const void *w, int N, int K, int dtype, uint32_t *codes, void *scales, void *biases, void *stream);
+int pie_dequantize_w4g64(const uint32_t *codes, const void *scales, const void *biases, int N, int K, int dtype,
+                         void *w_out, void *stream);
+
+/* ---------------------------------------------------------------- weight streaming layout ("W4S")
+ * Load-time repack of one MLX-quantised Linear (weight/scales/biases triplet, models/utils.py:96-111) into
+ * the layout the GEMV streams: units of 2304 B = one ROW PAIR x one 2048-wide K slice
+ * (2 x [64 lanes x 16 B] nibble-reordered codes + [64 lanes x 4 B] {scale,bias}); unit index = pair*n_slices + slice.
+ * row_map (device int32 [N_out], may be NULL = identity) gives, per packed row, the source row of
+ * `codes`; N_out must be even.  This is how q|k|v are concatenated with RoPE partners adjacent and
+ * gate|up interleaved.  pie_w4s_bytes() is the size of `packed`. */
+size_t pie_w4s_bytes(int N_out, int K);
+int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K,
+                     const int32_t *row_map, int N_out, void *packed, void *stream);
+
+/* ---------------------------------------------------------------- mx.quantized_matmul(x, w, scales, biases,
+ * transpose=True, group_size=64, bits=4) via nn.QuantizedLinear.__call__ (K1).
+ * Call sites: models/llama/language.py:83 (q,k,v), :108 (o), :127 (gate,up,down), :207/:209 (lm_head).
+ * x [M,K] T, packed = W4S of a [N,K] weight, lin_bias T [N] or NULL (nn.QuantizedLinear bias), y [M,N] T.
+ * Weights are re-streamed once per row of x (M is the prompt length at prefill, 1 at decode). */
+int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y,
+                    int dtype, void *stream);
+
+/* nn.QuantizedEmbedding.__call__ (models/llama/language.py:176): dequantise gathered rows of the
+ * MLX-layout table.  ids device int32 [L] -> out [L,H] T. */
+int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases,
+                        int V, int H, int dtype, void *out, void *stream);
+
+/* ---------------------------------------------------------------- mx.fast.rms_norm(x, w, eps) (K3)
+ * Call sites: nn.RMSNorm at models/llama/language.py:137-141, :168.  x,y [rows,H] T, w [H] T. */
+int pie_rms_norm(const void *x, const void *w, float eps, int rows, int H, int dtype, void *y, void *stream);
+
+/* ---------------------------------------------------------------- mx.fast.rope(x, D, traditional=False,
+ * base=None, scale=1.0, offset, freqs) (K4).  Call site: models/llama/utils.py:42-50.
+ * x,y [heads,L,D] T; freqs device fp32 [D/2]; position of row l = offset + l. */
+int pie_rope(const void *x, int heads, int L, int D, const float *freqs, int offset, int dtype, void *y, void *stream);
+
+/* ---------------------------------------------------------------- mx.fast.scaled_dot_product_attention (K2)
+ * Call site: models/base.py:111-113 <- models/llama/language.py:98-105.  Decode form (L = 1, mask = None):
+ * q [Hq,1,D] T; k,v [Hkv,cap,D] T of which the first T positions are attended (the strided view
+ * cache/kv_cache/reusable.py:142 returns); out [Hq,1,D] T.  GQA: q-head h uses kv-head h / (Hq/Hkv).
+ * fp32 scores / softmax / PV, one rounding at the end (MLX fused-kernel contract).
+ * workspace: device scratch of pie_sdpa_decode_workspace_bytes(Hq, D) bytes. */
+size_t pie_sdpa_decode_workspace_bytes(int Hq, int D);
+int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv, int T, int cap, int D, float scale,
+                    int dtype, void *out, void *workspace, void *stream);
+
+/* nn.silu(a) * b (models/llama/language.py:127) and the residual adds (:151,:153) (K6, K7). */
+int pie_silu_mul(const void *a, const void *b, size_t n, int dtype, void *y, void *stream);
+int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *stream);
+
+/* ---------------------------------------------------------------- logits tail (K9)
+ * engine/inference_engine.py:268-271 + samplers/__init__.py:37-38: logprobs = f32(logits) - logsumexp,
+ * token = first argmax.  logits [V] T, logprobs fp32 [V], token device int32 [1]. */
+int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, int32_t *token, void *stream);
+
+/* ---------------------------------------------------------------- fused decode step
+ * One forward of Model.__call__ (models/llama/language.py:199-210) for inputs[1,1] over per-layer
+ * ReusableKVCache buffers (cache/kv_cache/reusable.py:96-142) followed by the tail of _inference
+ * (engine/inference_engine.py:252-271) with the greedy sampler, as ~6 launches per layer:
+ *   rmsnorm+qkv GEMV+RoPE+cache append | split-KV attention | combine | o_proj+residual |
+ *   rmsnorm+gate/up GEMV+SwiGLU | down_proj+residual ; then rmsnorm+lm_head ; log-softmax+argmax.
+ * Position and token live in device memory so the captured hipGraph is replayable. */
+typedef struct pie_decoder pie_decoder;
+
+typedef struct {
+    int dtype;          /* PIE_BF16 / PIE_F16 */
+    int hidden, n_layers, n_heads, n_kv_heads, head_dim, inter, vocab;
+    float rms_eps;
+    int tie_word_embeddings; /* lm_head = embed_tokens.as_linear (language.py:206-207) */
+    int kv_splits;      /* split-KV factor of the attention kernel (0 = default) */
+} pie_decoder_config;
+
+typedef struct {
+    const void *attn_norm, *mlp_norm;   /* T [hidden] */
+    const void *wqkv;                    /* W4S of [q;k;v] rows in RoPE-paired order (pie_qkv_row_map) */
+    const void *wo;                      /* W4S [hidden, n_heads*head_dim] */
+    const void *wgateup;                 /* W4S of interleaved (gate_i, up_i) rows */
+    const void *wdown;                   /* W4S [hidden, inter] */
+} pie_layer_weights;
+
+typedef struct {
+    const uint32_t *embed_codes;         /* MLX layout [vocab, hidden/8] */
+    const void *embed_scales, *embed_biases; /* T [vocab, hidden/64] */
+    const void *final_norm;              /* T [hidden] */
+    const void *lm_head;                 /* W4S [vocab, hidden] (of embed_tokens when tied) */
+    const float *rope_freqs;             /* fp32 [head_dim/2], Llama3RoPE._freqs (models/llama/utils.py:39) */
+} pie_global_weights;
+
+/* Host helpers producing the row maps the decoder's fused epilogues assume (host int32 arrays). */
+int pie_qkv_row_map(int n_heads, int n_kv_heads, int head_dim, int32_t *map /* [(n_heads+2*n_kv_heads)*head_dim] */);
+int pie_gateup_row_map(int inter, int32_t *map /* [2*inter], source rows of cat(gate, up) */);
+
+int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out);
+int pie_decoder_destroy(pie_decoder *d);
+int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w);
+int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w);
+/* Per-layer cache buffers [n_kv_heads, capacity, head_dim] T (ReusableKVCache.keys/values with B=1);
+ * call again whenever a cache re-allocates (reusable.py:167-203).  k_ptrs/v_ptrs: HOST arrays of device pointers. */
+int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *const *v_ptrs, int capacity, void *stream);
+/* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
+ * previous step's argmax). */
+int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);
+/* Runs one step.  flags: PIE_STEP_LOGITS computes lm_head + logprobs + argmax (else the step only fills
+ * the KV caches: prompt tokens before the last); PIE_STEP_GRAPH replays a captured hipGraph of the step
+ * (captured on first use per flag set).  After the step the device-side offset is incremented and, with
+ * PIE_STEP_LOGITS, the device-side token is the greedy choice. */
+enum { PIE_STEP_LOGITS = 1, PIE_STEP_GRAPH = 2 };
+int pie_decoder_step(pie_decoder *d, int flags, void *stream);
+/* Prompt processing by iterated decode steps (the build's round-1 prefill; a batched MFMA prefill is the
+ * "next" row of SURVEY.md 8f): runs the step for ids[0..L) (device int32), all launches queued back to back
+ * with no host round trip.  logits_all == NULL: lm_head + tail only for the last token (the engine only
+ * reads logits[:, -1, :], engine/inference_engine.py:254).  logits_all != NULL: T [L, vocab], lm_head on every
+ * position like the reference's Model.__call__ (language.py:205-209). */
+int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream);
+/* Output buffers of the step, allocated by the caller (device): logits T [vocab], logprobs fp32 [vocab],
+ * token int32 [1] (the greedy choice), hidden T [hidden] (the residual stream; after a step it holds the
+ * output of the last block, the input of the final norm).  history (optional, int32 [history_len]): the tail
+ * kernel stores the greedy token chosen for position p at history[p], so the host can read the generated ids
+ * later in one copy instead of synchronising every step (PromptCache.computed_ids, cache/prompt_cache.py:43-50).
+ * Required before the first step. */
+int pie_decoder_bind_outputs(pie_decoder *d, void *logits, float *logprobs, int32_t *token, void *hidden, int32_t *history,
+                             int history_len);
+/* Copies a device-resident token id into the decoder's device-side state (the input of the next
+ * pie_decoder_step) without a host round trip; a no-op when `token_dev` is the bound token output. */
+int pie_decoder_set_token_from(pie_decoder *d, const int32_t *token_dev, void *stream);
+/* The step's launches by name.  pie_decoder_launch_kernel() enqueues ONE of them with exactly the arguments
+ * the step uses (for per-kernel timing with events / rocprof; it does not advance the decode state, and
+ * PIE_K_TAIL, which does, is refused).  pie_decoder_kernel_bytes() is that launch's algorithmic HBM traffic
+ * (weights 0.5625 B/parameter + norm weights + KV rows; activations of a few KB are excluded). */
+enum { PIE_K_EMBED = 0, PIE_K_QKV = 1, PIE_K_ATTN = 2, PIE_K_OPROJ = 3, PIE_K_GATEUP = 4, PIE_K_DOWN = 5, PIE_K_LMHEAD = 6, PIE_K_TAIL = 7 };
+int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream);
+size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
+/* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
+size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIE_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libpie_hip.so (include/pie_hip.h).
+
+The product path has no CPU fallback: if the library is missing or the device is not a gfx950 the
+import of anything that computes fails loudly here.  PyTorch is only the allocator / stream provider.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+PIE_BF16, PIE_F16 = 1, 2
+PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
+KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
+
+EXPORTS = [
+    "pie_hello", "pie_version", "pie_last_error", "pie_device_info",
+    "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_qgemv_w4g64",
+    "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode",
+    "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_qkv_row_map", "pie_gateup_row_map",
+    "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
+    "pie_decoder_set_kv", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill",
+    "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
+    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes",
+]
+
+
+class pie_decoder_config(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("hidden", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
+                ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("inter", C.c_int), ("vocab", C.c_int),
+                ("rms_eps", C.c_float), ("tie_word_embeddings", C.c_int), ("kv_splits", C.c_int)]
+
+
+class pie_layer_weights(C.Structure):
+    _fields_ = [("attn_norm", C.c_void_p), ("mlp_norm", C.c_void_p), ("wqkv", C.c_void_p), ("wo", C.c_void_p),
+                ("wgateup", C.c_void_p), ("wdown", C.c_void_p)]
+
+
+class pie_global_weights(C.Structure):
+    _fields_ = [("embed_codes", C.c_void_p), ("embed_scales", C.c_void_p), ("embed_biases", C.c_void_p),
+                ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_freqs", C.c_void_p)]
+
+
+def lib_path() -> Path:
+    env = os.environ.get("PIE_HIP_LIB")
+    return Path(env) if env else _PKG / "lib" / "libpie_hip.so"
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libpie_hip.so; raises RuntimeError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m proxy_inference_engine_amd.build` "
+            "(the MI355X path has no CPU or PyTorch fallback)")
+    lib = C.CDLL(str(path))
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{path} does not export {name}")
+    for name in ("pie_hello", "pie_version", "pie_last_error"):
+        getattr(lib, name).restype = C.c_char_p
+    for name in ("pie_w4s_bytes", "pie_sdpa_decode_workspace_bytes", "pie_decoder_step_bytes", "pie_decoder_kernel_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+    lib.pie_sdpa_decode.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pie_rms_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_silu_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_add.argtypes = lib.pie_silu_mul.argtypes
+    lib.pie_decoder_step_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = load().pie_last_error().decode("utf-8", "replace")
+    if rc in (-1, -2, -3):  # PIE_E_ARG / SHAPE / ALIGN: the caller's fault
+        raise ValueError(f"pie_hip: {msg} (code {rc})")
+    raise RuntimeError(f"pie_hip: {msg} (code {rc})")
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("proxy_inference_engine_amd needs an MI355X (gfx950); no HIP device is visible")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return PIE_BF16
+    if dt == torch.float16:
+        return PIE_F16
+    raise ValueError(f"activation dtype must be bfloat16 or float16, got {dt}")
+
+
+def p(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(None) if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def hello() -> str:
+    """pie_core.hello() of the reference (src/pie_core/src/bindings.cpp:8)."""
+    return load().pie_hello().decode("utf-8")

@@ -1,0 +1,81 @@
+"""PromptCache: per-layer KV caches + the token history they encode, with longest-common-prefix reuse
+between consecutive requests (mirror of cache/prompt_cache.py:13-76 of the reference).
+
+`computed_ids` is a host list that is resolved LAZILY: update() may be handed device tensors (the greedy tokens
+the tail kernel wrote into the decoder's history buffer); they are read back in one copy the first time the
+history is needed (the next request's prefix match, a logits processor) instead of one host sync per generated
+token -- the role mx.async_eval plays in the reference's loop (engine/inference_engine.py:279,289).
+Disk persistence (cache_prompt / load_cached_prompt, prompt_cache.py:78-125) is outside the decode path
+(SURVEY.md 8f-4); load_cached_prompt is kept as a no-op so prepare_engine-style callers work.
+"""
+from __future__ import annotations
+
+import torch
+
+from .kv_cache import BaseCache, ReusableKVCache
+
+
+def _as_list(ids) -> list[int]:
+    if isinstance(ids, torch.Tensor):
+        return [int(v) for v in ids.reshape(-1).tolist()]
+    return [int(v) for v in ids]
+
+
+class PromptCache:
+    def __init__(self, directory=None, cache: list[BaseCache] | None = None, computed_ids=None):
+        self.cache_directory = directory
+        self.cache: list[BaseCache] = cache or []
+        self._ids: list[int] = _as_list(computed_ids) if computed_ids is not None else []
+        self._pending: list[torch.Tensor] = []  # device tensors not yet read back
+
+    @property
+    def computed_ids(self) -> list[int]:
+        if self._pending:
+            flat = torch.cat([t.reshape(-1) for t in self._pending]) if len(self._pending) > 1 else self._pending[0].reshape(-1)
+            self._ids.extend(int(v) for v in flat.tolist())  # one device->host copy for all pending tokens
+            self._pending = []
+        return self._ids
+
+    @computed_ids.setter
+    def computed_ids(self, ids) -> None:
+        self._ids, self._pending = _as_list(ids), []
+
+    def __call__(self, prompt_ids):
+        return self.reuse_cache(prompt_ids)
+
+    def create_kv_cache(self, model) -> None:
+        if hasattr(model, "make_cache") and callable(model.make_cache):
+            self.cache = model.make_cache()
+            return
+        assert hasattr(model, "layers") and isinstance(model.layers, list), "Model must have a layers attribute"
+        self.cache = [ReusableKVCache() for _ in range(len(model.layers))]
+
+    def update(self, prompt_ids) -> None:
+        """Append processed ids (prompt_cache.py:43-50).  Device tensors are kept as they are until needed."""
+        if isinstance(prompt_ids, torch.Tensor) and prompt_ids.is_cuda:
+            self._pending.append(prompt_ids)
+        else:
+            self.computed_ids.extend(_as_list(prompt_ids))
+
+    def reuse_cache(self, prompt_ids):
+        """Returns the suffix of `prompt_ids` that still has to be processed; at least one token always is
+        (the comparison stops at len(prompt)-1, prompt_cache.py:64-67)."""
+        history = self.computed_ids
+        if not self.cache or not history:
+            return prompt_ids
+        ids = _as_list(prompt_ids)
+        common = 0
+        for i, tok in enumerate(history):
+            if i >= len(ids) - 1 or ids[i] != tok:
+                break
+            common += 1
+        if common == 0:
+            return prompt_ids
+        for layer_cache in self.cache:
+            assert isinstance(layer_cache, ReusableKVCache)
+            layer_cache.reuse(len(ids), common)
+        # Like the reference, computed_ids is NOT truncated here; update() appends the processed suffix.
+        return prompt_ids[common:]
+
+    def load_cached_prompt(self, token_ids) -> None:  # prompt_cache.py:102-125: disk lookup, out of scope
+        return None

@@ -1,0 +1,99 @@
+// common.hpp -- shared host/device helpers for libpie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/pie_hip.h"
+
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// ---------------------------------------------------------------- host side: error plumbing
+namespace pie {
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+}  // namespace pie
+
+#define PIE_HIP_TRY(expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return pie::fail(PIE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+#define PIE_LAUNCH_CHECK() PIE_HIP_TRY(hipGetLastError())
+
+#define PIE_REQUIRE(cond, code, msg)                 \
+    do {                                             \
+        if (!(cond)) return pie::fail((code), (msg)); \
+    } while (0)
+
+static inline bool pie_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---------------------------------------------------------------- device side: 16-bit float traits
+// T-typed values travel as raw u16 bits; math is fp32.  codes2() turns two 4-bit codes (one per 16-bit
+// half) into two T values OFFSET+q by OR-ing a magic exponent.
+struct BF16 {
+    // code pair -> dot2 operand: 0x4300|q is exactly 128+q in bf16; gfx950 has no packed bf16 add, so the
+    // offset stays in the dot product and is removed once per group (d - 128*sum(x)): with 8-bit results the
+    // fp32 cancellation error is ~1/60 ulp.
+    static constexpr float OFFSET = 128.0f;
+    static __device__ __forceinline__ u32 codes2(u32 masked) { return masked | 0x43004300u; }
+    static __device__ __forceinline__ float to_f32(u16 b) { return __builtin_bit_cast(float, (u32)b << 16); }
+    static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // v_cvt_pk_bf16_f32, RNE
+    static __device__ __forceinline__ float dot2(u32 a, u32 b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+    }
+};
+struct F16 {
+    // 0x6400|q is exactly 1024+q in f16; f16 results have 11 significant bits, too fine for the offset to
+    // ride through the fp32 dot product, so it is removed exactly with one v_pk_add_f16 per code pair.
+    static constexpr float OFFSET = 0.0f;
+    static __device__ __forceinline__ u32 codes2(u32 masked) {
+        f16x2_t v = __builtin_bit_cast(f16x2_t, masked | 0x64006400u);
+        v = v - (f16x2_t){(_Float16)1024.0f, (_Float16)1024.0f};
+        return __builtin_bit_cast(u32, v);
+    }
+    static __device__ __forceinline__ float to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+    static __device__ __forceinline__ float dot2(u32 a, u32 b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+    }
+};
+
+template <class T> __device__ __forceinline__ float lo_f32(u32 p) { return T::to_f32((u16)(p & 0xffffu)); }
+template <class T> __device__ __forceinline__ float hi_f32(u32 p) { return T::to_f32((u16)(p >> 16)); }
+template <class T> __device__ __forceinline__ u32 pack2(float lo, float hi) {
+    return (u32)T::from_f32(lo) | ((u32)T::from_f32(hi) << 16);
+}
+template <class T> __device__ __forceinline__ float round_T(float v) { return T::to_f32(T::from_f32(v)); }
+
+// ---------------------------------------------------------------- wave64 reductions (DPP, no LDS)
+// Sum over each 32-lane half of the wave; the result is valid in lanes 16..31 (low half) and 48..63 (high half).
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x140, 0xF, 0xF, true);  // row_mirror -> every lane of a 16-row holds the row sum
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x142, 0xA, 0xF, false); // row_bcast15 into rows 1 and 3
+    return v;
+}
+// Full-wave sum / max, broadcast to every lane.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// W4S geometry (see include/pie_hip.h): one unit = row pair x 2048-wide K slice.
+constexpr int W4S_UNIT_BYTES = 2304;
+constexpr int W4S_SLICE_K = 2048;
+static inline __host__ __device__ int w4s_slices(int K) { return (K + W4S_SLICE_K - 1) / W4S_SLICE_K; }

@@ -1,0 +1,376 @@
+// decoder.hip -- native decode-step runtime: the fused launch sequence of one Model.__call__
+// (models/llama/language.py:199-210) for inputs[1,1] + the tail of _inference
+// (engine/inference_engine.py:252-271), replayable as a hipGraph because position, token and the KV
+// buffer addresses are read from device memory.
+//
+// Launches per step: embed | per layer { rmsnorm+qkv+rope+append, split-KV attention, combine,
+// o_proj+residual, rmsnorm+gate/up+swiglu, down+residual } | rmsnorm+lm_head(+tile stats) | finish.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "attention.hpp"
+#include "tail.hpp"
+#include "w4_gemv.hpp"
+
+namespace {
+thread_local std::string g_last_error;
+}
+namespace pie {
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+}  // namespace pie
+
+__global__ void k_advance(DecState *s) { s->pos += 1; }
+__global__ void k_set_state(DecState *s, int pos, int token, int cap) {
+    if (pos >= 0) s->pos = pos;
+    if (token >= 0) s->token = token;
+    if (cap >= 0) s->cap = cap;
+}
+
+struct pie_decoder {
+    pie_decoder_config cfg;
+    std::vector<pie_layer_weights> layers;
+    std::vector<char> layer_set;
+    pie_global_weights glob;
+    bool glob_set = false, kv_set = false;
+    // device-side state and scratch (owned)
+    DecState *state = nullptr;
+    unsigned long long *kv_table = nullptr;  // [2*n_layers]
+    u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
+    float *part_acc = nullptr, *part_ml = nullptr;
+    // caller-owned outputs (pie_decoder_bind_outputs)
+    u16 *h = nullptr, *logits = nullptr;
+    float *logprobs = nullptr;
+    bool out_set = false;
+    LogitStat *stats = nullptr;
+    int *token_out = nullptr, *history = nullptr;
+    int hist_cap = 0;
+    int n_stats = 0, splits = 16;
+    hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
+};
+
+static int dev_alloc(void **p, size_t bytes) {
+    PIE_HIP_TRY(hipMalloc(p, bytes));
+    PIE_HIP_TRY(hipMemset(*p, 0, bytes));
+    return PIE_OK;
+}
+
+static void drop_graphs(pie_decoder *d) {
+    for (int i = 0; i < 2; ++i)
+        if (d->graph[i]) {
+            (void)hipGraphExecDestroy(d->graph[i]);
+            d->graph[i] = nullptr;
+        }
+}
+
+// One launch of the step's sequence (PIE_K_* of include/pie_hip.h); `li` is the layer for per-layer kernels.
+static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st) {
+    const pie_decoder_config &c = d->cfg;
+    const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
+    const pie_layer_weights &w = d->layers[li];
+    switch (which) {
+        case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
+            return pie_embedding_w4g64(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H,
+                                       c.dtype, d->h, st);
+        case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
+            GemvArgs a = {};
+            a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
+            a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
+            a.freqs = d->glob.rope_freqs, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
+            a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
+            return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
+        }
+        case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
+            AttnArgs a = {};
+            a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
+            a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
+            a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
+            return attn_decode_launch(c.dtype, D, a, st);
+        }
+        case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
+            GemvArgs a = {};
+            a.w = (const char *)w.wo, a.K = QD, a.N = H, a.x = d->attn, a.resid = d->h;
+            return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
+        }
+        case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
+            GemvArgs a = {};
+            a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
+            a.y = d->act;
+            return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
+        }
+        case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
+            GemvArgs a = {};
+            a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h;
+            return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
+        }
+        case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials
+            GemvArgs a = {};
+            a.w = (const char *)d->glob.lm_head, a.K = H, a.N = c.vocab, a.x = d->h, a.norm_w = (const u16 *)d->glob.final_norm, a.eps = c.rms_eps;
+            a.y = logits_dst, a.stats = d->stats;
+            return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_LOGITS, a, 1, st);
+        }
+        case PIE_K_TAIL:  // log-softmax + greedy argmax, advances the device-side state (inference_engine.py:268-271)
+            return logits_tail_launch(c.dtype, logits_dst, c.vocab, d->stats, d->n_stats, d->logprobs, d->token_out, d->state, d->history, d->hist_cap, st);
+        default: return pie::fail(PIE_E_ARG, "pie_decoder: unknown kernel id");
+    }
+}
+
+// The launch sequence of one step.  token_ptr: device int32 holding the input token id.
+static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
+    int rc = enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
+    if (rc) return rc;
+    for (int li = 0; li < d->cfg.n_layers; ++li)
+        for (int k : {PIE_K_QKV, PIE_K_ATTN, PIE_K_OPROJ, PIE_K_GATEUP, PIE_K_DOWN})
+            if ((rc = enqueue_kernel(d, k, li, token_ptr, logits_dst, st))) return rc;
+    if (!with_logits) {
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, d->state);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
+    if ((rc = enqueue_kernel(d, PIE_K_LMHEAD, 0, token_ptr, logits_dst, st))) return rc;
+    return enqueue_kernel(d, PIE_K_TAIL, 0, token_ptr, logits_dst, st);
+}
+
+extern "C" {
+
+const char *pie_hello(void) { return "pie_core \xe2\x9c\x93"; }
+const char *pie_version(void) { return "pie_hip 0.1.0 (gfx950)"; }
+const char *pie_last_error(void) { return g_last_error.c_str(); }
+
+int pie_device_info(char *name, int name_len, int *n_cus, size_t *hbm_bytes) {
+    int dev = 0;
+    PIE_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    PIE_HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) {
+        strncpy(name, p.gcnArchName, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (n_cus) *n_cus = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    return PIE_OK;
+}
+
+int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
+    PIE_REQUIRE(cfg && out, PIE_E_ARG, "pie_decoder_create: null pointer");
+    const pie_decoder_config &c = *cfg;
+    PIE_REQUIRE(c.dtype == PIE_BF16 || c.dtype == PIE_F16, PIE_E_ARG, "pie_decoder_create: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE(c.hidden > 0 && c.hidden % 64 == 0 && c.inter > 0 && c.inter % 64 == 0, PIE_E_SHAPE,
+                "pie_decoder_create: hidden and intermediate sizes must be multiples of 64 (int4 group size)");
+    PIE_REQUIRE(c.head_dim == 64 || c.head_dim == 128, PIE_E_SHAPE, "pie_decoder_create: head_dim must be 64 or 128");
+    PIE_REQUIRE(c.n_layers > 0 && c.n_heads > 0 && c.n_kv_heads > 0 && c.n_heads % c.n_kv_heads == 0, PIE_E_SHAPE, "pie_decoder_create: bad head counts");
+    PIE_REQUIRE(c.vocab > 0 && c.vocab % 2 == 0, PIE_E_SHAPE, "pie_decoder_create: vocab must be even");
+    PIE_REQUIRE(w4s_slices(c.hidden) <= 16 && w4s_slices(c.inter) <= 16 && w4s_slices(c.n_heads * c.head_dim) <= 16, PIE_E_SHAPE,
+                "pie_decoder_create: K > 32768 not supported");
+    pie_decoder *d = new (std::nothrow) pie_decoder();
+    PIE_REQUIRE(d, PIE_E_HIP, "pie_decoder_create: out of host memory");
+    d->cfg = c;
+    d->layers.resize(c.n_layers);
+    d->layer_set.assign(c.n_layers, 0);
+    d->splits = c.kv_splits > 0 ? (c.kv_splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : c.kv_splits) : 16;
+    int RL, U;
+    int rc = w4s_gemv_geometry(c.vocab, c.hidden, &RL, &U);
+    if (rc) { delete d; return rc; }
+    d->n_stats = (c.vocab / 2 + RL * U - 1) / (RL * U);
+    const int QD = c.n_heads * c.head_dim;
+#define PIE_ALLOC(ptr, bytes) if ((rc = dev_alloc((void **)&(ptr), (bytes)))) { pie_decoder_destroy(d); return rc; }
+    PIE_ALLOC(d->state, sizeof(DecState));
+    PIE_ALLOC(d->kv_table, sizeof(unsigned long long) * 2 * c.n_layers);
+    PIE_ALLOC(d->qbuf, 2 * (size_t)QD);
+    PIE_ALLOC(d->attn, 2 * (size_t)QD);
+    PIE_ALLOC(d->act, 2 * (size_t)c.inter);
+    PIE_ALLOC(d->part_acc, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * c.head_dim);
+    PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
+    PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
+#undef PIE_ALLOC
+    *out = d;
+    return PIE_OK;
+}
+
+int pie_decoder_destroy(pie_decoder *d) {
+    if (!d) return PIE_OK;
+    drop_graphs(d);
+    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete d;
+    return PIE_OK;
+}
+
+int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w) {
+    PIE_REQUIRE(d && w, PIE_E_ARG, "pie_decoder_set_layer: null pointer");
+    PIE_REQUIRE(layer >= 0 && layer < d->cfg.n_layers, PIE_E_ARG, "pie_decoder_set_layer: layer out of range");
+    PIE_REQUIRE(w->attn_norm && w->mlp_norm && w->wqkv && w->wo && w->wgateup && w->wdown, PIE_E_ARG, "pie_decoder_set_layer: null weight");
+    PIE_REQUIRE(pie_aligned(w->wqkv, 256) && pie_aligned(w->wo, 256) && pie_aligned(w->wgateup, 256) && pie_aligned(w->wdown, 256) &&
+                    pie_aligned(w->attn_norm, 16) && pie_aligned(w->mlp_norm, 16),
+                PIE_E_ALIGN, "pie_decoder_set_layer: W4S buffers need 256-byte, norm weights 16-byte alignment");
+    d->layers[layer] = *w;
+    d->layer_set[layer] = 1;
+    drop_graphs(d);
+    return PIE_OK;
+}
+
+int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w) {
+    PIE_REQUIRE(d && w, PIE_E_ARG, "pie_decoder_set_globals: null pointer");
+    PIE_REQUIRE(w->embed_codes && w->embed_scales && w->embed_biases && w->final_norm && w->lm_head && w->rope_freqs, PIE_E_ARG,
+                "pie_decoder_set_globals: null weight");
+    PIE_REQUIRE(pie_aligned(w->lm_head, 256) && pie_aligned(w->final_norm, 16) && pie_aligned(w->embed_codes, 16), PIE_E_ALIGN,
+                "pie_decoder_set_globals: misaligned weight");
+    d->glob = *w;
+    d->glob_set = true;
+    drop_graphs(d);
+    return PIE_OK;
+}
+
+int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *const *v_ptrs, int capacity, void *stream) {
+    PIE_REQUIRE(d && k_ptrs && v_ptrs, PIE_E_ARG, "pie_decoder_set_kv: null pointer");
+    PIE_REQUIRE(capacity > 0, PIE_E_SHAPE, "pie_decoder_set_kv: capacity must be positive");
+    const int L = d->cfg.n_layers;
+    std::vector<unsigned long long> tab(2 * (size_t)L);
+    for (int i = 0; i < L; ++i) {
+        PIE_REQUIRE(k_ptrs[i] && v_ptrs[i] && pie_aligned(k_ptrs[i], 16) && pie_aligned(v_ptrs[i], 16), PIE_E_ALIGN,
+                    "pie_decoder_set_kv: null or misaligned cache buffer");
+        tab[i] = (unsigned long long)(uintptr_t)k_ptrs[i];
+        tab[L + i] = (unsigned long long)(uintptr_t)v_ptrs[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // pageable source: the copy is staged before the call returns, so `tab` may go out of scope
+    PIE_HIP_TRY(hipMemcpyAsync(d->kv_table, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, st, d->state, -1, -1, capacity);
+    PIE_LAUNCH_CHECK();
+    d->kv_set = true;
+    return PIE_OK;
+}
+
+int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream) {
+    PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_set_state: null decoder");
+    PIE_REQUIRE(offset >= 0, PIE_E_ARG, "pie_decoder_set_state: negative offset");
+    PIE_REQUIRE(token < d->cfg.vocab, PIE_E_ARG, "pie_decoder_set_state: token id out of range");
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, (hipStream_t)stream, d->state, offset, token, -1);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+static int ready(pie_decoder *d) {
+    PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder: null decoder");
+    PIE_REQUIRE(d->glob_set && d->kv_set && d->out_set, PIE_E_STATE, "pie_decoder: set_globals, set_kv and bind_outputs must be called before stepping");
+    for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder: a layer has no weights (pie_decoder_set_layer)");
+    return PIE_OK;
+}
+
+int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
+    int rc = ready(d);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool with_logits = (flags & PIE_STEP_LOGITS) != 0;
+    if (!(flags & PIE_STEP_GRAPH)) return enqueue_step(d, &d->state->token, with_logits, d->logits, st);
+    const int gi = with_logits ? 1 : 0;
+    if (!d->graph[gi]) {
+        if (d->graph[gi]) {
+            (void)hipGraphExecDestroy(d->graph[gi]);
+            d->graph[gi] = nullptr;
+        }
+        // Capture on a private stream (the caller's may be the legacy default stream, which cannot be captured);
+        // the instantiated graph is then launched on the caller's stream.
+        hipGraph_t g = nullptr;
+        hipStream_t cs = nullptr;
+        PIE_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(cs);
+            return pie::fail(PIE_E_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+        }
+        rc = enqueue_step(d, &d->state->token, with_logits, d->logits, cs);
+        e = hipStreamEndCapture(cs, &g);
+        (void)hipStreamDestroy(cs);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess) return pie::fail(PIE_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&d->graph[gi], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return pie::fail(PIE_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    PIE_HIP_TRY(hipGraphLaunch(d->graph[gi], st));
+    return PIE_OK;
+}
+
+int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream) {
+    int rc = ready(d);
+    if (rc) return rc;
+    PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < L; ++l) {
+        const bool last = l == L - 1;
+        u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;
+        if ((rc = enqueue_step(d, ids + l, last || logits_all != nullptr, dst, st))) return rc;
+    }
+    if (logits_all)  // keep pie_decoder_outputs()'s logits pointer meaningful: last row
+        PIE_HIP_TRY(hipMemcpyAsync(d->logits, (u16 *)logits_all + (size_t)(L - 1) * d->cfg.vocab, 2 * (size_t)d->cfg.vocab,
+                                   hipMemcpyDeviceToDevice, st));
+    return PIE_OK;
+}
+
+int pie_decoder_bind_outputs(pie_decoder *d, void *logits, float *logprobs, int32_t *token, void *hidden, int32_t *history,
+                             int history_len) {
+    PIE_REQUIRE(d && logits && logprobs && token && hidden, PIE_E_ARG, "pie_decoder_bind_outputs: null pointer");
+    PIE_REQUIRE(pie_aligned(logits, 16) && pie_aligned(hidden, 16) && pie_aligned(logprobs, 4) && pie_aligned(token, 4), PIE_E_ALIGN,
+                "pie_decoder_bind_outputs: logits/hidden need 16-byte alignment");
+    PIE_REQUIRE(history_len >= 0 && (history || history_len == 0), PIE_E_ARG, "pie_decoder_bind_outputs: bad history buffer");
+    d->logits = (u16 *)logits, d->logprobs = logprobs, d->token_out = token, d->h = (u16 *)hidden;
+    d->history = history, d->hist_cap = history_len;
+    d->out_set = true;
+    drop_graphs(d);
+    return PIE_OK;
+}
+
+int pie_decoder_set_token_from(pie_decoder *d, const int32_t *token_dev, void *stream) {
+    PIE_REQUIRE(d && token_dev, PIE_E_ARG, "pie_decoder_set_token_from: null pointer");
+    if (token_dev == d->token_out) return PIE_OK;  // the tail kernel already stored it in the device-side state
+    PIE_HIP_TRY(hipMemcpyAsync(&d->state->token, token_dev, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PIE_OK;
+}
+
+int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream) {
+    int rc = ready(d);
+    if (rc) return rc;
+    PIE_REQUIRE(layer >= 0 && layer < d->cfg.n_layers, PIE_E_ARG, "pie_decoder_launch_kernel: layer out of range");
+    PIE_REQUIRE(which != PIE_K_TAIL, PIE_E_ARG, "pie_decoder_launch_kernel: the tail advances the decode state; not launchable alone");
+    return enqueue_kernel(d, which, layer, &d->state->token, d->logits, (hipStream_t)stream);
+}
+
+size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T) {
+    if (!d) return 0;
+    const pie_decoder_config &c = d->cfg;
+    const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
+    auto lin = [](size_t n, size_t k) { return n * k / 2 + 2 * (n * k / 64) * 2; };
+    switch (which) {
+        case PIE_K_QKV: return lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2;
+        case PIE_K_ATTN: return 2 * KVD * 2 * (size_t)T;
+        case PIE_K_OPROJ: return lin(H, QD);
+        case PIE_K_GATEUP: return lin(2 * I, H) + H * 2;
+        case PIE_K_DOWN: return lin(H, I);
+        case PIE_K_LMHEAD: return lin(c.vocab, H) + H * 2;
+        case PIE_K_TAIL: return (size_t)c.vocab * 4;
+        default: return 0;
+    }
+}
+
+size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits) {
+    if (!d) return 0;
+    const pie_decoder_config &c = d->cfg;
+    const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
+    // int4 codes + 16-bit scale and bias per group of 64 = 0.5625 B / parameter  
+    auto lin = [](size_t n, size_t k) { return n * k / 2 + 2 * (n * k / 64) * 2; };
+    size_t per_layer = lin(QD + 2 * KVD, H) + lin(H, QD) + lin(2 * I, H) + lin(H, I);
+    size_t bytes = (size_t)c.n_layers * (per_layer + 2 * H * 2 /* norm weights */ + 2 * KVD * 2 * (size_t)T /* KV read */ + 2 * KVD * 2 /* KV write */);
+    if (with_logits) bytes += lin(c.vocab, H) + H * 2 + (size_t)c.vocab * 4 /* fp32 logprobs */;
+    return bytes;
+}
+
+}  // extern "C"

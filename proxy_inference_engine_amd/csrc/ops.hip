@@ -1,0 +1,196 @@
+// ops.hip -- op-level entry points that are not the W4S GEMV: attention (decode), RMSNorm, RoPE,
+// SiLU*mul, residual add, and the log-softmax / argmax tail.  One C-ABI function per MLX op the reference
+// calls on the decode path (see include/pie_hip.h for the call sites).
+#include "attention.hpp"
+#include "tail.hpp"
+
+// ---------------------------------------------------------------- attention launch
+template <class T, int D>
+static int attn_launch_rep(int rep, const AttnArgs &a, hipStream_t st) {
+    dim3 grid(a.Hkv, a.splits), block(256);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8>), grid, block, 0, st, a); break;
+        default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+    }
+    PIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(D), 0, st, a, D);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int attn_decode_launch(int dtype, int D, AttnArgs &a, hipStream_t stream) {
+    PIE_REQUIRE(a.Hkv > 0 && a.Hq % a.Hkv == 0, PIE_E_SHAPE, "sdpa_decode: Hq must be a multiple of Hkv");
+    PIE_REQUIRE(a.splits >= 1 && a.splits <= ATTN_MAX_SPLITS, PIE_E_ARG, "sdpa_decode: bad split count");
+    const int rep = a.Hq / a.Hkv;
+    if (dtype == PIE_BF16 && D == 128) return attn_launch_rep<BF16, 128>(rep, a, stream);
+    if (dtype == PIE_BF16 && D == 64) return attn_launch_rep<BF16, 64>(rep, a, stream);
+    if (dtype == PIE_F16 && D == 128) return attn_launch_rep<F16, 128>(rep, a, stream);
+    if (dtype == PIE_F16 && D == 64) return attn_launch_rep<F16, 64>(rep, a, stream);
+    return pie::fail(PIE_E_SHAPE, "sdpa_decode: head_dim must be 64 or 128 and dtype bf16/f16");
+}
+
+// ---------------------------------------------------------------- mx.fast.rms_norm: one workgroup per row
+template <class T>
+__global__ void __launch_bounds__(256) k_rms_norm(const u16 *x, const u16 *w, float eps, int H, u16 *y) {
+    __shared__ float red[4];
+    const u16 *xr = x + (size_t)blockIdx.x * H;
+    u16 *yr = y + (size_t)blockIdx.x * H;
+    float ssq = 0.0f;
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        uint4 v = *reinterpret_cast<const uint4 *>(xr + i);
+        const u32 vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lo = lo_f32<T>(vv[j]), hi = hi_f32<T>(vv[j]);
+            ssq = fmaf(lo, lo, ssq);
+            ssq = fmaf(hi, hi, ssq);
+        }
+    }
+    ssq = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        uint4 v = *reinterpret_cast<const uint4 *>(xr + i);
+        uint4 g = *reinterpret_cast<const uint4 *>(w + i);
+        const u32 vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = pack2<T>(round_T<T>(lo_f32<T>(vv[j]) * inv) * lo_f32<T>(gg[j]), round_T<T>(hi_f32<T>(vv[j]) * inv) * hi_f32<T>(gg[j]));
+        *reinterpret_cast<uint4 *>(yr + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------- mx.fast.rope (rotate-half), one thread per pair
+template <class T>
+__global__ void k_rope(const u16 *x, int heads, int L, int D, const float *freqs, int offset, u16 *y) {
+    const int half = D >> 1;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)heads * L * half) return;
+    const int i = (int)(idx % half);
+    const size_t row = idx / half;  // h*L + l
+    const int l = (int)(row % L);
+    const float theta = (float)(offset + l) * (1.0f / freqs[i]);
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    const float a = T::to_f32(x[row * D + i]), b = T::to_f32(x[row * D + i + half]);
+    y[row * D + i] = T::from_f32(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, sn)));
+    y[row * D + i + half] = T::from_f32(__fadd_rn(__fmul_rn(a, sn), __fmul_rn(b, cs)));
+}
+
+// ---------------------------------------------------------------- nn.silu(a) * b and a + b, 8 elements per thread
+template <class T, int OP>
+__global__ void k_binary(const u16 *a, const u16 *b, size_t n, u16 *y) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 8 <= n) {
+        uint4 av = *reinterpret_cast<const uint4 *>(a + i), bv = *reinterpret_cast<const uint4 *>(b + i);
+        const u32 aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float al = lo_f32<T>(aa[j]), ah = hi_f32<T>(aa[j]), bl = lo_f32<T>(bb[j]), bh = hi_f32<T>(bb[j]);
+            if (OP == 0) {
+                al = round_T<T>(al / (1.0f + expf(-al))) * bl;
+                ah = round_T<T>(ah / (1.0f + expf(-ah))) * bh;
+            } else {
+                al += bl, ah += bh;
+            }
+            o[j] = pack2<T>(al, ah);
+        }
+        *reinterpret_cast<uint4 *>(y + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (size_t k = i; k < n; ++k) {
+            float av = T::to_f32(a[k]), bv = T::to_f32(b[k]);
+            y[k] = T::from_f32(OP == 0 ? round_T<T>(av / (1.0f + expf(-av))) * bv : av + bv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- C ABI
+template <class F16K, class BF16K>
+static int by_dtype(int dtype, F16K f16k, BF16K bf16k, const char *who) {
+    if (dtype == PIE_BF16) bf16k();
+    else if (dtype == PIE_F16) f16k();
+    else return pie::fail(PIE_E_ARG, std::string(who) + ": dtype must be PIE_BF16 or PIE_F16");
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+extern "C" {
+
+size_t pie_sdpa_decode_workspace_bytes(int Hq, int D) {
+    if (Hq <= 0 || D <= 0) return 0;
+    return (size_t)Hq * ATTN_MAX_SPLITS * (D + 2) * sizeof(float);
+}
+
+int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv, int T, int cap, int D, float scale,
+                    int dtype, void *out, void *workspace, void *stream) {
+    PIE_REQUIRE(q && k && v && out && workspace, PIE_E_ARG, "pie_sdpa_decode: null pointer");
+    PIE_REQUIRE(T >= 1 && T <= cap, PIE_E_SHAPE, "pie_sdpa_decode: need 1 <= T <= cap");
+    PIE_REQUIRE(pie_aligned(q, 16) && pie_aligned(k, 16) && pie_aligned(v, 16), PIE_E_ALIGN, "pie_sdpa_decode: 16-byte alignment required");
+    AttnArgs a = {};
+    a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v;
+    a.T = T, a.cap = cap, a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
+    a.splits = T >= 2048 ? ATTN_MAX_SPLITS : (T >= 64 ? 16 : 1);
+    a.part_acc = (float *)workspace;
+    a.part_ml = a.part_acc + (size_t)Hq * ATTN_MAX_SPLITS * D;
+    a.out = (u16 *)out;
+    return attn_decode_launch(dtype, D, a, (hipStream_t)stream);
+}
+
+int pie_rms_norm(const void *x, const void *w, float eps, int rows, int H, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && w && y, PIE_E_ARG, "pie_rms_norm: null pointer");
+    PIE_REQUIRE(rows > 0 && H > 0 && H % 8 == 0, PIE_E_SHAPE, "pie_rms_norm: H must be a multiple of 8");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(w, 16) && pie_aligned(y, 16), PIE_E_ALIGN, "pie_rms_norm: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    return by_dtype(
+        dtype, [&] { hipLaunchKernelGGL(k_rms_norm<F16>, dim3(rows), dim3(256), 0, st, (const u16 *)x, (const u16 *)w, eps, H, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_rms_norm<BF16>, dim3(rows), dim3(256), 0, st, (const u16 *)x, (const u16 *)w, eps, H, (u16 *)y); },
+        "pie_rms_norm");
+}
+
+int pie_rope(const void *x, int heads, int L, int D, const float *freqs, int offset, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && freqs && y, PIE_E_ARG, "pie_rope: null pointer");
+    PIE_REQUIRE(heads > 0 && L > 0 && D > 0 && D % 2 == 0 && offset >= 0, PIE_E_SHAPE, "pie_rope: bad shape");
+    const size_t n = (size_t)heads * L * (D / 2);
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    return by_dtype(
+        dtype, [&] { hipLaunchKernelGGL(k_rope<F16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_rope<BF16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, (u16 *)y); }, "pie_rope");
+}
+
+static int binary(int op, const void *a, const void *b, size_t n, int dtype, void *y, void *stream, const char *who) {
+    PIE_REQUIRE(a && b && y, PIE_E_ARG, std::string(who) + ": null pointer");
+    PIE_REQUIRE(n > 0, PIE_E_SHAPE, std::string(who) + ": empty input");
+    PIE_REQUIRE(pie_aligned(a, 16) && pie_aligned(b, 16) && pie_aligned(y, 16), PIE_E_ALIGN, std::string(who) + ": 16-byte alignment required");
+    dim3 grid((unsigned)((n + 2047) / 2048)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (op == 0)
+        return by_dtype(
+            dtype, [&] { hipLaunchKernelGGL((k_binary<F16, 0>), grid, block, 0, st, (const u16 *)a, (const u16 *)b, n, (u16 *)y); },
+            [&] { hipLaunchKernelGGL((k_binary<BF16, 0>), grid, block, 0, st, (const u16 *)a, (const u16 *)b, n, (u16 *)y); }, who);
+    return by_dtype(
+        dtype, [&] { hipLaunchKernelGGL((k_binary<F16, 1>), grid, block, 0, st, (const u16 *)a, (const u16 *)b, n, (u16 *)y); },
+        [&] { hipLaunchKernelGGL((k_binary<BF16, 1>), grid, block, 0, st, (const u16 *)a, (const u16 *)b, n, (u16 *)y); }, who);
+}
+
+int pie_silu_mul(const void *a, const void *b, size_t n, int dtype, void *y, void *stream) {
+    return binary(0, a, b, n, dtype, y, stream, "pie_silu_mul");
+}
+int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *stream) {
+    return binary(1, a, b, n, dtype, y, stream, "pie_add");
+}
+
+int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, int32_t *token, void *stream) {
+    PIE_REQUIRE(logits && logprobs && token, PIE_E_ARG, "pie_logprobs_argmax: null pointer");
+    PIE_REQUIRE(V > 0, PIE_E_SHAPE, "pie_logprobs_argmax: empty vocabulary");
+    return logits_tail_launch(dtype, (const u16 *)logits, V, nullptr, 0, logprobs, token, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+// w4_gemv.hip -- int4 group-64 weights: quantise, repack into the W4S streaming layout, embedding
+// row dequant, and the op-level entry point of the streaming GEMV (pie_qgemv_w4g64).
+#include "w4_gemv.hpp"
+
+// ---------------------------------------------------------------- mx.quantize / mx.dequantize
+// One thread per group of 64 (load-time utility, not on the decode path).  Same operation order as the
+// published algorithm with IEEE fp32 division, so codes/scales/biases are
+// bit-identical to the oracle's.  Built with -ffp-contract=off.
+template <class T>
+__global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *scales, u16 *biases) {
+    const int G = K >> 6;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)N * G) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(w + gid * 64);
+    float v[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint4 q = src[i];
+        const u32 qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[8 * i + 2 * j] = lo_f32<T>(qq[j]);
+            v[8 * i + 2 * j + 1] = hi_f32<T>(qq[j]);
+        }
+    }
+    float w_max = v[0], w_min = v[0];
+#pragma unroll
+    for (int i = 1; i < 64; ++i) {
+        w_max = v[i] > w_max ? v[i] : w_max;
+        w_min = v[i] < w_min ? v[i] : w_min;
+    }
+    const bool side = fabsf(w_min) > fabsf(w_max);
+    float scale = fmaxf(__fdiv_rn(__fsub_rn(w_max, w_min), 15.0f), 1e-7f);
+    scale = side ? scale : -scale;
+    const float edge = side ? w_min : w_max;
+    const float q0 = rintf(__fdiv_rn(edge, scale));
+    const bool at_zero = q0 == 0.0f;
+    scale = at_zero ? scale : __fdiv_rn(edge, q0);
+    const float bias = at_zero ? 0.0f : edge;
+    scales[gid] = T::from_f32(scale);
+    biases[gid] = T::from_f32(bias);
+    u32 *dst = codes + gid * 8;
+#pragma unroll
+    for (int wd = 0; wd < 8; ++wd) {
+        u32 word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float c = rintf(__fdiv_rn(__fsub_rn(v[8 * wd + j], bias), scale));
+            c = c < 0.0f ? 0.0f : (c > 15.0f ? 15.0f : c);
+            word |= ((u32)c) << (4 * j);
+        }
+        dst[wd] = word;
+    }
+}
+
+// out[n,k] = T(scale*q + bias): separate multiply and add roundings, like the oracle.
+template <class T>
+__device__ __forceinline__ void dequant_word(u32 word, float s, float b, u16 *out8) {
+    u32 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float lo = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j)) & 0xFu)), b);
+        float hi = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j + 4)) & 0xFu)), b);
+        o[j] = pack2<T>(lo, hi);
+    }
+    *reinterpret_cast<uint4 *>(out8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <class T>
+__global__ void k_dequantize_w4g64(const u32 *codes, const u16 *scales, const u16 *biases, size_t n_words, u16 *out) {
+    const size_t wid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= n_words) return;
+    dequant_word<T>(codes[wid], T::to_f32(scales[wid >> 3]), T::to_f32(biases[wid >> 3]), out + wid * 8);
+}
+
+// nn.QuantizedEmbedding.__call__ (language.py:176): out[l,:] = dequantize(row ids[l]).
+template <class T>
+__global__ void k_embedding_w4g64(const int *ids, const u32 *codes, const u16 *scales, const u16 *biases, int V, int H,
+                                  u16 *out) {
+    const int l = blockIdx.x;
+    int id = ids[l];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const int words = H >> 3;
+    const u32 *row = codes + (size_t)id * words;
+    const u16 *srow = scales + (size_t)id * (H >> 6), *brow = biases + (size_t)id * (H >> 6);
+    for (int wd = threadIdx.x; wd < words; wd += blockDim.x)
+        dequant_word<T>(row[wd], T::to_f32(srow[wd >> 3]), T::to_f32(brow[wd >> 3]), out + (size_t)l * H + (size_t)wd * 8);
+}
+
+// ---------------------------------------------------------------- W4S repack
+// One thread per output dword.  Unit layout (2304 B): dwords [0,256) code piece 0 (lane l -> dwords 4l..4l+3),
+// [256,512) code piece 1, [512,576) {scale | bias<<16} per lane.  Lane l: row = row_map[2*pair + (l>>5)],
+// group = 32*slice + (l&31); piece j, dword t = source word 8*group + 4j + t with its nibbles reordered so that
+// (w >> 4i) & 0x000F000F yields codes (2i, 2i+1) in the two 16-bit halves.
+__global__ void k_repack_w4s(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map,
+                             int n_pairs, int ns, u32 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 576;
+    if (idx >= total) return;
+    const size_t unit = idx / 576;
+    const int dw = (int)(idx % 576);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    int lane, j = 0, t = 0;
+    const bool is_sb = dw >= 512;
+    if (is_sb) {
+        lane = dw - 512;
+    } else {
+        j = dw >> 8;
+        lane = (dw & 255) >> 2;
+        t = dw & 3;
+    }
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int g = 32 * s + (lane & 31);
+    const int G = K >> 6;
+    u32 out = 0;
+    if (g < G && row >= 0 && row < N_src) {
+        if (is_sb) {
+            out = (u32)scales[(size_t)row * G + g] | ((u32)biases[(size_t)row * G + g] << 16);
+        } else {
+            const u32 src = codes[(size_t)row * (K >> 3) + 8 * g + 4 * j + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out |= ((src >> (8 * i)) & 0xFu) << (4 * i);
+                out |= ((src >> (8 * i + 4)) & 0xFu) << (16 + 4 * i);
+            }
+        }
+    }
+    packed[idx] = out;
+}
+
+// ---------------------------------------------------------------- launch geometry
+template <class T, int PRO, int EPI>
+static int launch_u(int U, const GemvArgs &a, dim3 grid, dim3 block, hipStream_t st) {
+    switch (U) {
+        case 4: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 4>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 2>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 1>), grid, block, 0, st, a); break;
+    }
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+template <class T>
+static int launch_t(int pro, int epi, int U, const GemvArgs &a, dim3 grid, dim3 block, hipStream_t st) {
+    if (pro == PRO_NONE && epi == EPI_STORE) return launch_u<T, PRO_NONE, EPI_STORE>(U, a, grid, block, st);
+    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_u<T, PRO_NONE, EPI_RESIDUAL>(U, a, grid, block, st);
+    if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) return launch_u<T, PRO_RMSNORM, EPI_ROPE_KV>(U, a, grid, block, st);
+    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_u<T, PRO_RMSNORM, EPI_SWIGLU>(U, a, grid, block, st);
+    if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_u<T, PRO_RMSNORM, EPI_LOGITS>(U, a, grid, block, st);
+    return pie::fail(PIE_E_ARG, "w4s_gemv: unsupported prologue/epilogue combination");
+}
+
+int w4s_gemv_geometry(int N, int K, int *row_lanes, int *unroll) {
+    const int ns = w4s_slices(K);
+    if (ns > 16) return pie::fail(PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
+    const int RL = ns >= 5 ? 1 : (ns >= 3 ? 2 : (ns == 2 ? 4 : 8));
+    const int n_pairs = N / 2;
+    int U = 4;  // most bytes in flight per wave, as long as the grid still covers the chip twice
+    while (U > 1 && (n_pairs + U * RL - 1) / (U * RL) < 512) U >>= 1;
+    *row_lanes = RL;
+    *unroll = U;
+    return PIE_OK;
+}
+
+int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t stream) {
+    PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
+    PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
+    int RL, U;
+    int rc = w4s_gemv_geometry(a.N, a.K, &RL, &U);
+    if (rc) return rc;
+    a.n_slices = w4s_slices(a.K);
+    a.row_lanes = RL;
+    a.n_pairs = a.N / 2;
+    const int P = U * RL;
+    dim3 grid((a.n_pairs + P - 1) / P, M), block(64 * a.n_slices * RL);
+    if (dtype == PIE_BF16) return launch_t<BF16>(pro, epi, U, a, grid, block, stream);
+    if (dtype == PIE_F16) return launch_t<F16>(pro, epi, U, a, grid, block, stream);
+    return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+size_t pie_w4s_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w4s_slices(K) * W4S_UNIT_BYTES;
+}
+
+int pie_quantize_w4g64(const void *w, int N, int K, int dtype, uint32_t *codes, void *scales, void *biases, void *stream) {
+    PIE_REQUIRE(w && codes && scales && biases, PIE_E_ARG, "pie_quantize_w4g64: null pointer");
+    PIE_REQUIRE(N > 0 && K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_quantize_w4g64: K must be a multiple of 64");
+    PIE_REQUIRE(pie_aligned(w, 16) && pie_aligned(codes, 16), PIE_E_ALIGN, "pie_quantize_w4g64: 16-byte alignment required");
+    const size_t groups = (size_t)N * (K / 64);
+    dim3 grid((unsigned)((groups + 127) / 128)), block(128);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PIE_BF16)
+        hipLaunchKernelGGL(k_quantize_w4g64<BF16>, grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_F16)
+        hipLaunchKernelGGL(k_quantize_w4g64<F16>, grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else
+        return pie::fail(PIE_E_ARG, "pie_quantize_w4g64: bad dtype");
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_dequantize_w4g64(const uint32_t *codes, const void *scales, const void *biases, int N, int K, int dtype, void *w_out,
+                         void *stream) {
+    PIE_REQUIRE(codes && scales && biases && w_out, PIE_E_ARG, "pie_dequantize_w4g64: null pointer");
+    PIE_REQUIRE(N > 0 && K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_dequantize_w4g64: K must be a multiple of 64");
+    PIE_REQUIRE(pie_aligned(w_out, 16), PIE_E_ALIGN, "pie_dequantize_w4g64: output must be 16-byte aligned");
+    const size_t n_words = (size_t)N * (K / 8);
+    dim3 grid((unsigned)((n_words + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PIE_BF16)
+        hipLaunchKernelGGL(k_dequantize_w4g64<BF16>, grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+    else if (dtype == PIE_F16)
+        hipLaunchKernelGGL(k_dequantize_w4g64<F16>, grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+    else
+        return pie::fail(PIE_E_ARG, "pie_dequantize_w4g64: bad dtype");
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map,
+                     int N_out, void *packed, void *stream) {
+    PIE_REQUIRE(codes && scales && biases && packed, PIE_E_ARG, "pie_repack_w4g64: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_w4g64: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_repack_w4g64: K must be a multiple of 64");
+    PIE_REQUIRE(w4s_slices(K) <= 16, PIE_E_SHAPE, "pie_repack_w4g64: K > 32768 not supported");
+    PIE_REQUIRE(pie_aligned(packed, 256), PIE_E_ALIGN, "pie_repack_w4g64: packed must be 256-byte aligned");
+    const int n_pairs = N_out / 2, ns = w4s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 576;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_repack_w4s, grid, block, 0, (hipStream_t)stream, codes, (const u16 *)scales, (const u16 *)biases, N_src, K,
+                       row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype,
+                    void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w4g64: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w4g64: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w4g64: misaligned pointer");
+    GemvArgs a = {};
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
+}
+
+int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
+                        int dtype, void *out, void *stream) {
+    PIE_REQUIRE(ids && codes && scales && biases && out, PIE_E_ARG, "pie_embedding_w4g64: null pointer");
+    PIE_REQUIRE(L > 0 && V > 0 && H > 0 && H % 64 == 0, PIE_E_SHAPE, "pie_embedding_w4g64: H must be a multiple of 64");
+    PIE_REQUIRE(pie_aligned(out, 16), PIE_E_ALIGN, "pie_embedding_w4g64: out must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PIE_BF16)
+        hipLaunchKernelGGL(k_embedding_w4g64<BF16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out);
+    else if (dtype == PIE_F16)
+        hipLaunchKernelGGL(k_embedding_w4g64<F16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out);
+    else
+        return pie::fail(PIE_E_ARG, "pie_embedding_w4g64: bad dtype");
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qkv_row_map(int n_heads, int n_kv_heads, int head_dim, int32_t *map) {
+    if (!map || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || (head_dim & 1)) return pie::fail(PIE_E_ARG, "pie_qkv_row_map: bad argument");
+    const int D = head_dim, half = D / 2;
+    int r = 0;
+    for (int h = 0; h < n_heads + n_kv_heads; ++h)  // q heads then k heads: RoPE partners (i, i+D/2) adjacent
+        for (int i = 0; i < half; ++i) {
+            map[r++] = h * D + i;
+            map[r++] = h * D + i + half;
+        }
+    for (int j = 0; j < n_kv_heads * D; ++j) map[r++] = (n_heads + n_kv_heads) * D + j;  // v rows in natural order
+    return PIE_OK;
+}
+
+int pie_gateup_row_map(int inter, int32_t *map) {
+    if (!map || inter <= 0) return pie::fail(PIE_E_ARG, "pie_gateup_row_map: bad argument");
+    for (int i = 0; i < inter; ++i) {
+        map[2 * i] = i;              // gate_i
+        map[2 * i + 1] = inter + i;  // up_i
+    }
+    return PIE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+"""Op-level host mirror of the MLX ops the reference's decode path calls, on torch (ROCm) tensors.
+
+Same names and argument meaning as the `mx.*` call sites (paths relative to
+/root/reference/src/proxy_inference_engine/):
+  quantize / dequantize            <- mx.quantize / mx.dequantize   (cache/kv_cache/cache.py:144-147)
+  quantized_matmul                 <- mx.quantized_matmul           (via nn.QuantizedLinear, models/utils.py:111)
+  rms_norm, rope, scaled_dot_product_attention  <- mx.fast.*        (language.py:137-141, llama/utils.py:42-50, base.py:111-113)
+Every function launches hand-written HIP kernels through the C ABI on torch's current stream;
+there is no torch-op or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _ffi
+
+U32 = torch.int32  # uint32 code words are carried in int32 tensors (same bits)
+
+
+def _dev(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise ValueError("pie_hip ops take device tensors (ROCm); got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("pie_hip ops take contiguous tensors")
+
+
+def quantize(w: torch.Tensor, group_size: int = 64, bits: int = 4):
+    """mx.quantize(w, group_size=64, bits=4): w [N,K] -> (codes [N,K/8] uint32-in-int32, scales, biases [N,K/64])."""
+    if group_size != 64 or bits != 4:
+        raise ValueError("only group_size=64, bits=4 (the reference's checkpoint format) is implemented")
+    _dev(w)
+    N, K = w.shape
+    if K % 64:
+        raise ValueError(f"last dimension must be a multiple of 64, got {K}")
+    codes = torch.empty((N, K // 8), dtype=U32, device=w.device)
+    scales = torch.empty((N, K // 64), dtype=w.dtype, device=w.device)
+    biases = torch.empty_like(scales)
+    _ffi.check(_ffi.load().pie_quantize_w4g64(_ffi.p(w), N, K, _ffi.dtype_code(w.dtype), _ffi.p(codes), _ffi.p(scales),
+                                              _ffi.p(biases), _ffi.stream()))
+    return codes, scales, biases
+
+
+def dequantize(codes: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, group_size: int = 64, bits: int = 4):
+    if group_size != 64 or bits != 4:
+        raise ValueError("only group_size=64, bits=4 is implemented")
+    for t in (codes, scales, biases):
+        _dev(t)
+    N, K = codes.shape[0], codes.shape[1] * 8
+    out = torch.empty((N, K), dtype=scales.dtype, device=codes.device)
+    _ffi.check(_ffi.load().pie_dequantize_w4g64(_ffi.p(codes), _ffi.p(scales), _ffi.p(biases), N, K,
+                                                _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
+    return out
+
+
+@dataclass
+class W4SWeight:
+    """One quantised Linear in the W4S streaming layout (include/pie_hip.h)."""
+    packed: torch.Tensor          # uint8 [pie_w4s_bytes(N, K)]
+    N: int
+    K: int
+    dtype: torch.dtype
+    lin_bias: torch.Tensor | None = None
+
+    @property
+    def nbytes(self) -> int:
+        return self.packed.numel()
+
+
+def repack_w4s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W4SWeight:
+    """Load-time repack of an MLX triplet (weight, scales, biases) [N_src,K] into W4S.
+    row_map (int32 [N_out]) selects / reorders source rows (q|k|v concatenation, gate/up interleave)."""
+    for t in (codes, scales, biases):
+        _dev(t)
+    N_src, K = codes.shape[0], codes.shape[1] * 8
+    N_out = N_src if row_map is None else int(row_map.numel())
+    if N_out % 2:
+        raise ValueError("W4S needs an even number of rows")
+    nbytes = _ffi.load().pie_w4s_bytes(N_out, K)
+    if nbytes == 0:
+        raise ValueError(f"unsupported shape for W4S: N={N_out}, K={K}")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+    if row_map is not None:
+        row_map = row_map.to(device=codes.device, dtype=torch.int32).contiguous()
+    _ffi.check(_ffi.load().pie_repack_w4g64(_ffi.p(codes), _ffi.p(scales), _ffi.p(biases), N_src, K, _ffi.p(row_map), N_out,
+                                            _ffi.p(packed), _ffi.stream()))
+    return W4SWeight(packed, N_out, K, scales.dtype, lin_bias)
+
+
+def quantized_matmul(x: torch.Tensor, w: W4SWeight, transpose: bool = True, group_size: int = 64, bits: int = 4):
+    """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4) on a W4S weight:
+    x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""
+    if not transpose or group_size != 64 or bits != 4:
+        raise ValueError("only transpose=True, group_size=64, bits=4 is implemented (the nn.QuantizedLinear form)")
+    _dev(x)
+    if x.shape[-1] != w.K or x.dtype != w.dtype:
+        raise ValueError(f"x [..., {x.shape[-1]}] {x.dtype} does not match weight K={w.K} {w.dtype}")
+    M = x.numel() // w.K
+    y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
+    _ffi.check(_ffi.load().pie_qgemv_w4g64(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y),
+                                           _ffi.dtype_code(x.dtype), _ffi.stream()))
+    return y
+
+
+def embedding(ids: torch.Tensor, codes, scales, biases) -> torch.Tensor:
+    """nn.QuantizedEmbedding.__call__: ids int32 [L] -> [L, H]."""
+    _dev(ids)
+    ids = ids.to(torch.int32).contiguous().view(-1)
+    V, H = codes.shape[0], codes.shape[1] * 8
+    out = torch.empty((ids.numel(), H), dtype=scales.dtype, device=codes.device)
+    _ffi.check(_ffi.load().pie_embedding_w4g64(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H,
+                                               _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
+    return out
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """mx.fast.rms_norm(x, weight, eps) over the last axis."""
+    _dev(x), _dev(weight)
+    H = x.shape[-1]
+    y = torch.empty_like(x)
+    _ffi.check(_ffi.load().pie_rms_norm(_ffi.p(x), _ffi.p(weight), float(eps), x.numel() // H, H, _ffi.dtype_code(x.dtype),
+                                        _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def rope(x: torch.Tensor, dims: int, traditional: bool = False, base=None, scale: float = 1.0, offset: int = 0,
+         freqs: torch.Tensor | None = None) -> torch.Tensor:
+    """mx.fast.rope(x[..., heads, L, D], dims, traditional=False, base=None, scale=1.0, offset, freqs)."""
+    if traditional or base is not None or scale != 1.0 or freqs is None or dims != x.shape[-1]:
+        raise ValueError("only the Llama3RoPE form is implemented: traditional=False, base=None, scale=1.0, freqs given, dims=D")
+    _dev(x), _dev(freqs)
+    L, D = x.shape[-2:]
+    y = torch.empty_like(x)
+    _ffi.check(_ffi.load().pie_rope(_ffi.p(x), x.numel() // (L * D), L, D, _ffi.p(freqs), int(offset),
+                                    _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+_sdpa_ws: dict = {}
+
+
+def scaled_dot_product_attention(q, k, v, scale: float, mask=None, T: int | None = None) -> torch.Tensor:
+    """mx.fast.scaled_dot_product_attention for the decode step: q [1,Hq,1,D]; k,v [1,Hkv,cap,D] buffers whose
+    first T positions are attended (default: all); mask must be None (L == 1: models/base.py:39-53)."""
+    if mask is not None or q.shape[-2] != 1 or q.shape[0] != 1:
+        raise NotImplementedError("decode form only: batch 1, one query position, mask=None")
+    for t in (q, k, v):
+        _dev(t)
+    Hq, D = q.shape[1], q.shape[3]
+    Hkv, cap = k.shape[1], k.shape[2]
+    T = cap if T is None else int(T)
+    key = (q.device, Hq, D)
+    ws = _sdpa_ws.get(key)
+    if ws is None:
+        ws = torch.empty(_ffi.load().pie_sdpa_decode_workspace_bytes(Hq, D), dtype=torch.uint8, device=q.device)
+        _sdpa_ws[key] = ws
+    out = torch.empty_like(q)
+    _ffi.check(_ffi.load().pie_sdpa_decode(_ffi.p(q), _ffi.p(k), _ffi.p(v), Hq, Hkv, T, cap, D, float(scale),
+                                           _ffi.dtype_code(q.dtype), _ffi.p(out), _ffi.p(ws), _ffi.stream()))
+    return out
+
+
+def silu_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.silu(a) * b (models/llama/language.py:127)."""
+    _dev(a), _dev(b)
+    y = torch.empty_like(a)
+    _ffi.check(_ffi.load().pie_silu_mul(_ffi.p(a), _ffi.p(b), a.numel(), _ffi.dtype_code(a.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dev(a), _dev(b)
+    y = torch.empty_like(a)
+    _ffi.check(_ffi.load().pie_add(_ffi.p(a), _ffi.p(b), a.numel(), _ffi.dtype_code(a.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def logprobs_argmax(logits: torch.Tensor):
+    """engine/inference_engine.py:268-271 + greedy sampler: returns (token int32 [1], logprobs fp32 [V])."""
+    _dev(logits)
+    logits = logits.reshape(-1)
+    V = logits.numel()
+    lp = torch.empty(V, dtype=torch.float32, device=logits.device)
+    tok = torch.empty(1, dtype=torch.int32, device=logits.device)
+    _ffi.check(_ffi.load().pie_logprobs_argmax(_ffi.p(logits), V, _ffi.dtype_code(logits.dtype), _ffi.p(lp), _ffi.p(tok),
+                                               _ffi.stream()))
+    return tok, lp
+
+
+def qkv_row_map(n_heads: int, n_kv_heads: int, head_dim: int) -> torch.Tensor:
+    n = (n_heads + 2 * n_kv_heads) * head_dim
+    arr = (C.c_int32 * n)()
+    _ffi.check(_ffi.load().pie_qkv_row_map(n_heads, n_kv_heads, head_dim, arr))
+    return torch.tensor(list(arr), dtype=torch.int32)
+
+
+def gateup_row_map(inter: int) -> torch.Tensor:
+    arr = (C.c_int32 * (2 * inter))()
+    _ffi.check(_ffi.load().pie_gateup_row_map(inter, arr))
+    return torch.tensor(list(arr), dtype=torch.int32)

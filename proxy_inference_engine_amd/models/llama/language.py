@@ -1,0 +1,241 @@
+"""Llama-shaped decoder on the MI355X decode runtime.
+
+Host-side mirror of models/llama/language.py of the reference (ModelArgs :13-29, Attention :32-108,
+MLP :111-127, TransformerBlock :130-154, LlamaModel :157-187, Model :190-219).  The reference builds a lazy MLX
+graph of ~17 primitives per layer; here `Model` owns a native decoder (csrc/decoder.hip) that runs the same
+graph as 6 fused HIP launches per layer, and this file only (1) repacks the checkpoint's MLX-quantised triplets
+into the W4S streaming layout at load, and (2) keeps the reference's calling convention:
+
+    logits[1, L, V] = model(inputs[1, L], mask=None, cache=[ReusableKVCache, ...])
+
+Only int4 group-64 checkpoints (config["quantization"] = {"group_size": 64, "bits": 4}) run on this path;
+see DESIGN.md for the dense 16-bit row.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import base
+from ... import _ffi, hip_ops
+from ...cache.kv_cache import BaseCache, ReusableKVCache
+from .utils import Llama3RoPE
+
+
+class ModelArgs(base.BaseModelArgs):
+    """config.json keys the Llama path reads (language.py:13-29; unknown keys are ignored)."""
+    model_type: str = "llama"
+    hidden_size: int = 0
+    num_hidden_layers: int = 0
+    intermediate_size: int = 0
+    num_attention_heads: int = 0
+    rms_norm_eps: float = 1e-5
+    vocab_size: int = 0
+    head_dim: int | None = None
+    max_position_embeddings: int | None = None
+    num_key_value_heads: int | None = None
+    attention_bias: bool = False
+    mlp_bias: bool = False
+    rope_theta: float = 10000
+    rope_traditional: bool = False
+    rope_scaling: dict | None = None
+    tie_word_embeddings: bool = True
+    quantization: dict | None = None
+
+
+class TransformerBlock:
+    """One entry of `model.layers` (PromptCache.create_kv_cache counts them, prompt_cache.py:39-41).
+    Holds the layer's device weights; the arithmetic of language.py:144-154 runs inside the decoder."""
+
+    def __init__(self, attn_norm, mlp_norm, wqkv, wo, wgateup, wdown):
+        self.input_layernorm = attn_norm
+        self.post_attention_layernorm = mlp_norm
+        self.wqkv, self.wo, self.wgateup, self.wdown = wqkv, wo, wgateup, wdown
+
+    def nbytes(self) -> int:
+        return sum(w.nbytes for w in (self.wqkv, self.wo, self.wgateup, self.wdown))
+
+
+def _triplet(weights: dict, prefix: str):
+    try:
+        return weights[f"{prefix}.weight"], weights[f"{prefix}.scales"], weights[f"{prefix}.biases"]
+    except KeyError as e:
+        raise ValueError(
+            f"{prefix}: expected an MLX-quantised triplet (.weight/.scales/.biases); dense 16-bit Linear layers are "
+            "not on the MI355X decode path yet") from e
+
+
+class Model:
+    def __init__(self, args: ModelArgs, weights: dict[str, torch.Tensor], kv_splits: int = 0):
+        """weights: the checkpoint in the layout models/utils.py:51-125 of the reference consumes (HF names,
+        `.weight` uint32 codes carried as int32, `.scales`/`.biases` in the activation dtype), on the GPU."""
+        self.args = args
+        self.model_type = args.model_type
+        device = _ffi.require_gpu()
+        q = args.quantization or {}
+        if q.get("group_size") != 64 or q.get("bits") != 4:
+            raise ValueError("the MI355X decode path needs an int4 group_size=64 checkpoint (config['quantization'])")
+        if args.attention_bias or args.mlp_bias or args.rope_traditional:
+            raise NotImplementedError("attention_bias / mlp_bias / rope_traditional are not on this path yet")
+        self.n_heads = args.num_attention_heads
+        self.n_kv_heads = args.num_key_value_heads or self.n_heads
+        self.head_dim = args.head_dim or args.hidden_size // self.n_heads
+        self.dtype = weights["model.norm.weight"].dtype
+        self.device = device
+        H, I, V = args.hidden_size, args.intermediate_size, args.vocab_size
+        weights = base.sanitize(weights, args.tie_word_embeddings)  # language.py:212-219
+
+        rs = args.rope_scaling or {}
+        max_len = args.max_position_embeddings or 8192  # language.py:56
+        self.rope = Llama3RoPE(max_len, max_len, self.head_dim, args.rope_theta, float(rs.get("factor", 1.0)),
+                               float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 1.0)), device=device)
+
+        qkv_map = hip_ops.qkv_row_map(self.n_heads, self.n_kv_heads, self.head_dim).to(device)
+        gu_map = hip_ops.gateup_row_map(I).to(device)
+        self.layers: list[TransformerBlock] = []
+        for i in range(args.num_hidden_layers):
+            pfx = f"model.layers.{i}"
+            qkv = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, f"{pfx}.self_attn.{n}_proj") for n in "qkv"))]
+            gu = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, f"{pfx}.mlp.{n}_proj") for n in ("gate", "up")))]
+            self.layers.append(TransformerBlock(
+                weights[f"{pfx}.input_layernorm.weight"].contiguous(),
+                weights[f"{pfx}.post_attention_layernorm.weight"].contiguous(),
+                hip_ops.repack_w4s(*qkv, row_map=qkv_map),
+                hip_ops.repack_w4s(*_triplet(weights, f"{pfx}.self_attn.o_proj")),
+                hip_ops.repack_w4s(*gu, row_map=gu_map),
+                hip_ops.repack_w4s(*_triplet(weights, f"{pfx}.mlp.down_proj")),
+            ))
+        self.embed_tokens = tuple(t.contiguous() for t in _triplet(weights, "model.embed_tokens"))
+        self.norm = weights["model.norm.weight"].contiguous()
+        head = "model.embed_tokens" if args.tie_word_embeddings else "lm_head"  # language.py:206-209
+        self.lm_head = hip_ops.repack_w4s(*_triplet(weights, head))
+
+        # decoder-owned outputs live in torch tensors so callers can read them without copies
+        self.logits = torch.zeros(V, dtype=self.dtype, device=device)
+        self.logprobs = torch.zeros(V, dtype=torch.float32, device=device)
+        self.token = torch.zeros(1, dtype=torch.int32, device=device)
+        self.hidden = torch.zeros(H, dtype=self.dtype, device=device)
+
+        lib = _ffi.load()
+        cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
+                                      self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits))
+        self._dec = C.c_void_p()
+        _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
+        for i, blk in enumerate(self.layers):
+            lw = _ffi.pie_layer_weights(blk.input_layernorm.data_ptr(), blk.post_attention_layernorm.data_ptr(),
+                                        blk.wqkv.packed.data_ptr(), blk.wo.packed.data_ptr(), blk.wgateup.packed.data_ptr(),
+                                        blk.wdown.packed.data_ptr())
+            _ffi.check(lib.pie_decoder_set_layer(self._dec, i, C.byref(lw)))
+        gw = _ffi.pie_global_weights(self.embed_tokens[0].data_ptr(), self.embed_tokens[1].data_ptr(), self.embed_tokens[2].data_ptr(),
+                                     self.norm.data_ptr(), self.lm_head.packed.data_ptr(), self.rope.freqs.data_ptr())
+        _ffi.check(lib.pie_decoder_set_globals(self._dec, C.byref(gw)))
+        # device-side token history: history[p] = greedy token chosen for position p (written by the tail kernel)
+        self.history = torch.zeros(1 << 20, dtype=torch.int32, device=device)
+        _ffi.check(lib.pie_decoder_bind_outputs(self._dec, _ffi.p(self.logits), _ffi.p(self.logprobs), _ffi.p(self.token), _ffi.p(self.hidden),
+                                                _ffi.p(self.history), self.history.numel()))
+        self._kv_key = None      # (pointers, capacity) currently in the decoder's device table
+        self._dev_offset = None  # device-side cache offset the decoder believes in
+        torch.cuda.synchronize(device)
+
+    def __del__(self):
+        dec = getattr(self, "_dec", None)
+        if dec is not None and dec.value:
+            try:
+                _ffi.load().pie_decoder_destroy(dec)
+            except Exception:
+                pass
+            self._dec = None
+
+    # ------------------------------------------------------------------ cache plumbing
+    def make_cache(self) -> list[BaseCache]:
+        return [ReusableKVCache() for _ in self.layers]
+
+    def _sync_cache(self, cache: list[ReusableKVCache], n_new: int) -> None:
+        """The host half of cache.update_and_fetch for every layer (reusable.py:113-131), then make the decoder's
+        device-side view (buffer addresses, capacity, offset) match the Python objects."""
+        if len(cache) != len(self.layers):
+            raise ValueError(f"expected {len(self.layers)} layer caches, got {len(cache)}")
+        off = cache[0].offset
+        for c in cache:
+            if not isinstance(c, ReusableKVCache):
+                raise TypeError("the decode path runs on ReusableKVCache (prompt_cache.py:73)")
+            if c.offset != off:
+                raise ValueError("layer caches disagree on offset")
+            c.reserve(n_new, self.n_kv_heads, self.head_dim, self.dtype, self.device)
+        cap = min(c.capacity for c in cache)
+        key = (tuple(c.keys.data_ptr() for c in cache), tuple(c.values.data_ptr() for c in cache), cap)
+        lib = _ffi.load()
+        if key != self._kv_key:
+            n = len(cache)
+            kp = (C.c_void_p * n)(*key[0])
+            vp = (C.c_void_p * n)(*key[1])
+            _ffi.check(lib.pie_decoder_set_kv(self._dec, kp, vp, cap, _ffi.stream()))
+            self._kv_key = key
+        if self._dev_offset != off:
+            _ffi.check(lib.pie_decoder_set_state(self._dec, off, -1, _ffi.stream()))
+            self._dev_offset = off
+
+    def _advance(self, cache, n: int) -> None:
+        for c in cache:
+            c.advance(n)  # reusable.py:139
+        self._dev_offset += n
+
+    # ------------------------------------------------------------------ reference calling convention
+    def __call__(self, inputs: torch.Tensor, mask=None, cache: list[BaseCache] | None = None) -> torch.Tensor:
+        """Model.__call__ (language.py:199-210): inputs [1, L] -> logits [1, L, V] in the activation dtype,
+        lm_head on every position like the reference (the engine's fast path is `step`)."""
+        if mask is not None:
+            raise NotImplementedError("explicit masks are not supported: the causal mask of models/base.py:37-53 is implicit")
+        if inputs.dim() != 2 or inputs.shape[0] != 1:
+            raise ValueError("batch-1 path: inputs must be [1, L]")
+        if cache is None:
+            cache = self.make_cache()  # reference: cache=None means no caching; a throw-away cache is equivalent
+        ids = inputs.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+        L = ids.numel()
+        self._sync_cache(cache, L)
+        out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
+        _ffi.check(_ffi.load().pie_decoder_prefill(self._dec, _ffi.p(ids), L, _ffi.p(out), _ffi.stream()))
+        self._advance(cache, L)
+        return out.unsqueeze(0)
+
+    def step(self, ids: torch.Tensor | None, cache: list[BaseCache], graph: bool = True):
+        """Fast path of _inference (engine/inference_engine.py:252-271) for the greedy sampler without logits
+        processors: forwards `ids` [L] (device int32) and returns (token[1], logprobs[V], logits[V]).
+        `ids=None` feeds back the previous step's greedy token, which already sits in the decoder's device-side
+        state (no copy, no host sync).  L == 1 replays the captured hipGraph.
+        token is a view of the device-side history at the new position (stable); logprobs / logits are the
+        decoder's output buffers, valid until the next call."""
+        lib = _ffi.load()
+        if ids is None:
+            L = 1
+            self._sync_cache(cache, L)
+        else:
+            ids = ids.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+            L = ids.numel()
+            self._sync_cache(cache, L)
+            if L == 1:
+                _ffi.check(lib.pie_decoder_set_token_from(self._dec, _ffi.p(ids), _ffi.stream()))
+        if L == 1:
+            flags = _ffi.PIE_STEP_LOGITS | (_ffi.PIE_STEP_GRAPH if graph else 0)
+            _ffi.check(lib.pie_decoder_step(self._dec, flags, _ffi.stream()))
+        else:
+            _ffi.check(lib.pie_decoder_prefill(self._dec, _ffi.p(ids), L, None, _ffi.stream()))
+        self._advance(cache, L)
+        pos = self._dev_offset  # position the chosen token will occupy
+        token = self.history[pos:pos + 1] if pos < self.history.numel() else self.token.clone()
+        return token, self.logprobs, self.logits
+
+    def step_bytes(self, T: int, with_logits: bool = True) -> int:
+        """Algorithmic HBM bytes of one decode step at context length T."""
+        return int(_ffi.load().pie_decoder_step_bytes(self._dec, int(T), int(with_logits)))
+
+    def launch_kernel(self, name: str, layer: int = 0) -> None:
+        """Enqueues ONE launch of the step's sequence (for per-kernel timing); needs a prior step() for valid state."""
+        _ffi.check(_ffi.load().pie_decoder_launch_kernel(self._dec, _ffi.KERNELS[name], int(layer), _ffi.stream()))
+
+    def kernel_bytes(self, name: str, T: int) -> int:
+        return int(_ffi.load().pie_decoder_kernel_bytes(self._dec, _ffi.KERNELS[name], int(T)))
+
+    def weight_bytes(self) -> int:
+        return sum(b.nbytes() for b in self.layers) + self.lm_head.nbytes

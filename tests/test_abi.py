@@ -1,0 +1,51 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads without a GPU and exports every symbol
+include/pie_hip.h declares (no compute calls here)."""
+import ctypes
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "pie_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pie_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from proxy_inference_engine_amd import _ffi, build
+    lib_path = build.build()
+    assert lib_path.exists()
+    lib = ctypes.CDLL(str(lib_path))
+    syms = declared_symbols()
+    assert len(syms) >= 25 and "pie_qgemv_w4g64" in syms and "pie_decoder_step" in syms
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/pie_hip.h but not exported: {missing}"
+    assert sorted(_ffi.EXPORTS) == syms, "the ctypes binding and the header list different entry points"
+
+
+def test_hello_and_size_helpers_without_gpu():
+    from proxy_inference_engine_amd import _ffi
+    import proxy_inference_engine
+    assert proxy_inference_engine.pie_core.hello() == "pie_core ✓"      # tests/python/test_basic.py:16 of the reference
+    lib = _ffi.load()
+    assert lib.pie_version().startswith(b"pie_hip")
+    assert lib.pie_w4s_bytes(4096, 4096) == 2048 * 2 * 2304                # pairs x slices x unit
+    assert lib.pie_w4s_bytes(4096, 14336) == 2048 * 7 * 2304
+    assert lib.pie_w4s_bytes(3, 4096) == 0 and lib.pie_w4s_bytes(4, 100) == 0
+    n = (4 + 2 * 2) * 64
+    arr = (ctypes.c_int32 * n)()
+    assert lib.pie_qkv_row_map(4, 2, 64, arr) == 0
+    m = list(arr)
+    assert sorted(m) == list(range(n)) and m[:4] == [0, 32, 1, 33] and m[-1] == n - 1
+    assert lib.pie_qkv_row_map(4, 2, 63, arr) != 0 and b"pie_qkv_row_map" in lib.pie_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for f in (ROOT / "proxy_inference_engine_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".hpp", ".cpp", ".h") and "oracle" in f.read_text(errors="ignore").replace("the oracle", ""):
+            if re.search(r"(import|from|include|CDLL).*oracle", f.read_text(errors="ignore")):
+                bad.append(str(f))
+    assert not bad, bad

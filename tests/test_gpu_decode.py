@@ -1,0 +1,182 @@
+"""-m gpu: the fused decode step / engine loop (HIP, through the C ABI) against the CPU oracle.
+
+Parity bar: greedy token ids identical to the oracle on every teacher-forced step whose oracle
+top-1/top-2 margin exceeds the 16-bit error bound; logits / logprobs / hidden states within
+4 eps_T * max|ref| (max) and 1 eps_T * rms(ref) (rms), eps = 2^-8 (bf16) / 2^-11 (f16): tests/_util.py
+assert_vec_close.  (BASELINE.md's absolute 2e-2 presumed O(1) logits; one bf16 ulp of a logit of 20 is 0.125.)
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pie_oracle as po
+from tests._util import EPS, assert_vec_close, codes_dev, to_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+DT = "bfloat16"
+
+
+def margin_bound(logits, dtype=DT):
+    """A greedy id is only required to match when the oracle's top-1/top-2 gap exceeds twice the logits bound."""
+    return 2 * 4.0 * EPS[dtype] * float(np.abs(logits).max())
+
+
+def device_weights(w: dict, dtype: str) -> dict:
+    out = {}
+    for k, v in w.items():
+        out[k] = codes_dev(v) if v.dtype == np.uint32 else to_dev(v, dtype)
+    return out
+
+
+def build(cfg, w, dtype=DT, **kw):
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    return Model(ModelArgs(**cfg), device_weights(w, dtype), **kw)
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    g = np.load(golden_dir / "tiny_llama_w4_bf16.npz")
+    cfg = json.loads(str(g["config_json"]))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    return g, cfg, w, build(cfg, w)
+
+
+def test_model_call_matches_golden_prefill(tiny):
+    g, cfg, w, model = tiny
+    cache = model.make_cache()
+    ids = torch.from_numpy(g["prompt"].astype(np.int64))[None].cuda()
+    logits = model(ids, cache=cache)                                   # [1, L, V], lm_head on every position
+    assert logits.shape == (1, len(g["prompt"]), cfg["vocab_size"]) and cache[0].offset == len(g["prompt"])
+    assert_vec_close(logits[0, -1].float().cpu().numpy(), po.from_bits(g["prefill_last_logits"], DT), DT, what="prefill logits")
+    assert_vec_close(model.hidden.float().cpu().numpy(), po.from_bits(g["prefill_hidden_last"], DT), DT, what="prefill hidden")
+    # every position against the oracle (which also computes lm_head on all L positions)
+    want = po.OracleLlama(cfg, w, DT).forward(g["prompt"], [po.OracleKVCache() for _ in range(cfg["num_hidden_layers"])])
+    for l in range(len(g["prompt"])):
+        assert_vec_close(logits[0, l].float().cpu().numpy(), want[l], DT, what=f"position {l}")
+    assert cache[0].keys.shape == (1, cfg["num_key_value_heads"], 256, 64)   # step-256 capacity (reusable.py:154)
+
+
+def test_engine_generate_step_matches_golden_tokens(tiny):
+    from proxy_inference_engine_amd import InferenceEngine
+    g, cfg, w, model = tiny
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(g["prompt"], temp=0)
+    gen = eng.generate_step(torch.from_numpy(g["prompt"]))
+    n = len(g["tokens"])
+    mb = margin_bound(po.from_bits(g["prefill_last_logits"], DT))
+    safe = int(np.argmax(g["margins"] < mb)) if (g["margins"] < mb).any() else n   # free-running prefix that must match
+    for i in range(n):
+        tok, lp = next(gen)
+        lp = lp.cpu().numpy()
+        if i < safe:
+            assert int(tok.item()) == int(g["tokens"][i]), f"step {i}"
+            assert_vec_close(lp, g["logprobs"][i], DT, what=f"logprobs step {i}")
+        assert abs(np.exp(lp.astype(np.float64)).sum() - 1.0) < 1e-4
+    assert safe >= 1
+    assert eng.prompt_cache.cache[0].offset == len(g["prompt"]) + n - 1
+    # second request with the same prompt: longest-common-prefix reuse re-processes exactly one token
+    eng2_first = next(eng.generate_step(torch.from_numpy(g["prompt"])))[0]
+    assert int(eng2_first.item()) == int(g["tokens"][0])
+    assert eng.prompt_cache.cache[0].offset == len(g["prompt"])
+
+
+def test_teacher_forced_steps_and_graph_replay_identical(tiny):
+    g, cfg, w, model = tiny
+    orc = po.OracleLlama(cfg, w, DT)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    orc.forward(g["prompt"], ocache)
+    results = {}
+    for graph in (False, True):
+        cache = model.make_cache()
+        model.step(torch.from_numpy(g["prompt"]).cuda(), cache)
+        out = []
+        for i, t in enumerate(g["tokens"][:-1]):
+            tok, lp, logits = model.step(torch.tensor([int(t)], dtype=torch.int32, device="cuda"), cache, graph=graph)
+            out.append((int(tok.item()), to_bits(logits).copy(), lp.cpu().numpy().copy()))
+        results[graph] = out
+    for (ta, la, _), (tb, lb, _) in zip(results[False], results[True]):
+        assert ta == tb and np.array_equal(la, lb)                     # graph replay == eager launches, bit for bit
+    checked = 0
+    for i, t in enumerate(g["tokens"][:-1]):                           # teacher-forced against the oracle
+        want = orc.forward(np.array([t]), ocache)[0]
+        otok, olp = po.logprobs_argmax(want)
+        tok, lbits, lp = results[True][i]
+        assert_vec_close(po.from_bits(lbits, DT), want, DT, what=f"logits step {i}")
+        assert_vec_close(lp, olp, DT, what=f"logprobs step {i}")
+        top2 = np.sort(olp)[-2:]
+        if top2[1] - top2[0] > margin_bound(want):
+            assert tok == otok, f"step {i}"
+            checked += 1
+    assert checked >= 3
+
+
+def test_cache_growth_across_step_boundary(tiny):
+    """Decode across the 256-position capacity boundary: the cache re-allocates (256 -> 512) and the decoder must
+    pick up the new buffers; compare logits right before / after the growth with the oracle."""
+    g, cfg, w, model = tiny
+    rng = np.random.default_rng(21)
+    prompt = rng.integers(0, cfg["vocab_size"], 250)
+    forced = rng.integers(0, cfg["vocab_size"], 12)
+    orc = po.OracleLlama(cfg, w, DT)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    orc.forward(prompt, ocache)
+    cache = model.make_cache()
+    model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert cache[0].capacity == 256
+    for i, t in enumerate(forced):
+        want = orc.forward(np.array([t]), ocache)[0]
+        _, _, logits = model.step(torch.tensor([int(t)], dtype=torch.int32, device="cuda"), cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, DT, what=f"step {i} offset {cache[0].offset}")
+    assert cache[0].capacity == 512 and cache[0].offset == 262 and ocache[0].keys.shape[2] == 512
+    assert float(cache[0].keys[0, :, 262:].abs().max()) == 0.0        # untouched tail stays zero-initialised
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_llama8b_shaped_layers_vs_oracle(dtype):
+    """Real kernel geometry (H=4096, I=14336, 32/8 heads, D=128: K slices 2 and 7), 2 layers, V=8192."""
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=1, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(2).integers(0, cfg["vocab_size"], 6)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache)[-1]
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="prefill")
+    for _ in range(3):
+        t = int(tok.item())
+        want = orc.forward(np.array([t]), ocache)[0]
+        otok, olp = po.logprobs_argmax(want)
+        tok, lp, logits = model.step(tok, cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode")
+        top2 = np.sort(olp)[-2:]
+        if top2[1] - top2[0] > margin_bound(want, dtype):
+            assert int(tok.item()) == otok
+    assert model.step_bytes(128) == sum(
+        (n * k // 2 + 2 * (n * k // 64) * 2) for n, k in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]) * 2 \
+        + 2 * (2 * 4096 * 2 + 2 * 1024 * 2 * 128 + 2 * 1024 * 2) + (8192 * 4096 // 2 + 2 * (8192 * 4096 // 64) * 2) + 4096 * 2 + 8192 * 4
+
+
+def test_tied_embeddings_and_errors(tiny):
+    g, cfg, w, _ = tiny
+    cfg2 = dict(cfg, tie_word_embeddings=True)
+    w2 = {k: v for k, v in w.items() if not k.startswith("lm_head")}
+    model = build(cfg2, w2)
+    orc = po.OracleLlama(cfg2, w2, DT)
+    ids = g["prompt"][:9]
+    want = orc.forward(ids, [po.OracleKVCache() for _ in orc.layers])[-1]
+    _, _, logits = model.step(torch.from_numpy(ids).cuda(), model.make_cache())
+    assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
+    with pytest.raises(ValueError):
+        build(dict(cfg, quantization=None), w)                          # dense checkpoints are not on this path
+    with pytest.raises(NotImplementedError):
+        from proxy_inference_engine_amd.samplers import make_sampler
+        make_sampler(temp=1.0)
+    with pytest.raises(ValueError):
+        model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])

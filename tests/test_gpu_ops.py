@@ -1,0 +1,178 @@
+"""-m gpu: each HIP op behind the C ABI against the CPU oracle and the committed golden vectors.
+
+Integer work (codes, packing, argmax index) must be bit-exact; 16-bit float outputs must be within 1 ulp of the
+oracle on at most 2 % of elements (fp32 accumulation order differs), fp32 logprobs within 1e-4 absolute."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pie_oracle as po
+from tests._util import assert_bits_close, codes_dev, to_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+DT = "bfloat16"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from proxy_inference_engine_amd import _ffi, hip_ops
+    _ffi.require_gpu()
+    assert _ffi.hello() == "pie_core ✓"
+    return hip_ops
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(golden_dir / "ops_bf16.npz")
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_quantize_bit_exact_and_dequantize(ops, dt):
+    rng = np.random.default_rng(5)
+    w = po.round_T(rng.standard_normal((96, 512)) * 0.02, dt)
+    w[3, :64] = 0.0                       # degenerate group: scale = eps path
+    w[4, :64] = 0.25                      # constant group
+    wq, s, b = po.quantize(w, 64, 4, dt)
+    codes, scales, biases = ops.quantize(to_dev(po.to_bits(w, dt), dt))
+    assert np.array_equal(codes.cpu().numpy().view(np.uint32), wq)
+    assert np.array_equal(to_bits(scales), s) and np.array_equal(to_bits(biases), b)
+    deq = ops.dequantize(codes, scales, biases)
+    assert np.array_equal(to_bits(deq), po.to_bits(po.dequantize(wq, s, b, 64, 4, dt), dt))
+
+
+@pytest.mark.parametrize("tag", ["gemv4096", "gemv14336"])
+def test_qgemv_golden(ops, gold, tag):
+    w = ops.repack_w4s(codes_dev(gold[f"{tag}_wq"]), to_dev(gold[f"{tag}_scales"], DT), to_dev(gold[f"{tag}_biases"], DT))
+    y = ops.quantized_matmul(to_dev(gold[f"{tag}_x"], DT), w)
+    assert_bits_close(to_bits(y), gold[f"{tag}_y"], what=tag)
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K,M", [(64, 64, 1), (6, 192, 2), (130, 2048, 1), (34, 2112, 3), (256, 5632, 1), (32, 8192, 1), (18, 28672, 1)])
+def test_qgemv_shapes_vs_oracle(ops, dt, N, K, M):
+    """Ragged shapes: K not a multiple of the 2048 slice, odd pair counts, several rows of x, a linear bias."""
+    rng = np.random.default_rng(N * 7 + K)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.03, dt)
+    wq, s, b = po.quantize(w, 64, 4, dt)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    lb = po.to_bits(rng.standard_normal(N) * 0.1, dt) if N % 4 == 0 else None
+    want = po.quantized_matmul(x, wq, s, b, dtype=dt, lin_bias=lb)
+    wt = ops.repack_w4s(codes_dev(wq), to_dev(s, dt), to_dev(b, dt), lin_bias=None if lb is None else to_dev(lb, dt))
+    got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt)
+    assert got.shape == (M, N)
+    assert_bits_close(to_bits(got), po.to_bits(want, dt), what=f"qgemv {N}x{K} M={M} {dt}")
+
+
+def test_qgemv_row_map_and_linearity(ops):
+    """row_map reorders rows; y(x1 + x2) == y(x1) + y(x2) up to rounding (size-independent property)."""
+    rng = np.random.default_rng(9)
+    N, K = 128, 4096
+    w = po.round_T(rng.standard_normal((N, K)) * 0.02, DT)
+    wq, s, b = po.quantize(w, 64, 4, DT)
+    perm = rng.permutation(N).astype(np.int32)
+    wt = ops.repack_w4s(codes_dev(wq), to_dev(s, DT), to_dev(b, DT), row_map=torch.from_numpy(perm))
+    x = po.round_T(rng.standard_normal((1, K)), DT)
+    got = ops.quantized_matmul(to_dev(po.to_bits(x, DT), DT), wt)
+    want = po.quantized_matmul(x, wq, s, b, dtype=DT)[:, perm]
+    assert_bits_close(to_bits(got), po.to_bits(want, DT), what="row_map")
+    x2 = po.round_T(rng.standard_normal((1, K)), DT)
+    xs = po.round_T(x + x2, DT)
+    ya, yb, ys = (ops.quantized_matmul(to_dev(po.to_bits(v, DT), DT), wt).float().cpu().numpy() for v in (x, x2, xs))
+    wd = po.dequantize(wq, s, b, 64, 4, "float32" if False else DT).astype(np.float64)[perm]   # T-rounded affine weights
+    resid = (xs.astype(np.float64) - x - x2) @ wd.T                                              # rounding of x1+x2 to T
+    assert np.max(np.abs(ys - ya - yb - resid)) <= 4 * 2.0 ** -8 * np.abs(ys).max()
+
+
+def test_embedding_exact(ops):
+    rng = np.random.default_rng(2)
+    w = po.round_T(rng.standard_normal((100, 256)) * 0.02, DT)
+    wq, s, b = po.quantize(w, 64, 4, DT)
+    ids = np.array([0, 99, 17, 17], np.int32)
+    got = ops.embedding(torch.from_numpy(ids).cuda(), codes_dev(wq), to_dev(s, DT), to_dev(b, DT))
+    assert np.array_equal(to_bits(got), po.to_bits(po.dequantize(wq, s, b, 64, 4, DT)[ids], DT))
+
+
+def test_rms_norm_golden(ops, gold):
+    y = ops.rms_norm(to_dev(gold["rms_x"], DT), to_dev(gold["rms_w"], DT), float(gold["rms_eps"]))
+    assert_bits_close(to_bits(y), gold["rms_y"], what="rms_norm")
+
+
+def test_rope_golden_and_identity(ops, gold):
+    freqs = torch.from_numpy(gold["rope_freqs"]).cuda()
+    x = to_dev(gold["rope_x"], DT)
+    y = ops.rope(x, 128, offset=int(gold["rope_offset"]), freqs=freqs)
+    assert_bits_close(to_bits(y), gold["rope_y"], what="rope")
+    assert np.array_equal(to_bits(ops.rope(x, 128, offset=0, freqs=freqs)), gold["rope_x"])   # position 0 = identity
+    xl = po.round_T(np.random.default_rng(3).standard_normal((4, 5, 64)), DT)                 # L > 1, D = 64
+    f64 = po.llama3_rope_freqs(64, 10000.0)
+    got = ops.rope(to_dev(po.to_bits(xl, DT), DT), 64, offset=250, freqs=torch.from_numpy(f64).cuda())
+    assert_bits_close(to_bits(got), po.to_bits(po.rope(xl, f64, 250, DT), DT), what="rope L>1")
+
+
+def test_sdpa_decode_golden(ops, gold):
+    q = to_dev(gold["sdpa_q"], DT).view(1, 8, 1, 128)
+    k = to_dev(gold["sdpa_k"], DT).view(1, 2, 512, 128)
+    v = to_dev(gold["sdpa_v"], DT).view(1, 2, 512, 128)
+    o = ops.scaled_dot_product_attention(q, k, v, float(gold["sdpa_scale"]), T=int(gold["sdpa_T"]))
+    assert_bits_close(to_bits(o), gold["sdpa_out"], what="sdpa")
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("Hq,Hkv,D,T,cap", [(4, 2, 64, 1, 256), (8, 8, 64, 37, 256), (32, 4, 64, 300, 512), (32, 8, 128, 2500, 2560), (8, 1, 128, 129, 256)])
+def test_sdpa_decode_shapes_vs_oracle(ops, dt, Hq, Hkv, D, T, cap):
+    rng = np.random.default_rng(Hq + T)
+    q = po.round_T(rng.standard_normal((Hq, 1, D)), dt)
+    k = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+    v = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+    k[:, T:] = 1e4                                                   # stale rows past T must not be attended
+    want = po.sdpa(q, k, v, D ** -0.5, None, dt, True, T=T)
+    got = ops.scaled_dot_product_attention(to_dev(po.to_bits(q, dt), dt).view(1, Hq, 1, D), to_dev(po.to_bits(k, dt), dt).view(1, Hkv, cap, D),
+                                           to_dev(po.to_bits(v, dt), dt).view(1, Hkv, cap, D), D ** -0.5, T=T)
+    assert_bits_close(to_bits(got), po.to_bits(want, dt), max_ulp=2 if dt == "bfloat16" else 4, what=f"sdpa {Hq}/{Hkv} D{D} T{T} {dt}")
+
+
+def test_sdpa_online_softmax_rescale_forced(ops):
+    """A late key with a far larger score forces the running-max rescale in every lane group and split."""
+    rng = np.random.default_rng(4)
+    Hq, Hkv, D, T = 8, 2, 128, 777
+    q = po.round_T(rng.standard_normal((Hq, 1, D)), DT)
+    k = po.round_T(rng.standard_normal((Hkv, 1024, D)) * 0.1, DT)
+    v = po.round_T(rng.standard_normal((Hkv, 1024, D)), DT)
+    for pos in (5, 300, 776):
+        k[:, pos] = po.round_T(q[::4, 0] * (3.0 + pos / 100), DT)
+    want = po.sdpa(q, k, v, D ** -0.5, None, DT, True, T=T)
+    got = ops.scaled_dot_product_attention(to_dev(po.to_bits(q, DT), DT).view(1, Hq, 1, D), to_dev(po.to_bits(k, DT), DT).view(1, Hkv, 1024, D),
+                                           to_dev(po.to_bits(v, DT), DT).view(1, Hkv, 1024, D), D ** -0.5, T=T)
+    assert_bits_close(to_bits(got), po.to_bits(want, DT), max_ulp=2, what="sdpa spike")
+
+
+def test_silu_mul_add_golden(ops, gold):
+    a, b = to_dev(gold["act_a"], DT), to_dev(gold["act_b"], DT)
+    assert_bits_close(to_bits(ops.silu_mul(a, b)), gold["act_silu_mul"], max_frac=0.01, what="silu_mul")
+    assert np.array_equal(to_bits(ops.add(a, b)), gold["act_add"])
+    assert np.array_equal(to_bits(ops.add(a[:13 * 8 + 3].clone(), b[:13 * 8 + 3].clone())), gold["act_add"][:107])   # ragged tail
+
+
+def test_logits_tail_golden_and_ties(ops, gold):
+    tok, lp = ops.logprobs_argmax(to_dev(gold["tail_logits"], DT))
+    assert int(tok.item()) == int(gold["tail_token"])
+    # fp32 logsumexp over 128256 terms: the oracle's sequential sum itself carries ~1e-5 relative error
+    assert np.max(np.abs(lp.cpu().numpy() - gold["tail_logprobs"])) <= 1e-4
+    x = np.zeros(5000, np.float32)
+    x[[4000, 777, 4999]] = 3.0                                       # ties: first maximal index wins
+    tok, lp = ops.logprobs_argmax(to_dev(po.to_bits(x, DT), DT))
+    assert int(tok.item()) == 777
+    assert abs(float(torch.exp(lp.double()).sum()) - 1.0) < 1e-5
+
+
+def test_error_conventions(ops):
+    """Bad arguments raise ValueError (PIE_E_ARG/SHAPE/ALIGN), like the reference's sampler/loader checks."""
+    with pytest.raises(ValueError):
+        ops.quantize(torch.zeros((4, 100), dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.quantize(torch.zeros((4, 128), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.rms_norm(torch.zeros((1, 64), dtype=torch.bfloat16), torch.zeros(64, dtype=torch.bfloat16), 1e-5)  # CPU tensor
+    with pytest.raises(NotImplementedError):
+        q = torch.zeros((1, 4, 2, 64), dtype=torch.bfloat16, device="cuda")
+        ops.scaled_dot_product_attention(q, q, q, 0.125)
