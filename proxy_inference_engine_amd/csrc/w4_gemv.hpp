@@ -6,14 +6,17 @@
 //
 // HBM-bound (3.6 FLOP/B at M=1): the design goal is bytes in flight, not math.
 //   * a wave owns one 2048-wide K slice; lane (l & 31) owns one quantisation group of that slice and keeps
-//     its 64 activations in 32 VGPRs for the whole kernel; lanes 0-31 / 32-63 work on the two rows of a pair;
-//   * per unit a lane issues 2 x global_load_dwordx4 (codes) + 1 x global_load_dword ({scale,bias}); all U
-//     units of a wave are issued before anything is consumed (U x 2304 B in flight per wave), straight to
-//     VGPRs (no LDS round trip: a streamed-once operand gains nothing from staging);
-//   * dequant = v_and_or_b32 with the MAGIC|code trick (bf16 0x4300|q == 128+q exactly), 2 codes per op,
-//     multiply-accumulate = v_dot2c_f32_bf16 against the packed activations; the +128 offset and the group
-//     bias fold into one fma with the lane's activation sum:  scale*(d - 128*sx) + bias*sx;
-//   * 32-lane DPP reduction per row, cross-slice reduction through 4 KB of LDS, epilogue on <= 32 threads.
+//     its 64 activations in 32 VGPRs; lanes 0-31 / 32-63 work on the two rows of a pair;
+//   * activations: the workgroup loads x ONCE, coalesced (16 B per thread), BEFORE the weight stream is issued
+//     (vmcnt retires in order: x must not queue behind the weights), applies the fused RMSNorm on 8 elements per
+//     thread, and publishes x through a conflict-free LDS image [8 pieces][groups|1][16 B]; each lane then
+//     pulls its group with 8 x ds_read_b128.  Per-group activation sums travel the same way;
+//   * weights: per unit a lane issues 2 x global_load_dwordx4 (codes) + 1 x global_load_dword ({scale,bias}),
+//     all U units of a wave up front, straight to VGPRs (a streamed-once operand gains nothing from LDS);
+//   * dequant = v_and_or_b32 with the magic-exponent trick, 2 codes per op; multiply-accumulate =
+//     v_dot2c_f32_bf16 against the packed activations; the +128 offset and the group bias fold into one fma
+//     with the group's activation sum:  scale*(d - 128*sx) + bias*sx;
+//   * 32-lane DPP reduction per row, cross-slice reduction through LDS, epilogue on <= 32 threads.
 #pragma once
 #include "common.hpp"
 
@@ -51,6 +54,22 @@ struct GemvArgs {
     LogitStat *stats;     // EPI_LOGITS
 };
 
+// LDS carve-up (dynamic, 16-byte aligned): x image | group sums | cross-slice partials | block reduction scratch
+struct GemvLds {
+    int stride;  // 16-byte slots per piece row: groups | 1 (odd -> conflict-free ds_write_b128 across the 8 pieces)
+    int off_sx, off_part, off_red, total;
+};
+static inline __host__ __device__ GemvLds gemv_lds(int K, int n_slices) {
+    GemvLds l;
+    const int G = K >> 6;
+    l.stride = G | 1;
+    l.off_sx = 8 * l.stride * 16;
+    l.off_part = l.off_sx + ((G * 4 + 15) & ~15);
+    l.off_red = l.off_part + n_slices * 64 * 4;
+    l.total = l.off_red + 32 * 4;
+    return l;
+}
+
 template <class T>
 __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, const u32 (&xr)[32]) {
     float d = 0.0f;
@@ -66,10 +85,15 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
     return d;
 }
 
+template <class T>
+__device__ __forceinline__ float sum8(const uint4 &v) {
+    return ((lo_f32<T>(v.x) + hi_f32<T>(v.x)) + (lo_f32<T>(v.y) + hi_f32<T>(v.y))) +
+           ((lo_f32<T>(v.z) + hi_f32<T>(v.z)) + (lo_f32<T>(v.w) + hi_f32<T>(v.w)));
+}
+
 template <class T, int PRO, int EPI, int U>
 __global__ void __launch_bounds__(1024) k_w4s_gemv(const GemvArgs a) {
-    __shared__ float part[16 * 64];  // [slice][row in tile]
-    __shared__ float red[16];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ns = a.n_slices, RL = a.row_lanes;
@@ -77,8 +101,23 @@ __global__ void __launch_bounds__(1024) k_w4s_gemv(const GemvArgs a) {
     const int P = U * RL;
     const int pair0 = blockIdx.x * P;
     const int m = blockIdx.y;
+    const int NT = blockDim.x;
+    const GemvLds L = gemv_lds(a.K, ns);
+    float *sxs = reinterpret_cast<float *>(smem + L.off_sx);
+    float *part = reinterpret_cast<float *>(smem + L.off_part);
+    float *red = reinterpret_cast<float *>(smem + L.off_red);
 
-    // 1. weight stream first: nothing below depends on it until the dot products.
+    // 1. activations first (<= 4 pieces of 8 elements per thread, coalesced), then the weight stream.
+    const int n_pieces = a.K >> 3;
+    const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)m * a.K);
+    uint4 xv[4], nv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int j = threadIdx.x + i * NT;
+        j = j < n_pieces ? j : n_pieces - 1;
+        xv[i] = xg[j];
+        if (PRO == PRO_RMSNORM) nv[i] = reinterpret_cast<const uint4 *>(a.norm_w)[j];
+    }
     uint4 c0[U], c1[U];
     u32 sb[U];
 #pragma unroll
@@ -91,57 +130,70 @@ __global__ void __launch_bounds__(1024) k_w4s_gemv(const GemvArgs a) {
         sb[u] = *reinterpret_cast<const u32 *>(unit + 2048 + lane * 4);
     }
 
-    // 2. this lane's 64 activations (one quantisation group), L2-resident.
+    // 2. fused mx.fast.rms_norm (nn.RMSNorm, language.py:137-141,168): w * T(x * rsqrt(mean(x^2) + eps)), 8 elements per thread
+    if (PRO == PRO_RMSNORM) {
+        float ssq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (threadIdx.x + i * NT < n_pieces) {
+                const u32 v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = lo_f32<T>(v[k]), hi = hi_f32<T>(v[k]);
+                    ssq = fmaf(lo, lo, ssq);
+                    ssq = fmaf(hi, hi, ssq);
+                }
+            }
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[wave] = ssq;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int i = 0; i < (NT >> 6); ++i) tot += red[i];
+        const float inv = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 v[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, g[4] = {nv[i].x, nv[i].y, nv[i].z, nv[i].w};
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = pack2<T>(round_T<T>(lo_f32<T>(v[k]) * inv) * lo_f32<T>(g[k]), round_T<T>(hi_f32<T>(v[k]) * inv) * hi_f32<T>(g[k]));
+            xv[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    // publish x: piece j = 8*group + r lands at slot (r*stride + group); group sums via 3 xor-shuffles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = threadIdx.x + i * NT;
+        const bool ok = j < n_pieces;
+        float ps = ok ? sum8<T>(xv[i]) : 0.0f;
+        ps += __shfl_xor(ps, 1, 64);
+        ps += __shfl_xor(ps, 2, 64);
+        ps += __shfl_xor(ps, 4, 64);
+        if (ok) {
+            *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = xv[i];
+            if ((j & 7) == 0) sxs[j >> 3] = ps;
+        }
+    }
+    __syncthreads();
+
+    // 3. this lane's group: 64 activations in 32 VGPRs + their sum
     const int n_groups = a.K >> 6;
     const int g = s * 32 + (lane & 31);
     const bool gvalid = g < n_groups;
     const int gc = gvalid ? g : n_groups - 1;
     u32 xr[32];
-    {
-        const uint4 *xp = reinterpret_cast<const uint4 *>(a.x + (size_t)m * a.K + (size_t)gc * 64);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint4 v = xp[i];
-            xr[4 * i + 0] = gvalid ? v.x : 0u;
-            xr[4 * i + 1] = gvalid ? v.y : 0u;
-            xr[4 * i + 2] = gvalid ? v.z : 0u;
-            xr[4 * i + 3] = gvalid ? v.w : 0u;
-        }
+    for (int r = 0; r < 8; ++r) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(smem + ((size_t)r * L.stride + gc) * 16);
+        xr[4 * r + 0] = gvalid ? v.x : 0u;
+        xr[4 * r + 1] = gvalid ? v.y : 0u;
+        xr[4 * r + 2] = gvalid ? v.z : 0u;
+        xr[4 * r + 3] = gvalid ? v.w : 0u;
     }
-    if (PRO == PRO_RMSNORM) {
-        // mx.fast.rms_norm (nn.RMSNorm, language.py:137-141,168): w * T(x * rsqrt(mean(x^2) + eps))
-        float ssq = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            float lo = lo_f32<T>(xr[i]), hi = hi_f32<T>(xr[i]);
-            ssq = fmaf(lo, lo, ssq);
-            ssq = fmaf(hi, hi, ssq);
-        }
-        ssq = wave_sum(lane < 32 ? ssq : 0.0f);
-        if (rl == 0 && lane == 0) red[s] = ssq;
-        __syncthreads();
-        float tot = 0.0f;
-        for (int i = 0; i < ns; ++i) tot += red[i];
-        const float inv = 1.0f / sqrtf(tot / (float)a.K + a.eps);
-        const uint4 *wp = reinterpret_cast<const uint4 *>(a.norm_w + (size_t)gc * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint4 nw = wp[i];
-            const u32 nwv[4] = {nw.x, nw.y, nw.z, nw.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32 xv = xr[4 * i + j];
-                float lo = round_T<T>(lo_f32<T>(xv) * inv) * lo_f32<T>(nwv[j]);
-                float hi = round_T<T>(hi_f32<T>(xv) * inv) * hi_f32<T>(nwv[j]);
-                xr[4 * i + j] = gvalid ? pack2<T>(lo, hi) : 0u;
-            }
-        }
-    }
-    float sx = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) sx += lo_f32<T>(xr[i]) + hi_f32<T>(xr[i]);
+    const float sx = gvalid ? sxs[gc] : 0.0f;
 
-    // 3. dequant + dot, 32-lane reduction, partials to LDS.
+    // 4. dequant + dot, 32-lane reduction, partials to LDS.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const float d = w4s_unit_dot<T>(c0[u], c1[u], xr);
@@ -152,7 +204,7 @@ __global__ void __launch_bounds__(1024) k_w4s_gemv(const GemvArgs a) {
     }
     __syncthreads();
 
-    // 4. cross-slice sum + epilogue: thread t < P owns pair t of the tile (rows 2t, 2t+1).
+    // 5. cross-slice sum + epilogue: thread t < P owns pair t of the tile (rows 2t, 2t+1).
     const int t = threadIdx.x;
     float va = 0.0f, vb = 0.0f;
     const int pair = pair0 + t;

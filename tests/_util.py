@@ -29,11 +29,11 @@ def assert_bits_close(got_bits, want_bits, max_ulp=1, max_frac=0.02, what=""):
 EPS = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}
 
 
-def assert_vec_close(got, want, dtype, c_max=4.0, c_rms=1.0, what=""):
+def assert_vec_close(got, want, dtype, c_max=4.0, c_rms=4.0, what=""):
     """End-to-end tolerance for activations / logits that passed through many 16-bit rounding points.
     Every op boundary rounds to T (eps = 2^-8 bf16, 2^-11 f16) and the HIP kernels accumulate in fp32 in a
     different order than the oracle, so single-ulp landings compound through the layers (measured on MI355X,
-    2 layers: max error 2.5 eps*max|ref|, see scripts/diag_parity.py).  Bound, stated in units of one ulp of the
+    2 layers: max error 2.5 eps*max|ref|, rms error 1.3-2.3 eps*rms(ref), see scripts/diag_parity.py).  Bound, stated in units of one ulp of the
     largest reference element:   max|got-want| <= c_max * eps * max|want|   and   rms(got-want) <= c_rms * eps * rms(want)."""
     got, want = np.asarray(got, np.float64).reshape(-1), np.asarray(want, np.float64).reshape(-1)
     eps = EPS[dtype]

@@ -1,0 +1,125 @@
+// tools/w4s_bench.hip -- kernel-level microbenchmark for the W4S GEMV (developer tool, not part of the product).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/w4s_bench.hip proxy_inference_engine_amd/csrc/w4_gemv.hip \
+//        proxy_inference_engine_amd/csrc/decoder.hip proxy_inference_engine_amd/csrc/ops.hip -o tools/w4s_bench
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../proxy_inference_engine_amd/csrc/w4_gemv.hpp"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+// A. pure streaming of W4S units: what the access pattern alone can do.
+template <int U, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_stream(const char *w, size_t n_units, u32 *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t unit0 = ((size_t)blockIdx.x * WAVES + wave) * U;
+    uint4 c0[U], c1[U];
+    u32 sb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        size_t un = unit0 + u;
+        un = un < n_units ? un : n_units - 1;
+        const char *p = w + un * W4S_UNIT_BYTES;
+        c0[u] = *reinterpret_cast<const uint4 *>(p + lane * 16);
+        c1[u] = *reinterpret_cast<const uint4 *>(p + 1024 + lane * 16);
+        sb[u] = *reinterpret_cast<const u32 *>(p + 2048 + lane * 4);
+    }
+    u32 acc = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= c0[u].x ^ c0[u].y ^ c0[u].z ^ c0[u].w ^ c1[u].x ^ c1[u].y ^ c1[u].z ^ c1[u].w ^ sb[u];
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;
+}
+
+// B. streaming + the dequant/dot math on register-resident x (no prologue, no reduction)
+template <int U, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_stream_dot(const char *w, size_t n_units, const u32 *x, float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t unit0 = ((size_t)blockIdx.x * WAVES + wave) * U;
+    uint4 c0[U], c1[U];
+    u32 sb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        size_t un = unit0 + u;
+        un = un < n_units ? un : n_units - 1;
+        const char *p = w + un * W4S_UNIT_BYTES;
+        c0[u] = *reinterpret_cast<const uint4 *>(p + lane * 16);
+        c1[u] = *reinterpret_cast<const uint4 *>(p + 1024 + lane * 16);
+        sb[u] = *reinterpret_cast<const u32 *>(p + 2048 + lane * 4);
+    }
+    u32 xr[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xr[i] = x[i * 64 + lane];
+    float tot = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float d = w4s_unit_dot<BF16>(c0[u], c1[u], xr);
+        tot += lo_f32<BF16>(sb[u]) * d + hi_f32<BF16>(sb[u]);
+    }
+    if (tot == 1.2345f) out[blockIdx.x] = tot;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+    void start() { CK(hipEventRecord(a, 0)); }
+    float stop() { CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
+};
+
+int main(int argc, char **argv) {
+    const size_t W_BYTES = (size_t)1536 << 20;  // 1.5 GiB of weights: cycling through it defeats the 256 MiB Infinity Cache
+    char *w; u32 *x; float *outf; u16 *y; u16 *xin, *normw, *resid;
+    CK(hipMalloc(&w, W_BYTES));
+    CK(hipMalloc(&x, 64 * 64 * 4)); CK(hipMalloc(&outf, 1 << 20)); CK(hipMalloc(&y, 1 << 20));
+    CK(hipMalloc(&xin, 65536)); CK(hipMalloc(&normw, 65536)); CK(hipMalloc(&resid, 65536));
+    {   // random fill (host side, small pattern repeated)
+        std::vector<u32> h(1 << 20);
+        for (auto &v : h) v = (u32)rand() * 2654435761u;
+        for (size_t off = 0; off < W_BYTES; off += h.size() * 4) CK(hipMemcpy(w + off, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        std::vector<u16> hx(32768, 0x3f80);
+        CK(hipMemcpy(x, hx.data(), 64 * 64 * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(xin, hx.data(), 65536, hipMemcpyHostToDevice));
+        CK(hipMemcpy(normw, hx.data(), 65536, hipMemcpyHostToDevice));
+        CK(hipMemset(resid, 0, 65536));
+    }
+    Timer t;
+    auto report = [&](const char *name, size_t bytes_per_launch, int launches, float ms) {
+        printf("%-44s %8.2f us/launch  %8.1f GB/s\n", name, 1e3 * ms / launches, bytes_per_launch * (double)launches / (ms * 1e-3) / 1e9);
+    };
+    // gate/up sized problem: 14336 pairs x 2 slices = 28672 units = 66 MB
+    const size_t units = 28672, bytes = units * W4S_UNIT_BYTES;
+    const int slots = (int)(W_BYTES / bytes), reps = 60;
+#define RUN_STREAM(U, WAVES)                                                                                         \
+    {                                                                                                                \
+        int grid = (int)((units + (size_t)U * WAVES - 1) / ((size_t)U * WAVES));                                     \
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_stream<U, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, w + (size_t)(i % slots) * bytes, units, (u32 *)outf); \
+        CK(hipDeviceSynchronize()); t.start();                                                                       \
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_stream<U, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, w + (size_t)(i % slots) * bytes, units, (u32 *)outf); \
+        char nm[64]; snprintf(nm, 64, "stream        U=%d waves/WG=%d grid=%d", U, WAVES, grid); report(nm, bytes, reps, t.stop());         \
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_stream_dot<U, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, w + (size_t)(i % slots) * bytes, units, x, outf); \
+        CK(hipDeviceSynchronize()); t.start();                                                                       \
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_stream_dot<U, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, w + (size_t)(i % slots) * bytes, units, x, outf); \
+        snprintf(nm, 64, "stream+dot    U=%d waves/WG=%d grid=%d", U, WAVES, grid); report(nm, bytes, reps, t.stop());              \
+    }
+    RUN_STREAM(1, 4) RUN_STREAM(2, 4) RUN_STREAM(4, 4) RUN_STREAM(8, 4) RUN_STREAM(4, 8) RUN_STREAM(2, 8) RUN_STREAM(8, 8) RUN_STREAM(4, 16) RUN_STREAM(16, 4)
+
+    // product kernel variants through the launcher
+    struct Case { const char *name; int pro, epi, N, K; };
+    Case cases[] = {{"gemv store      N=28672 K=4096", PRO_NONE, EPI_STORE, 28672, 4096}, {"gemv rms+swiglu N=28672 K=4096", PRO_RMSNORM, EPI_SWIGLU, 28672, 4096},
+                    {"gemv residual   N=4096  K=14336", PRO_NONE, EPI_RESIDUAL, 4096, 14336}, {"gemv residual   N=4096  K=4096", PRO_NONE, EPI_RESIDUAL, 4096, 4096},
+                    {"gemv store      N=6144  K=4096", PRO_NONE, EPI_STORE, 6144, 4096}, {"gemv store      N=128256 K=4096", PRO_NONE, EPI_STORE, 128256, 4096}};
+    for (auto &c : cases) {
+        size_t b = (size_t)(c.N / 2) * w4s_slices(c.K) * W4S_UNIT_BYTES;
+        int sl = (int)(W_BYTES / b);
+        auto launch = [&](int i) {
+            GemvArgs a = {};
+            a.w = w + (size_t)(i % sl) * b, a.K = c.K, a.N = c.N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
+            if (w4s_gemv_launch(PIE_BF16, c.pro, c.epi, a, 1, 0)) { printf("launch failed: %s\n", pie_last_error()); exit(1); }
+        };
+        for (int i = 0; i < 3; ++i) launch(i);
+        CK(hipDeviceSynchronize()); t.start();
+        for (int i = 0; i < reps; ++i) launch(i);
+        report(c.name, b, reps, t.stop());
+    }
+    return 0;
+}
