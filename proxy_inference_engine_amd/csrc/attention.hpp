@@ -2,16 +2,39 @@
 //
 // Replaces mx.fast.scaled_dot_product_attention(q, k, v, scale, mask=None) at models/base.py:111-113
 // (<- models/llama/language.py:98-105) for the decode step.  HBM-bound KV read; K/V rows go straight to
-// VGPRs in 16-byte pieces (a wave-load covers 64/LPT whole rows, coalesced), every q-head of the GQA
-// group is scored against the same loaded K/V so the cache is read once; online softmax in fp32 per
-// lane-group, merged through LDS; one partial (m, l, acc[D]) per (q-head, split), merged by
-// k_attn_combine (fp32 until the single rounding at the end = MLX fused-kernel contract).
+// VGPRs in 16-byte pieces (a wave-load covers 64/LPT whole rows, coalesced) through a register ring that keeps
+// ATTN_DEPTH row-blocks in flight per wave; every q-head of the GQA group is scored against the same loaded K/V
+// so the cache is read once; online softmax in fp32 per lane-group, merged in-wave by shuffles and across the
+// 4 waves through LDS; one partial (m, l, acc[D]) per (q-head, split).  The partials are merged either by
+// k_attn_combine (op-level API) or by the o_proj GEMV's staging prologue (decoder), fp32 until the single
+// rounding at the end = MLX fused-kernel contract.
 #pragma once
 #include "common.hpp"
-#include "w4_gemv.hpp"  // DecState
 
-constexpr int ATTN_MAX_SPLITS = 64;
+constexpr int ATTN_MAX_SPLITS = 16;
+constexpr int ATTN_DEPTH = 4;
 constexpr float ATTN_NEG = -3.0e38f;
+
+// Device-resident decode state: lets one captured graph serve every step.
+struct DecState {
+    int pos;    // cache.offset before the step (reusable.py:111)
+    int token;  // input token of the step / greedy output after it
+    int cap;    // capacity of the per-layer KV buffers (tokens)
+    int pad;
+};
+
+// How T cached positions are cut into splits: fixed launch geometry (graph-replayable), data-dependent activity.
+struct AttnSplit {
+    int chunk, active;
+};
+static inline __host__ __device__ AttnSplit attn_split(int T, int splits) {
+    AttnSplit s;
+    int chunk = (T + splits - 1) / splits;
+    chunk = chunk < 32 ? 32 : chunk;  // never less than two row-blocks per wave: short contexts use fewer splits
+    s.chunk = chunk;
+    s.active = (T + chunk - 1) / chunk;
+    return s;
+}
 
 struct AttnArgs {
     const u16 *q;         // [Hq, D]
@@ -32,6 +55,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
     constexpr int TPW = 64 / LPT;  // token rows per wave-load
     constexpr int NSUB = 4;        // one merged online-softmax stream per wave reaches LDS
+    constexpr int DA = ATTN_DEPTH;
     __shared__ float s_m[REP][NSUB], s_l[REP][NSUB];
     __shared__ float s_acc[REP][NSUB][D];
 
@@ -40,14 +64,28 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
     const int ts = lane / LPT, dc = lane % LPT;
     const int Ttot = a.state ? a.state->pos + 1 : a.T;
     const int cap = a.state ? a.state->cap : a.cap;
-    const int chunk = (Ttot + a.splits - 1) / a.splits;
-    const int t_begin = split * chunk;
-    const int t_end = min(Ttot, t_begin + chunk);
+    const AttnSplit sp = attn_split(Ttot, a.splits);
+    if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
+    const int t_begin = split * sp.chunk;
+    const int t_end = min(Ttot, t_begin + sp.chunk);
 
     const u16 *kbase = a.k ? a.k : reinterpret_cast<const u16 *>(a.kv_table[a.layer]);
     const u16 *vbase = a.k ? a.v : reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]);
     kbase += (size_t)g * cap * D + dc * 8;
     vbase += (size_t)g * cap * D + dc * 8;
+
+    // row-blocks of this wave: block b covers tokens t_begin + (4*b + wave)*TPW + [0, TPW)
+    const int first = t_begin + wave * TPW;
+    const int n_blk = first < t_end ? (t_end - first + 4 * TPW - 1) / (4 * TPW) : 0;
+    uint4 kq[DA], vq[DA];
+    auto issue = [&](int d, int b) {
+        int t = first + b * 4 * TPW + ts;
+        t = t < t_end ? t : t_end - 1;  // clamp, never branch around a load
+        kq[d] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D);
+        vq[d] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D);
+    };
+#pragma unroll
+    for (int d = 0; d < DA; ++d) issue(d, d);
 
     u32 qr[REP][4];
 #pragma unroll
@@ -63,31 +101,34 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         for (int j = 0; j < 8; ++j) acc[h][j] = 0.0f;
     }
 
-    for (int t0 = t_begin + wave * TPW; t0 < t_end; t0 += 4 * TPW) {
-        const int t = t0 + ts;
-        const bool valid = t < t_end;
-        const int tc = valid ? t : t_end - 1;
-        const uint4 kv = *reinterpret_cast<const uint4 *>(kbase + (size_t)tc * D);
-        const uint4 vv = *reinterpret_cast<const uint4 *>(vbase + (size_t)tc * D);
-        const u32 kw[4] = {kv.x, kv.y, kv.z, kv.w};
-        float vf[8];
-        vf[0] = lo_f32<T>(vv.x), vf[1] = hi_f32<T>(vv.x), vf[2] = lo_f32<T>(vv.y), vf[3] = hi_f32<T>(vv.y);
-        vf[4] = lo_f32<T>(vv.z), vf[5] = hi_f32<T>(vv.z), vf[6] = lo_f32<T>(vv.w), vf[7] = hi_f32<T>(vv.w);
+    for (int base = 0; base < n_blk; base += DA) {
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            float sc = 0.0f;
+        for (int d = 0; d < DA; ++d) {
+            const int b = base + d;
+            if (b < n_blk) {  // wave-uniform
+                const bool valid = first + b * 4 * TPW + ts < t_end;
+                const u32 kw[4] = {kq[d].x, kq[d].y, kq[d].z, kq[d].w};
+                float vf[8];
+                vf[0] = lo_f32<T>(vq[d].x), vf[1] = hi_f32<T>(vq[d].x), vf[2] = lo_f32<T>(vq[d].y), vf[3] = hi_f32<T>(vq[d].y);
+                vf[4] = lo_f32<T>(vq[d].z), vf[5] = hi_f32<T>(vq[d].z), vf[6] = lo_f32<T>(vq[d].w), vf[7] = hi_f32<T>(vq[d].w);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc = T::dot2(qr[h][j], kw[j], sc);
+                for (int h = 0; h < REP; ++h) {
+                    float sc = 0.0f;
 #pragma unroll
-            for (int o = LPT / 2; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
-            sc *= a.scale;
-            const float m_new = valid ? fmaxf(m[h], sc) : m[h];
-            const float alpha = expf(m[h] - m_new);
-            const float p = valid ? expf(sc - m_new) : 0.0f;
-            l[h] = l[h] * alpha + p;
+                    for (int j = 0; j < 4; ++j) sc = T::dot2(qr[h][j], kw[j], sc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(acc[h][j], alpha, p * vf[j]);
-            m[h] = m_new;
+                    for (int o = LPT / 2; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+                    sc *= a.scale;
+                    const float m_new = valid ? fmaxf(m[h], sc) : m[h];
+                    const float alpha = expf(m[h] - m_new);
+                    const float p = valid ? expf(sc - m_new) : 0.0f;
+                    l[h] = l[h] * alpha + p;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(acc[h][j], alpha, p * vf[j]);
+                    m[h] = m_new;
+                }
+            }
+            issue(d, b + DA);
         }
     }
 
@@ -105,48 +146,93 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
             m[h] = m_new;
         }
     }
-    const int sub = wave;
     if (ts == 0) {
 #pragma unroll
         for (int h = 0; h < REP; ++h) {
-            if (dc == 0) s_m[h][sub] = m[h], s_l[h][sub] = l[h];
+            if (dc == 0) s_m[h][wave] = m[h], s_l[h][wave] = l[h];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s_acc[h][sub][dc * 8 + j] = acc[h][j];
+            for (int j = 0; j < 8; ++j) s_acc[h][wave][dc * 8 + j] = acc[h][j];
         }
     }
     __syncthreads();
     for (int o = threadIdx.x; o < REP * D; o += 256) {
         const int h = o / D, d = o % D;
         float M = ATTN_NEG;
+#pragma unroll
         for (int i = 0; i < NSUB; ++i) M = fmaxf(M, s_m[h][i]);
-        float L = 0.0f, A = 0.0f;
+        float Lsum = 0.0f, A = 0.0f;
+#pragma unroll
         for (int i = 0; i < NSUB; ++i) {
             const float w = expf(s_m[h][i] - M);
-            L = fmaf(w, s_l[h][i], L);
+            Lsum = fmaf(w, s_l[h][i], Lsum);
             A = fmaf(w, s_acc[h][i][d], A);
         }
         const int hq = g * REP + h;
         a.part_acc[((size_t)hq * a.splits + split) * D + d] = A;
         if (d == 0) {
             a.part_ml[((size_t)hq * a.splits + split) * 2 + 0] = M;
-            a.part_ml[((size_t)hq * a.splits + split) * 2 + 1] = L;
+            a.part_ml[((size_t)hq * a.splits + split) * 2 + 1] = Lsum;
         }
     }
 }
 
-// out[h, d] = T( sum_j w_j acc_j[d] / sum_j w_j l_j ),  w_j = exp(m_j - max m).  Grid Hq, block D.
-template <class T>
-__global__ void k_attn_combine(const AttnArgs a, int D) {
-    const int h = blockIdx.x, d = threadIdx.x;
-    float M = ATTN_NEG;
-    for (int j = 0; j < a.splits; ++j) M = fmaxf(M, a.part_ml[((size_t)h * a.splits + j) * 2]);
-    float L = 0.0f, A = 0.0f;
-    for (int j = 0; j < a.splits; ++j) {
-        const float w = expf(a.part_ml[((size_t)h * a.splits + j) * 2] - M);
-        L = fmaf(w, a.part_ml[((size_t)h * a.splits + j) * 2 + 1], L);
-        A = fmaf(w, a.part_acc[((size_t)h * a.splits + j) * D + d], A);
+// Merge of the active splits for 8 consecutive dims [d0, d0+8) of q-head h (fp32):
+// out[d] = sum_j w_j acc_j[d] / sum_j w_j l_j,  w_j = exp(m_j - max m).  Split in a load half and a math half so a
+// caller can put other loads in flight between them.  Loads are issued for all MAXS slots (clamped to an active
+// one) so they are independent; inactive slots get weight 0.
+template <int MAXS>
+struct AttnMergeRegs {
+    float mj[MAXS], lj[MAXS];
+    float4 a0[MAXS], a1[MAXS];
+};
+template <int MAXS>
+__device__ __forceinline__ void attn_merge_load(const float *part_acc, const float *part_ml, int splits, int active, int h, int D, int d0,
+                                                AttnMergeRegs<MAXS> &r) {
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        const int jc = j < active ? j : active - 1;
+        const float2 ml = *reinterpret_cast<const float2 *>(part_ml + ((size_t)h * splits + jc) * 2);
+        r.mj[j] = ml.x, r.lj[j] = ml.y;
+        const float *pa = part_acc + ((size_t)h * splits + jc) * D + d0;
+        r.a0[j] = *reinterpret_cast<const float4 *>(pa), r.a1[j] = *reinterpret_cast<const float4 *>(pa + 4);
     }
-    a.out[(size_t)h * D + d] = T::from_f32(A / L);
+}
+template <int MAXS>
+__device__ __forceinline__ void attn_merge_finish(const AttnMergeRegs<MAXS> &r, int active, float (&out)[8]) {
+    float M = ATTN_NEG;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) M = fmaxf(M, j < active ? r.mj[j] : ATTN_NEG);
+    float Lsum = 0.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        const float w = j < active ? expf(r.mj[j] - M) : 0.0f;
+        Lsum = fmaf(w, r.lj[j], Lsum);
+        A[0] = fmaf(w, r.a0[j].x, A[0]), A[1] = fmaf(w, r.a0[j].y, A[1]), A[2] = fmaf(w, r.a0[j].z, A[2]), A[3] = fmaf(w, r.a0[j].w, A[3]);
+        A[4] = fmaf(w, r.a1[j].x, A[4]), A[5] = fmaf(w, r.a1[j].y, A[5]), A[6] = fmaf(w, r.a1[j].z, A[6]), A[7] = fmaf(w, r.a1[j].w, A[7]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = A[i] / Lsum;
+}
+template <int MAXS>
+__device__ __forceinline__ void attn_merge8(const float *part_acc, const float *part_ml, int splits, int active, int h, int D, int d0,
+                                            float (&out)[8]) {
+    AttnMergeRegs<MAXS> r;
+    attn_merge_load<MAXS>(part_acc, part_ml, splits, active, h, D, d0, r);
+    attn_merge_finish<MAXS>(r, active, out);
 }
 
-int attn_decode_launch(int dtype, int D, AttnArgs &a, hipStream_t stream);
+// Stand-alone merge (op-level pie_sdpa_decode): grid Hq, block D/8 threads, 8 dims each.
+template <class T>
+__global__ void k_attn_combine(const AttnArgs a, int D) {
+    const int h = blockIdx.x, d0 = threadIdx.x * 8;
+    const int Ttot = a.state ? a.state->pos + 1 : a.T;
+    const int active = attn_split(Ttot, a.splits).active;
+    float o[8];
+    if (a.splits <= 4) attn_merge8<4>(a.part_acc, a.part_ml, a.splits, active, h, D, d0, o);
+    else attn_merge8<16>(a.part_acc, a.part_ml, a.splits, active, h, D, d0, o);  // launcher caps splits at 16
+    *reinterpret_cast<uint4 *>(a.out + (size_t)h * D + d0) =
+        make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+}
+
+// combine = false: leave the partials for the consumer's prologue (decoder: o_proj GEMV, PRO_ATTN).
+int attn_decode_launch(int dtype, int D, AttnArgs &a, bool combine, hipStream_t stream);

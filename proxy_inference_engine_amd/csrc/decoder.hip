@@ -89,12 +89,13 @@ static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_pt
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
-            return attn_decode_launch(c.dtype, D, a, st);
+            return attn_decode_launch(c.dtype, D, a, false, st);  // partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
-            a.w = (const char *)w.wo, a.K = QD, a.N = H, a.x = d->attn, a.resid = d->h;
-            return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
+            a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h;
+            a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
+            return w4s_gemv_launch(c.dtype, PRO_ATTN, EPI_RESIDUAL, a, 1, st);
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
@@ -171,11 +172,9 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     d->cfg = c;
     d->layers.resize(c.n_layers);
     d->layer_set.assign(c.n_layers, 0);
-    d->splits = c.kv_splits > 0 ? (c.kv_splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : c.kv_splits) : 16;
-    int RL, U;
-    int rc = w4s_gemv_geometry(c.vocab, c.hidden, &RL, &U);
-    if (rc) { delete d; return rc; }
-    d->n_stats = (c.vocab / 2 + RL * U - 1) / (RL * U);
+    d->splits = c.kv_splits > 0 ? (c.kv_splits > GEMV_ATTN_SPLITS ? GEMV_ATTN_SPLITS : c.kv_splits) : GEMV_ATTN_SPLITS;
+    int rc = PIE_OK;
+    d->n_stats = w4s_gemv_waves(c.vocab, c.hidden);
     const int QD = c.n_heads * c.head_dim;
 #define PIE_ALLOC(ptr, bytes) if ((rc = dev_alloc((void **)&(ptr), (bytes)))) { pie_decoder_destroy(d); return rc; }
     PIE_ALLOC(d->state, sizeof(DecState));

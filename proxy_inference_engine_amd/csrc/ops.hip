@@ -6,7 +6,7 @@
 
 // ---------------------------------------------------------------- attention launch
 template <class T, int D>
-static int attn_launch_rep(int rep, const AttnArgs &a, hipStream_t st) {
+static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     dim3 grid(a.Hkv, a.splits), block(256);
     switch (rep) {
         case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
@@ -16,19 +16,21 @@ static int attn_launch_rep(int rep, const AttnArgs &a, hipStream_t st) {
         default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be 1, 2, 4 or 8");
     }
     PIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(D), 0, st, a, D);
-    PIE_LAUNCH_CHECK();
+    if (combine) {
+        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(D / 8), 0, st, a, D);
+        PIE_LAUNCH_CHECK();
+    }
     return PIE_OK;
 }
 
-int attn_decode_launch(int dtype, int D, AttnArgs &a, hipStream_t stream) {
+int attn_decode_launch(int dtype, int D, AttnArgs &a, bool combine, hipStream_t stream) {
     PIE_REQUIRE(a.Hkv > 0 && a.Hq % a.Hkv == 0, PIE_E_SHAPE, "sdpa_decode: Hq must be a multiple of Hkv");
     PIE_REQUIRE(a.splits >= 1 && a.splits <= ATTN_MAX_SPLITS, PIE_E_ARG, "sdpa_decode: bad split count");
     const int rep = a.Hq / a.Hkv;
-    if (dtype == PIE_BF16 && D == 128) return attn_launch_rep<BF16, 128>(rep, a, stream);
-    if (dtype == PIE_BF16 && D == 64) return attn_launch_rep<BF16, 64>(rep, a, stream);
-    if (dtype == PIE_F16 && D == 128) return attn_launch_rep<F16, 128>(rep, a, stream);
-    if (dtype == PIE_F16 && D == 64) return attn_launch_rep<F16, 64>(rep, a, stream);
+    if (dtype == PIE_BF16 && D == 128) return attn_launch_rep<BF16, 128>(rep, a, combine, stream);
+    if (dtype == PIE_BF16 && D == 64) return attn_launch_rep<BF16, 64>(rep, a, combine, stream);
+    if (dtype == PIE_F16 && D == 128) return attn_launch_rep<F16, 128>(rep, a, combine, stream);
+    if (dtype == PIE_F16 && D == 64) return attn_launch_rep<F16, 64>(rep, a, combine, stream);
     return pie::fail(PIE_E_SHAPE, "sdpa_decode: head_dim must be 64 or 128 and dtype bf16/f16");
 }
 
@@ -136,11 +138,11 @@ int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv
     AttnArgs a = {};
     a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v;
     a.T = T, a.cap = cap, a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
-    a.splits = T >= 2048 ? ATTN_MAX_SPLITS : (T >= 64 ? 16 : 1);
+    a.splits = T >= 1024 ? ATTN_MAX_SPLITS : (T >= 128 ? 4 : 1);
     a.part_acc = (float *)workspace;
     a.part_ml = a.part_acc + (size_t)Hq * ATTN_MAX_SPLITS * D;
     a.out = (u16 *)out;
-    return attn_decode_launch(dtype, D, a, (hipStream_t)stream);
+    return attn_decode_launch(dtype, D, a, true, (hipStream_t)stream);
 }
 
 int pie_rms_norm(const void *x, const void *w, float eps, int rows, int H, int dtype, void *y, void *stream) {

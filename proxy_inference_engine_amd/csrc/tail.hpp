@@ -46,17 +46,28 @@ __global__ void __launch_bounds__(256) k_logits_stats(const u16 *logits, int V, 
     }
 }
 
+constexpr int TAIL_MAX_STATS = 4096;  // 256 threads x 16 register-resident partials
+
 template <class T>
 __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V, const LogitStat *stats, int n_stats, float *logprobs,
                                                        int *token, DecState *state, int *history, int hist_cap) {
     __shared__ float s_max[4], s_sum[4];
     __shared__ int s_arg[4];
+    // every workgroup merges all partials: 16 independent 16-byte loads per thread, then two register passes
+    LogitStat st[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(stats + (i < n_stats ? i : n_stats - 1));
+        st[k].max = i < n_stats ? __builtin_bit_cast(float, raw.x) : -INFINITY;
+        st[k].sumexp = i < n_stats ? __builtin_bit_cast(float, raw.y) : 0.0f;
+        st[k].argmax = i < n_stats ? (int)raw.z : 0x7fffffff;
+    }
     float mx = -INFINITY;
     int arg = 0x7fffffff;
-    for (int i = threadIdx.x; i < n_stats; i += 256) {
-        const LogitStat st = stats[i];
-        if (st.max > mx || (st.max == mx && st.argmax < arg)) mx = st.max, arg = st.argmax;
-    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (st[k].max > mx || (st[k].max == mx && st[k].argmax < arg)) mx = st[k].max, arg = st[k].argmax;
     const float wmax = wave_max(mx);
     int cand = (mx == wmax) ? arg : 0x7fffffff;
 #pragma unroll
@@ -66,20 +77,29 @@ __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V,
     __syncthreads();
     float M = s_max[0];
     int tok = s_arg[0];
+#pragma unroll
     for (int w = 1; w < 4; ++w)
         if (s_max[w] > M || (s_max[w] == M && s_arg[w] < tok)) M = s_max[w], tok = s_arg[w];
     float se = 0.0f;
-    for (int i = threadIdx.x; i < n_stats; i += 256) {
-        const LogitStat st = stats[i];
-        se += st.sumexp > 0.0f ? st.sumexp * expf(st.max - M) : 0.0f;
-    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) se += st[k].sumexp > 0.0f ? st[k].sumexp * expf(st[k].max - M) : 0.0f;
     se = wave_sum(se);
     if ((threadIdx.x & 63) == 0) s_sum[wave] = se;
     __syncthreads();
-    const float lse = M + logf(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-    const int slice = (V + gridDim.x - 1) / gridDim.x;
+    const float lse = M + logf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+    const int slice = (((V + gridDim.x - 1) / gridDim.x) + 7) & ~7;  // 8 logits per thread and pass
     const int begin = blockIdx.x * slice, end = min(V, begin + slice);
-    for (int i = begin + threadIdx.x; i < end; i += 256) logprobs[i] = T::to_f32(logits[i]) - lse;
+    for (int i = begin + threadIdx.x * 8; i < end; i += 256 * 8) {
+        if (i + 8 <= end && (V & 7) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(logits + i);
+            float4 o0 = make_float4(lo_f32<T>(v.x) - lse, hi_f32<T>(v.x) - lse, lo_f32<T>(v.y) - lse, hi_f32<T>(v.y) - lse);
+            float4 o1 = make_float4(lo_f32<T>(v.z) - lse, hi_f32<T>(v.z) - lse, lo_f32<T>(v.w) - lse, hi_f32<T>(v.w) - lse);
+            *reinterpret_cast<float4 *>(logprobs + i) = o0;
+            *reinterpret_cast<float4 *>(logprobs + i + 4) = o1;
+        } else {
+            for (int k = i; k < min(i + 8, end); ++k) logprobs[k] = T::to_f32(logits[k]) - lse;
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *token = tok;
         if (state) {
@@ -96,6 +116,7 @@ __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V,
 static inline int logits_tail_launch(int dtype, const u16 *logits, int V, const LogitStat *stats, int n_stats, float *logprobs,
                                      int *token, DecState *state, int *history, int hist_cap, hipStream_t st) {
     if (dtype != PIE_BF16 && dtype != PIE_F16) return pie::fail(PIE_E_ARG, "logits tail: dtype must be PIE_BF16 or PIE_F16");
+    if (stats && n_stats > TAIL_MAX_STATS) return pie::fail(PIE_E_SHAPE, "logits tail: too many partials");
     LogitStat *tmp = nullptr;
     if (!stats) {
         if (hipMallocAsync((void **)&tmp, sizeof(LogitStat) * TAIL_STAT_TILES, st) != hipSuccess)

@@ -130,56 +130,52 @@ __global__ void k_repack_w4s(const u32 *codes, const u16 *scales, const u16 *bia
 }
 
 // ---------------------------------------------------------------- launch geometry
-template <class T, int PRO, int EPI>
-static int launch_u(int U, const GemvArgs &a, dim3 grid, dim3 block, hipStream_t st) {
-    const unsigned lds = (unsigned)gemv_lds(a.K, a.n_slices).total;
-    if (lds > 65536u) return pie::fail(PIE_E_SHAPE, "w4s_gemv: activation vector does not fit the 64 KB LDS image");
-    switch (U) {
-        case 4: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 4>), grid, block, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 2>), grid, block, lds, st, a); break;
-        default: hipLaunchKernelGGL((k_w4s_gemv<T, PRO, EPI, 1>), grid, block, lds, st, a); break;
-    }
+template <class T, int NPT>
+static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
+    const dim3 block(GEMV_WAVES * 64);
+    if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT>), grid, block, lds, st, a);
+    else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT>), grid, block, lds, st, a);
+    else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT)>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_SWIGLU, NPT>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_LOGITS) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_LOGITS, NPT>), grid, block, lds, st, a);
+    else return pie::fail(PIE_E_ARG, "w4s_gemv: unsupported prologue/epilogue combination");
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
 
 template <class T>
-static int launch_t(int pro, int epi, int U, const GemvArgs &a, dim3 grid, dim3 block, hipStream_t st) {
-    if (pro == PRO_NONE && epi == EPI_STORE) return launch_u<T, PRO_NONE, EPI_STORE>(U, a, grid, block, st);
-    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return launch_u<T, PRO_NONE, EPI_RESIDUAL>(U, a, grid, block, st);
-    if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) return launch_u<T, PRO_RMSNORM, EPI_ROPE_KV>(U, a, grid, block, st);
-    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return launch_u<T, PRO_RMSNORM, EPI_SWIGLU>(U, a, grid, block, st);
-    if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return launch_u<T, PRO_RMSNORM, EPI_LOGITS>(U, a, grid, block, st);
-    return pie::fail(PIE_E_ARG, "w4s_gemv: unsupported prologue/epilogue combination");
+static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
+    const int npt = ((a.K >> 3) + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);  // activation pieces per staging thread
+    if (npt <= 1) return launch_n<T, 1>(pro, epi, a, grid, lds, st);
+    if (npt <= 2) return launch_n<T, 2>(pro, epi, a, grid, lds, st);
+    if (npt <= 4) return launch_n<T, 4>(pro, epi, a, grid, lds, st);
+    return launch_n<T, 8>(pro, epi, a, grid, lds, st);
 }
 
-int w4s_gemv_geometry(int N, int K, int *row_lanes, int *unroll) {
-    const int ns = w4s_slices(K);
-    if (ns > 16) return pie::fail(PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
-    const int RL = ns >= 5 ? 1 : (ns >= 3 ? 2 : (ns == 2 ? 4 : 8));
+// Persistent grid: one wave per row pair until the chip is full (16 waves per CU), then longer runs per wave.
+int w4s_gemv_waves(int N, int K) {
+    (void)K;
     const int n_pairs = N / 2;
-    // measured (tools/w4s_bench, 66 MB stream + dot): U=2 with 8 waves per workgroup is the fastest shape
-    // (5.4 TB/s vs 4.8 at U=4 and 4.4 at U=1); fall back to U=1 while the grid would not cover the chip twice.
-    int U = 2;
-    while (U > 1 && (n_pairs + U * RL - 1) / (U * RL) < 512) U >>= 1;
-    *row_lanes = RL;
-    *unroll = U;
-    return PIE_OK;
+    int waves = n_pairs < GEMV_MAX_WAVES ? n_pairs : GEMV_MAX_WAVES;
+    const int need = (n_pairs + GEMV_MAX_RUN - 1) / GEMV_MAX_RUN;  // a wave's run must fit its epilogue lanes
+    return waves > need ? waves : need;
 }
 
 int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t stream) {
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
-    int RL, U;
-    int rc = w4s_gemv_geometry(a.N, a.K, &RL, &U);
-    if (rc) return rc;
+    PIE_REQUIRE(w4s_slices(a.K) <= 16, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
+    PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
+                "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
     a.n_slices = w4s_slices(a.K);
-    a.row_lanes = RL;
     a.n_pairs = a.N / 2;
-    const int P = U * RL;
-    dim3 grid((a.n_pairs + P - 1) / P, M), block(64 * a.n_slices * RL);
-    if (dtype == PIE_BF16) return launch_t<BF16>(pro, epi, U, a, grid, block, stream);
-    if (dtype == PIE_F16) return launch_t<F16>(pro, epi, U, a, grid, block, stream);
+    a.n_waves = w4s_gemv_waves(a.N, a.K);
+    const unsigned lds = (unsigned)gemv_lds(a.K).total;
+    PIE_REQUIRE(lds <= 65536u, PIE_E_SHAPE, "w4s_gemv: activation vector does not fit the 64 KB LDS image");
+    dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, M);
+    if (dtype == PIE_BF16) return launch_t<BF16>(pro, epi, a, grid, lds, stream);
+    if (dtype == PIE_F16) return launch_t<F16>(pro, epi, a, grid, lds, stream);
     return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
 }
 
