@@ -101,11 +101,13 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         for (int j = 0; j < 8; ++j) acc[h][j] = 0.0f;
     }
 
+    // One running max per wave and head (shared by the TPW token groups): the groups' partial (l, acc) then merge by
+    // plain sums.  Reductions: DPP inside a 16-lane row, v_permlane{16,32}_swap across rows -- no LDS traffic.
     for (int base = 0; base < n_blk; base += DA) {
 #pragma unroll
         for (int d = 0; d < DA; ++d) {
             const int b = base + d;
-            if (b < n_blk) {  // wave-uniform
+            if (b < n_blk) {  // wave-uniform; every block has at least one valid token (ts == 0)
                 const bool valid = first + b * 4 * TPW + ts < t_end;
                 const u32 kw[4] = {kq[d].x, kq[d].y, kq[d].z, kq[d].w};
                 float vf[8];
@@ -116,10 +118,12 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
                     float sc = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sc = T::dot2(qr[h][j], kw[j], sc);
-#pragma unroll
-                    for (int o = LPT / 2; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
-                    sc *= a.scale;
-                    const float m_new = valid ? fmaxf(m[h], sc) : m[h];
+                    sc = LPT == 16 ? lanes16_sum(sc) : lanes8_sum(sc);
+                    sc = valid ? sc * a.scale : ATTN_NEG;
+                    float bm = sc;  // block max over the wave's token groups
+                    if (LPT == 8) bm = fmaxf(bm, ror8(bm));
+                    bm = xor32_max(xor16_max(bm));
+                    const float m_new = fmaxf(m[h], bm);
                     const float alpha = expf(m[h] - m_new);
                     const float p = valid ? expf(sc - m_new) : 0.0f;
                     l[h] = l[h] * alpha + p;
@@ -132,18 +136,15 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         }
     }
 
-    // merge the TPW lane-groups of the wave (lanes with equal dc) with xor shuffles, then one stream per wave
+    // sum the token groups of the wave (lanes with equal dc), then one stream per wave goes to LDS
 #pragma unroll
-    for (int o = LPT; o < 64; o <<= 1) {
+    for (int h = 0; h < REP; ++h) {
+        if (LPT == 8) l[h] += ror8(l[h]);
+        l[h] = xor32_sum(xor16_sum(l[h]));
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            const float m_o = __shfl_xor(m[h], o, 64), l_o = __shfl_xor(l[h], o, 64);
-            const float m_new = fmaxf(m[h], m_o);
-            const float wa = expf(m[h] - m_new), wb = expf(m_o - m_new);
-            l[h] = l[h] * wa + l_o * wb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * wa + __shfl_xor(acc[h][j], o, 64) * wb;
-            m[h] = m_new;
+        for (int j = 0; j < 8; ++j) {
+            if (LPT == 8) acc[h][j] += ror8(acc[h][j]);
+            acc[h][j] = xor32_sum(xor16_sum(acc[h][j]));
         }
     }
     if (ts == 0) {

@@ -81,6 +81,44 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     v += __builtin_amdgcn_update_dpp(0.0f, v, 0x142, 0xA, 0xF, false); // row_bcast15 into rows 1 and 3
     return v;
 }
+// Cross-row exchanges without LDS (gfx950 v_permlane{16,32}_swap): swapping a value with itself leaves one partner's
+// copy in r[0] and the other's in r[1] in BOTH lanes of a pair, so symmetric combines need no select.
+__device__ __forceinline__ float xor16_sum(float v) {  // v + value of the lane 16 away (row 0<->1, 2<->3)
+    const int vi = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const int vi = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane32_swap(vi, vi, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const int vi = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);
+    return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const int vi = __builtin_bit_cast(int, v);
+    auto r = __builtin_amdgcn_permlane32_swap(vi, vi, false, false);
+    return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+// Sum over each aligned group of 8 / 16 lanes (DPP inside one 16-lane row), result in every lane of the group.
+__device__ __forceinline__ float lanes8_sum(float v) {
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float lanes16_sum(float v) {
+    v = lanes8_sum(v);
+    v += __builtin_amdgcn_update_dpp(0.0f, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float ror8(float v) {  // value of the lane 8 away inside the 16-lane row
+    return __builtin_amdgcn_update_dpp(0.0f, v, 0x128, 0xF, 0xF, true);
+}
+
 // Full-wave sum / max, broadcast to every lane.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
