@@ -51,7 +51,7 @@ def cpu_baseline(cfg, weights_host, n_tokens):
     """Oracle decode tokens/s on the host cores: 4-token prompt (last_only lm_head), then `n_tokens` timed steps."""
     from oracle import pie_oracle as po
 
-    threads = len(os.sched_getaffinity(0))
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("PIE_CPU_THREADS", "16")))  # the 1-GPU box's CPU share
     po.set_threads(threads)
     model = po.OracleLlama(cfg, weights_host, "bfloat16")
     cache = [po.OracleKVCache() for _ in model.layers]
@@ -149,6 +149,11 @@ def main():
     k_bytes = model.kernel_bytes("gate_up", T_mid)
     k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
 
+    traffic = None
+    tf = ROOT / "profiles" / "r01_traffic.json"  # PMC passes (separate rocprofv3 runs), see profiles/README.md
+    if tf.exists() and not args.layers:
+        traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+
     out = {
         "metric": "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,10 +161,10 @@ def main():
         "dtype": "bf16 activations / fp32 accumulate over uint4 g=64 weights", "data": "synthetic",
         "config": {"workload": f"Llama-3-8B-shaped (H4096 L{n_l} 32/8 heads I14336 V128256) int4 g=64 greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
-                   "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 2 + 6 * n_l + 1,
+                   "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
                    "hipgraph": True},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": k_bytes,
+                     "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,
                      "ms_per_launch": k_ms,
                      "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "bytes_per_step": step_bytes}},
     }
