@@ -37,11 +37,12 @@ static inline bool pie_aligned(const void *p, size_t a) { return (reinterpret_ca
 // T-typed values travel as raw u16 bits; math is fp32.  codes2() turns two 4-bit codes (one per 16-bit
 // half) into two T values OFFSET+q by OR-ing a magic exponent.
 struct BF16 {
-    // code pair -> dot2 operand: 0x4300|q is exactly 128+q in bf16; gfx950 has no packed bf16 add, so the
-    // offset stays in the dot product and is removed once per group (d - 128*sum(x)): with 8-bit results the
-    // fp32 cancellation error is ~1/60 ulp.
-    static constexpr float OFFSET = 128.0f;
-    static __device__ __forceinline__ u32 codes2(u32 masked) { return masked | 0x43004300u; }
+    // code pair -> dot2 operand: the bare nibble 0x000q IS a bf16 (denormal, q * 2^-133), and v_dot2c_f32_bf16
+    // honours denormal inputs exactly (probed on MI355X), so no exponent has to be OR-ed in: the activations are
+    // published pre-scaled by XSCALE = 2^64 (exact) and the group sum is rescaled by DSCALE = 2^69 (exact).
+    // Products stay normal fp32 numbers for |q*x| > 2^-57; nothing overflows below |x| = 2^63.
+    static constexpr float OFFSET = 0.0f, XSCALE = 0x1p64f, DSCALE = 0x1p69f;
+    static __device__ __forceinline__ u32 codes2(u32 masked) { return masked; }
     static __device__ __forceinline__ float to_f32(u16 b) { return __builtin_bit_cast(float, (u32)b << 16); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // v_cvt_pk_bf16_f32, RNE
     static __device__ __forceinline__ float dot2(u32 a, u32 b, float c) {
@@ -51,7 +52,7 @@ struct BF16 {
 struct F16 {
     // 0x6400|q is exactly 1024+q in f16; f16 results have 11 significant bits, too fine for the offset to
     // ride through the fp32 dot product, so it is removed exactly with one v_pk_add_f16 per code pair.
-    static constexpr float OFFSET = 0.0f;
+    static constexpr float OFFSET = 0.0f, XSCALE = 1.0f, DSCALE = 1.0f;
     static __device__ __forceinline__ u32 codes2(u32 masked) {
         f16x2_t v = __builtin_bit_cast(f16x2_t, masked | 0x64006400u);
         v = v - (f16x2_t){(_Float16)1024.0f, (_Float16)1024.0f};

@@ -15,9 +15,10 @@
 //     retires in order), fused RMSNorm on 8 elements per thread, then a conflict-free LDS image
 //     [8 pieces][groups|1][16 B]; per unit a lane pulls its quantisation group (64 activations) back with
 //     8 x ds_read_b128 (LDS traffic = 3.5x the HBM traffic = 14 % of the LDS rate);
-//   * dequant = v_and_or_b32 with the magic-exponent trick, 2 codes per op; multiply-accumulate =
-//     v_dot2c_f32_bf16 against the packed activations; the +128 offset and the group bias fold into one fma
-//     with the group's activation sum:  scale*(d - 128*sx) + bias*sx;
+//   * dequant: none -- a masked nibble pair (w >> 4i) & 0x000F000F is fed to v_dot2c_f32_bf16 as two bf16
+//     DENORMALS (q * 2^-133, honoured exactly by the instruction) against activations pre-scaled by 2^64; per
+//     group one fma applies scale (times 2^69) and bias*sum(x).  v_and_or_b32 and v_dot2c are both half-rate on
+//     gfx950 (tools/inst_rate), so dropping the exponent OR saves 21 % of the loop's VALU cycles;
 //   * a row pair's K slices accumulate in a register; 32-lane DPP reduction; the two row sums are parked in LDS
 //     and the epilogue runs once after the stream, one lane per row pair (coalesced stores, vectorised RoPE/SiLU):
 //     global stores inside the loop would share vmcnt with the loads and make the compiler drain the ring.
@@ -89,6 +90,14 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
         }
     }
     return (d[0] + d[1]) + (d[2] + d[3]);
+}
+
+// 8 packed activations times the trait's exact power-of-two pre-scale (identity for f16)
+template <class T>
+__device__ __forceinline__ uint4 scale8(const uint4 &v) {
+    if (T::XSCALE == 1.0f) return v;
+    return make_uint4(pack2<T>(lo_f32<T>(v.x) * T::XSCALE, hi_f32<T>(v.x) * T::XSCALE), pack2<T>(lo_f32<T>(v.y) * T::XSCALE, hi_f32<T>(v.y) * T::XSCALE),
+                      pack2<T>(lo_f32<T>(v.z) * T::XSCALE, hi_f32<T>(v.z) * T::XSCALE), pack2<T>(lo_f32<T>(v.w) * T::XSCALE, hi_f32<T>(v.w) * T::XSCALE));
 }
 
 template <class T>
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x141, 0xF, 0xF, true);  // row_half_mirror: 8-lane sums
             if (ok) {
-                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = xv[i];
+                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = scale8<T>(xv[i]);
                 if ((j & 7) == 0) sxs[j >> 3] = ps;
             }
         }
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const float dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
                                            : w4s_unit_dot<T>(c0[d], c1[d], xr);
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
-                const float pr = fmaf(scale, dd - T::OFFSET * sx, bias * sx);
+                const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
                 acc += gvalid ? pr : 0.0f;  // padded groups carry zero codes and zero {scale,bias}; the select keeps a NaN x out
                 if (++sl == ns) {
                     const float tot = half_wave_sum(acc);
