@@ -43,12 +43,25 @@ struct BF16 {
     // Products stay normal fp32 numbers for |q*x| > 2^-57; nothing overflows below |x| = 2^63.
     static constexpr float OFFSET = 0.0f, XSCALE = 0x1p64f, DSCALE = 0x1p69f;
     static __device__ __forceinline__ u32 codes2(u32 masked) { return masked; }
+    // One code word (8 codes) against 4 packed activation pairs.  Gradual underflow makes 0x00q0 exactly 16*q*2^-133
+    // as well (q >= 8 spills into the exponent LSB, which is precisely the denormal->normal transition), so code
+    // positions 1 and 3 are masked in place and their chains carry a factor 16 that the caller divides out: one shift
+    // per word instead of three.
+    static constexpr float ODD_SCALE = 0.0625f;
+    static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]);
     static __device__ __forceinline__ float to_f32(u16 b) { return __builtin_bit_cast(float, (u32)b << 16); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // v_cvt_pk_bf16_f32, RNE
     static __device__ __forceinline__ float dot2(u32 a, u32 b, float c) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
     }
 };
+__device__ __forceinline__ void BF16::dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]) {
+    const u32 w8 = w >> 8;
+    d[0] = dot2(w & 0x000F000Fu, x0, d[0]);
+    d[1] = dot2(w & 0x00F000F0u, x1, d[1]);
+    d[2] = dot2(w8 & 0x000F000Fu, x2, d[2]);
+    d[3] = dot2(w8 & 0x00F000F0u, x3, d[3]);
+}
 struct F16 {
     // 0x6400|q is exactly 1024+q in f16; f16 results have 11 significant bits, too fine for the offset to
     // ride through the fp32 dot product, so it is removed exactly with one v_pk_add_f16 per code pair.
@@ -57,6 +70,13 @@ struct F16 {
         f16x2_t v = __builtin_bit_cast(f16x2_t, masked | 0x64006400u);
         v = v - (f16x2_t){(_Float16)1024.0f, (_Float16)1024.0f};
         return __builtin_bit_cast(u32, v);
+    }
+    static constexpr float ODD_SCALE = 1.0f;
+    static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]) {
+        d[0] = dot2(codes2(w & 0x000F000Fu), x0, d[0]);
+        d[1] = dot2(codes2((w >> 4) & 0x000F000Fu), x1, d[1]);
+        d[2] = dot2(codes2((w >> 8) & 0x000F000Fu), x2, d[2]);
+        d[3] = dot2(codes2((w >> 12) & 0x000F000Fu), x3, d[3]);
     }
     static __device__ __forceinline__ float to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (_Float16)f); }

@@ -82,14 +82,8 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
     float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // four independent v_dot2c chains (one per code position) for ILP
     const u32 w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 q2 = T::codes2((w[t] >> (4 * i)) & 0x000F000Fu);  // codes (2i, 2i+1) of word t as two T values
-            d[i] = T::dot2(q2, xr[4 * t + i], d[i]);
-        }
-    }
-    return (d[0] + d[1]) + (d[2] + d[3]);
+    for (int t = 0; t < 8; ++t) T::dot_word(w[t], xr[4 * t], xr[4 * t + 1], xr[4 * t + 2], xr[4 * t + 3], d);
+    return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
 }
 
 // 8 packed activations times the trait's exact power-of-two pre-scale (identity for f16)
