@@ -48,6 +48,12 @@ struct AttnArgs {
     float *part_acc;  // [Hq, splits, D]
     float *part_ml;   // [Hq, splits, 2]
     u16 *out;         // [Hq, D]
+    // Infinity-Cache warm-up riding on the idle CUs of this launch: blocks with blockIdx.y >= splits stream these
+    // byte ranges (the next kernels' weights) and discard them, so the small GEMVs that follow start from MALL hits.
+    const char *pf_ptr[2];
+    unsigned long long pf_bytes[2];
+    int pf_rows;      // extra blockIdx.y rows doing prefetch (0 = none)
+    unsigned *pf_sink;
 };
 
 template <class T, int D, int REP>
@@ -60,6 +66,21 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
     __shared__ float s_acc[REP][NSUB][D];
 
     const int g = blockIdx.x, split = blockIdx.y;
+    if (split >= a.splits) {  // prefetch role (uniform per workgroup)
+        const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
+        unsigned acc = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned long long n16 = a.pf_bytes[r] >> 4;  // 16-byte pieces
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr[r]);
+            for (unsigned long long i = (unsigned long long)bid * 256 + threadIdx.x; i < n16; i += (unsigned long long)nblk * 256) {
+                const uint4 v = src[i];
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+        if (acc == 0x9e3779b9u) a.pf_sink[0] = acc;  // keeps the loads alive; practically never taken
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
     const int Ttot = a.state ? a.state->pos + 1 : a.T;

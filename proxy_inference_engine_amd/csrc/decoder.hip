@@ -13,6 +13,9 @@
 #include "tail.hpp"
 #include "w4_gemv.hpp"
 
+int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+
 namespace {
 thread_local std::string g_last_error;
 }
@@ -41,7 +44,10 @@ struct pie_decoder {
     DecState *state = nullptr;
     unsigned long long *kv_table = nullptr;  // [2*n_layers]
     u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
-    float *part_acc = nullptr, *part_ml = nullptr;
+    float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
+    unsigned *pf_sink = nullptr;
+    int pf_rows = 0;
+    size_t pf_gateup_bytes = 0;
     // caller-owned outputs (pie_decoder_bind_outputs)
     u16 *h = nullptr, *logits = nullptr;
     float *logprobs = nullptr;
@@ -74,13 +80,13 @@ static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_pt
     const pie_layer_weights &w = d->layers[li];
     switch (which) {
         case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
-            return pie_embedding_w4g64(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H,
-                                       c.dtype, d->h, st);
+            return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, d->h,
+                                    d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st);
         case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
             GemvArgs a = {};
             a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
-            a.freqs = d->glob.rope_freqs, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
+            a.freqs = d->glob.rope_freqs, a.rope_cs = d->rope_cs, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
@@ -89,6 +95,10 @@ static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_pt
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
+            // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
+            a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
+            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = pie_w4s_bytes(H, QD);
+            a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
             return attn_decode_launch(c.dtype, D, a, false, st);  // partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
@@ -185,6 +195,16 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->part_acc, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * c.head_dim);
     PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
+    PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
+    PIE_ALLOC(d->pf_sink, 16);
+    {
+        const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)
+        const long mb = e ? atol(e) : 0;
+        const size_t gu = pie_w4s_bytes(2 * c.inter, c.hidden);
+        d->pf_gateup_bytes = mb <= 0 ? 0 : ((size_t)mb << 20 < gu ? (size_t)mb << 20 : gu);
+        d->pf_rows = mb < 0 ? 0 : (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;  // fill the CUs attention leaves idle
+        if (d->pf_rows < 0) d->pf_rows = 0;
+    }
 #undef PIE_ALLOC
     *out = d;
     return PIE_OK;
@@ -193,7 +213,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
 int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
-    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats};
+    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete d;

@@ -7,7 +7,7 @@
 // ---------------------------------------------------------------- attention launch
 template <class T, int D>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
-    dim3 grid(a.Hkv, a.splits), block(256);
+    dim3 grid(a.Hkv, a.splits + a.pf_rows), block(256);
     switch (rep) {
         case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;

@@ -76,7 +76,15 @@ __global__ void k_dequantize_w4g64(const u32 *codes, const u16 *scales, const u1
 // nn.QuantizedEmbedding.__call__ (language.py:176): out[l,:] = dequantize(row ids[l]).
 template <class T>
 __global__ void k_embedding_w4g64(const int *ids, const u32 *codes, const u16 *scales, const u16 *biases, int V, int H,
-                                  u16 *out) {
+                                  u16 *out, const float *freqs, const DecState *state, float *rope_cs, int half) {
+    // decoder only: the step's RoPE table (cos, sin of pos / freqs[i], llama/utils.py:42-50) is computed once here
+    // and read by the 32 QKV epilogues instead of one full-precision sincosf per row pair and layer
+    if (rope_cs && blockIdx.x == 0 && (int)threadIdx.x < half) {
+        const float theta = (float)state->pos * (1.0f / freqs[threadIdx.x]);
+        float sn, cs;
+        sincosf(theta, &sn, &cs);
+        rope_cs[2 * threadIdx.x] = cs, rope_cs[2 * threadIdx.x + 1] = sn;
+    }
     const int l = blockIdx.x;
     int id = ids[l];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
@@ -180,6 +188,9 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
 }
 
 // ---------------------------------------------------------------- C ABI
+int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+
 extern "C" {
 
 size_t pie_w4s_bytes(int N_out, int K) {
@@ -254,19 +265,29 @@ int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, cons
 
 int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
                         int dtype, void *out, void *stream) {
+    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+}  // extern "C"
+
+int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st) {
     PIE_REQUIRE(ids && codes && scales && biases && out, PIE_E_ARG, "pie_embedding_w4g64: null pointer");
     PIE_REQUIRE(L > 0 && V > 0 && H > 0 && H % 64 == 0, PIE_E_SHAPE, "pie_embedding_w4g64: H must be a multiple of 64");
     PIE_REQUIRE(pie_aligned(out, 16), PIE_E_ALIGN, "pie_embedding_w4g64: out must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
+    PIE_REQUIRE(half <= 256, PIE_E_SHAPE, "embedding: head_dim too large for the RoPE table");
     if (dtype == PIE_BF16)
-        hipLaunchKernelGGL(k_embedding_w4g64<BF16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out);
+        hipLaunchKernelGGL(k_embedding_w4g64<BF16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out,
+                           freqs, state, rope_cs, half);
     else if (dtype == PIE_F16)
-        hipLaunchKernelGGL(k_embedding_w4g64<F16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out);
+        hipLaunchKernelGGL(k_embedding_w4g64<F16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out,
+                           freqs, state, rope_cs, half);
     else
         return pie::fail(PIE_E_ARG, "pie_embedding_w4g64: bad dtype");
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
+
+extern "C" {
 
 int pie_qkv_row_map(int n_heads, int n_kv_heads, int head_dim, int32_t *map) {
     if (!map || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || (head_dim & 1)) return pie::fail(PIE_E_ARG, "pie_qkv_row_map: bad argument");

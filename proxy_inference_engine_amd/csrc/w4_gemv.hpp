@@ -52,6 +52,7 @@ struct GemvArgs {
     u16 *resid;           // EPI_RESIDUAL: residual stream, updated in place
     // EPI_ROPE_KV
     const float *freqs;
+    const float *rope_cs;  // optional [head_dim/2][2] (cos, sin) of the step's position, filled by the embedding kernel
     const DecState *state;
     u16 *q_out;
     const unsigned long long *kv_table;  // [2*n_layers] device pointers: K buffers then V buffers
@@ -168,9 +169,20 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             c0[d] = c1[d] = make_uint4(lane, i, d, 7);
             sb[d] = 0x3c003c00u;
         } else {
-            c0[d] = *reinterpret_cast<const uint4 *>(unit);
-            c1[d] = *reinterpret_cast<const uint4 *>(unit + 1024);
-            sb[d] = *reinterpret_cast<const u32 *>(unit + 2048 - lane * 12);
+            if (EPI == EPI_LOGITS) {
+                // lm_head (295 MB) exceeds the 256 MiB Infinity Cache: non-temporal loads measured 53.6 -> 48.3 us;
+                // on the per-layer matrices (<= 66 MB) nt was 8-15 % SLOWER, so they keep the default policy
+                typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
+                const u32x4_t v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(unit));
+                const u32x4_t v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(unit + 1024));
+                c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+                c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+                sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(unit + 2048 - lane * 12));
+            } else {
+                c0[d] = *reinterpret_cast<const uint4 *>(unit);
+                c1[d] = *reinterpret_cast<const uint4 *>(unit + 1024);
+                sb[d] = *reinterpret_cast<const u32 *>(unit + 2048 - lane * 12);
+            }
         }
     };
 #pragma unroll
@@ -330,9 +342,12 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             if (R < q_rows + k_rows) {
                 const int rr = R < q_rows ? R : R - q_rows;
                 const int head = rr / HD, ii = (rr % HD) >> 1;
-                const float theta = (float)pos * (1.0f / a.freqs[ii]);
                 float sn, cs;
-                sincosf(theta, &sn, &cs);
+                if (a.rope_cs) {
+                    cs = a.rope_cs[2 * ii], sn = a.rope_cs[2 * ii + 1];
+                } else {
+                    sincosf((float)pos * (1.0f / a.freqs[ii]), &sn, &cs);
+                }
                 u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD
                                       : reinterpret_cast<u16 *>(a.kv_table[a.layer]) + ((size_t)head * cap + pos) * HD;
                 dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
