@@ -131,21 +131,21 @@ def main():
 
     # dominant kernel (gate/up GEMV: 38 % of the step's bytes), timed alone with HIP events on the launch stream,
     # cycling through the layers so every launch streams weights that are not in the 256 MiB Infinity Cache.
-    reps = 4
+    # Events bracket a whole sweep over the layers (back-to-back launches on the launch stream), so the figure is the
+    # kernel's steady-state duration -- what rocprofv3 --kernel-trace reports per dispatch -- not launch gaps.
+    reps = 8
     n_l = cfg["num_hidden_layers"]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * n_l)]
     for li in range(n_l):
         model.launch_kernel("gate_up", li)
     torch.cuda.synchronize()
-    i = 0
-    for _ in range(reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in ev:
+        e0.record()
         for li in range(n_l):
-            ev[i][0].record()
             model.launch_kernel("gate_up", li)
-            ev[i][1].record()
-            i += 1
+        e1.record()
     torch.cuda.synchronize()
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k_ms = float(np.median([a.elapsed_time(b) for a, b in ev])) / n_l
     k_bytes = model.kernel_bytes("gate_up", T_mid)
     k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
 

@@ -156,6 +156,26 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             if (PRO == PRO_RMSNORM) nv[i] = reinterpret_cast<const uint4 *>(a.norm_w)[j];
         }
     }
+    // epilogue-side operands, fetched now so their latency hides under the stream (lane l owns pair gw + l*W)
+    const bool live = lane < run;
+    const int pair = gw + lane * W;
+    const int R = 2 * pair;  // packed row index; the pair is rows R, R+1
+    u32 pre_u = 0;           // EPI_RESIDUAL: the residual pair; EPI_STORE: the linear bias pair
+    float pre_cs = 1.0f, pre_sn = 0.0f;
+    int pos = 0, cap = 0;
+    u16 *kdst = nullptr, *vdst = nullptr;
+    if (EPI == EPI_RESIDUAL && live) pre_u = *reinterpret_cast<const u32 *>(a.resid + R);
+    if (EPI == EPI_STORE && a.lin_bias && live) pre_u = *reinterpret_cast<const u32 *>(a.lin_bias + R);
+    if (EPI == EPI_ROPE_KV) {
+        pos = a.state->pos, cap = a.state->cap;
+        kdst = reinterpret_cast<u16 *>(a.kv_table[a.layer]);
+        vdst = reinterpret_cast<u16 *>(a.kv_table[a.n_layers + a.layer]);
+        if (live && R < (a.n_heads + a.n_kv_heads) * a.head_dim) {
+            const int ii = (R % a.head_dim) >> 1;
+            if (a.rope_cs) pre_cs = a.rope_cs[2 * ii], pre_sn = a.rope_cs[2 * ii + 1];
+            else sincosf((float)pos * (1.0f / a.freqs[ii]), &pre_sn, &pre_cs);
+        }
+    }
     uint4 c0[D], c1[D];
     u32 sb[D];
     const int last_pair = run > 0 ? run - 1 : 0;
@@ -286,9 +306,6 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     }
 
     // 4. epilogue: lane l owns local pair l (rows R, R+1 of the packed order); consecutive lanes -> consecutive addresses.
-    const bool live = lane < run;
-    const int pair = gw + lane * W;
-    const int R = 2 * pair;
     float va = 0.0f, vb = 0.0f;
     if (live) {
         const float2 o = *reinterpret_cast<const float2 *>(outp + 2 * lane);
@@ -297,9 +314,8 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     if (EPI == EPI_STORE || EPI == EPI_LOGITS) {
         float oa = round_T<T>(va), ob = round_T<T>(vb);
         if (EPI == EPI_STORE && a.lin_bias && live) {
-            const u32 lb = *reinterpret_cast<const u32 *>(a.lin_bias + R);
-            oa = round_T<T>(oa + lo_f32<T>(lb));
-            ob = round_T<T>(ob + hi_f32<T>(lb));
+            oa = round_T<T>(oa + lo_f32<T>(pre_u));
+            ob = round_T<T>(ob + hi_f32<T>(pre_u));
         }
         if (live) *reinterpret_cast<u32 *>(a.y + (size_t)m * a.N + R) = pack2<T>(oa, ob);
         if (EPI == EPI_LOGITS) {  // per-wave log-softmax partial: max, first argmax, sum exp(x - max)
@@ -319,11 +335,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     } else if (EPI == EPI_RESIDUAL) {
         // h = x + r (language.py:151,153): Linear output rounded to T, then the add rounded to T
-        if (live) {
-            u32 *hp = reinterpret_cast<u32 *>(a.resid + R);
-            const u32 h = *hp;
-            *hp = pack2<T>(lo_f32<T>(h) + round_T<T>(va), hi_f32<T>(h) + round_T<T>(vb));
-        }
+        if (live) *reinterpret_cast<u32 *>(a.resid + R) = pack2<T>(lo_f32<T>(pre_u) + round_T<T>(va), hi_f32<T>(pre_u) + round_T<T>(vb));
     } else if (EPI == EPI_SWIGLU) {
         // down_proj input: nn.silu(gate) * up (language.py:127); packed rows (2i, 2i+1) = (gate_i, up_i)
         if (live) {
@@ -336,27 +348,18 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:136-137).
         if (live) {
             const int HD = a.head_dim, half = HD >> 1;
-            const int pos = a.state->pos, cap = a.state->cap;
             const int q_rows = a.n_heads * HD, k_rows = a.n_kv_heads * HD;
             const float ra = round_T<T>(va), rb = round_T<T>(vb);
             if (R < q_rows + k_rows) {
                 const int rr = R < q_rows ? R : R - q_rows;
                 const int head = rr / HD, ii = (rr % HD) >> 1;
-                float sn, cs;
-                if (a.rope_cs) {
-                    cs = a.rope_cs[2 * ii], sn = a.rope_cs[2 * ii + 1];
-                } else {
-                    sincosf((float)pos * (1.0f / a.freqs[ii]), &sn, &cs);
-                }
-                u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD
-                                      : reinterpret_cast<u16 *>(a.kv_table[a.layer]) + ((size_t)head * cap + pos) * HD;
-                dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
-                dst[ii + half] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
+                u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD : kdst + ((size_t)head * cap + pos) * HD;
+                dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, pre_cs), __fmul_rn(rb, pre_sn)));
+                dst[ii + half] = T::from_f32(__fadd_rn(__fmul_rn(ra, pre_sn), __fmul_rn(rb, pre_cs)));
             } else {
                 const int rr = R - q_rows - k_rows;
                 const int head = rr / HD, dd2 = rr % HD;
-                u16 *dst = reinterpret_cast<u16 *>(a.kv_table[a.n_layers + a.layer]) + ((size_t)head * cap + pos) * HD + dd2;
-                *reinterpret_cast<u32 *>(dst) = pack2<T>(ra, rb);
+                *reinterpret_cast<u32 *>(vdst + ((size_t)head * cap + pos) * HD + dd2) = pack2<T>(ra, rb);
             }
         }
     }

@@ -150,5 +150,35 @@ int main(int argc, char **argv) {
         RUN_ABL(PRO_NONE, EPI_STORE, 0, "abl store full")
         RUN_ABL(PRO_NONE, EPI_STORE, 4, "abl store no-x-staging")
     }
+    // ablations of the product kernel on the qkv shape (N=6144, K=4096)
+    {
+        const int N = 6144, K = 4096;
+        size_t b = (size_t)(N / 2) * w4s_slices(K) * W4S_UNIT_BYTES;
+        int sl = (int)(W_BYTES / b);
+        auto mk = [&](int i) {
+            GemvArgs a = {};
+            a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
+            a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
+            return a;
+        };
+        const unsigned lds = (unsigned)gemv_lds(K).total;
+#undef RUN_ABL
+#define RUN_ABL(PRO, EPI, ABL, label)                                                                                     \
+        {                                                                                                                  \
+            dim3 grid((w4s_gemv_waves(N, K) + GEMV_WAVES - 1) / GEMV_WAVES), block(64 * GEMV_WAVES);                        \
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO, EPI, 1, ABL>), grid, block, lds, 0, mk(i)); \
+            CK(hipDeviceSynchronize()); t.start();                                                                         \
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO, EPI, 1, ABL>), grid, block, lds, 0, mk(i)); \
+            report(label, b, reps, t.stop());                                                                              \
+        }
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 0, "abl6144 rms+swiglu full")
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 1, "abl6144 rms+swiglu no-weight-loads")
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 2, "abl6144 rms+swiglu no-dot")
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 4, "abl6144 rms+swiglu no-x-staging")
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 6, "abl6144 rms+swiglu loads only")
+        RUN_ABL(PRO_RMSNORM, EPI_SWIGLU, 7, "abl6144 rms+swiglu nothing")
+        RUN_ABL(PRO_NONE, EPI_STORE, 0, "abl6144 store full")
+        RUN_ABL(PRO_NONE, EPI_STORE, 4, "abl6144 store no-x-staging")
+    }
     return 0;
 }
