@@ -7,9 +7,9 @@
 // HBM-bound (3.6 FLOP/B at M=1): the design goal is bytes in flight, not math.  Measured on MI355X
 // (tools/w4s_bench, 66 MB gate/up problem): the bare W4S stream reaches 5.7 TB/s; a workgroup-per-tile kernel
 // lost half of that to per-tile activation staging, barriers and epilogues, hence this structure:
-//   * PERSISTENT WAVES: the grid is sized to the chip (<= 16 waves per CU); each wave owns a contiguous run of
+//   * PERSISTENT WAVES: the grid is sized to the chip (one 8-wave workgroup per CU); each wave owns a contiguous run of
 //     row pairs and streams their units (row pair x 2048-wide K slice, 2304 B) through a register ring that
-//     keeps D units (3 loads each: 2 x dwordx4 codes + 1 x dword {scale,bias}) in flight; no barrier, no
+//     keeps 4 units (3 loads each: 2 x dwordx4 codes + 1 x dword {scale,bias}) in flight; no barrier, no
 //     cross-wave reduction inside the loop;
 //   * activations: the workgroup stages x ONCE: coalesced 16-byte loads issued BEFORE the weight stream (vmcnt
 //     retires in order), fused RMSNorm on 8 elements per thread, then a conflict-free LDS image
@@ -33,7 +33,8 @@ enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOG
 
 constexpr int GEMV_WAVES = 8;        // waves per workgroup
 constexpr int GEMV_DEPTH = 4;        // units in flight per wave
-constexpr int GEMV_MAX_WAVES = 4096; // 256 CUs x 16 waves: what the register budget keeps resident
+constexpr int GEMV_MAX_WAVES = 2048; // 256 CUs x ONE 8-wave workgroup: measured best (sweep 1024..6144 in DESIGN.md); the
+                                     // activation staging is paid once per CU and no CU runs a second, later wave of groups
 constexpr int GEMV_MAX_RUN = 64;     // row pairs per wave (one epilogue lane each)
 
 struct LogitStat {  // per-wave partial of the log-softmax / argmax tail
