@@ -9,7 +9,7 @@
 // lost half of that to per-tile activation staging, barriers and epilogues, hence this structure:
 //   * PERSISTENT WAVES: the grid is sized to the chip (one 8-wave workgroup per CU); each wave owns a contiguous run of
 //     row pairs and streams their units (row pair x 2048-wide K slice, 2304 B) through a register ring that
-//     keeps 4 units (3 loads each: 2 x dwordx4 codes + 1 x dword {scale,bias}) in flight; no barrier, no
+//     keeps 2 units (3 buffer loads each: 2 x dwordx4 codes + 1 x dword {scale,bias}) in flight; no barrier, no
 //     cross-wave reduction inside the loop;
 //   * activations: the workgroup stages x ONCE: coalesced 16-byte loads issued BEFORE the weight stream (vmcnt
 //     retires in order), fused RMSNorm on 8 elements per thread, then a conflict-free LDS image
@@ -32,7 +32,7 @@ constexpr int GEMV_ATTN_SPLITS = 4;  // split-KV factor the PRO_ATTN prologue me
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4 };
 
 constexpr int GEMV_WAVES = 8;        // waves per workgroup
-constexpr int GEMV_DEPTH = 4;        // units in flight per wave
+constexpr int GEMV_DEPTH = 2;        // units in flight per wave (swept 2..12 on MI355X: 2-3 best, deeper rings are slower)
 constexpr int GEMV_MAX_WAVES = 2048; // 256 CUs x ONE 8-wave workgroup: measured best (sweep 1024..6144 in DESIGN.md); the
                                      // activation staging is paid once per CU and no CU runs a second, later wave of groups
 constexpr int GEMV_MAX_RUN = 64;     // row pairs per wave (one epilogue lane each)
@@ -179,31 +179,30 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     }
     uint4 c0[D], c1[D];
     u32 sb[D];
-    const int last_pair = run > 0 ? run - 1 : 0;
+    // Weight loads go through a buffer descriptor over the whole matrix: a ring slot that has no unit left to fetch is
+    // given an out-of-range offset, which the hardware bounds check drops (no memory traffic, no branch around a load).
+    // (Clamping to the last unit instead cost up to D redundant loads per wave: 70 % extra at 7-unit runs.)
+    typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
+    const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * W4S_UNIT_BYTES);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.w), 0, (int)w_bytes, 0x00020000);
+    const unsigned woff0 = (unsigned)((size_t)gw * ns * W4S_UNIT_BYTES) + lane * 16;  // this wave's first unit, this lane's piece
+    const unsigned pstride32 = (unsigned)pstride;
     int iss_sl = 0, iss_pl = 0;  // slice / local pair of the next unit to issue
-    auto issue = [&](int d, int) {  // ring slot d <- next unit of this wave (clamped: waves always load valid memory)
-        const int pc = iss_pl < last_pair ? iss_pl : last_pair;
-        const char *unit = wbase + (size_t)pc * pstride + (size_t)iss_sl * W4S_UNIT_BYTES;
-        const int i = pc;
+    auto issue = [&](int d, int) {  // ring slot d <- next unit of this wave
+        const unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * W4S_UNIT_BYTES : 0xFFFFF000u;
         if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
         if (ABL & 1) {
-            c0[d] = c1[d] = make_uint4(lane, i, d, 7);
+            c0[d] = c1[d] = make_uint4(lane, off, d, 7);
             sb[d] = 0x3c003c00u;
         } else {
-            if (EPI == EPI_LOGITS) {
-                // lm_head (295 MB) exceeds the 256 MiB Infinity Cache: non-temporal loads measured 53.6 -> 48.3 us;
-                // on the per-layer matrices (<= 66 MB) nt was 8-15 % SLOWER, so they keep the default policy
-                typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
-                const u32x4_t v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(unit));
-                const u32x4_t v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(unit + 1024));
-                c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
-                c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
-                sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(unit + 2048 - lane * 12));
-            } else {
-                c0[d] = *reinterpret_cast<const uint4 *>(unit);
-                c1[d] = *reinterpret_cast<const uint4 *>(unit + 1024);
-                sb[d] = *reinterpret_cast<const u32 *>(unit + 2048 - lane * 12);
-            }
+            // lm_head (295 MB) exceeds the 256 MiB Infinity Cache: non-temporal loads (aux = 2) measured 53.6 -> 48.3 us;
+            // on the per-layer matrices (<= 66 MB) nt was 8-15 % SLOWER, so they keep the default policy
+            constexpr int AUX = EPI == EPI_LOGITS ? 2 : 0;
+            const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, AUX);
+            const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, AUX);
+            c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+            c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+            sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
         }
     };
 #pragma unroll
