@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_hidden_layers (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=3)
+    ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
     return ap.parse_args()
 

@@ -3,6 +3,7 @@
 //        proxy_inference_engine_amd/csrc/decoder.hip proxy_inference_engine_amd/csrc/ops.hip -o tools/w4s_bench
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../proxy_inference_engine_amd/csrc/w4_gemv.hpp"
@@ -100,6 +101,21 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize()); t.start();                                                                       \
         for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_stream_dot<U, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, w + (size_t)(i % slots) * bytes, units, x, outf); \
         snprintf(nm, 64, "stream+dot    U=%d waves/WG=%d grid=%d", U, WAVES, grid); report(nm, bytes, reps, t.stop());              \
+    }
+    if (argc > 1 && std::string(argv[1]) == "pmc") {
+        // counter-collection mode (rocprofv3 --pmc ...): only the calibration stream and the cold gate/up product kernel,
+        // so per-kernel averages are not mixed across shapes or cache states
+        RUN_STREAM(1, 4)
+        const int N = 28672, K = 4096;
+        size_t b = (size_t)(N / 2) * w4s_slices(K) * W4S_UNIT_BYTES;
+        int sl = (int)(W_BYTES / b);
+        for (int i = 0; i < 64; ++i) {
+            GemvArgs a = {};
+            a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
+            if (w4s_gemv_launch(PIE_BF16, PRO_RMSNORM, EPI_SWIGLU, a, 1, 0)) { printf("launch failed: %s\n", pie_last_error()); exit(1); }
+        }
+        CK(hipDeviceSynchronize());
+        return 0;
     }
     RUN_STREAM(1, 4) RUN_STREAM(2, 4) RUN_STREAM(4, 4) RUN_STREAM(8, 4) RUN_STREAM(4, 8) RUN_STREAM(2, 8) RUN_STREAM(8, 8) RUN_STREAM(4, 16) RUN_STREAM(16, 4)
 
