@@ -158,7 +158,7 @@ def main():
         "metric": "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 activations / fp32 accumulate over uint4 g=64 weights", "data": "synthetic",
+        "dtype": "bf16", "dtype_detail": "uint4 g=64 weights x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
         "config": {"workload": f"Llama-3-8B-shaped (H4096 L{n_l} 32/8 heads I14336 V128256) int4 g=64 greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,

@@ -163,6 +163,37 @@ def test_llama8b_shaped_layers_vs_oracle(dtype):
         + 2 * (2 * 4096 * 2 + 2 * 1024 * 2 * 128 + 2 * 1024 * 2) + (8192 * 4096 // 2 + 2 * (8192 * 4096 // 64) * 2) + 4096 * 2 + 8192 * 4
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_tinyllama_shaped_layers_vs_oracle(dtype):
+    """BASELINE.json configs[0] geometry (TinyLlama-1.1B: H=2048, I=5632 = 2.75 K-slices, 32/4 heads -> 8 q-heads per
+    kv-head, D=64, V=32000), 2 layers, int4 g=64: ragged last K slice, REP=8 attention, D=64 RoPE / cache rows."""
+    cfg = {"model_type": "llama", "hidden_size": 2048, "num_hidden_layers": 2, "intermediate_size": 5632,
+           "num_attention_heads": 32, "num_key_value_heads": 4, "rms_norm_eps": 1e-5, "vocab_size": 32000,
+           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=4, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(8).integers(0, cfg["vocab_size"], 70)       # > 64 positions: several attention splits
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache)[-1]
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="prefill")
+    matched = 0
+    for _ in range(4):
+        t = int(tok.item())
+        want = orc.forward(np.array([t]), ocache)[0]
+        otok, olp = po.logprobs_argmax(want)
+        tok, lp, logits = model.step(None, cache)                               # device-side feed-back of the greedy token
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode")
+        top2 = np.sort(olp)[-2:]
+        if top2[1] - top2[0] > margin_bound(want, dtype):
+            assert int(tok.item()) == otok
+            matched += 1
+    assert cache[0].keys.shape == (1, 4, 256, 64) and cache[0].offset == 74 and matched >= 1
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
