@@ -11,8 +11,8 @@
 #pragma once
 #include "common.hpp"
 
-constexpr int ATTN_MAX_SPLITS = 16;
-constexpr int ATTN_DEPTH = 4;
+constexpr int ATTN_MAX_SPLITS = 32;  // 8 kv-heads x 32 splits = one workgroup per CU
+constexpr int ATTN_DEPTH = 4;  // swept 4 vs 8 with 8-wave workgroups: 8 is 2-3 % slower at every context (VALU-bound, not latency-bound)
 constexpr float ATTN_NEG = -3.0e38f;
 
 // Device-resident decode state: lets one captured graph serve every step.
@@ -56,11 +56,14 @@ struct AttnArgs {
     unsigned *pf_sink;
 };
 
+constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VALU scoring overlaps the other's loads)
+
 template <class T, int D, int REP>
-__global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
+__global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs a) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
     constexpr int TPW = 64 / LPT;  // token rows per wave-load
-    constexpr int NSUB = 4;        // one merged online-softmax stream per wave reaches LDS
+    constexpr int NSUB = ATTN_WAVES;  // one merged online-softmax stream per wave reaches LDS
+    constexpr int NT = ATTN_WAVES * 64;
     constexpr int DA = ATTN_DEPTH;
     __shared__ float s_m[REP][NSUB], s_l[REP][NSUB];
     __shared__ float s_acc[REP][NSUB][D];
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         for (int r = 0; r < 2; ++r) {
             const unsigned long long n16 = a.pf_bytes[r] >> 4;  // 16-byte pieces
             const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr[r]);
-            for (unsigned long long i = (unsigned long long)bid * 256 + threadIdx.x; i < n16; i += (unsigned long long)nblk * 256) {
+            for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
                 const uint4 v = src[i];
                 acc ^= v.x ^ v.y ^ v.z ^ v.w;
             }
@@ -95,12 +98,12 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
     kbase += (size_t)g * cap * D + dc * 8;
     vbase += (size_t)g * cap * D + dc * 8;
 
-    // row-blocks of this wave: block b covers tokens t_begin + (4*b + wave)*TPW + [0, TPW)
+    // row-blocks of this wave: block b covers tokens t_begin + (NSUB*b + wave)*TPW + [0, TPW)
     const int first = t_begin + wave * TPW;
-    const int n_blk = first < t_end ? (t_end - first + 4 * TPW - 1) / (4 * TPW) : 0;
+    const int n_blk = first < t_end ? (t_end - first + NSUB * TPW - 1) / (NSUB * TPW) : 0;
     uint4 kq[DA], vq[DA];
     auto issue = [&](int d, int b) {
-        int t = first + b * 4 * TPW + ts;
+        int t = first + b * NSUB * TPW + ts;
         t = t < t_end ? t : t_end - 1;  // clamp, never branch around a load
         kq[d] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D);
         vq[d] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D);
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         for (int d = 0; d < DA; ++d) {
             const int b = base + d;
             if (b < n_blk) {  // wave-uniform; every block has at least one valid token (ts == 0)
-                const bool valid = first + b * 4 * TPW + ts < t_end;
+                const bool valid = first + b * NSUB * TPW + ts < t_end;
                 const u32 kw[4] = {kq[d].x, kq[d].y, kq[d].z, kq[d].w};
                 float vf[8];
                 vf[0] = lo_f32<T>(vq[d].x), vf[1] = hi_f32<T>(vq[d].x), vf[2] = lo_f32<T>(vq[d].y), vf[3] = hi_f32<T>(vq[d].y);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const AttnArgs a) {
         }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < REP * D; o += 256) {
+    for (int o = threadIdx.x; o < REP * D; o += NT) {
         const int h = o / D, d = o % D;
         float M = ATTN_NEG;
 #pragma unroll
@@ -243,15 +246,32 @@ __device__ __forceinline__ void attn_merge8(const float *part_acc, const float *
     attn_merge_finish<MAXS>(r, active, out);
 }
 
-// Stand-alone merge (op-level pie_sdpa_decode): grid Hq, block D/8 threads, 8 dims each.
+// Stand-alone merge (op-level pie_sdpa_decode, and the decoder at long context where more than GEMV_ATTN_SPLITS splits
+// are needed to spread the work over the chip): grid Hq, block D/8 threads, 8 dims each; any split count.  Same
+// ascending-j fmaf order as attn_merge_finish, so both merge paths round identically.
 template <class T>
 __global__ void k_attn_combine(const AttnArgs a, int D) {
     const int h = blockIdx.x, d0 = threadIdx.x * 8;
     const int Ttot = a.state ? a.state->pos + 1 : a.T;
     const int active = attn_split(Ttot, a.splits).active;
+    const float *ml = a.part_ml + (size_t)h * a.splits * 2;
+    const float *pa = a.part_acc + (size_t)h * a.splits * D + d0;
+    float M = ATTN_NEG;
+#pragma unroll 8
+    for (int j = 0; j < active; ++j) M = fmaxf(M, ml[2 * j]);
+    float Lsum = 0.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int j = 0; j < active; ++j) {
+        const float2 mj = *reinterpret_cast<const float2 *>(ml + 2 * j);
+        const float4 a0 = *reinterpret_cast<const float4 *>(pa + (size_t)j * D), a1 = *reinterpret_cast<const float4 *>(pa + (size_t)j * D + 4);
+        const float w = expf(mj.x - M);
+        Lsum = fmaf(w, mj.y, Lsum);
+        A[0] = fmaf(w, a0.x, A[0]), A[1] = fmaf(w, a0.y, A[1]), A[2] = fmaf(w, a0.z, A[2]), A[3] = fmaf(w, a0.w, A[3]);
+        A[4] = fmaf(w, a1.x, A[4]), A[5] = fmaf(w, a1.y, A[5]), A[6] = fmaf(w, a1.z, A[6]), A[7] = fmaf(w, a1.w, A[7]);
+    }
     float o[8];
-    if (a.splits <= 4) attn_merge8<4>(a.part_acc, a.part_ml, a.splits, active, h, D, d0, o);
-    else attn_merge8<16>(a.part_acc, a.part_ml, a.splits, active, h, D, d0, o);  // launcher caps splits at 16
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = A[i] / Lsum;
     *reinterpret_cast<uint4 *>(a.out + (size_t)h * D + d0) =
         make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
 }

@@ -47,6 +47,7 @@ struct pie_decoder {
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     unsigned *pf_sink = nullptr;
     int pf_rows = 0;
+    bool pf_enable = true;
     size_t pf_gateup_bytes = 0;
     // caller-owned outputs (pie_decoder_bind_outputs)
     u16 *h = nullptr, *logits = nullptr;
@@ -55,9 +56,35 @@ struct pie_decoder {
     LogitStat *stats = nullptr;
     int *token_out = nullptr, *history = nullptr;
     int hist_cap = 0;
-    int n_stats = 0, splits = 16;
+    int n_stats = 0, splits = GEMV_ATTN_SPLITS;
+    // Attention plan, chosen from the cache capacity (host-known): short caches use <= 4 splits whose partials the o_proj
+    // prologue merges (one launch less); long ones spread up to 32 splits per kv-head over the chip and merge them with
+    // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
+    bool combine = false;
+    int merge_max_cap = 512, kv_cap = 0;
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
 };
+
+// Picks the split count / merge path for the current cache capacity; returns true when the launch sequence changed.
+static bool plan_attention(pie_decoder *d) {
+    const pie_decoder_config &c = d->cfg;
+    int splits;
+    if (c.kv_splits > 0) splits = c.kv_splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : c.kv_splits;
+    else if (d->kv_cap <= d->merge_max_cap) splits = GEMV_ATTN_SPLITS;
+    else {
+        splits = d->kv_cap / 64;  // >= 64 positions per workgroup, 16 per wave
+        const int fill = 256 / c.n_kv_heads > 0 ? 256 / c.n_kv_heads : 1;
+        if (splits > fill) splits = fill;
+        if (splits > ATTN_MAX_SPLITS) splits = ATTN_MAX_SPLITS;
+        if (splits < GEMV_ATTN_SPLITS) splits = GEMV_ATTN_SPLITS;
+    }
+    const bool combine = splits > GEMV_ATTN_SPLITS;
+    const bool changed = splits != d->splits || combine != d->combine;
+    d->splits = splits, d->combine = combine;
+    d->pf_rows = d->pf_enable ? (256 - c.n_kv_heads * splits) / c.n_kv_heads : 0;  // fill the CUs attention leaves idle
+    if (d->pf_rows < 0) d->pf_rows = 0;
+    return changed;
+}
 
 static int dev_alloc(void **p, size_t bytes) {
     PIE_HIP_TRY(hipMalloc(p, bytes));
@@ -99,11 +126,15 @@ static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_pt
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
             a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = pie_w4s_bytes(H, QD);
             a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
-            return attn_decode_launch(c.dtype, D, a, false, st);  // partials are merged by the o_proj prologue
+            return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
             a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h;
+            if (d->combine) {
+                a.x = d->attn;
+                return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
+            }
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
             return w4s_gemv_launch(c.dtype, PRO_ATTN, EPI_RESIDUAL, a, 1, st);
         }
@@ -182,7 +213,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     d->cfg = c;
     d->layers.resize(c.n_layers);
     d->layer_set.assign(c.n_layers, 0);
-    d->splits = c.kv_splits > 0 ? (c.kv_splits > GEMV_ATTN_SPLITS ? GEMV_ATTN_SPLITS : c.kv_splits) : GEMV_ATTN_SPLITS;
+    if (const char *e = getenv("PIE_ATTN_MERGE_MAX_CAP")) d->merge_max_cap = atoi(e);  // tuning knob: capacity up to which o_proj merges the splits
     int rc = PIE_OK;
     d->n_stats = w4s_gemv_waves(c.vocab, c.hidden);
     const int QD = c.n_heads * c.head_dim;
@@ -202,10 +233,10 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
         const long mb = e ? atol(e) : 0;
         const size_t gu = pie_w4s_bytes(2 * c.inter, c.hidden);
         d->pf_gateup_bytes = mb <= 0 ? 0 : ((size_t)mb << 20 < gu ? (size_t)mb << 20 : gu);
-        d->pf_rows = mb < 0 ? 0 : (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;  // fill the CUs attention leaves idle
-        if (d->pf_rows < 0) d->pf_rows = 0;
+        d->pf_enable = mb >= 0;
     }
 #undef PIE_ALLOC
+    plan_attention(d);
     *out = d;
     return PIE_OK;
 }
@@ -262,6 +293,8 @@ int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *co
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, st, d->state, -1, -1, capacity);
     PIE_LAUNCH_CHECK();
     d->kv_set = true;
+    d->kv_cap = capacity;
+    if (plan_attention(d)) drop_graphs(d);  // the launch sequence changed: captured graphs are stale
     return PIE_OK;
 }
 

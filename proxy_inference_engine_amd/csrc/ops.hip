@@ -7,7 +7,7 @@
 // ---------------------------------------------------------------- attention launch
 template <class T, int D>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
-    dim3 grid(a.Hkv, a.splits + a.pf_rows), block(256);
+    dim3 grid(a.Hkv, a.splits + a.pf_rows), block(ATTN_WAVES * 64);
     switch (rep) {
         case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;
@@ -138,7 +138,7 @@ int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv
     AttnArgs a = {};
     a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v;
     a.T = T, a.cap = cap, a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
-    a.splits = T >= 1024 ? ATTN_MAX_SPLITS : (T >= 128 ? 4 : 1);
+    a.splits = T >= 2048 ? ATTN_MAX_SPLITS : (T >= 512 ? 16 : (T >= 128 ? 4 : 1));
     a.part_acc = (float *)workspace;
     a.part_ml = a.part_acc + (size_t)Hq * ATTN_MAX_SPLITS * D;
     a.out = (u16 *)out;

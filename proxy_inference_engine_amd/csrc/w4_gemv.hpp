@@ -130,7 +130,6 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const int W = a.n_waves;
     const int run = gw < a.n_pairs ? (a.n_pairs - gw + W - 1) / W : 0;  // <= GEMV_MAX_RUN (host-checked)
     const int n_units = run * ns;
-    const char *wbase = a.w + (size_t)(run > 0 ? gw : 0) * ns * W4S_UNIT_BYTES + lane * 16;
     const size_t pstride = (size_t)W * ns * W4S_UNIT_BYTES;  // bytes between consecutive pairs of this wave
 
     // 1. activations first (coalesced, 8 elements per piece), then the head of the weight stream.

@@ -112,10 +112,16 @@ def test_teacher_forced_steps_and_graph_replay_identical(tiny):
     assert checked >= 3
 
 
-def test_cache_growth_across_step_boundary(tiny):
+@pytest.mark.parametrize("merge_cap", [None, "256"])
+def test_cache_growth_across_step_boundary(tiny, merge_cap, monkeypatch):
     """Decode across the 256-position capacity boundary: the cache re-allocates (256 -> 512) and the decoder must
-    pick up the new buffers; compare logits right before / after the growth with the oracle."""
+    pick up the new buffers; compare logits right before / after the growth with the oracle.  merge_cap = 256 also
+    moves the attention plan at the boundary: 4 splits merged by the o_proj prologue -> 8 splits + k_attn_combine, so the
+    captured graph has to be rebuilt mid-stream."""
     g, cfg, w, model = tiny
+    if merge_cap:
+        monkeypatch.setenv("PIE_ATTN_MERGE_MAX_CAP", merge_cap)
+        model = build(cfg, w)
     rng = np.random.default_rng(21)
     prompt = rng.integers(0, cfg["vocab_size"], 250)
     forced = rng.integers(0, cfg["vocab_size"], 12)
@@ -192,6 +198,24 @@ def test_tinyllama_shaped_layers_vs_oracle(dtype):
             assert int(tok.item()) == otok
             matched += 1
     assert cache[0].keys.shape == (1, 4, 256, 64) and cache[0].offset == 74 and matched >= 1
+
+
+def test_forced_split_counts_match_oracle(tiny):
+    """kv_splits pins the attention plan: 1 and 4 (merged in the o_proj prologue), 8 and 32 (k_attn_combine launch)."""
+    g, cfg, w, _ = tiny
+    orc = po.OracleLlama(cfg, w, DT)
+    prompt = np.random.default_rng(5).integers(0, cfg["vocab_size"], 150)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache, last_only=True)
+    ref_bits = None
+    for splits in (1, 4, 8, 32):
+        model = build(cfg, w, kv_splits=splits)
+        cache = model.make_cache()
+        _, _, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, DT, what=f"kv_splits={splits}")
+        if splits == 4:
+            ref_bits = to_bits(logits).copy()
+    assert ref_bits is not None
 
 
 def test_tied_embeddings_and_errors(tiny):
