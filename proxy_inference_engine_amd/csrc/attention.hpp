@@ -14,6 +14,12 @@
 constexpr int ATTN_MAX_SPLITS = 32;  // 8 kv-heads x 32 splits = one workgroup per CU
 constexpr int ATTN_DEPTH = 4;  // swept 4 vs 8 with 8-wave workgroups: 8 is 2-3 % slower at every context (VALU-bound, not latency-bound)
 constexpr float ATTN_NEG = -3.0e38f;
+// Softmax runs in the base-2 domain: scores are scaled by scale*log2(e) once and every exponential is one v_exp_f32
+// (expf() expands to ~9 VALU instructions for range handling the scores never need; the loop is VALU-bound at long
+// context).  Running maxima m (and the m of the split partials) are therefore log2-domain values; l and acc are the
+// same linear-domain sums either way.
+constexpr float ATTN_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float attn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Device-resident decode state: lets one captured graph serve every step.
 struct DecState {
@@ -86,6 +92,7 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
+    const float sl2 = a.scale * ATTN_LOG2E;
     const int Ttot = a.state ? a.state->pos + 1 : a.T;
     const int cap = a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
@@ -125,8 +132,7 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
         for (int j = 0; j < 8; ++j) acc[h][j] = 0.0f;
     }
 
-    // One running max per wave and head (shared by the TPW token groups): the groups' partial (l, acc) then merge by
-    // plain sums.  Reductions: DPP inside a 16-lane row, v_permlane{16,32}_swap across rows -- no LDS traffic.
+    // Reductions: DPP inside a 16-lane row; v_permlane{16,32}_swap across rows only in the post-loop merge -- no LDS traffic.
     for (int base = 0; base < n_blk; base += DA) {
 #pragma unroll
         for (int d = 0; d < DA; ++d) {
@@ -137,36 +143,71 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
                 float vf[8];
                 vf[0] = lo_f32<T>(vq[d].x), vf[1] = hi_f32<T>(vq[d].x), vf[2] = lo_f32<T>(vq[d].y), vf[3] = hi_f32<T>(vq[d].y);
                 vf[4] = lo_f32<T>(vq[d].z), vf[5] = hi_f32<T>(vq[d].z), vf[6] = lo_f32<T>(vq[d].w), vf[7] = hi_f32<T>(vq[d].w);
+                // Scores of all heads first, the DPP reduction steps written head-interleaved (each step depends on the
+                // previous one of the same head: back to back they cost a wait state each).  Every 16-lane token group keeps
+                // its OWN running max: no cross-row reduction per block, and the rescale is an exec-masked branch that is
+                // rarely taken after the first blocks.  The groups are merged once, after the loop.
+                float sc[REP];
 #pragma unroll
                 for (int h = 0; h < REP; ++h) {
-                    float sc = 0.0f;
+                    sc[h] = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sc = T::dot2(qr[h][j], kw[j], sc);
-                    sc = LPT == 16 ? lanes16_sum(sc) : lanes8_sum(sc);
-                    sc = valid ? sc * a.scale : ATTN_NEG;
-                    float bm = sc;  // block max over the wave's token groups
-                    if (LPT == 8) bm = fmaxf(bm, ror8(bm));
-                    bm = xor32_max(xor16_max(bm));
-                    const float m_new = fmaxf(m[h], bm);
-                    const float alpha = expf(m[h] - m_new);
-                    const float p = valid ? expf(sc - m_new) : 0.0f;
-                    l[h] = l[h] * alpha + p;
+                    for (int j = 0; j < 4; ++j) sc[h] = T::dot2(qr[h][j], kw[j], sc[h]);
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(acc[h][j], alpha, p * vf[j]);
-                    m[h] = m_new;
+                for (int h = 0; h < REP; ++h) sc[h] += __builtin_amdgcn_update_dpp(0.0f, sc[h], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+#pragma unroll
+                for (int h = 0; h < REP; ++h) sc[h] += __builtin_amdgcn_update_dpp(0.0f, sc[h], 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+#pragma unroll
+                for (int h = 0; h < REP; ++h) sc[h] += __builtin_amdgcn_update_dpp(0.0f, sc[h], 0x141, 0xF, 0xF, true);  // row_half_mirror
+                if (LPT == 16) {
+#pragma unroll
+                    for (int h = 0; h < REP; ++h) sc[h] += __builtin_amdgcn_update_dpp(0.0f, sc[h], 0x140, 0xF, 0xF, true);  // row_mirror
+                }
+                bool grow = false;
+#pragma unroll
+                for (int h = 0; h < REP; ++h) {
+                    sc[h] = valid ? sc[h] * sl2 : ATTN_NEG;
+                    grow |= sc[h] > m[h];
+                }
+                if (grow) {
+#pragma unroll
+                    for (int h = 0; h < REP; ++h) {
+                        const float m_new = sc[h] > m[h] ? sc[h] : m[h];
+                        const float alpha = attn_exp2(m[h] - m_new);
+                        l[h] *= alpha;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[h][j] *= alpha;
+                        m[h] = m_new;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < REP; ++h) {
+                    const float p = valid ? attn_exp2(sc[h] - m[h]) : 0.0f;
+                    l[h] += p;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(p, vf[j], acc[h][j]);
                 }
             }
             issue(d, b + DA);
         }
     }
 
-    // sum the token groups of the wave (lanes with equal dc), then one stream per wave goes to LDS
+    // merge the token groups of the wave (lanes with equal dc): common max, rescale, plain sums; then one stream per
+    // wave goes to LDS
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
+        float mw = m[h];
+        if (LPT == 8) mw = fmaxf(mw, ror8(mw));
+        mw = xor32_max(xor16_max(mw));
+        const float wg = attn_exp2(m[h] - mw);  // 0 for a group that saw no valid position (m = ATTN_NEG)
+        m[h] = mw;
+        l[h] *= wg;
         if (LPT == 8) l[h] += ror8(l[h]);
         l[h] = xor32_sum(xor16_sum(l[h]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            acc[h][j] *= wg;
             if (LPT == 8) acc[h][j] += ror8(acc[h][j]);
             acc[h][j] = xor32_sum(xor16_sum(acc[h][j]));
         }
@@ -188,7 +229,7 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
         float Lsum = 0.0f, A = 0.0f;
 #pragma unroll
         for (int i = 0; i < NSUB; ++i) {
-            const float w = expf(s_m[h][i] - M);
+            const float w = attn_exp2(s_m[h][i] - M);
             Lsum = fmaf(w, s_l[h][i], Lsum);
             A = fmaf(w, s_acc[h][i][d], A);
         }
@@ -230,7 +271,7 @@ __device__ __forceinline__ void attn_merge_finish(const AttnMergeRegs<MAXS> &r, 
     float Lsum = 0.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < MAXS; ++j) {
-        const float w = j < active ? expf(r.mj[j] - M) : 0.0f;
+        const float w = j < active ? attn_exp2(r.mj[j] - M) : 0.0f;
         Lsum = fmaf(w, r.lj[j], Lsum);
         A[0] = fmaf(w, r.a0[j].x, A[0]), A[1] = fmaf(w, r.a0[j].y, A[1]), A[2] = fmaf(w, r.a0[j].z, A[2]), A[3] = fmaf(w, r.a0[j].w, A[3]);
         A[4] = fmaf(w, r.a1[j].x, A[4]), A[5] = fmaf(w, r.a1[j].y, A[5]), A[6] = fmaf(w, r.a1[j].z, A[6]), A[7] = fmaf(w, r.a1[j].w, A[7]);
@@ -247,33 +288,45 @@ __device__ __forceinline__ void attn_merge8(const float *part_acc, const float *
 }
 
 // Stand-alone merge (op-level pie_sdpa_decode, and the decoder at long context where more than GEMV_ATTN_SPLITS splits
-// are needed to spread the work over the chip): grid Hq, block D/8 threads, 8 dims each; any split count.  Same
-// ascending-j fmaf order as attn_merge_finish, so both merge paths round identically.
+// are needed to spread the work over the chip): grid Hq, block 256 threads = (D/8 pieces of 8 dims) x (256/(D/8) split
+// groups).  Thread (piece, group g) folds splits g, g + NG, ... (all loads independent: one latency, not `active`
+// of them in series -- the serial version cost 7 us per layer at 32 splits); the groups are then summed in fixed order.
 template <class T>
-__global__ void k_attn_combine(const AttnArgs a, int D) {
-    const int h = blockIdx.x, d0 = threadIdx.x * 8;
+__global__ void __launch_bounds__(256) k_attn_combine(const AttnArgs a, int D) {
+    __shared__ float s_part[32][16][9];  // [group][piece][l, acc[8]]
+    const int h = blockIdx.x, PPH = D >> 3, NG = 256 / PPH;
+    const int pc = threadIdx.x % PPH, grp = threadIdx.x / PPH, d0 = pc * 8, lane = threadIdx.x & 63;
     const int Ttot = a.state ? a.state->pos + 1 : a.T;
-    const int active = attn_split(Ttot, a.splits).active;
+    const int active = attn_split(Ttot, a.splits).active;  // <= ATTN_MAX_SPLITS <= 64
     const float *ml = a.part_ml + (size_t)h * a.splits * 2;
     const float *pa = a.part_acc + (size_t)h * a.splits * D + d0;
-    float M = ATTN_NEG;
-#pragma unroll 8
-    for (int j = 0; j < active; ++j) M = fmaxf(M, ml[2 * j]);
+    const float M = wave_max(lane < active ? ml[2 * lane] : ATTN_NEG);
     float Lsum = 0.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int j = 0; j < active; ++j) {
+    for (int j = grp; j < active; j += NG) {
         const float2 mj = *reinterpret_cast<const float2 *>(ml + 2 * j);
         const float4 a0 = *reinterpret_cast<const float4 *>(pa + (size_t)j * D), a1 = *reinterpret_cast<const float4 *>(pa + (size_t)j * D + 4);
-        const float w = expf(mj.x - M);
+        const float w = attn_exp2(mj.x - M);
         Lsum = fmaf(w, mj.y, Lsum);
         A[0] = fmaf(w, a0.x, A[0]), A[1] = fmaf(w, a0.y, A[1]), A[2] = fmaf(w, a0.z, A[2]), A[3] = fmaf(w, a0.w, A[3]);
         A[4] = fmaf(w, a1.x, A[4]), A[5] = fmaf(w, a1.y, A[5]), A[6] = fmaf(w, a1.z, A[6]), A[7] = fmaf(w, a1.w, A[7]);
     }
-    float o[8];
+    s_part[grp][pc][0] = Lsum;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = A[i] / Lsum;
-    *reinterpret_cast<uint4 *>(a.out + (size_t)h * D + d0) =
-        make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+    for (int i = 0; i < 8; ++i) s_part[grp][pc][1 + i] = A[i];
+    __syncthreads();
+    if (grp == 0) {
+        const int ng = active < NG ? active : NG;  // groups beyond the active splits hold zeros
+        for (int g = 1; g < ng; ++g) {
+            Lsum += s_part[g][pc][0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) A[i] += s_part[g][pc][1 + i];
+        }
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = A[i] / Lsum;
+        *reinterpret_cast<uint4 *>(a.out + (size_t)h * D + d0) =
+            make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+    }
 }
 
 // combine = false: leave the partials for the consumer's prologue (decoder: o_proj GEMV, PRO_ATTN).

@@ -117,12 +117,14 @@ __device__ __forceinline__ float xor32_sum(float v) {
 __device__ __forceinline__ float xor16_max(float v) {
     const int vi = __builtin_bit_cast(int, v);
     auto r = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);
-    return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    // v_med3_f32(a, b, +inf) = max(a, b) in ONE instruction: fmaxf() on values that come out of a bit cast costs two
+    // extra canonicalising v_max each (the compiler must quiet a possible signalling NaN)
+    return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]), __builtin_inff());
 }
 __device__ __forceinline__ float xor32_max(float v) {
     const int vi = __builtin_bit_cast(int, v);
     auto r = __builtin_amdgcn_permlane32_swap(vi, vi, false, false);
-    return fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    return __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]), __builtin_inff());
 }
 // Sum over each aligned group of 8 / 16 lanes (DPP inside one 16-lane row), result in every lane of the group.
 __device__ __forceinline__ float lanes8_sum(float v) {

@@ -61,7 +61,7 @@ struct pie_decoder {
     // prologue merges (one launch less); long ones spread up to 32 splits per kv-head over the chip and merge them with
     // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
     bool combine = false;
-    int merge_max_cap = 512, kv_cap = 0;
+    int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
 };
 

@@ -17,7 +17,7 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
     }
     PIE_LAUNCH_CHECK();
     if (combine) {
-        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(D / 8), 0, st, a, D);
+        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(256), 0, st, a, D);
         PIE_LAUNCH_CHECK();
     }
     return PIE_OK;
