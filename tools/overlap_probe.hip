@@ -1,0 +1,125 @@
+// tools/overlap_probe.hip -- developer probe: does software-pipelining DEPENDENT kernels across two graph branches pay?
+//
+// A decode step is ~160 dependent launches whose fixed cost (launch gap ~1.7 us + ring fill / activation staging) is half
+// of each small kernel.  Idea under test: kernel i+1 runs CONCURRENTLY with kernel i on a second stream, prefetches its
+// (input-independent) weights, then spins on a device-side counter that kernel i's workgroups bump after a release
+// fence; only then does it read kernel i's output.  Streams alternate, so at most two kernels are resident and stream
+// order keeps kernel i+2 behind kernel i (no deadlock; the spin is bounded anyway).
+//
+// Measures one "step" of 32 x {14, 1, 9, 66, 33} MB streaming kernels: serial graph vs pipelined graph, and checks that
+// every consumer saw its producer's data (memory-ordering check).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+struct Args {
+    const uint4 *w;       // this kernel's "weights"
+    size_t n16;           // 16-byte pieces
+    unsigned *counters;   // [n_kernels] completion counters (monotonic across graph launches)
+    const unsigned *epoch;
+    int idx, wait;
+    int proto;            // bit0 acquire fence, bit1 release fence, bit2 data moves through agent-scope atomics instead
+    const float *xin;     // producer's output [gridDim.x * 16]
+    float *xout;          // this kernel's output
+    unsigned *errors;     // [0] ordering errors, [1] spin timeouts
+    unsigned *sink;
+};
+
+__global__ void __launch_bounds__(512) k_stage(const Args a) {
+    const size_t stride = (size_t)gridDim.x * 512;
+    size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+    // 1. input-independent prefetch: first two pieces of this thread's stream
+    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
+    if (i < a.n16) p0 = a.w[i];
+    if (i + stride < a.n16) p1 = a.w[i + stride];
+    const unsigned ep = *a.epoch;
+    // 2. wait for the producer (all of its workgroups), bounded
+    if (a.wait && a.idx > 0) {
+        if (threadIdx.x == 0) {
+            const unsigned target = (ep + 1) * gridDim.x;
+            int polls = 0;
+            while (__hip_atomic_load(a.counters + a.idx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++polls > (1 << 20)) { atomicAdd(a.errors + 1, 1u); break; }
+            }
+        }
+        __syncthreads();
+        if (a.proto & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // 3. consume the producer's output: every workgroup reads all of it
+    float xs = 0.0f;
+    if (a.idx > 0) {
+        const float want = (float)(ep * 1000 + a.idx - 1);
+        for (int j = threadIdx.x; j < (int)gridDim.x * 16; j += 512) {
+            const float v = (a.proto & 4) ? __hip_atomic_load(a.xin + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.xin[j];
+            if (v != want && a.wait) atomicAdd(a.errors, 1u);
+            xs += v;
+        }
+    }
+    // 4. the stream
+    unsigned acc = p0.x ^ p0.y ^ p0.z ^ p0.w ^ p1.x ^ p1.y ^ p1.z ^ p1.w;
+    for (i += 2 * stride; i < a.n16; i += stride) {
+        const uint4 v = a.w[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345u && xs == 1.5f) a.sink[0] = acc;
+    // 5. publish + release
+    if (threadIdx.x < 16) {
+        const float v = (float)(ep * 1000 + a.idx);
+        if (a.proto & 4) __hip_atomic_store(a.xout + blockIdx.x * 16 + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.xout[blockIdx.x * 16 + threadIdx.x] = v;
+    }
+    __syncthreads();  // s_waitcnt vmcnt(0): the stores above have been acknowledged
+    if (threadIdx.x == 0) {
+        if (a.proto & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(a.counters + a.idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void k_epoch(unsigned *epoch) { epoch[0] += 1; }
+
+int main() {
+    const int L = 32, per = 5, N = L * per, WG = 256;
+    const size_t mb[per] = {14, 1, 9, 66, 33};
+    uint4 *big; const size_t BIG = (size_t)1 << 30; CK(hipMalloc(&big, BIG)); CK(hipMemset(big, 1, BIG));
+    unsigned *counters, *epoch, *errors, *sink; float *x[2];
+    CK(hipMalloc(&counters, N * 4)); CK(hipMalloc(&epoch, 4)); CK(hipMalloc(&errors, 8)); CK(hipMalloc(&sink, 4));
+    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&x[i], WG * 16 * 4)); CK(hipMemset(x[i], 0, WG * 16 * 4)); }
+    hipStream_t s[2]; for (auto &st : s) CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t fork, join, e0, e1; CK(hipEventCreate(&fork)); CK(hipEventCreate(&join)); CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
+    for (int mode = 0; mode < 8; ++mode) {  // 0 serial, 1 pipelined over two branches, 2 two branches without the wait (timing only), 3 one branch with waits (always satisfied)
+        CK(hipMemset(counters, 0, N * 4)); CK(hipMemset(epoch, 0, 4)); CK(hipMemset(errors, 0, 8));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
+        const bool two = mode == 1 || mode == 2 || mode == 7;
+        const int proto = mode == 4 ? 2 : mode == 5 ? 1 : (mode == 6 || mode == 7) ? 4 : 3;
+        if (two) { CK(hipEventRecord(fork, s[0])); CK(hipStreamWaitEvent(s[1], fork, 0)); }
+        size_t off = 0;
+        for (int i = 0; i < N; ++i) {
+            Args a;
+            const size_t bytes = mb[i % per] << 20;
+            if (off + bytes > BIG) off = 0;
+            a.w = big + off / 16, a.n16 = bytes / 16, off += bytes;
+            a.counters = counters, a.epoch = epoch, a.idx = i, a.wait = (mode != 0 && mode != 2), a.proto = proto;
+            a.xin = x[(i + 1) & 1], a.xout = x[i & 1], a.errors = errors, a.sink = sink;
+            hipLaunchKernelGGL(k_stage, dim3(WG), dim3(512), 0, s[two ? (i & 1) : 0], a);
+        }
+        if (two) { CK(hipEventRecord(join, s[1])); CK(hipStreamWaitEvent(s[0], join, 0)); }
+        hipLaunchKernelGGL(k_epoch, dim3(1), dim3(1), 0, s[0], epoch);
+        CK(hipStreamEndCapture(s[0], &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, 0));
+        CK(hipDeviceSynchronize());
+        const int reps = 20;
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, 0));
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned err[2]; CK(hipMemcpy(err, errors, 8, hipMemcpyDeviceToHost));
+        // serial mode runs x through the same ping-pong buffers, so the ordering check is valid there too
+        printf("%-10s %8.1f us per step (%d kernels, %.2f us each)  ordering errors %u  spin timeouts %u\n", (const char *[]){"serial", "pipelined", "2br-nowait", "1br-wait", "1br-release", "1br-acquire", "1br-atomics", "2br-atomics"}[mode],
+               1e3 * ms / reps, N, 1e3 * ms / reps / N, err[0], err[1]);
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    }
+    return 0;
+}
