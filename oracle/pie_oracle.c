@@ -424,9 +424,51 @@ typedef struct {
     orc_linear_t lm_head;             /* unused when tied */
 } orc_llama_t;
 
+/* mx.quantized_matmul has two regimes in MLX (mlx/backend/metal/quantized.cpp + kernels/quantized.h, dependency pinned
+ * only as "mlx" in pyproject.toml:29): few rows -> qmv kernels, the exact fp32 affine sum of orc_quantized_matmul_t;
+ * many rows (prompt processing) -> qmm kernels, whose block loader DEQUANTISES the weights to T (dequantize<T>) and feeds
+ * a T x T -> fp32 MMA.  g_qmm_min_rows is the row count from which the second form is used (MLX's own switch-over is
+ * device dependent; 16 mirrors the product's prefill threshold; 0 = always the exact form). */
+static int g_qmm_min_rows = 16;
+void orc_set_qmm_min_rows(int n) { g_qmm_min_rows = n < 0 ? 0 : n; }
+int orc_get_qmm_min_rows(void) { return g_qmm_min_rows; }
+
+/* y = T( x @ mx.dequantize(w).T ) with fp32 accumulation: the qmm regime. */
+void orc_quantized_matmul_dequant(const float *x, int M, const uint32_t *wq, const void *scales, const void *biases,
+                                  int N, int K, int group_size, int bits, int dtype, const void *lin_bias, float *y) {
+    const int per_word = 32 / bits, G = K / group_size;
+    const uint32_t mask = (1u << bits) - 1u;
+#pragma omp parallel
+    {
+        float *wrow = malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            for (int k = 0; k < K; ++k) {
+                uint32_t word = wq[(size_t)n * (K / per_word) + k / per_word];
+                float q = (float)((word >> (bits * (k % per_word))) & mask);
+                float s = ldT(scales, (size_t)n * G + k / group_size, dtype);
+                float b = ldT(biases, (size_t)n * G + k / group_size, dtype);
+                wrow[k] = rnd(s * q + b, dtype);
+            }
+            for (int m = 0; m < M; ++m) {
+                const float *xr = x + (size_t)m * K;
+                float acc = 0.0f;
+                for (int k = 0; k < K; ++k) acc += xr[k] * wrow[k];
+                float out = rnd(acc, dtype);
+                if (lin_bias) out = rnd(out + ldT(lin_bias, n, dtype), dtype);
+                y[(size_t)m * N + n] = out;
+            }
+        }
+        free(wrow);
+    }
+}
+
 static void lin(const orc_llama_t *m, const orc_linear_t *p, const float *x, int M, int N, int K,
                 float *y) {
-    if (m->quantized && p->scales)
+    if (m->quantized && p->scales && g_qmm_min_rows > 0 && M >= g_qmm_min_rows)
+        orc_quantized_matmul_dequant(x, M, (const uint32_t *)p->w, p->scales, p->biases, N, K, m->group_size,
+                                     m->bits, m->dtype, p->lin_bias, y);
+    else if (m->quantized && p->scales)
         orc_quantized_matmul_t(x, M, (const uint32_t *)p->w, p->scales, p->biases, N, K, m->group_size,
                                m->bits, m->dtype, p->lin_bias, y);
     else

@@ -87,6 +87,16 @@ def max_threads() -> int:
     return lib().orc_max_threads()
 
 
+def set_qmm_min_rows(n: int) -> None:
+    """Row count from which quantised Linears use MLX's qmm form (weights dequantised to T, then a T x T -> fp32
+    matmul) instead of the exact fp32 affine sum of the qmv kernels; 0 = never.  Default 16 (pie_oracle.c)."""
+    lib().orc_set_qmm_min_rows(C.c_int(n))
+
+
+def get_qmm_min_rows() -> int:
+    return int(lib().orc_get_qmm_min_rows())
+
+
 # ------------------------------------------------------------------ dtype plumbing (numpy, bit-exact with the C helpers)
 def to_bits(x, dtype) -> np.ndarray:
     """float32 values -> storage bits of `dtype` (round-to-nearest-even)."""
@@ -138,8 +148,9 @@ def dequantize(wq, scales, biases, group_size=64, bits=4, dtype="bfloat16"):
     return out
 
 
-def quantized_matmul(x, wq, scales, biases, transpose=True, group_size=64, bits=4, dtype="bfloat16", lin_bias=None):
-    """mx.quantized_matmul(x, w, scales, biases, transpose=True, ...) (Appendix A.2).  x [..., K] -> [..., N]."""
+def quantized_matmul(x, wq, scales, biases, transpose=True, group_size=64, bits=4, dtype="bfloat16", lin_bias=None, regime="qmv"):
+    """mx.quantized_matmul(x, w, scales, biases, transpose=True, ...) (Appendix A.2).  x [..., K] -> [..., N].
+    regime: "qmv" = exact fp32 affine sum (few rows), "qmm" = weights dequantised to T first (MLX's matrix kernels)."""
     assert transpose, "the hot path only uses transpose=True (nn.QuantizedLinear)"
     x = _f32(x)
     K = x.shape[-1]
@@ -147,8 +158,8 @@ def quantized_matmul(x, wq, scales, biases, transpose=True, group_size=64, bits=
     assert wq.shape[1] * 32 // bits == K
     M = x.size // K
     y = np.empty((M, N), np.float32)
-    lib().orc_quantized_matmul_t(_p(x), M, _p(wq), _p(scales), _p(biases), N, K, group_size, bits,
-                                 _dt(dtype), _p(lin_bias), _p(y))
+    fn = lib().orc_quantized_matmul_t if regime == "qmv" else lib().orc_quantized_matmul_dequant
+    fn(_p(x), M, _p(wq), _p(scales), _p(biases), N, K, group_size, bits, _dt(dtype), _p(lin_bias), _p(y))
     return y.reshape(*x.shape[:-1], N)
 
 

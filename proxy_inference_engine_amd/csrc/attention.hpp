@@ -50,6 +50,7 @@ struct AttnArgs {
     const DecState *state;  // nullable: T = state->pos + 1, cap = state->cap
     int T, cap;
     int Hq, Hkv, splits;
+    int rows;             // prefill: query rows (blockIdx.z); row r attends T + r positions (causal inside the chunk); 0 = 1
     float scale;
     float *part_acc;  // [Hq, splits, D]
     float *part_ml;   // [Hq, splits, 2]
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;
-    const int Ttot = a.state ? a.state->pos + 1 : a.T;
+    const int row = blockIdx.z;  // query row of a prefill chunk (0 at decode)
+    const int Ttot = (a.state ? a.state->pos + 1 : a.T) + row;
     const int cap = a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
     if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     u32 qr[REP][4];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
-        uint4 qv = *reinterpret_cast<const uint4 *>(a.q + (size_t)(g * REP + h) * D + dc * 8);
+        uint4 qv = *reinterpret_cast<const uint4 *>(a.q + ((size_t)row * a.Hq + g * REP + h) * D + dc * 8);
         qr[h][0] = qv.x, qr[h][1] = qv.y, qr[h][2] = qv.z, qr[h][3] = qv.w;
     }
     float m[REP], l[REP], acc[REP][8];
@@ -233,11 +235,11 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
             Lsum = fmaf(w, s_l[h][i], Lsum);
             A = fmaf(w, s_acc[h][i][d], A);
         }
-        const int hq = g * REP + h;
-        a.part_acc[((size_t)hq * a.splits + split) * D + d] = A;
+        const size_t hq = (size_t)row * a.Hq + g * REP + h;
+        a.part_acc[(hq * a.splits + split) * D + d] = A;
         if (d == 0) {
-            a.part_ml[((size_t)hq * a.splits + split) * 2 + 0] = M;
-            a.part_ml[((size_t)hq * a.splits + split) * 2 + 1] = Lsum;
+            a.part_ml[(hq * a.splits + split) * 2 + 0] = M;
+            a.part_ml[(hq * a.splits + split) * 2 + 1] = Lsum;
         }
     }
 }
@@ -294,12 +296,13 @@ __device__ __forceinline__ void attn_merge8(const float *part_acc, const float *
 template <class T>
 __global__ void __launch_bounds__(256) k_attn_combine(const AttnArgs a, int D) {
     __shared__ float s_part[32][16][9];  // [group][piece][l, acc[8]]
-    const int h = blockIdx.x, PPH = D >> 3, NG = 256 / PPH;
+    const int row = blockIdx.y, PPH = D >> 3, NG = 256 / PPH;
+    const size_t h = (size_t)row * a.Hq + blockIdx.x;
     const int pc = threadIdx.x % PPH, grp = threadIdx.x / PPH, d0 = pc * 8, lane = threadIdx.x & 63;
-    const int Ttot = a.state ? a.state->pos + 1 : a.T;
+    const int Ttot = (a.state ? a.state->pos + 1 : a.T) + row;
     const int active = attn_split(Ttot, a.splits).active;  // <= ATTN_MAX_SPLITS <= 64
-    const float *ml = a.part_ml + (size_t)h * a.splits * 2;
-    const float *pa = a.part_acc + (size_t)h * a.splits * D + d0;
+    const float *ml = a.part_ml + h * a.splits * 2;
+    const float *pa = a.part_acc + h * a.splits * D + d0;
     const float M = wave_max(lane < active ? ml[2 * lane] : ATTN_NEG);
     float Lsum = 0.0f, A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = grp; j < active; j += NG) {
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(256) k_attn_combine(const AttnArgs a, int D) {
         float o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = A[i] / Lsum;
-        *reinterpret_cast<uint4 *>(a.out + (size_t)h * D + d0) =
+        *reinterpret_cast<uint4 *>(a.out + h * D + d0) =
             make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
     }
 }

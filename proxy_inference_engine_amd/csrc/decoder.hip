@@ -12,6 +12,7 @@
 #include "attention.hpp"
 #include "tail.hpp"
 #include "w4_gemv.hpp"
+#include "decoder.hpp"
 
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
                      void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
@@ -33,37 +34,6 @@ __global__ void k_set_state(DecState *s, int pos, int token, int cap) {
     if (token >= 0) s->token = token;
     if (cap >= 0) s->cap = cap;
 }
-
-struct pie_decoder {
-    pie_decoder_config cfg;
-    std::vector<pie_layer_weights> layers;
-    std::vector<char> layer_set;
-    pie_global_weights glob;
-    bool glob_set = false, kv_set = false;
-    // device-side state and scratch (owned)
-    DecState *state = nullptr;
-    unsigned long long *kv_table = nullptr;  // [2*n_layers]
-    u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
-    float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
-    unsigned *pf_sink = nullptr;
-    int pf_rows = 0;
-    bool pf_enable = true;
-    size_t pf_gateup_bytes = 0;
-    // caller-owned outputs (pie_decoder_bind_outputs)
-    u16 *h = nullptr, *logits = nullptr;
-    float *logprobs = nullptr;
-    bool out_set = false;
-    LogitStat *stats = nullptr;
-    int *token_out = nullptr, *history = nullptr;
-    int hist_cap = 0;
-    int n_stats = 0, splits = GEMV_ATTN_SPLITS;
-    // Attention plan, chosen from the cache capacity (host-known): short caches use <= 4 splits whose partials the o_proj
-    // prologue merges (one launch less); long ones spread up to 32 splits per kv-head over the chip and merge them with
-    // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
-    bool combine = false;
-    int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
-    hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
-};
 
 // Picks the split count / merge path for the current cache capacity; returns true when the launch sequence changed.
 static bool plan_attention(pie_decoder *d) {
@@ -101,7 +71,7 @@ static void drop_graphs(pie_decoder *d) {
 }
 
 // One launch of the step's sequence (PIE_K_* of include/pie_hip.h); `li` is the layer for per-layer kernels.
-static int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st) {
+int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
     const pie_layer_weights &w = d->layers[li];
@@ -244,6 +214,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
 int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
+    prefill_free(d);
     void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -357,6 +328,7 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     if (rc) return rc;
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
+    if (L >= prefill_min_rows()) return prefill_batched(d, ids, L, logits_all, st);  // MLX's qmm regime: dequantise-to-T GEMMs
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
         u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;

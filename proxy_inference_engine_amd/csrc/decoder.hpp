@@ -1,0 +1,46 @@
+// decoder.hpp -- the decoder object shared by decoder.hip (single-token step) and prefill.hip (batched prompt).
+#pragma once
+#include <vector>
+
+#include "attention.hpp"
+#include "tail.hpp"
+#include "w4_gemv.hpp"
+
+struct pie_decoder {
+    pie_decoder_config cfg;
+    std::vector<pie_layer_weights> layers;
+    std::vector<char> layer_set;
+    pie_global_weights glob;
+    bool glob_set = false, kv_set = false;
+    // device-side state and scratch (owned)
+    DecState *state = nullptr;
+    unsigned long long *kv_table = nullptr;  // [2*n_layers]
+    u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
+    float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
+    unsigned *pf_sink = nullptr;
+    int pf_rows = 0;
+    bool pf_enable = true;
+    size_t pf_gateup_bytes = 0;
+    // caller-owned outputs (pie_decoder_bind_outputs)
+    u16 *h = nullptr, *logits = nullptr;
+    float *logprobs = nullptr;
+    bool out_set = false;
+    LogitStat *stats = nullptr;
+    int *token_out = nullptr, *history = nullptr;
+    int hist_cap = 0;
+    int n_stats = 0, splits = GEMV_ATTN_SPLITS;
+    // Attention plan, chosen from the cache capacity (host-known): short caches use <= 4 splits whose partials the o_proj
+    // prologue merges (one launch less); long ones spread up to 32 splits per kv-head over the chip and merge them with
+    // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
+    bool combine = false;
+    int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
+    hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
+    struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
+};
+
+// prefill.hip: batched prompt processing (L >= prefill_min_rows() tokens): per layer the W4S weights are dequantised to T
+// and multiplied by hipBLASLt, with hand-written HIP kernels for RoPE + cache append, causal attention and SwiGLU.
+int prefill_min_rows();
+int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st);
+void prefill_free(pie_decoder *d);
+int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st);

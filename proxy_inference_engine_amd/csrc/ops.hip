@@ -7,7 +7,8 @@
 // ---------------------------------------------------------------- attention launch
 template <class T, int D>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
-    dim3 grid(a.Hkv, a.splits + a.pf_rows), block(ATTN_WAVES * 64);
+    const int rows = a.rows > 0 ? a.rows : 1;
+    dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
     switch (rep) {
         case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;
@@ -17,7 +18,7 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
     }
     PIE_LAUNCH_CHECK();
     if (combine) {
-        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq), dim3(256), 0, st, a, D);
+        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, rows), dim3(256), 0, st, a, D);
         PIE_LAUNCH_CHECK();
     }
     return PIE_OK;

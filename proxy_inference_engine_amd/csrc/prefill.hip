@@ -1,0 +1,321 @@
+// prefill.hip -- batched prompt processing: Model.__call__(inputs[1, L], cache) for L > 1
+// (models/llama/language.py:199-210 with the causal mask of models/base.py:18-53), SURVEY.md 8 row f1.
+//
+// At L > 1 the reference's nn.QuantizedLinear reaches MLX's matrix kernels (qmm), which dequantise the int4 block to T
+// and feed a T x T -> fp32 MMA; the vector kernels (qmv, exact fp32 affine math) serve only the few-row case.  This file
+// follows that split: prompts of prefill_min_rows() tokens or more run here, shorter ones as iterated decode steps.
+//
+// MI355X design: 288 GB of HBM make a transient T copy of one layer's weights cheap, and a T x T GEMM is a plain library
+// GEMM, so per layer and chunk
+//   * k_dequant_w4s   W4S units -> T [N, K]  (the mx.dequantize arithmetic: T(fp32(s*q) + b)), into one reused scratch;
+//   * hipBLASLt       y[M, N] = x[M, K] . W_T[N, K]^T, fp32 accumulate, one rounding  (dlopen'ed: the process may
+//                     already hold torch's copy of the library, and a second copy must not be loaded next to it);
+//   * hand-written HIP for everything around it: RMSNorm rows, RoPE + cache append from the packed q|k|v rows, causal
+//     attention (the decode kernel with one query row per blockIdx.z: row r attends offset + r + 1 positions), the
+//     split merge, SwiGLU on the interleaved gate/up rows, residual adds.
+// The chunk is bounded (PIE_PREFILL_CHUNK, default 1024 rows) so scratch stays small next to the weights.
+#include <dlfcn.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <cstdlib>
+#include <map>
+#include <tuple>
+
+#include "decoder.hpp"
+
+int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+
+// ---------------------------------------------------------------- kernels
+// W4S -> T row-major [N, K]; one thread per code word (8 weights, 16 B out).  Same arithmetic as k_dequantize_w4g64.
+template <class T>
+__global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = K >> 3;  // words per row
+    if (idx >= (size_t)N * wpr) return;
+    const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
+    const int g = wk >> 3, lane = (r & 1) * 32 + (g & 31), j = (wk & 7) >> 2, t = wk & 3;
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W4S_UNIT_BYTES / 4);
+    const u32 word = unit[j * 256 + lane * 4 + t], sb = unit[512 + lane];
+    const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
+    u32 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // codes (2i, 2i+1) sit in the low / high half at nibble i (the W4S nibble order)
+        const float lo = __fadd_rn(__fmul_rn(s, (float)((word >> (4 * i)) & 0xFu)), b);
+        const float hi = __fadd_rn(__fmul_rn(s, (float)((word >> (16 + 4 * i)) & 0xFu)), b);
+        o[i] = pack2<T>(lo, hi);
+    }
+    *reinterpret_cast<uint4 *>(out + (size_t)r * K + (size_t)wk * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:134-137) for M rows of the packed
+// q|k|v projection: packed columns (2i, 2i+1) of a q/k head are its dims (i, i + D/2); v columns are natural.
+// grid M, one thread per packed column pair.
+template <class T>
+__global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
+                                                         const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
+                                                         int n_kv_heads, int HD, u16 *q_out) {
+    const int m = blockIdx.x, pos = state->pos + m, cap = state->cap, half = HD >> 1;
+    const int q_cols = n_heads * HD, k_cols = n_kv_heads * HD;
+    u16 *kdst = reinterpret_cast<u16 *>(kv_table[layer]), *vdst = reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
+    const u16 *row = qkv + (size_t)m * n_cols;
+    for (int p = threadIdx.x; p < (n_cols >> 1); p += blockDim.x) {
+        const int R = 2 * p;
+        const u32 pr = *reinterpret_cast<const u32 *>(row + R);
+        const float ra = lo_f32<T>(pr), rb = hi_f32<T>(pr);
+        if (R < q_cols + k_cols) {
+            const int rr = R < q_cols ? R : R - q_cols;
+            const int head = rr / HD, ii = (rr % HD) >> 1;
+            float sn, cs;
+            sincosf((float)pos * (1.0f / freqs[ii]), &sn, &cs);
+            u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + pos) * HD;
+            dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
+            dst[ii + half] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
+        } else {
+            const int rr = R - q_cols - k_cols;
+            *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + pos) * HD + rr % HD) = pr;
+        }
+    }
+}
+
+// nn.silu(gate) * up (language.py:127) on interleaved columns (2i, 2i+1) = (gate_i, up_i); 4 outputs per thread.
+template <class T>
+__global__ void k_swiglu_rows(const u16 *gu, size_t n_out, u16 *act) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n_out) return;  // n_out is a multiple of 4 (inter % 64 == 0)
+    const uint4 v = *reinterpret_cast<const uint4 *>(gu + 2 * i);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    u16 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float g = lo_f32<T>(w[k]), u = hi_f32<T>(w[k]);
+        o[k] = T::from_f32(round_T<T>(g / (1.0f + expf(-g))) * u);
+    }
+    *reinterpret_cast<uint2 *>(act + i) = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
+}
+
+__global__ void k_add_pos(DecState *s, int delta) { s->pos += delta; }
+
+// ---------------------------------------------------------------- hipBLASLt through dlopen
+namespace {
+struct LtApi {
+    void *lib = nullptr;
+    decltype(&hipblasLtCreate) Create = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
+    decltype(&hipblasLtMatmul) Matmul = nullptr;
+    hipblasLtHandle_t handle = nullptr;
+    hipblasLtMatmulPreference_t pref = nullptr;
+    void *workspace = nullptr;
+    size_t ws_bytes = 64u << 20;
+    struct Plan {
+        hipblasLtMatmulDesc_t desc;
+        hipblasLtMatrixLayout_t la, lb, lc;
+        hipblasLtMatmulAlgo_t algo;
+    };
+    std::map<std::tuple<int, int, int, int>, Plan> plans;  // (dtype, M, N, K)
+};
+LtApi g_lt;
+
+int lt_init() {
+    if (g_lt.handle) return PIE_OK;
+    const char *names[] = {"libhipblaslt.so.1", "libhipblaslt.so", "/opt/rocm/lib/libhipblaslt.so"};
+    for (const char *n : names)  // a copy the process already holds (torch's) wins over loading a second one
+        if ((g_lt.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    for (const char *n : names)
+        if (!g_lt.lib) g_lt.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    PIE_REQUIRE(g_lt.lib, PIE_E_STATE, std::string("prefill: cannot load hipBLASLt: ") + dlerror());
+#define LT_SYM(field, name)                                                        \
+    g_lt.field = reinterpret_cast<decltype(g_lt.field)>(dlsym(g_lt.lib, #name)); \
+    PIE_REQUIRE(g_lt.field, PIE_E_STATE, "prefill: hipBLASLt lacks " #name)
+    LT_SYM(Create, hipblasLtCreate);
+    LT_SYM(DescCreate, hipblasLtMatmulDescCreate);
+    LT_SYM(DescSet, hipblasLtMatmulDescSetAttribute);
+    LT_SYM(LayoutCreate, hipblasLtMatrixLayoutCreate);
+    LT_SYM(PrefCreate, hipblasLtMatmulPreferenceCreate);
+    LT_SYM(PrefSet, hipblasLtMatmulPreferenceSetAttribute);
+    LT_SYM(Heuristic, hipblasLtMatmulAlgoGetHeuristic);
+    LT_SYM(Matmul, hipblasLtMatmul);
+#undef LT_SYM
+    PIE_REQUIRE(g_lt.Create(&g_lt.handle) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtCreate failed");
+    PIE_REQUIRE(g_lt.PrefCreate(&g_lt.pref) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtMatmulPreferenceCreate failed");
+    PIE_HIP_TRY(hipMalloc(&g_lt.workspace, g_lt.ws_bytes));
+    g_lt.PrefSet(g_lt.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g_lt.ws_bytes, sizeof(g_lt.ws_bytes));
+    return PIE_OK;
+}
+
+// y[M, N] = x[M, K] . w[N, K]^T  (row-major T in, fp32 accumulate, T out).  Column-major view: Y'[N, M] = W'^T . X'.
+int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
+    int rc = lt_init();
+    if (rc) return rc;
+    const auto key = std::make_tuple(dtype, M, N, K);
+    auto it = g_lt.plans.find(key);
+    if (it == g_lt.plans.end()) {
+        LtApi::Plan p;
+        const hipDataType dt = dtype == PIE_BF16 ? HIP_R_16BF : HIP_R_16F;
+        PIE_REQUIRE(g_lt.DescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: matmul desc");
+        const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+        g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+        g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+        PIE_REQUIRE(g_lt.LayoutCreate(&p.la, dt, K, N, K) == HIPBLAS_STATUS_SUCCESS && g_lt.LayoutCreate(&p.lb, dt, K, M, K) == HIPBLAS_STATUS_SUCCESS &&
+                        g_lt.LayoutCreate(&p.lc, dt, N, M, N) == HIPBLAS_STATUS_SUCCESS,
+                    PIE_E_HIP, "prefill: matrix layouts");
+        hipblasLtMatmulHeuristicResult_t res[1];
+        int n_res = 0;
+        const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, 1, res, &n_res);
+        PIE_REQUIRE(hs == HIPBLAS_STATUS_SUCCESS && n_res > 0, PIE_E_HIP, "prefill: hipBLASLt has no kernel for this GEMM shape");
+        p.algo = res[0].algo;
+        it = g_lt.plans.emplace(key, p).first;
+    }
+    const float alpha = 1.0f, beta = 0.0f;
+    const LtApi::Plan &p = it->second;
+    const hipblasStatus_t ms = g_lt.Matmul(g_lt.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, y, p.lc, y, p.lc, &p.algo, g_lt.workspace,
+                                           g_lt.ws_bytes, st);
+    PIE_REQUIRE(ms == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtMatmul failed");
+    return PIE_OK;
+}
+}  // namespace
+
+// ---------------------------------------------------------------- scratch
+struct PrefillScratch {
+    int rows = 0;           // chunk capacity (rows)
+    size_t w_elems = 0;     // capacity of the dequantised-weight buffer (elements)
+    u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
+    float *part_acc = nullptr, *part_ml = nullptr;
+    int part_splits = 0;
+};
+
+static void scratch_release(PrefillScratch *s) {
+    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    *s = PrefillScratch();
+}
+
+void prefill_free(pie_decoder *d) {
+    if (!d->prefill) return;
+    scratch_release(d->prefill);
+    delete d->prefill;
+    d->prefill = nullptr;
+}
+
+int prefill_min_rows() {  // read per call (not cached): tests and tools switch regimes inside one process
+    const char *e = getenv("PIE_PREFILL_MIN");  // prompts shorter than this run as iterated decode steps (MLX's qmv regime)
+    const int n = e ? atoi(e) : 16;
+    return n < 2 ? 2 : n;
+}
+
+static int prefill_chunk_rows() {
+    const char *e = getenv("PIE_PREFILL_CHUNK");
+    const int n = e ? atoi(e) : 1024;
+    return n < 16 ? 16 : (n > 8192 ? 8192 : n);
+}
+
+static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits) {
+    if (!d->prefill) d->prefill = new PrefillScratch();
+    PrefillScratch *s = d->prefill;
+    const pie_decoder_config &c = d->cfg;
+    const size_t QD = (size_t)c.n_heads * c.head_dim, NQKV = QD + 2 * (size_t)c.n_kv_heads * c.head_dim;
+    if (rows > s->rows || splits > s->part_splits) {
+        const size_t we = s->w_elems > w_elems ? s->w_elems : w_elems;
+        scratch_release(s);
+        const size_t R = (size_t)rows;
+#define PF_ALLOC(ptr, bytes) PIE_HIP_TRY(hipMalloc((void **)&(ptr), (bytes)))
+        PF_ALLOC(s->x, 2 * R * c.hidden);
+        PF_ALLOC(s->xn, 2 * R * c.hidden);
+        PF_ALLOC(s->r, 2 * R * c.hidden);
+        PF_ALLOC(s->qkv, 2 * R * NQKV);
+        PF_ALLOC(s->q, 2 * R * QD);
+        PF_ALLOC(s->attn, 2 * R * QD);
+        PF_ALLOC(s->gu, 2 * R * 2 * c.inter);
+        PF_ALLOC(s->act, 2 * R * c.inter);
+        PF_ALLOC(s->part_acc, 4 * R * c.n_heads * splits * c.head_dim);
+        PF_ALLOC(s->part_ml, 4 * R * c.n_heads * splits * 2);
+        PF_ALLOC(s->wT, 2 * we);
+        s->rows = rows, s->part_splits = splits, s->w_elems = we;
+    }
+    if (w_elems > s->w_elems) {
+        if (s->wT) (void)hipFree(s->wT);
+        s->wT = nullptr;
+        PF_ALLOC(s->wT, 2 * w_elems);
+        s->w_elems = w_elems;
+    }
+#undef PF_ALLOC
+    return PIE_OK;
+}
+
+// ---------------------------------------------------------------- the batched forward
+template <class T>
+static int linear_rows(pie_decoder *d, const void *w4s, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st) {
+    const size_t words = (size_t)N * (K >> 3);
+    hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K),
+                       d->prefill->wT);
+    PIE_LAUNCH_CHECK();
+    return gemm_xwt(d->cfg.dtype, x, d->prefill->wT, y, M, N, K, st);
+}
+
+template <class T>
+static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
+    const pie_decoder_config &c = d->cfg;
+    const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
+    const int chunk = prefill_chunk_rows() < L ? prefill_chunk_rows() : L;
+    size_t w_elems = (size_t)2 * I * H;
+    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
+    if (logits_all && (size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    int rc = scratch_reserve(d, chunk, w_elems, d->splits);
+    if (rc) return rc;
+    PrefillScratch *s = d->prefill;
+    for (int c0 = 0; c0 < L; c0 += chunk) {
+        const int M = L - c0 < chunk ? L - c0 : chunk;
+        // h = embed_tokens(inputs)  (language.py:176)
+        if ((rc = embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
+                                   nullptr, nullptr, 0, st)))
+            return rc;
+        for (int li = 0; li < c.n_layers; ++li) {
+            const pie_layer_weights &w = d->layers[li];
+            // Attention.__call__ (language.py:75-108) on input_layernorm(x)
+            if ((rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st))) return rc;
+            hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
+                               c.n_layers, c.n_heads, c.n_kv_heads, D, s->q);
+            PIE_LAUNCH_CHECK();
+            AttnArgs a = {};
+            a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
+            a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.rows = M, a.scale = 1.0f / sqrtf((float)D);
+            a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
+            if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st))) return rc;
+            if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // h = x + r (language.py:151)
+            // MLP.__call__ (language.py:126-127) on post_attention_layernorm(h)
+            if ((rc = pie_rms_norm(s->x, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st))) return rc;
+            const size_t n_act = (size_t)M * I;
+            hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
+            PIE_LAUNCH_CHECK();
+            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st))) return rc;
+            if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // out = h + r (language.py:153)
+        }
+        if (logits_all) {  // lm_head on every position, like the reference (language.py:205-209)
+            if ((rc = pie_rms_norm(s->x, d->glob.final_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, M, (u16 *)logits_all + (size_t)c0 * c.vocab, st))) return rc;
+        }
+        const bool last = c0 + M >= L;
+        if (last)  // the last position continues through the decode step's lm_head + tail below
+            PIE_HIP_TRY(hipMemcpyAsync(d->h, s->x + (size_t)(M - 1) * H, 2 * (size_t)H, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_add_pos, dim3(1), dim3(1), 0, st, d->state, last ? M - 1 : M);
+        PIE_LAUNCH_CHECK();
+    }
+    // logits[:, -1, :] -> logprobs -> greedy token; the tail advances the device-side offset past the last prompt token
+    if ((rc = enqueue_kernel(d, PIE_K_LMHEAD, 0, nullptr, d->logits, st))) return rc;
+    return enqueue_kernel(d, PIE_K_TAIL, 0, nullptr, d->logits, st);
+}
+
+int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
+    const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
+    PIE_REQUIRE(rep == 1 || rep == 2 || rep == 4 || rep == 8, PIE_E_SHAPE, "prefill: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+    return d->cfg.dtype == PIE_BF16 ? prefill_t<BF16>(d, ids, L, logits_all, st) : prefill_t<F16>(d, ids, L, logits_all, st);
+}

@@ -218,6 +218,65 @@ def test_forced_split_counts_match_oracle(tiny):
     assert ref_bits is not None
 
 
+def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
+    """Prompt processing.  Prompts of >= PIE_PREFILL_MIN (16) tokens run as batched GEMMs on weights
+    dequantised to T (MLX's qmm regime, oracle qmm_min_rows = 16), in chunks of PIE_PREFILL_CHUNK rows; shorter ones as
+    iterated decode steps (qmv regime: exact fp32 affine sums).  Both against the oracle in the matching regime, every
+    position, with a ragged last chunk (100 = 3 x 32 + 4) and a second call that continues at a non-zero offset."""
+    g, cfg, w, model = tiny
+    rng = np.random.default_rng(31)
+    prompt, more = rng.integers(0, cfg["vocab_size"], 100), rng.integers(0, cfg["vocab_size"], 40)
+    orc = po.OracleLlama(cfg, w, DT)
+    for regime, rows, env in (("batched", 16, {"PIE_PREFILL_CHUNK": "32"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
+        for k in ("PIE_PREFILL_CHUNK", "PIE_PREFILL_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        po.set_qmm_min_rows(rows)
+        try:
+            ocache = [po.OracleKVCache() for _ in orc.layers]
+            want1 = orc.forward(prompt, ocache)
+            want2 = orc.forward(more, ocache)
+        finally:
+            po.set_qmm_min_rows(16)
+        cache = model.make_cache()
+        got1 = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        got2 = model(torch.from_numpy(more)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        assert cache[0].offset == 140
+        for l in range(100):
+            assert_vec_close(got1[l], want1[l], DT, what=f"{regime} position {l}")
+        for l in range(40):
+            assert_vec_close(got2[l], want2[l], DT, what=f"{regime} continuation position {100 + l}")
+        # the cache rows written by the batched RoPE + append kernel, against the oracle's cache
+        k_gpu = cache[0].keys[0, :, :140].float().cpu().numpy()
+        assert_vec_close(k_gpu.ravel(), ocache[0].keys[0, :, :140].ravel(), DT, what=f"{regime} layer-0 keys")
+
+
+def test_batched_prefill_llama8b_shapes(monkeypatch):
+    """The real GEMM shapes (N = 6144 / 4096 / 28672, K = 4096 / 14336) on two Llama-3-8B-shaped layers: 48-token prompt
+    through the batched path, then decode steps on the cache it filled."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=3, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(12).integers(0, cfg["vocab_size"], 48)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what="prefill hidden")
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="prefill logits")
+    for _ in range(2):
+        t = int(tok.item())
+        want = orc.forward(np.array([t]), ocache)[0]
+        tok, lp, logits = model.step(None, cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode after batched prefill")
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)

@@ -166,3 +166,34 @@ def test_kv_cache_growth_and_prefix_reuse():
     rest = pc(np.concatenate([np.arange(50), np.arange(900, 1200)]))
     assert len(rest) == 300 and pc.cache[0].offset == 50 and pc.cache[0].keys.shape[2] == 512
     assert pc(np.array([999, 1, 2])).tolist() == [999, 1, 2]       # no common prefix: cache untouched
+
+
+def test_qmm_regime_is_dequantize_then_matmul_and_close_to_qmv():
+    """MLX's two quantized_matmul regimes (oracle/pie_oracle.c: lin): the qmm form equals mx.dequantize followed by a dense
+    T x T -> fp32 matmul, and stays within a fraction of an output ulp (rms) of the exact qmv form."""
+    rng = np.random.default_rng(5)
+    N, K, M = 96, 256, 20
+    wq, sc, bi = po.quantize(po.round_T(rng.standard_normal((N, K)) * 0.05, "bfloat16"), dtype="bfloat16")
+    x = po.round_T(rng.standard_normal((M, K)), "bfloat16")
+    exact = po.quantized_matmul(x, wq, sc, bi, dtype="bfloat16")
+    dense = po.linear(x, po.to_bits(po.dequantize(wq, sc, bi, dtype="bfloat16"), "bfloat16"), "bfloat16")
+    assert np.array_equal(po.quantized_matmul(x, wq, sc, bi, dtype="bfloat16", regime="qmm"), dense)
+    cfg = dict(po.TINY_CONFIG)
+    w = po.synth_checkpoint(cfg, seed=2, dtype="bfloat16")
+    orc = po.OracleLlama(cfg, w, "bfloat16")
+    ids = rng.integers(0, cfg["vocab_size"], 20)
+    try:
+        po.set_qmm_min_rows(0)
+        a = orc.forward(ids, [po.OracleKVCache() for _ in orc.layers])
+        po.set_qmm_min_rows(16)
+        b = orc.forward(ids, [po.OracleKVCache() for _ in orc.layers])
+        c = orc.forward(ids[:15], [po.OracleKVCache() for _ in orc.layers])   # below the threshold: the exact form
+    finally:
+        po.set_qmm_min_rows(16)
+    assert po.get_qmm_min_rows() == 16
+    assert np.array_equal(c, a[:15])                                   # causal model: first 15 rows do not see the rest
+    assert not np.array_equal(a, b)                                    # the regimes differ ...
+    err = np.abs(a - b)
+    assert err.max() <= 4 * 2.0 ** -8 * np.abs(a).max()                # ... inside the end-to-end parity bound
+    d = np.abs(exact - dense)
+    assert d.max() <= 2.0 ** -7 * np.abs(exact).max() and (d > 0).mean() < 0.6
