@@ -22,6 +22,7 @@
 #include <tuple>
 
 #include "decoder.hpp"
+#include "prefill_attn.hpp"
 
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
                      void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
@@ -269,6 +270,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
     int rc = scratch_reserve(d, chunk, w_elems, d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
+    const char *am = getenv("PIE_PREFILL_ATTN");  // "valu" forces the row-per-launch-slice VALU kernel (tests compare the two)
+    const bool mfma_attn = D == 128 && !(am && am[0] == 'v');
     for (int c0 = 0; c0 < L; c0 += chunk) {
         const int M = L - c0 < chunk ? L - c0 : chunk;
         // h = embed_tokens(inputs)  (language.py:176)
@@ -283,11 +286,18 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                c.n_layers, c.n_heads, c.n_kv_heads, D, s->q);
             PIE_LAUNCH_CHECK();
-            AttnArgs a = {};
-            a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
-            a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.rows = M, a.scale = 1.0f / sqrtf((float)D);
-            a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
-            if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+            if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
+                PrefillAttnArgs pa = {};
+                pa.q = s->q, pa.kv_table = d->kv_table, pa.layer = li, pa.n_layers = c.n_layers, pa.state = d->state;
+                pa.M = M, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
+                if ((rc = prefill_attn_launch_t<T>(pa, st))) return rc;
+            } else {  // head_dim 64: the VALU decode kernel, one query row per blockIdx.z
+                AttnArgs a = {};
+                a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
+                a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.rows = M, a.scale = 1.0f / sqrtf((float)D);
+                a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
+                if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+            }
             if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st))) return rc;
             if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // h = x + r (language.py:151)
             // MLP.__call__ (language.py:126-127) on post_attention_layernorm(h)

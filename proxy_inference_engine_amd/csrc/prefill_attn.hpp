@@ -1,0 +1,203 @@
+// prefill_attn.hpp -- causal flash attention for prompt chunks on the MFMA units (head_dim 128).
+//
+// Replaces mx.fast.scaled_dot_product_attention(q, k, v, scale, mask=causal) at models/base.py:111-113 for L > 1
+// (mask built by models/base.py:18-53: query row r at absolute position offset + r sees keys 0 .. offset + r).
+// The VALU decode kernel run once per query row costs 27 wave-instructions per (query, key, kv-group): O(L^2) and the
+// whole prefill beyond ~1k tokens.  Here one workgroup owns (32 query rows) x (one kv-head group); wave w owns q-head
+// g*REP + w, so a staged K/V block serves all q-heads of the group.
+//
+// Per 32-key block, per wave (v_mfma_f32_32x32x16, fp32 accumulators):
+//   S^T[key, row]  = K . Q^T        8 MFMAs;  A = K rows from the LDS image (ds_read_b128), B = Q fragments kept in VGPRs.
+//                                   Orientation chosen so the softmax reduction runs over REGISTERS (keys), not lanes,
+//                                   and so P^T is directly the B operand of the next product (no lane movement);
+//   online softmax in fp32, base 2 (one v_exp_f32 per score), running max / sum per query row = per lane pair;
+//   O^T[dim, row] += V^T . P^T      A = V^T via ds_read_b64_tr_b16 (hardware transpose of the row-major V image),
+//                                   B = P^T split into hi + lo halves of T (2 x 8 MFMAs): P keeps ~16 mantissa bits, the
+//                                   "fp32 until one rounding" contract of the fused kernel within 2^-17.
+// K/V blocks are fetched to registers one block ahead and written to a 16 KB swizzled LDS image (the guide's dual-use
+// layout (b): conflict-free for both the row reads and the transposed reads).
+#pragma once
+#include "attention.hpp"
+#include "common.hpp"
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct PrefillAttnArgs {
+    const u16 *q;                        // [M, Hq, 128]
+    const unsigned long long *kv_table;  // K buffers then V buffers, [Hkv, cap, 128] each
+    int layer, n_layers;
+    const DecState *state;               // pos = offset of row 0, cap
+    int M, Hq, Hkv;
+    float scale;
+    u16 *out;                            // [M, Hq, 128]
+};
+
+template <class T> struct MfmaT;
+template <> struct MfmaT<BF16> {
+    static __device__ __forceinline__ f32x16_t run(const uint4 &a, const uint4 &b, const f32x16_t &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct MfmaT<F16> {
+    static __device__ __forceinline__ f32x16_t run(const uint4 &a, const uint4 &b, const f32x16_t &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` (0..31) in a [32][128 x 16-bit] LDS tile
+__device__ __forceinline__ int pa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <class T, int REP>
+__global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs a) {
+    constexpr int D = 128, BK = 32, NT = REP * 64, CPT = (BK * 16 + NT - 1) / NT;  // 16-byte chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) char k_lds[BK * 256], v_lds[BK * 256];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 32, g = blockIdx.y, hq = g * REP + wave;
+    const int pos0 = a.state->pos, cap = a.state->cap;
+    const int r_last = (r0 + 31 < a.M ? r0 + 31 : a.M - 1);
+    const int t_last = pos0 + r_last;            // last key any row of this tile attends
+    const int n_blocks = t_last / BK + 1;
+    const u16 *kbase = reinterpret_cast<const u16 *>(a.kv_table[a.layer]) + (size_t)g * cap * D;
+    const u16 *vbase = reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]) + (size_t)g * cap * D;
+
+    // staging: chunk id x = threadIdx.x + i*NT -> (row = x / 16, ch = x % 16); keys past t_last are clamped (masked later)
+    uint4 kreg[CPT], vreg[CPT];
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int x = threadIdx.x + i * NT;
+            x = x < BK * 16 ? x : BK * 16 - 1;
+            int t = b * BK + (x >> 4);
+            t = t < t_last ? t : t_last;
+            kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x & 15) * 8);
+            vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x & 15) * 8);
+        }
+    };
+    auto publish = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int x = threadIdx.x + i * NT;
+            if (x < BK * 16) {
+                *reinterpret_cast<uint4 *>(k_lds + pa_off(x >> 4, x & 15)) = kreg[i];
+                *reinterpret_cast<uint4 *>(v_lds + pa_off(x >> 4, x & 15)) = vreg[i];
+            }
+        }
+    };
+    fetch(0);
+
+    // Q fragments (B operand of K . Q^T): lane (row c, half h), k-step s holds Q[r0 + c][hq][16 s + 8 h .. + 8]
+    const int qrow = r0 + c < a.M ? r0 + c : a.M - 1;
+    uint4 qf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const uint4 *>(a.q + ((size_t)qrow * a.Hq + hq) * D + 16 * s + 8 * h);
+    const int t_row = pos0 + r0 + c;  // last key this lane's query row attends (rows past M are padding: never stored)
+    const float sl2 = a.scale * ATTN_LOG2E;
+
+    f32x16_t oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.0f;
+    float m_run = ATTN_NEG, l_run = 0.0f;
+
+    // transposed-read addressing (guide T10): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
+    // 4-row x 16-column block; lane i of the group receives column i, row q in element q
+    const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+
+    for (int b = 0; b < n_blocks; ++b) {
+        __syncthreads();  // every wave is done reading the previous block's image
+        publish();
+        __syncthreads();
+        if (b + 1 < n_blocks) fetch(b + 1);
+
+        // S^T = K . Q^T : rows = keys (registers), cols = query rows (lanes)
+        f32x16_t sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint4 kf = *reinterpret_cast<const uint4 *>(k_lds + pa_off(c, 2 * s + h));
+            sacc = MfmaT<T>::run(kf, qf[s], sacc);
+        }
+        // online softmax over keys: register i <-> key t0 + (i & 3) + 8 (i >> 2) + 4 h
+        const int t0 = b * BK;
+        float sc[16], mloc = ATTN_NEG;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            sc[i] = t <= t_row ? sacc[i] * sl2 : ATTN_NEG;
+            mloc = fmaxf(mloc, sc[i]);
+        }
+        mloc = xor32_max(mloc);  // the other 16 keys of the block live in the partner lane
+        const float m_new = fmaxf(m_run, mloc);
+        if (m_new > m_run) {  // rare after the first blocks
+            const float alpha = attn_exp2(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+            m_run = m_new;
+        }
+        u32 phi[8], plo[8];
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const int ta = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float pa = ta <= t_row ? attn_exp2(sc[i] - m_run) : 0.0f;
+            const float pb = ta + 1 <= t_row ? attn_exp2(sc[i + 1] - m_run) : 0.0f;
+            l_run += pa + pb;
+            const float ha = round_T<T>(pa), hb = round_T<T>(pb);
+            phi[i >> 1] = pack2<T>(ha, hb);
+            plo[i >> 1] = pack2<T>(pa - ha, pb - hb);
+        }
+        // O^T += V^T . P^T : k-step s covers keys 16 s .. 16 s + 15 in the operand order 16 s + 8 (j >> 2) + 4 h + (j & 3)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint4 bh = make_uint4(phi[4 * s], phi[4 * s + 1], phi[4 * s + 2], phi[4 * s + 3]);
+            const uint4 bl = make_uint4(plo[4 * s], plo[4 * s + 1], plo[4 * s + 2], plo[4 * s + 3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int ch = 4 * dt + 2 * (grp & 1) + (tp >> 1);
+                const v4i16_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off(16 * s + 4 * h + tq, ch) + 8 * (tp & 1)));
+                const v4i16_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off(16 * s + 8 + 4 * h + tq, ch) + 8 * (tp & 1)));
+                const uint2 a0 = __builtin_bit_cast(uint2, lo4), a1 = __builtin_bit_cast(uint2, hi4);
+                const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                oacc[dt] = MfmaT<T>::run(vf, bh, oacc[dt]);
+                oacc[dt] = MfmaT<T>::run(vf, bl, oacc[dt]);
+            }
+        }
+    }
+    // normalise: the pair (lane, lane ^ 32) shares the query row and holds the two halves of the row sum
+    const float inv = 1.0f / xor32_sum(l_run);
+    if (r0 + c < a.M) {
+        u16 *orow = a.out + ((size_t)(r0 + c) * a.Hq + hq) * D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // registers 4k .. 4k+3 <-> dims 32 dt + 8 k + 4 h + {0..3}
+                const uint2 o = make_uint2(pack2<T>(oacc[dt][4 * k] * inv, oacc[dt][4 * k + 1] * inv),
+                                           pack2<T>(oacc[dt][4 * k + 2] * inv, oacc[dt][4 * k + 3] * inv));
+                *reinterpret_cast<uint2 *>(orow + 32 * dt + 8 * k + 4 * h) = o;
+            }
+    }
+}
+
+template <class T>
+static int prefill_attn_launch_t(const PrefillAttnArgs &a, hipStream_t st) {
+    const dim3 grid((a.M + 31) / 32, a.Hkv);
+    switch (a.Hq / a.Hkv) {
+        case 1: hipLaunchKernelGGL((k_prefill_attn<T, 1>), grid, dim3(64), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_prefill_attn<T, 2>), grid, dim3(128), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_prefill_attn<T, 4>), grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_prefill_attn<T, 8>), grid, dim3(512), 0, st, a); break;
+        default: return pie::fail(PIE_E_SHAPE, "prefill attention: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+    }
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}

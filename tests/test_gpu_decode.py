@@ -277,6 +277,41 @@ def test_batched_prefill_llama8b_shapes(monkeypatch):
         assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode after batched prefill")
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
+    """head_dim 128 prompts use the MFMA causal flash-attention kernel (prefill_attn.hpp).  One Llama-3-8B-shaped layer,
+    300-token prompt (ten key blocks, diagonal masking, a ragged last query tile: 300 = 9 x 32 + 12) and a 45-token
+    continuation at offset 300 (query rows that start in the middle of a key block): against the oracle and against the
+    VALU kernel run once per query row (PIE_PREFILL_ATTN=valu), on logits, hidden state and the cache rows."""
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 1, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 2048,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=9, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    rng = np.random.default_rng(17)
+    p1, p2 = rng.integers(0, cfg["vocab_size"], 300), rng.integers(0, cfg["vocab_size"], 45)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want1 = orc.forward(p1, ocache)
+    want2 = orc.forward(p2, ocache)
+    got = {}
+    for mode in ("mfma", "valu"):
+        monkeypatch.setenv("PIE_PREFILL_ATTN", mode)
+        cache = model.make_cache()
+        a = model(torch.from_numpy(p1)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        b = model(torch.from_numpy(p2)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        got[mode] = (a, b)
+        for l in (0, 1, 31, 32, 33, 63, 64, 150, 287, 288, 299):
+            assert_vec_close(a[l], want1[l], dtype, what=f"{mode} position {l}")
+        for l in (0, 3, 4, 20, 44):
+            assert_vec_close(b[l], want2[l], dtype, what=f"{mode} continuation position {300 + l}")
+    # the two attention kernels agree to about one T rounding (rms), half the oracle tolerance
+    for x, y in zip(got["mfma"], got["valu"]):
+        d = np.abs(x - y)
+        assert d.max() <= 2 * EPS[dtype] * np.abs(y).max() and np.sqrt((d ** 2).mean()) <= 2 * EPS[dtype] * np.sqrt((y ** 2).mean())
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
