@@ -94,11 +94,15 @@ class InferenceEngine:
                     state = "root"
             sampler = self.samplers[state]
             procs = self.logits_processors.get(state) or []
-            if not procs and getattr(sampler, "is_greedy", False):
-                # fused tail: log-softmax + argmax on device, hipGraph replay for L == 1, no host sync
-                tok, logprobs, _ = self.model.step(None if fed_back else ids, self.prompt_cache.cache)
+            if not procs:
+                # fused step: hipGraph replay for L == 1, log-softmax (+ greedy argmax) in the HIP tail, no host sync
+                greedy_fused = getattr(sampler, "is_greedy", False)
+                tok, logprobs, _ = self.model.step(None if (fed_back and greedy_fused) else ids, self.prompt_cache.cache)
                 self.prompt_cache.update(ids)                                  # :255 (device ids resolve lazily)
-                return tok, logprobs
+                if greedy_fused:
+                    return tok, logprobs
+                # stochastic sampler (:271): drawn on the device; the token tensor feeds the next step without a read-back
+                return sampler(logprobs[None]).reshape(1).to(torch.int32), logprobs
             logits = self.model(ids[None], cache=self.prompt_cache.cache)      # :252
             last = logits[:, -1, :]                                            # :254
             self.prompt_cache.update(ids)                                      # :255

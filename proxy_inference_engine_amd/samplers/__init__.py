@@ -2,8 +2,10 @@
 
 `make_sampler(temp=0)` -- the greedy branch (samplers/__init__.py:37-38) -- is the parity target of the decode
 path and runs in the fused HIP tail (argmax of the fp32 log-probabilities, first maximal index).
-The stochastic branches (top-p, min-p, top-k, categorical: samplers/{top_p,min_p,top_k,categorical}.py) are the
-"next" row SURVEY.md 8f-4; asking for them raises NotImplementedError instead of silently sampling differently.
+The stochastic branches (top-p, min-p, top-k, categorical: samplers/{top_p,min_p,top_k,categorical}.py, SURVEY.md
+8f-4) restate the reference's filters op for op on the device that holds the log-probabilities (no host sync: the
+drawn token stays a device tensor and feeds the next step); their random stream is torch's, not MLX's, so parity is
+the kept-token set (exact) and the distribution, not the individual draw.  `seed(n)` = mx.random.seed(n).
 """
 from __future__ import annotations
 
@@ -12,6 +14,11 @@ from collections.abc import Callable
 import torch
 
 from .. import hip_ops
+from ._rng import seed
+from .categorical import categorical_sampling
+from .min_p import min_p_sampling
+from .top_k import top_k_sampling
+from .top_p import top_p_sampling
 
 
 def greedy(logprobs: torch.Tensor) -> torch.Tensor:
@@ -36,9 +43,14 @@ def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_
                  top_k: int = -1) -> Callable[[torch.Tensor], torch.Tensor]:
     if temp == 0:
         return greedy
-    raise NotImplementedError(
-        "only the greedy sampler (temp=0) is on the MI355X decode path; top-p/min-p/top-k/categorical sampling is "
-        "SURVEY.md 8f-4 (pass temp=0: the reference's default temp=1.0 samples, inference_engine.py:305)")
+    elif top_p > 0 and top_p < 1.0:
+        return lambda x: top_p_sampling(x, top_p, temp)
+    elif min_p != 0.0:
+        return lambda x: min_p_sampling(x, min_p, min_tokens_to_keep, temp)
+    elif top_k > 0:
+        return lambda x: top_k_sampling(x, top_k, temp)
+    else:
+        return lambda x: categorical_sampling(x, temp)
 
 
 greedy.is_greedy = True  # lets the engine pick the fused tail

@@ -312,6 +312,37 @@ def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
         assert d.max() <= 2 * EPS[dtype] * np.abs(y).max() and np.sqrt((d ** 2).mean()) <= 2 * EPS[dtype] * np.sqrt((y ** 2).mean())
 
 
+def test_engine_with_stochastic_samplers(tiny):
+    """The reference's DEFAULT request samples (temp = 1.0, inference_engine.py:305).  generate_step with top-k = 1 must
+    reproduce the greedy sequence token for token (the filter leaves one candidate), a min-p run must only emit tokens
+    the filter keeps, and the prompt cache must record the DRAWN tokens (they are what the KV cache encodes)."""
+    from proxy_inference_engine_amd import InferenceEngine
+    from proxy_inference_engine_amd import samplers
+    g, cfg, w, model = tiny
+    prompt = torch.from_numpy(g["prompt"])
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(prompt, temp=0)
+    gen = eng.generate_step(prompt)
+    greedy = [int(next(gen)[0].item()) for _ in range(8)]
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(prompt, temp=0.7, top_k=1)
+    gen = eng.generate_step(prompt)
+    assert [int(next(gen)[0].item()) for _ in range(8)] == greedy
+    samplers.seed(3)
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(prompt, temp=1.0, min_p=0.2)
+    gen = eng.generate_step(prompt)
+    drawn = []
+    for _ in range(12):
+        tok, lp = next(gen)
+        lp = lp.float().cpu().numpy()
+        t = int(tok.item())
+        assert lp[t] >= lp.max() + np.log(0.2) - 1e-6                   # inside the min-p set of THIS step's distribution
+        drawn.append(t)
+    assert eng.prompt_cache.computed_ids[-11:] == drawn[:11] and eng.prompt_cache.cache[0].offset == len(g["prompt"]) + 11
+    assert len(set(drawn)) > 1 or drawn != greedy[:12]                 # it actually sampled something
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
@@ -324,8 +355,5 @@ def test_tied_embeddings_and_errors(tiny):
     assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
     with pytest.raises(ValueError):
         build(dict(cfg, quantization=None), w)                          # dense checkpoints are not on this path
-    with pytest.raises(NotImplementedError):
-        from proxy_inference_engine_amd.samplers import make_sampler
-        make_sampler(temp=1.0)
     with pytest.raises(ValueError):
         model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])

@@ -53,8 +53,7 @@ def test_prompt_cache_lcp_matches_oracle():
 
 
 def test_sampler_and_processor_conventions():
-    with pytest.raises(NotImplementedError):
-        make_sampler(temp=0.7, top_p=0.9)
+    assert not getattr(make_sampler(temp=0.7, top_p=0.9), "is_greedy", False)
     assert getattr(make_sampler(temp=0), "is_greedy", False)
     with pytest.raises(ValueError):
         make_repetition_penalty(-1.0)
@@ -72,3 +71,59 @@ def test_masks_and_model_args():
     a = ModelArgs(model_type="llama", hidden_size=64, num_hidden_layers=1, intermediate_size=128, num_attention_heads=2,
                   rms_norm_eps=1e-5, vocab_size=10, some_unknown_key=1)
     assert a.tie_word_embeddings is True and a.rope_theta == 10000 and not hasattr(a, "some_unknown_key")
+
+
+def _ref_sets(logprobs, temp, top_p=0.0, min_p=0.0, keep=1, top_k=-1):
+    """Numpy restatement of which vocabulary ids the reference's filters leave drawable (samplers/{top_p,min_p,top_k}.py)."""
+    x = logprobs.astype(np.float64) / temp
+    if 0 < top_p < 1.0:
+        p = np.exp(x - x.max()); p /= p.sum()
+        order = np.argsort(p, kind="stable")
+        cum = np.cumsum(p[order].astype(np.float32))
+        return set(order[cum > np.float32(1 - top_p)].tolist())
+    if min_p != 0.0:
+        order = np.argsort(-x, kind="stable")
+        kept = x[order] >= x[order][0] + np.log(min_p)
+        kept[:keep] = True
+        return set(order[kept].tolist())
+    if top_k > 0:
+        return set(np.argsort(-x, kind="stable")[:top_k].tolist())
+    return set(range(len(x)))
+
+
+@pytest.mark.parametrize("kw", [dict(top_p=0.6), dict(top_p=0.95), dict(min_p=0.1), dict(min_p=0.3, min_tokens_to_keep=4),
+                                dict(top_k=5), dict()])
+def test_stochastic_samplers_keep_sets_and_distribution(kw):
+    """samplers/*.py restated with torch ops: every draw lies in the set the reference's filter keeps (numpy restatement
+    above), every kept token with non-negligible mass is drawn, and the empirical frequencies follow the renormalised
+    probabilities (total variation < 0.05 over 4000 draws).  The random stream itself is torch's, not MLX's."""
+    from proxy_inference_engine_amd import samplers
+    rng = np.random.default_rng(11)
+    V, temp = 64, 0.8
+    logits = rng.standard_normal(V).astype(np.float32) * 2.0
+    logprobs = logits - np.log(np.exp(logits.astype(np.float64)).sum()).astype(np.float32)
+    sampler = make_sampler(temp=temp, **kw)
+    samplers.seed(1234)
+    x = torch.from_numpy(logprobs)[None].repeat(4000, 1)                # 4000 independent rows, one call
+    draws = sampler(x).numpy()
+    assert draws.shape == (4000,) and draws.dtype == np.int32
+    allowed = _ref_sets(logprobs, temp, kw.get("top_p", 0.0), kw.get("min_p", 0.0), kw.get("min_tokens_to_keep", 1), kw.get("top_k", -1))
+    assert set(draws.tolist()) <= allowed
+    p = np.exp(logprobs.astype(np.float64) / temp)
+    mask = np.zeros(V, bool); mask[list(allowed)] = True
+    p = np.where(mask, p, 0.0); p /= p.sum()
+    freq = np.bincount(draws, minlength=V) / 4000.0
+    assert 0.5 * np.abs(freq - p).sum() < 0.05
+    assert all(freq[i] > 0 for i in allowed if p[i] > 0.01)
+    samplers.seed(1234)
+    assert np.array_equal(sampler(x).numpy(), draws)                   # seed() restarts the stream
+
+
+def test_stochastic_sampler_argument_errors():
+    x = torch.zeros((1, 16))
+    with pytest.raises(ValueError):
+        make_sampler(temp=1.0, top_k=16)(x)                             # top_k must be < vocab (top_k.py:20-24)
+    with pytest.raises(ValueError):
+        make_sampler(temp=1.0, min_p=1.5)(x)                            # min_p.py:33-36
+    with pytest.raises(ValueError):
+        make_sampler(temp=1.0, min_p=0.1, min_tokens_to_keep=0)(x)      # min_p.py:37-40
