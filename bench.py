@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
+    ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
 
 
@@ -89,8 +90,10 @@ def main():
     cfg = dict(LLAMA3_8B)
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
+    if args.dense:
+        cfg["quantization"] = None
     weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
         weights_host = {k: (v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.view(torch.int16).cpu().numpy().view(np.uint16))
@@ -151,7 +154,7 @@ def main():
 
     traffic = None
     tf = ROOT / "profiles" / "r01_traffic.json"  # PMC passes (separate rocprofv3 runs), see profiles/README.md
-    if tf.exists() and not args.layers:
+    if tf.exists() and not args.layers and not args.dense:
         traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
 
     out = {
@@ -159,7 +162,7 @@ def main():
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "dtype_detail": "uint4 g=64 weights x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B-shaped (H4096 L{n_l} 32/8 heads I14336 V128256) int4 g=64 greedy decode, batch 1, "
+        "config": {"workload": f"Llama-3-8B-shaped (H4096 L{n_l} 32/8 heads I14336 V128256) {'dense bf16' if args.dense else 'int4 g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
                    "hipgraph": True},

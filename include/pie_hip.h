@@ -67,6 +67,16 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
 int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y,
                     int dtype, void *stream);
 
+/* ---------------------------------------------------------------- dense checkpoints (no "quantization" entry in
+ * config.json, models/utils.py:96-97): nn.Linear / nn.Embedding with 16-bit weights.  Same streaming kernel as the int4
+ * path on "W16S" units of 2048 B = one ROW PAIR x one 512-wide K slice (2 x [64 lanes x 16 B]); row_map as for
+ * pie_repack_w4g64.  pie_gemv_dense: y[M,N] = x[M,K] @ W.T (+ bias), fp32 accumulate, one rounding
+ * (call sites models/llama/language.py:83,108,127,209).  pie_embedding_dense: row gather (language.py:176). */
+size_t pie_w16s_bytes(int N_out, int K);
+int pie_repack_dense(const void *w, int N_src, int K, const int32_t *row_map, int N_out, void *packed, void *stream);
+int pie_gemv_dense(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
+int pie_embedding_dense(const int32_t *ids, int L, const void *table, int V, int H, int dtype, void *out, void *stream);
+
 /* nn.QuantizedEmbedding.__call__ (models/llama/language.py:176): dequantise gathered rows of the
  * MLX-layout table.  ids device int32 [L] -> out [L,H] T. */
 int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases,
@@ -115,7 +125,10 @@ typedef struct {
     float rms_eps;
     int tie_word_embeddings; /* lm_head = embed_tokens.as_linear (language.py:206-207) */
     int kv_splits;      /* split-KV factor of the attention kernel (0 = default) */
+    int weight_format;  /* PIE_W_INT4_G64 (MLX int4 group-64 triplets, W4S units) or PIE_W_DENSE (16-bit nn.Linear
+                           weights, W16S units; embed_codes is then the T [vocab, hidden] table, scales/biases NULL) */
 } pie_decoder_config;
+enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1 };
 
 typedef struct {
     const void *attn_norm, *mlp_norm;   /* T [hidden] */

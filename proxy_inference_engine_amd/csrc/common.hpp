@@ -158,3 +158,9 @@ __device__ __forceinline__ float wave_max(float v) {
 constexpr int W4S_UNIT_BYTES = 2304;
 constexpr int W4S_SLICE_K = 2048;
 static inline __host__ __device__ int w4s_slices(int K) { return (K + W4S_SLICE_K - 1) / W4S_SLICE_K; }
+// W16S (dense 16-bit weights, same streaming shape): one unit = row pair x 512-wide K slice = 2 x [64 lanes x 16 B];
+// lane l: row l >> 5, elements 512 s + 16 (l & 31) + 8 j of piece j.
+constexpr int W16S_UNIT_BYTES = 2048;
+constexpr int W16S_SLICE_K = 512;
+static inline __host__ __device__ int w16s_slices(int K) { return (K + W16S_SLICE_K - 1) / W16S_SLICE_K; }
+enum { FMT_W4S = 0, FMT_W16S = 1 };

@@ -75,15 +75,18 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
     const pie_layer_weights &w = d->layers[li];
+    const bool dense = c.weight_format == PIE_W_DENSE;
+    const int fmt = dense ? FMT_W16S : FMT_W4S;
     switch (which) {
         case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
+            if (dense) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, c.vocab, H, c.dtype, d->h, st);
             return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, d->h,
                                     d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st);
         case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
             GemvArgs a = {};
-            a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
+            a.fmt = fmt, a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
-            a.freqs = d->glob.rope_freqs, a.rope_cs = d->rope_cs, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
+            a.freqs = d->glob.rope_freqs, a.rope_cs = dense ? nullptr : d->rope_cs /* filled by the int4 embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
@@ -94,13 +97,13 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
             // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
-            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = pie_w4s_bytes(H, QD);
+            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : pie_w4s_bytes(H, QD);
             a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
-            a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h;
+            a.fmt = fmt, a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h;
             if (d->combine) {
                 a.x = d->attn;
                 return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
@@ -110,18 +113,18 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
-            a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
+            a.fmt = fmt, a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
             a.y = d->act;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
         }
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
-            a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h;
+            a.fmt = fmt, a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h;
             return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
         }
         case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials
             GemvArgs a = {};
-            a.w = (const char *)d->glob.lm_head, a.K = H, a.N = c.vocab, a.x = d->h, a.norm_w = (const u16 *)d->glob.final_norm, a.eps = c.rms_eps;
+            a.fmt = fmt, a.w = (const char *)d->glob.lm_head, a.K = H, a.N = c.vocab, a.x = d->h, a.norm_w = (const u16 *)d->glob.final_norm, a.eps = c.rms_eps;
             a.y = logits_dst, a.stats = d->stats;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_LOGITS, a, 1, st);
         }
@@ -176,8 +179,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_REQUIRE(c.head_dim == 64 || c.head_dim == 128, PIE_E_SHAPE, "pie_decoder_create: head_dim must be 64 or 128");
     PIE_REQUIRE(c.n_layers > 0 && c.n_heads > 0 && c.n_kv_heads > 0 && c.n_heads % c.n_kv_heads == 0, PIE_E_SHAPE, "pie_decoder_create: bad head counts");
     PIE_REQUIRE(c.vocab > 0 && c.vocab % 2 == 0, PIE_E_SHAPE, "pie_decoder_create: vocab must be even");
-    PIE_REQUIRE(w4s_slices(c.hidden) <= 16 && w4s_slices(c.inter) <= 16 && w4s_slices(c.n_heads * c.head_dim) <= 16, PIE_E_SHAPE,
-                "pie_decoder_create: K > 32768 not supported");
+    PIE_REQUIRE(c.hidden <= 32768 && c.inter <= 32768 && c.n_heads * c.head_dim <= 32768, PIE_E_SHAPE, "pie_decoder_create: K > 32768 not supported");
+    PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE, PIE_E_ARG, "pie_decoder_create: unknown weight_format");
     pie_decoder *d = new (std::nothrow) pie_decoder();
     PIE_REQUIRE(d, PIE_E_HIP, "pie_decoder_create: out of host memory");
     d->cfg = c;
@@ -201,7 +204,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)
         const long mb = e ? atol(e) : 0;
-        const size_t gu = pie_w4s_bytes(2 * c.inter, c.hidden);
+        const size_t gu = c.weight_format == PIE_W_DENSE ? pie_w16s_bytes(2 * c.inter, c.hidden) : pie_w4s_bytes(2 * c.inter, c.hidden);
         d->pf_gateup_bytes = mb <= 0 ? 0 : ((size_t)mb << 20 < gu ? (size_t)mb << 20 : gu);
         d->pf_enable = mb >= 0;
     }
@@ -237,8 +240,9 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
 
 int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w) {
     PIE_REQUIRE(d && w, PIE_E_ARG, "pie_decoder_set_globals: null pointer");
-    PIE_REQUIRE(w->embed_codes && w->embed_scales && w->embed_biases && w->final_norm && w->lm_head && w->rope_freqs, PIE_E_ARG,
-                "pie_decoder_set_globals: null weight");
+    PIE_REQUIRE(w->embed_codes && w->final_norm && w->lm_head && w->rope_freqs, PIE_E_ARG, "pie_decoder_set_globals: null weight");
+    PIE_REQUIRE(d->cfg.weight_format == PIE_W_DENSE || (w->embed_scales && w->embed_biases), PIE_E_ARG,
+                "pie_decoder_set_globals: an int4 embedding needs scales and biases");
     PIE_REQUIRE(pie_aligned(w->lm_head, 256) && pie_aligned(w->final_norm, 16) && pie_aligned(w->embed_codes, 16), PIE_E_ALIGN,
                 "pie_decoder_set_globals: misaligned weight");
     d->glob = *w;
@@ -372,7 +376,8 @@ size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T) {
     if (!d) return 0;
     const pie_decoder_config &c = d->cfg;
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
-    auto lin = [](size_t n, size_t k) { return n * k / 2 + 2 * (n * k / 64) * 2; };
+    const bool dense = c.weight_format == PIE_W_DENSE;
+    auto lin = [dense](size_t n, size_t k) { return dense ? n * k * 2 : n * k / 2 + 2 * (n * k / 64) * 2; };
     switch (which) {
         case PIE_K_QKV: return lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2;
         case PIE_K_ATTN: return 2 * KVD * 2 * (size_t)T;
@@ -389,8 +394,9 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits) {
     if (!d) return 0;
     const pie_decoder_config &c = d->cfg;
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
-    // int4 codes + 16-bit scale and bias per group of 64 = 0.5625 B / parameter  
-    auto lin = [](size_t n, size_t k) { return n * k / 2 + 2 * (n * k / 64) * 2; };
+    // int4 codes + 16-bit scale and bias per group of 64 = 0.5625 B / parameter  (SURVEY.md 8d); dense: 2 B / parameter
+    const bool dense = c.weight_format == PIE_W_DENSE;
+    auto lin = [dense](size_t n, size_t k) { return dense ? n * k * 2 : n * k / 2 + 2 * (n * k / 64) * 2; };
     size_t per_layer = lin(QD + 2 * KVD, H) + lin(H, QD) + lin(2 * I, H) + lin(H, I);
     size_t bytes = (size_t)c.n_layers * (per_layer + 2 * H * 2 /* norm weights */ + 2 * KVD * 2 * (size_t)T /* KV read */ + 2 * KVD * 2 /* KV write */);
     if (with_logits) bytes += lin(c.vocab, H) + H * 2 + (size_t)c.vocab * 4 /* fp32 logprobs */;

@@ -250,8 +250,14 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
 }
 
 // ---------------------------------------------------------------- the batched forward
+int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st);
+
 template <class T>
 static int linear_rows(pie_decoder *d, const void *w4s, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st) {
+    if (d->cfg.weight_format == PIE_W_DENSE) {  // nn.Linear: the W16S units go back to a plain [N, K] matrix (packed row order)
+        const int rc = unpack_w16s_launch(w4s, N, K, d->prefill->wT, st);
+        return rc ? rc : gemm_xwt(d->cfg.dtype, x, d->prefill->wT, y, M, N, K, st);
+    }
     const size_t words = (size_t)N * (K >> 3);
     hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K),
                        d->prefill->wT);
@@ -275,9 +281,11 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
     for (int c0 = 0; c0 < L; c0 += chunk) {
         const int M = L - c0 < chunk ? L - c0 : chunk;
         // h = embed_tokens(inputs)  (language.py:176)
-        if ((rc = embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
-                                   nullptr, nullptr, 0, st)))
-            return rc;
+        rc = c.weight_format == PIE_W_DENSE
+                 ? pie_embedding_dense(ids + c0, M, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
+                 : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
+                                    nullptr, nullptr, 0, st);
+        if (rc) return rc;
         for (int li = 0; li < c.n_layers; ++li) {
             const pie_layer_weights &w = d->layers[li];
             // Attention.__call__ (language.py:75-108) on input_layernorm(x)

@@ -139,28 +139,70 @@ __global__ void k_repack_w4s(const u32 *codes, const u16 *scales, const u16 *bia
     packed[idx] = out;
 }
 
+// Dense 16-bit weights [N_src, K] (nn.Linear) -> W16S.  One thread per 16-byte piece: unit (pair, slice), piece j, lane l:
+// row = row_map[2*pair + (l>>5)], elements 512*slice + 16*(l&31) + 8*j .. +8 (zero past K or for an unmapped row).
+__global__ void k_repack_w16s(const u16 *w, int N_src, int K, const int *row_map, int n_pairs, int ns, uint4 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 128;
+    if (idx >= total) return;
+    const size_t unit = idx >> 7;
+    const int j = (int)((idx >> 6) & 1), lane = (int)(idx & 63);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int k0 = W16S_SLICE_K * s + 16 * (lane & 31) + 8 * j;
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (row >= 0 && row < N_src && k0 < K) out = *reinterpret_cast<const uint4 *>(w + (size_t)row * K + k0);  // K % 8 == 0
+    packed[idx] = out;
+}
+// W16S -> row-major [N_packed, K] in the PACKED row order (prefill GEMMs read plain matrices).
+__global__ void k_unpack_w16s(const uint4 *packed, int N, int K, int ns, u16 *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece of the output
+    const int ppr = K >> 3;
+    if (idx >= (size_t)N * ppr) return;
+    const int r = (int)(idx / ppr), pc = (int)(idx % ppr), k0 = pc * 8;
+    const int s = k0 / W16S_SLICE_K, c = (k0 % W16S_SLICE_K) >> 4, j = (k0 >> 3) & 1;
+    reinterpret_cast<uint4 *>(out)[idx] = packed[(((size_t)(r >> 1) * ns + s) << 7) + (j << 6) + (r & 1) * 32 + c];
+}
+int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st) {
+    const size_t n = (size_t)N * (K >> 3);
+    hipLaunchKernelGGL(k_unpack_w16s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)packed, N, K, w16s_slices(K), (u16 *)out);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+// nn.Embedding (language.py:176) for dense checkpoints: row gather.
+__global__ void k_embedding_dense(const int *ids, const uint4 *table, int V, int H, uint4 *out) {
+    int id = ids[blockIdx.x];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    for (int i = threadIdx.x; i < (H >> 3); i += blockDim.x) out[(size_t)blockIdx.x * (H >> 3) + i] = table[(size_t)id * (H >> 3) + i];
+}
+
 // ---------------------------------------------------------------- launch geometry
-template <class T, int NPT>
+template <class T, int NPT, int FMT>
 static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
     const dim3 block(GEMV_WAVES * 64);
-    if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT>), grid, block, lds, st, a);
-    else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT>), grid, block, lds, st, a);
-    else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT)>), grid, block, lds, st, a);
-    else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT>), grid, block, lds, st, a);
-    else if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_SWIGLU, NPT>), grid, block, lds, st, a);
-    else if (pro == PRO_RMSNORM && epi == EPI_LOGITS) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_LOGITS, NPT>), grid, block, lds, st, a);
+    if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_SWIGLU, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_RMSNORM && epi == EPI_LOGITS) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_LOGITS, NPT, 0, FMT>), grid, block, lds, st, a);
     else return pie::fail(PIE_E_ARG, "w4s_gemv: unsupported prologue/epilogue combination");
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
 
+template <class T, int FMT>
+static int launch_f(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
+    const int npt = ((a.K >> 3) + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);  // activation pieces per staging thread
+    if (npt <= 1) return launch_n<T, 1, FMT>(pro, epi, a, grid, lds, st);
+    if (npt <= 2) return launch_n<T, 2, FMT>(pro, epi, a, grid, lds, st);
+    if (npt <= 4) return launch_n<T, 4, FMT>(pro, epi, a, grid, lds, st);
+    return launch_n<T, 8, FMT>(pro, epi, a, grid, lds, st);
+}
 template <class T>
 static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
-    const int npt = ((a.K >> 3) + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);  // activation pieces per staging thread
-    if (npt <= 1) return launch_n<T, 1>(pro, epi, a, grid, lds, st);
-    if (npt <= 2) return launch_n<T, 2>(pro, epi, a, grid, lds, st);
-    if (npt <= 4) return launch_n<T, 4>(pro, epi, a, grid, lds, st);
-    return launch_n<T, 8>(pro, epi, a, grid, lds, st);
+    return a.fmt == FMT_W16S ? launch_f<T, FMT_W16S>(pro, epi, a, grid, lds, st) : launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
 }
 
 // Persistent grid: one wave per row pair until the chip is full (16 waves per CU), then longer runs per wave.
@@ -180,10 +222,11 @@ int w4s_gemv_waves(int N, int K) {
 int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t stream) {
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
-    PIE_REQUIRE(w4s_slices(a.K) <= 16, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
+    PIE_REQUIRE(a.K <= 32768, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
+    PIE_REQUIRE(a.fmt == FMT_W4S || a.fmt == FMT_W16S, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
-    a.n_slices = w4s_slices(a.K);
+    a.n_slices = a.fmt == FMT_W16S ? w16s_slices(a.K) : w4s_slices(a.K);
     a.n_pairs = a.N / 2;
     a.n_waves = w4s_gemv_waves(a.N, a.K);
     const unsigned lds = (unsigned)gemv_lds(a.K).total;
@@ -252,6 +295,48 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_repack_w4s, grid, block, 0, (hipStream_t)stream, codes, (const u16 *)scales, (const u16 *)biases, N_src, K,
                        row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+size_t pie_w16s_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w16s_slices(K) * W16S_UNIT_BYTES;
+}
+
+int pie_repack_dense(const void *w, int N_src, int K, const int32_t *row_map, int N_out, void *packed, void *stream) {
+    PIE_REQUIRE(w && packed, PIE_E_ARG, "pie_repack_dense: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_dense: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0 && K <= 32768, PIE_E_SHAPE, "pie_repack_dense: K must be a multiple of 64, at most 32768");
+    PIE_REQUIRE(pie_aligned(packed, 256) && pie_aligned(w, 16), PIE_E_ALIGN, "pie_repack_dense: packed needs 256-byte, w 16-byte alignment");
+    const int n_pairs = N_out / 2, ns = w16s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 128;
+    hipLaunchKernelGGL(k_repack_w16s, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16 *)w, N_src, K, row_map,
+                       n_pairs, ns, (uint4 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_gemv_dense(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_gemv_dense: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_gemv_dense: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_gemv_dense: misaligned pointer");
+    GemvArgs a = {};
+    a.fmt = FMT_W16S;
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
+}
+
+int pie_embedding_dense(const int32_t *ids, int L, const void *table, int V, int H, int dtype, void *out, void *stream) {
+    PIE_REQUIRE(ids && table && out, PIE_E_ARG, "pie_embedding_dense: null pointer");
+    PIE_REQUIRE(L > 0 && V > 0 && H > 0 && H % 8 == 0, PIE_E_SHAPE, "pie_embedding_dense: H must be a multiple of 8");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_embedding_dense: bad dtype");
+    PIE_REQUIRE(pie_aligned(table, 16) && pie_aligned(out, 16), PIE_E_ALIGN, "pie_embedding_dense: 16-byte alignment required");
+    hipLaunchKernelGGL(k_embedding_dense, dim3(L), dim3(256), 0, (hipStream_t)stream, ids, (const uint4 *)table, V, H, (uint4 *)out);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }

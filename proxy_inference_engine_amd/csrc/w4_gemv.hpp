@@ -43,7 +43,8 @@ struct LogitStat {  // per-wave partial of the log-softmax / argmax tail
 };
 
 struct GemvArgs {
-    const char *w;  // W4S
+    int fmt;        // FMT_W4S (int4 g=64 units) or FMT_W16S (dense 16-bit units)
+    const char *w;  // W4S / W16S
     int n_pairs, n_slices, n_waves, K, N;
     const u16 *x;         // [M,K]
     const u16 *norm_w;    // PRO_RMSNORM
@@ -109,9 +110,13 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 // ABL: developer ablation switches for tools/w4s_bench (0 in every product instantiation):
 //   1 = no weight loads, 2 = no dot products, 4 = no activation staging / LDS reads
 // NPT: activation pieces (8 elements) per thread of the staging pass, ceil(K/8/512) rounded up to 1, 2, 4 or 8.
-template <class T, int PRO, int EPI, int NPT, int ABL = 0>
+// FMT: weight format of the stream.  FMT_W16S serves dense checkpoints (nn.Linear, language.py:83,108,127,209 when the
+//      config has no "quantization" entry): same persistent-wave stream, prologues and epilogues; a unit is 2 x 1 KB of
+//      16-bit weights, a lane multiplies its 16 weights with 16 activations (8 v_dot2), no scale/bias.
+template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs a) {
     constexpr int D = GEMV_DEPTH;
+    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : W4S_UNIT_BYTES;
     constexpr int NT = GEMV_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -130,7 +135,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const int W = a.n_waves;
     const int run = gw < a.n_pairs ? (a.n_pairs - gw + W - 1) / W : 0;  // <= GEMV_MAX_RUN (host-checked)
     const int n_units = run * ns;
-    const size_t pstride = (size_t)W * ns * W4S_UNIT_BYTES;  // bytes between consecutive pairs of this wave
+    const size_t pstride = (size_t)W * ns * UB;  // bytes between consecutive pairs of this wave
 
     // 1. activations first (coalesced, 8 elements per piece), then the head of the weight stream.
     const int n_pieces = a.K >> 3;
@@ -182,13 +187,13 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     // given an out-of-range offset, which the hardware bounds check drops (no memory traffic, no branch around a load).
     // (Clamping to the last unit instead cost up to D redundant loads per wave: 70 % extra at 7-unit runs.)
     typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
-    const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * W4S_UNIT_BYTES);
+    const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * UB);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.w), 0, (int)w_bytes, 0x00020000);
-    const unsigned woff0 = (unsigned)((size_t)gw * ns * W4S_UNIT_BYTES) + lane * 16;  // this wave's first unit, this lane's piece
+    const unsigned woff0 = (unsigned)((size_t)gw * ns * UB) + lane * 16;  // this wave's first unit, this lane's piece
     const unsigned pstride32 = (unsigned)pstride;
     int iss_sl = 0, iss_pl = 0;  // slice / local pair of the next unit to issue
     auto issue = [&](int d, int) {  // ring slot d <- next unit of this wave
-        const unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * W4S_UNIT_BYTES : 0xFFFFF000u;
+        const unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
         if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
         if (ABL & 1) {
             c0[d] = c1[d] = make_uint4(lane, off, d, 7);
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, AUX);
             c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
             c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
-            sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
+            if (FMT == FMT_W4S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
         }
     };
 #pragma unroll
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x141, 0xF, 0xF, true);  // row_half_mirror: 8-lane sums
             if (ok) {
-                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = scale8<T>(xv[i]);
+                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = FMT == FMT_W4S ? scale8<T>(xv[i]) : xv[i];
                 if ((j & 7) == 0) sxs[j >> 3] = ps;
             }
         }
@@ -278,6 +283,18 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         for (int d = 0; d < D; ++d) {
             const int i = base + d;
             if (i < n_units) {  // wave-uniform
+              if (FMT == FMT_W16S) {  // lane (row, chunk): 16 weights x 16 activations
+                const int chunk = sl * 32 + (lane & 31);
+                const bool cvalid = chunk * 16 < a.K;
+                const int cc = cvalid ? chunk : 0;
+                const uint4 x0 = *reinterpret_cast<const uint4 *>(smem + ((size_t)((cc & 3) * 2) * L.stride + (cc >> 2)) * 16);
+                const uint4 x1 = *reinterpret_cast<const uint4 *>(smem + ((size_t)((cc & 3) * 2 + 1) * L.stride + (cc >> 2)) * 16);
+                float d0 = T::dot2(c0[d].x, x0.x, 0.0f), d1 = T::dot2(c0[d].y, x0.y, 0.0f);
+                d0 = T::dot2(c0[d].z, x0.z, d0), d1 = T::dot2(c0[d].w, x0.w, d1);
+                d0 = T::dot2(c1[d].x, x1.x, d0), d1 = T::dot2(c1[d].y, x1.y, d1);
+                d0 = T::dot2(c1[d].z, x1.z, d0), d1 = T::dot2(c1[d].w, x1.w, d1);
+                acc += cvalid ? d0 + d1 : 0.0f;
+              } else {
                 const int g = sl * 32 + (lane & 31);
                 const bool gvalid = g < n_groups;
                 const int gc = gvalid ? g : n_groups - 1;
@@ -294,6 +311,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
                 const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
                 acc += gvalid ? pr : 0.0f;  // padded groups carry zero codes and zero {scale,bias}; the select keeps a NaN x out
+              }
                 if (++sl == ns) {
                     const float tot = half_wave_sum(acc);
                     if ((lane & 31) == 31) outp[2 * pl + (lane >> 5)] = tot;

@@ -89,6 +89,62 @@ def repack_w4s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_b
     return W4SWeight(packed, N_out, K, scales.dtype, lin_bias)
 
 
+@dataclass
+class W16SWeight:
+    """One dense 16-bit Linear in the W16S streaming layout (include/pie_hip.h)."""
+    packed: torch.Tensor          # uint8 [pie_w16s_bytes(N, K)]
+    N: int
+    K: int
+    dtype: torch.dtype
+    lin_bias: torch.Tensor | None = None
+
+    @property
+    def nbytes(self) -> int:
+        return self.packed.numel()
+
+
+def repack_dense(w: torch.Tensor, row_map: torch.Tensor | None = None, lin_bias=None) -> W16SWeight:
+    """Load-time repack of an nn.Linear weight [N_src, K] (bf16 / f16) into W16S; row_map as for repack_w4s."""
+    _dev(w)
+    if w.dtype not in (torch.bfloat16, torch.float16) or w.dim() != 2:
+        raise ValueError("dense weights must be 2-D bfloat16 / float16")
+    w = w.contiguous()
+    N_src, K = w.shape
+    N_out = N_src if row_map is None else int(row_map.numel())
+    nbytes = _ffi.load().pie_w16s_bytes(N_out, K)
+    if nbytes == 0:
+        raise ValueError(f"unsupported shape for W16S: N={N_out} (must be even), K={K} (multiple of 64)")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    if row_map is not None:
+        row_map = row_map.to(device=w.device, dtype=torch.int32).contiguous()
+    _ffi.check(_ffi.load().pie_repack_dense(_ffi.p(w), N_src, K, _ffi.p(row_map), N_out, _ffi.p(packed), _ffi.stream()))
+    return W16SWeight(packed, N_out, K, w.dtype, lin_bias)
+
+
+def linear(x: torch.Tensor, w: W16SWeight) -> torch.Tensor:
+    """nn.Linear.__call__ on a W16S weight: x [..., K] -> [..., N]; fp32 accumulate, one rounding (+ bias in T)."""
+    _dev(x)
+    if x.shape[-1] != w.K or x.dtype != w.dtype:
+        raise ValueError(f"x [..., {x.shape[-1]}] {x.dtype} does not match weight K={w.K} {w.dtype}")
+    M = x.numel() // w.K
+    y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
+    _ffi.check(_ffi.load().pie_gemv_dense(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y),
+                                          _ffi.dtype_code(x.dtype), _ffi.stream()))
+    return y
+
+
+def embedding_dense(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """nn.Embedding.__call__: ids int32 [L] -> [L, H] rows of the T [V, H] table."""
+    _dev(ids)
+    _dev(table)
+    ids = ids.to(torch.int32).contiguous().view(-1)
+    V, H = table.shape
+    out = torch.empty((ids.numel(), H), dtype=table.dtype, device=table.device)
+    _ffi.check(_ffi.load().pie_embedding_dense(_ffi.p(ids), ids.numel(), _ffi.p(table), V, H, _ffi.dtype_code(table.dtype), _ffi.p(out),
+                                               _ffi.stream()))
+    return out
+
+
 def quantized_matmul(x: torch.Tensor, w: W4SWeight, transpose: bool = True, group_size: int = 64, bits: int = 4):
     """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4) on a W4S weight:
     x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""

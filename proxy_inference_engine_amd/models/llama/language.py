@@ -66,6 +66,13 @@ def _triplet(weights: dict, prefix: str):
             "not on the MI355X decode path yet") from e
 
 
+def _dense(weights: dict, prefix: str, dtype: torch.dtype) -> torch.Tensor:
+    w = weights.get(f"{prefix}.weight")
+    if w is None or w.dtype != dtype or f"{prefix}.scales" in weights:
+        raise ValueError(f"{prefix}: expected a dense {dtype} weight (the config has no 'quantization' entry)")
+    return w
+
+
 class Model:
     def __init__(self, args: ModelArgs, weights: dict[str, torch.Tensor], kv_splits: int = 0):
         """weights: the checkpoint in the layout models/utils.py:51-125 of the reference consumes (HF names,
@@ -74,8 +81,10 @@ class Model:
         self.model_type = args.model_type
         device = _ffi.require_gpu()
         q = args.quantization or {}
-        if q.get("group_size") != 64 or q.get("bits") != 4:
-            raise ValueError("the MI355X decode path needs an int4 group_size=64 checkpoint (config['quantization'])")
+        self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
+        if q and (q.get("group_size") != 64 or q.get("bits") != 4):
+            raise ValueError("quantised checkpoints must be int4 group_size=64 (config['quantization']); other MLX "
+                             "quantisations are not on the MI355X path")
         if args.attention_bias or args.mlp_bias or args.rope_traditional:
             raise NotImplementedError("attention_bias / mlp_bias / rope_traditional are not on this path yet")
         self.n_heads = args.num_attention_heads
@@ -93,23 +102,33 @@ class Model:
 
         qkv_map = hip_ops.qkv_row_map(self.n_heads, self.n_kv_heads, self.head_dim).to(device)
         gu_map = hip_ops.gateup_row_map(I).to(device)
+
+        def pack(names: list[str], row_map=None):
+            """One streaming-layout matrix from the (concatenated) Linear weights `names`."""
+            if self.dense:
+                ws = [_dense(weights, n, self.dtype) for n in names]
+                return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map)
+            trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
+            return hip_ops.repack_w4s(*trip, row_map=row_map)
+
         self.layers: list[TransformerBlock] = []
         for i in range(args.num_hidden_layers):
             pfx = f"model.layers.{i}"
-            qkv = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, f"{pfx}.self_attn.{n}_proj") for n in "qkv"))]
-            gu = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, f"{pfx}.mlp.{n}_proj") for n in ("gate", "up")))]
             self.layers.append(TransformerBlock(
                 weights[f"{pfx}.input_layernorm.weight"].contiguous(),
                 weights[f"{pfx}.post_attention_layernorm.weight"].contiguous(),
-                hip_ops.repack_w4s(*qkv, row_map=qkv_map),
-                hip_ops.repack_w4s(*_triplet(weights, f"{pfx}.self_attn.o_proj")),
-                hip_ops.repack_w4s(*gu, row_map=gu_map),
-                hip_ops.repack_w4s(*_triplet(weights, f"{pfx}.mlp.down_proj")),
+                pack([f"{pfx}.self_attn.{n}_proj" for n in "qkv"], qkv_map),
+                pack([f"{pfx}.self_attn.o_proj"]),
+                pack([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map),
+                pack([f"{pfx}.mlp.down_proj"]),
             ))
-        self.embed_tokens = tuple(t.contiguous() for t in _triplet(weights, "model.embed_tokens"))
+        if self.dense:
+            self.embed_tokens = (_dense(weights, "model.embed_tokens", self.dtype).contiguous(), None, None)
+        else:
+            self.embed_tokens = tuple(t.contiguous() for t in _triplet(weights, "model.embed_tokens"))
         self.norm = weights["model.norm.weight"].contiguous()
         head = "model.embed_tokens" if args.tie_word_embeddings else "lm_head"  # language.py:206-209
-        self.lm_head = hip_ops.repack_w4s(*_triplet(weights, head))
+        self.lm_head = pack([head])
 
         # decoder-owned outputs live in torch tensors so callers can read them without copies
         self.logits = torch.zeros(V, dtype=self.dtype, device=device)
@@ -119,7 +138,8 @@ class Model:
 
         lib = _ffi.load()
         cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
-                                      self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits))
+                                      self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits),
+                                      1 if self.dense else 0)
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
         for i, blk in enumerate(self.layers):
@@ -127,7 +147,7 @@ class Model:
                                         blk.wqkv.packed.data_ptr(), blk.wo.packed.data_ptr(), blk.wgateup.packed.data_ptr(),
                                         blk.wdown.packed.data_ptr())
             _ffi.check(lib.pie_decoder_set_layer(self._dec, i, C.byref(lw)))
-        gw = _ffi.pie_global_weights(self.embed_tokens[0].data_ptr(), self.embed_tokens[1].data_ptr(), self.embed_tokens[2].data_ptr(),
+        gw = _ffi.pie_global_weights(self.embed_tokens[0].data_ptr(), *(t.data_ptr() if t is not None else None for t in self.embed_tokens[1:]),
                                      self.norm.data_ptr(), self.lm_head.packed.data_ptr(), self.rope.freqs.data_ptr())
         _ffi.check(lib.pie_decoder_set_globals(self._dec, C.byref(gw)))
         # device-side token history: history[p] = greedy token chosen for position p (written by the tail kernel)

@@ -81,7 +81,7 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
                          lm_head_gain: float = 1.0) -> dict[str, torch.Tensor]:
     """Random-weight checkpoint in the reference's on-disk layout, generated and quantised ON the GPU
     (hip_ops.quantize = the HIP restatement of mx.quantize).  Linear/Embedding W ~ N(0, 0.02^2) cast to `dtype`
-    then int4 g=64 quantised; norm weights 1 + N(0, 0.02^2)."""
+    then int4 g=64 quantised -- or left dense when the config has no "quantization" entry; norm weights 1 + N(0, 0.02^2)."""
     device = device or _ffi.require_gpu()
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -93,7 +93,10 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
 
     def put_linear(name: str, N: int, K: int, gain: float = 1.0) -> None:
         w = (torch.randn((N, K), generator=gen, device=device, dtype=torch.float32) * (0.02 * gain)).to(dtype)
-        out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w)
+        if config.get("quantization"):
+            out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w)
+        else:
+            out[f"{name}.weight"] = w
 
     def norm_w() -> torch.Tensor:
         return (1.0 + 0.02 * torch.randn(H, generator=gen, device=device, dtype=torch.float32)).to(dtype)

@@ -29,6 +29,23 @@ def assert_bits_close(got_bits, want_bits, max_ulp=1, max_frac=0.02, what=""):
 EPS = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}
 
 
+def assert_dot_close(got, want, dtype, max_frac=0.02, what="", mag=None):
+    """Outputs of long dot products: within one T-ulp of the oracle, where the ulp is taken at max(|want|, max|want| / 128)
+    (an element that cancels to nearly zero has a tiny ulp of its own, but its fp32 summation-order error is set by
+    the magnitude of the terms), and at most `max_frac` of the elements differ at all.  `mag`: magnitude of an
+    intermediate T-rounded value the element went through (e.g. the Linear output before its bias is added): a one-ulp
+    landing there is carried into the final value unchanged."""
+    got, want = np.asarray(got, np.float64).reshape(-1), np.asarray(want, np.float64).reshape(-1)
+    floor = np.abs(want).max() / 128.0
+    ref = np.abs(want) if mag is None else np.maximum(np.abs(want), np.abs(np.asarray(mag, np.float64).reshape(-1)))
+    tol = 2.0 * EPS[dtype] * np.maximum(ref, floor)
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond one ulp, worst {np.abs(got - want)[bad].max():.6g}"
+    frac = float((got != want).mean())
+    assert frac <= max_frac, f"{what}: {frac:.4%} of elements differ (limit {max_frac:.2%})"
+    return frac
+
+
 def assert_vec_close(got, want, dtype, c_max=4.0, c_rms=4.0, what=""):
     """End-to-end tolerance for activations / logits that passed through many 16-bit rounding points.
     Every op boundary rounds to T (eps = 2^-8 bf16, 2^-11 f16) and the HIP kernels accumulate in fp32 in a

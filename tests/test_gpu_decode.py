@@ -343,6 +343,45 @@ def test_engine_with_stochastic_samplers(tiny):
     assert len(set(drawn)) > 1 or drawn != greedy[:12]                 # it actually sampled something
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_dense_checkpoint_prefill_and_decode(dtype):
+    """BASELINE.json configs[0] / [2]: UNQUANTISED 16-bit checkpoints (nn.Linear / nn.Embedding, models/utils.py:96-97).
+    TinyLlama-proportioned dense model (H=512, I=1408 -> ragged last 512-wide K slice, 8/2 heads, D=64, 3 layers): a
+    9-token prompt through iterated decode steps, a 40-token prompt through the batched GEMM path, then greedy decode
+    with device-side feedback, all against the oracle's dense path (orc_linear)."""
+    cfg = {"model_type": "llama", "hidden_size": 512, "num_hidden_layers": 3, "intermediate_size": 1408,
+           "num_attention_heads": 8, "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 1024,
+           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": True}
+    w = po.synth_checkpoint(cfg, seed=21, dtype=dtype, lm_head_gain=4.0)
+    assert "model.embed_tokens.scales" not in w
+    model = build(cfg, w, dtype)
+    assert model.dense
+    orc = po.OracleLlama(cfg, w, dtype)
+    rng = np.random.default_rng(6)
+    for L in (9, 40):
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got_all[l], want_all[l], dtype, what=f"dense L={L} position {l}")
+        tok = model.token
+        matched = 0
+        for _ in range(4):
+            t = int(tok.item())
+            want = orc.forward(np.array([t]), ocache)[0]
+            otok, olp = po.logprobs_argmax(want)
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"dense decode after L={L}")
+            top2 = np.sort(olp)[-2:]
+            if top2[1] - top2[0] > margin_bound(want, dtype):
+                assert int(tok.item()) == otok
+                matched += 1
+        assert matched >= 1
+    assert model.step_bytes(100) > 2 * sum(v.size for k, v in w.items() if k.endswith("proj.weight"))  # 2 B per parameter
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
@@ -354,6 +393,8 @@ def test_tied_embeddings_and_errors(tiny):
     _, _, logits = model.step(torch.from_numpy(ids).cuda(), model.make_cache())
     assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
     with pytest.raises(ValueError):
-        build(dict(cfg, quantization=None), w)                          # dense checkpoints are not on this path
+        build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
+    with pytest.raises(ValueError):
+        build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other MLX quantisations are not on this path
     with pytest.raises(ValueError):
         model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import pie_oracle as po
-from tests._util import assert_bits_close, codes_dev, to_bits, to_dev
+from tests._util import assert_bits_close, assert_dot_close, codes_dev, to_bits, to_dev
 
 pytestmark = pytest.mark.gpu
 DT = "bfloat16"
@@ -176,3 +176,26 @@ def test_error_conventions(ops):
     with pytest.raises(NotImplementedError):
         q = torch.zeros((1, 4, 2, 64), dtype=torch.bfloat16, device="cuda")
         ops.scaled_dot_product_attention(q, q, q, 0.125)
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K,M", [(64, 512, 1), (130, 704, 3), (4096, 4096, 1), (256, 5632, 2)])
+def test_dense_gemv_and_embedding_vs_oracle(ops, dt, N, K, M):
+    """nn.Linear on the W16S stream (pie_repack_dense + pie_gemv_dense) against orc_linear, incl. K that is not a multiple
+    of the 512-wide slice (704, 5632), a row count that is not a multiple of the wave geometry, a bias, and a row map."""
+    rng = np.random.default_rng(N + K)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    b = po.round_T(rng.standard_normal(N), dt)
+    wd, xd = to_dev(po.to_bits(w, dt), dt), to_dev(po.to_bits(x, dt), dt)
+    got = ops.linear(xd, ops.repack_dense(wd, lin_bias=to_dev(po.to_bits(b, dt), dt)))
+    want = po.linear(x, po.to_bits(w, dt), dt, lin_bias=po.to_bits(b, dt))
+    assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"dense gemv {N}x{K} M={M} {dt}", mag=want - b[None, :])
+    perm = torch.from_numpy(rng.permutation(N).astype(np.int32))
+    got = ops.linear(xd, ops.repack_dense(wd, row_map=perm))
+    want = po.linear(x, po.to_bits(w[perm.numpy()], dt), dt)
+    assert_dot_close(got.float().cpu().numpy(), want, dt, what="dense gemv with row map")
+    if K % 8 == 0 and N >= 64:
+        ids = torch.tensor([0, N - 1, 5, 5], dtype=torch.int32, device="cuda")
+        rows = ops.embedding_dense(ids, wd)
+        assert np.array_equal(to_bits(rows), po.to_bits(w[[0, N - 1, 5, 5]], dt))
