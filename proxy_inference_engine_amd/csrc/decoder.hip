@@ -234,6 +234,7 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
                 PIE_E_ALIGN, "pie_decoder_set_layer: W4S buffers need 256-byte, norm weights 16-byte alignment");
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
+    prefill_free(d);  // resident T copies of the previous weights are stale
     drop_graphs(d);
     return PIE_OK;
 }

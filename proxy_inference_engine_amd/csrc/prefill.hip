@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <tuple>
 
 #include "decoder.hpp"
@@ -121,6 +122,7 @@ struct LtApi {
     std::map<std::tuple<int, int, int, int>, Plan> plans;  // (dtype, M, N, K)
 };
 LtApi g_lt;
+std::mutex g_lt_mutex;  // the handle, workspace and plan cache are process-wide; decoders on several host threads share them
 
 int lt_init() {
     if (g_lt.handle) return PIE_OK;
@@ -151,6 +153,7 @@ int lt_init() {
 
 // y[M, N] = x[M, K] . w[N, K]^T  (row-major T in, fp32 accumulate, T out).  Column-major view: Y'[N, M] = W'^T . X'.
 int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_lt_mutex);
     int rc = lt_init();
     if (rc) return rc;
     const auto key = std::make_tuple(dtype, M, N, K);
@@ -188,18 +191,27 @@ struct PrefillScratch {
     u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr;
     int part_splits = 0;
+    // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
+    // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
+    // that is a small share of the free memory (PIE_PREFILL_RESIDENT=0/1 overrides), built on first use.
+    std::map<const void *, u16 *> resident;
+    int resident_mode = -1;  // -1 undecided, 0 off, 1 on
 };
 
-static void scratch_release(PrefillScratch *s) {
+static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
     void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    auto keep = std::move(s->resident);
+    const int mode = s->resident_mode;
     *s = PrefillScratch();
+    s->resident = std::move(keep), s->resident_mode = mode;
 }
 
 void prefill_free(pie_decoder *d) {
     if (!d->prefill) return;
     scratch_release(d->prefill);
+    for (auto &kv : d->prefill->resident) (void)hipFree(kv.second);
     delete d->prefill;
     d->prefill = nullptr;
 }
@@ -252,17 +264,49 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
 // ---------------------------------------------------------------- the batched forward
 int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st);
 
-template <class T>
-static int linear_rows(pie_decoder *d, const void *w4s, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st) {
-    if (d->cfg.weight_format == PIE_W_DENSE) {  // nn.Linear: the W16S units go back to a plain [N, K] matrix (packed row order)
-        const int rc = unpack_w16s_launch(w4s, N, K, d->prefill->wT, st);
-        return rc ? rc : gemm_xwt(d->cfg.dtype, x, d->prefill->wT, y, M, N, K, st);
+// Decides once per decoder whether the layer matrices keep a resident T copy: 2 B per parameter of all layers must fit
+// in a quarter of the free device memory.
+static bool resident_enabled(pie_decoder *d) {
+    PrefillScratch *s = d->prefill;
+    if (s->resident_mode < 0) {
+        const pie_decoder_config &c = d->cfg;
+        const size_t QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
+        const size_t need = 2 * (size_t)c.n_layers * ((QD + 2 * KVD) * c.hidden + (size_t)c.hidden * QD + 3 * (size_t)c.inter * c.hidden);
+        size_t free_b = 0, total_b = 0;
+        const char *e = getenv("PIE_PREFILL_RESIDENT");
+        if (e) s->resident_mode = atoi(e) != 0;
+        else s->resident_mode = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4;
     }
+    return s->resident_mode == 1;
+}
+
+template <class T>
+static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 *dst, hipStream_t st) {
+    if (d->cfg.weight_format == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
     const size_t words = (size_t)N * (K >> 3);
-    hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K),
-                       d->prefill->wT);
+    hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
     PIE_LAUNCH_CHECK();
-    return gemm_xwt(d->cfg.dtype, x, d->prefill->wT, y, M, N, K, st);
+    return PIE_OK;
+}
+
+// y[M, N] = x[M, K] . W^T for one streaming-layout matrix.  keep: a layer matrix (eligible for the resident copy); the
+// lm_head of a logits-on-every-position call always goes through the scratch.
+template <class T>
+static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true) {
+    PrefillScratch *s = d->prefill;
+    u16 *wT = s->wT;
+    bool ready = false;
+    if (keep && resident_enabled(d)) {
+        auto it = s->resident.find(packed);
+        if (it != s->resident.end()) wT = it->second, ready = true;
+        else if (hipMalloc((void **)&wT, 2 * (size_t)N * K) == hipSuccess) s->resident[packed] = wT;
+        else (void)hipGetLastError(), wT = s->wT, s->resident_mode = 0;  // out of memory: fall back to the scratch from here on
+    }
+    if (!ready) {
+        const int rc = expand_weights<T>(d, packed, N, K, wT, st);
+        if (rc) return rc;
+    }
+    return gemm_xwt(d->cfg.dtype, x, wT, y, M, N, K, st);
 }
 
 template <class T>
@@ -319,7 +363,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
         }
         if (logits_all) {  // lm_head on every position, like the reference (language.py:205-209)
             if ((rc = pie_rms_norm(s->x, d->glob.final_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
-            if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, M, (u16 *)logits_all + (size_t)c0 * c.vocab, st))) return rc;
+            if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, M, (u16 *)logits_all + (size_t)c0 * c.vocab, st, false))) return rc;
         }
         const bool last = c0 + M >= L;
         if (last)  // the last position continues through the decode step's lm_head + tail below
