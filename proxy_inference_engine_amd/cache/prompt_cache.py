@@ -5,12 +5,20 @@ between consecutive requests (mirror of cache/prompt_cache.py:13-76 of the refer
 the tail kernel wrote into the decoder's history buffer); they are read back in one copy the first time the
 history is needed (the next request's prefix match, a logits processor) instead of one host sync per generated
 token -- the role mx.async_eval plays in the reference's loop (engine/inference_engine.py:279,289).
-Disk persistence (cache_prompt / load_cached_prompt, prompt_cache.py:78-125) is outside the decode path
-(SURVEY.md 8f-4); load_cached_prompt is kept as a no-op so prepare_engine-style callers work.
+Disk persistence (cache_prompt / load_cached_prompt, prompt_cache.py:78-125): one safetensors file per prompt hash in
+the cache directory, written / read through BaseCache.save_cache / load_cache.  Like the reference, errors are logged,
+never raised; unlike it the default directory is created when something is first saved, not at construction.
 """
 from __future__ import annotations
 
+import hashlib
+import json
+import logging
+import pathlib
+
 import torch
+
+logger = logging.getLogger(__name__)
 
 from .kv_cache import BaseCache, ReusableKVCache
 
@@ -23,7 +31,7 @@ def _as_list(ids) -> list[int]:
 
 class PromptCache:
     def __init__(self, directory=None, cache: list[BaseCache] | None = None, computed_ids=None):
-        self.cache_directory = directory
+        self.cache_directory = self._get_cache_directory(directory)
         self.cache: list[BaseCache] = cache or []
         self._ids: list[int] = _as_list(computed_ids) if computed_ids is not None else []
         self._pending: list[torch.Tensor] = []  # device tensors not yet read back
@@ -77,5 +85,42 @@ class PromptCache:
         # Like the reference, computed_ids is NOT truncated here; update() appends the processed suffix.
         return prompt_ids[common:]
 
-    def load_cached_prompt(self, token_ids) -> None:  # prompt_cache.py:102-125: disk lookup, out of scope
-        return None
+    def cache_prompt(self) -> None:
+        """Writes the KV caches and the token ids they encode to <dir>/<sha256(ids)>.safetensors (prompt_cache.py:78-100)."""
+        try:
+            self.cache_directory.mkdir(parents=True, exist_ok=True)
+            ids = self.computed_ids
+            path = self.cache_directory / f"{self._compute_prompt_hash(ids)}.safetensors"
+            BaseCache.save_cache(str(path), self.cache, {"computed_ids": json.dumps(ids)})
+            logger.debug("Cached system prompt to %s", path)
+        except Exception as e:  # noqa: BLE001  (the reference logs and carries on, prompt_cache.py:99-100)
+            logger.error("Failed to cache system prompt: %s", e)
+
+    def load_cached_prompt(self, token_ids) -> None:
+        """Restores caches + ids saved for exactly these token ids, if such a file exists (prompt_cache.py:102-125).
+        NB (reference behaviour, kept): a loaded ReusableKVCache reports offset = its saved capacity
+        (reusable.py:215-224); the reuse() call of the following request sets it to the matched prefix."""
+        try:
+            path = self.cache_directory / f"{self._compute_prompt_hash(_as_list(token_ids))}.safetensors"
+            if not path.exists():
+                logger.debug("No cache found for prompt %s", path.stem)
+                return
+            cache, metadata = BaseCache.load_cache(str(path))
+            ids = json.loads(metadata["computed_ids"])
+            assert isinstance(ids, list)
+            self.computed_ids = ids
+            self.cache = cache
+        except Exception as e:  # noqa: BLE001
+            logger.error("Failed to load cached system prompt: %s", e)
+
+    @staticmethod
+    def _get_cache_directory(directory=None) -> pathlib.Path:
+        if isinstance(directory, str):
+            directory = pathlib.Path(directory)
+        if isinstance(directory, pathlib.Path):
+            return directory
+        return pathlib.Path(__file__).parent.absolute() / ".cache"  # prompt_cache.py:142-150
+
+    @staticmethod
+    def _compute_prompt_hash(token_ids) -> str:
+        return hashlib.sha256(str(_as_list(token_ids)).encode()).hexdigest()  # prompt_cache.py:165-166

@@ -127,3 +127,30 @@ def test_stochastic_sampler_argument_errors():
         make_sampler(temp=1.0, min_p=1.5)(x)                            # min_p.py:33-36
     with pytest.raises(ValueError):
         make_sampler(temp=1.0, min_p=0.1, min_tokens_to_keep=0)(x)      # min_p.py:37-40
+
+
+def test_prompt_cache_persistence_round_trip(tmp_path):
+    """cache_prompt / load_cached_prompt (prompt_cache.py:78-125) through BaseCache.save_cache / load_cache
+    (kv_cache/__init__.py:163-210): file named by sha256 of the id list, arrays "<layer>.<0|1>", metadata
+    "0.<i>" / "1.computed_ids" / "2.<i>"; a request with the same ids then re-processes exactly one token."""
+    from safetensors import safe_open
+    pc = PromptCache(directory=tmp_path, cache=[ReusableKVCache() for _ in range(3)])
+    ids = list(range(40, 50))
+    for i, c in enumerate(pc.cache):
+        c.update_and_fetch(torch.full((1, 2, 10, 8), float(i + 1)), torch.full((1, 2, 10, 8), -float(i + 1)))
+    pc.update(ids)
+    pc.cache_prompt()
+    files = list(tmp_path.glob("*.safetensors"))
+    assert len(files) == 1 and files[0].stem == PromptCache._compute_prompt_hash(ids)
+    with safe_open(str(files[0]), framework="pt") as f:
+        assert sorted(f.keys()) == ["0.0", "0.1", "1.0", "1.1", "2.0", "2.1"]
+        assert f.metadata()["1.computed_ids"] == str(ids).replace("'", "") and f.metadata()["2.1"] == "ReusableKVCache"
+    fresh = PromptCache(directory=tmp_path)
+    fresh.load_cached_prompt(list(range(7)))                            # no such file: nothing happens
+    assert fresh.cache == [] and fresh.computed_ids == []
+    fresh.load_cached_prompt(ids)
+    assert fresh.computed_ids == ids and len(fresh.cache) == 3
+    assert fresh.cache[2].offset == 256                                 # the reference quirk: offset = saved capacity ...
+    assert torch.equal(fresh.cache[1].keys.cpu(), pc.cache[1].keys.cpu()) and float(fresh.cache[2].values[0, 0, 9, 0]) == -3.0
+    todo = fresh(ids)                                                   # ... until the prefix match trims it
+    assert list(todo) == ids[-1:] and fresh.cache[0].offset == 9
