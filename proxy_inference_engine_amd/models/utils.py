@@ -77,6 +77,14 @@ LLAMA3_8B = {
 }
 
 
+LLAMA3_70B = {
+    "model_type": "llama", "hidden_size": 8192, "num_hidden_layers": 80, "intermediate_size": 28672,
+    "num_attention_heads": 64, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 128256,
+    "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+    "quantization": {"group_size": 64, "bits": 4},
+}
+
+
 def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch.bfloat16, device=None,
                          lm_head_gain: float = 1.0) -> dict[str, torch.Tensor]:
     """Random-weight checkpoint in the reference's on-disk layout, generated and quantised ON the GPU

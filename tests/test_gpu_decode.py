@@ -382,6 +382,33 @@ def test_dense_checkpoint_prefill_and_decode(dtype):
     assert model.step_bytes(100) > 2 * sum(v.size for k, v in w.items() if k.endswith("proj.weight"))  # 2 B per parameter
 
 
+def test_llama70b_shaped_layer_on_one_gpu():
+    """BASELINE.json configs[4] geometry (Llama-3-70B: H=8192, I=28672, 64/8 heads -> 8 q-heads per kv-head, D=128),
+    one layer, int4 g=64.  The 70B int4 model is 40 GB and fits one 288 GB card, so it runs on the single-GPU path:
+    two activation pieces per staging thread (K=8192), a 57 KB LDS activation image (K=28672, 14 K-slices), REP=8
+    attention.  20-token batched prompt (MFMA attention with 8 waves per workgroup) + decode steps vs the oracle."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 8192, "num_hidden_layers": 1, "intermediate_size": 28672,
+           "num_attention_heads": 64, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 1024,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=5, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(3).integers(0, cfg["vocab_size"], 20)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what="70B-shaped prefill hidden")
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="70B-shaped prefill logits")
+    for _ in range(2):
+        t = int(tok.item())
+        want = orc.forward(np.array([t]), ocache)[0]
+        tok, lp, logits = model.step(None, cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="70B-shaped decode")
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
