@@ -136,6 +136,9 @@ typedef struct {
     const void *wo;                      /* W4S [hidden, n_heads*head_dim] */
     const void *wgateup;                 /* W4S of interleaved (gate_i, up_i) rows */
     const void *wdown;                   /* W4S [hidden, inter] */
+    /* optional Linear biases (attention_bias / mlp_bias, models/llama/language.py:42-53,117-126), T, NULL = none;
+       bqkv in the packed q|k|v row order (pie_qkv_row_map), bgateup interleaved (pie_gateup_row_map) */
+    const void *bqkv, *bo, *bgateup, *bdown;
 } pie_layer_weights;
 
 typedef struct {

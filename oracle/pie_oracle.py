@@ -467,7 +467,9 @@ def synth_checkpoint(config: dict, seed: int = 0, dtype: str = "bfloat16", lm_he
     q = config.get("quantization") or {}
     out: dict[str, np.ndarray] = {}
 
-    def put_linear(name, N, K, gain=1.0):
+    def put_linear(name, N, K, gain=1.0, bias=False):
+        if bias:  # nn.Linear(..., bias=True) for attention_bias / mlp_bias (language.py:42-53,117-126)
+            out[f"{name}.bias"] = to_bits(round_T(rng.standard_normal(N, dtype=np.float32) * 0.1, dtype), dtype)
         w = round_T(rng.standard_normal((N, K), dtype=np.float32) * (0.02 * gain), dtype)
         if q and K % 64 == 0:
             wq, s, b = quantize(w, q["group_size"], q["bits"], dtype)
@@ -480,13 +482,14 @@ def synth_checkpoint(config: dict, seed: int = 0, dtype: str = "bfloat16", lm_he
         p = f"model.layers.{i}"
         out[f"{p}.input_layernorm.weight"] = to_bits(1.0 + 0.02 * rng.standard_normal(H, dtype=np.float32), dtype)
         out[f"{p}.post_attention_layernorm.weight"] = to_bits(1.0 + 0.02 * rng.standard_normal(H, dtype=np.float32), dtype)
-        put_linear(f"{p}.self_attn.q_proj", nh * D, H)
-        put_linear(f"{p}.self_attn.k_proj", nkv * D, H)
-        put_linear(f"{p}.self_attn.v_proj", nkv * D, H)
-        put_linear(f"{p}.self_attn.o_proj", H, nh * D)
-        put_linear(f"{p}.mlp.gate_proj", I, H)
-        put_linear(f"{p}.mlp.up_proj", I, H)
-        put_linear(f"{p}.mlp.down_proj", H, I)
+        ab, mb = bool(config.get("attention_bias")), bool(config.get("mlp_bias"))
+        put_linear(f"{p}.self_attn.q_proj", nh * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.k_proj", nkv * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.v_proj", nkv * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.o_proj", H, nh * D, bias=ab)
+        put_linear(f"{p}.mlp.gate_proj", I, H, bias=mb)
+        put_linear(f"{p}.mlp.up_proj", I, H, bias=mb)
+        put_linear(f"{p}.mlp.down_proj", H, I, bias=mb)
     out["model.norm.weight"] = to_bits(1.0 + 0.02 * rng.standard_normal(H, dtype=np.float32), dtype)
     if not config.get("tie_word_embeddings", True):
         put_linear("lm_head", V, H, gain=lm_head_gain)

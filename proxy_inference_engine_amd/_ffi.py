@@ -36,7 +36,8 @@ class pie_decoder_config(C.Structure):
 
 class pie_layer_weights(C.Structure):
     _fields_ = [("attn_norm", C.c_void_p), ("mlp_norm", C.c_void_p), ("wqkv", C.c_void_p), ("wo", C.c_void_p),
-                ("wgateup", C.c_void_p), ("wdown", C.c_void_p)]
+                ("wgateup", C.c_void_p), ("wdown", C.c_void_p),
+                ("bqkv", C.c_void_p), ("bo", C.c_void_p), ("bgateup", C.c_void_p), ("bdown", C.c_void_p)]
 
 
 class pie_global_weights(C.Structure):

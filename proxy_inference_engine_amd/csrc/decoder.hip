@@ -88,6 +88,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
             a.freqs = d->glob.rope_freqs, a.rope_cs = dense ? nullptr : d->rope_cs /* filled by the int4 embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
+            a.lin_bias = (const u16 *)w.bqkv;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
@@ -103,7 +104,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h;
+            a.fmt = fmt, a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h, a.lin_bias = (const u16 *)w.bo;
             if (d->combine) {
                 a.x = d->attn;
                 return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
@@ -114,12 +115,12 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
             a.fmt = fmt, a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
-            a.y = d->act;
+            a.y = d->act, a.lin_bias = (const u16 *)w.bgateup;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
         }
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h;
+            a.fmt = fmt, a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
             return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
         }
         case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials

@@ -96,6 +96,19 @@ __global__ void k_swiglu_rows(const u16 *gu, size_t n_out, u16 *act) {
     *reinterpret_cast<uint2 *>(act + i) = make_uint2((u32)o[0] | ((u32)o[1] << 16), (u32)o[2] | ((u32)o[3] << 16));
 }
 
+// y[m, :] = T(y[m, :] + b) for the Linear biases (y already T-rounded by the GEMM); 8 columns per thread, N % 8 == 0.
+template <class T>
+__global__ void k_bias_rows(u16 *y, const u16 *b, size_t n8, int N8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(y)[i], bb = reinterpret_cast<const uint4 *>(b)[i % N8];
+    const u32 a[4] = {v.x, v.y, v.z, v.w}, c[4] = {bb.x, bb.y, bb.z, bb.w};
+    u32 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2<T>(lo_f32<T>(a[k]) + lo_f32<T>(c[k]), hi_f32<T>(a[k]) + hi_f32<T>(c[k]));
+    reinterpret_cast<uint4 *>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ void k_add_pos(DecState *s, int delta) { s->pos += delta; }
 
 // ---------------------------------------------------------------- hipBLASLt through dlopen
@@ -292,7 +305,8 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
 // y[M, N] = x[M, K] . W^T for one streaming-layout matrix.  keep: a layer matrix (eligible for the resident copy); the
 // lm_head of a logits-on-every-position call always goes through the scratch.
 template <class T>
-static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true) {
+static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
+                       const void *bias = nullptr) {
     PrefillScratch *s = d->prefill;
     u16 *wT = s->wT;
     bool ready = false;
@@ -306,7 +320,12 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
         const int rc = expand_weights<T>(d, packed, N, K, wT, st);
         if (rc) return rc;
     }
-    return gemm_xwt(d->cfg.dtype, x, wT, y, M, N, K, st);
+    const int rc = gemm_xwt(d->cfg.dtype, x, wT, y, M, N, K, st);
+    if (rc || !bias) return rc;
+    const size_t n8 = (size_t)M * N / 8;
+    hipLaunchKernelGGL(k_bias_rows<T>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, y, (const u16 *)bias, n8, N / 8);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
 }
 
 template <class T>
@@ -334,7 +353,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
             const pie_layer_weights &w = d->layers[li];
             // Attention.__call__ (language.py:75-108) on input_layernorm(x)
             if ((rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
-            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                c.n_layers, c.n_heads, c.n_kv_heads, D, s->q);
             PIE_LAUNCH_CHECK();
@@ -350,15 +369,15 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
                 a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
             }
-            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo))) return rc;
             if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // h = x + r (language.py:151)
             // MLP.__call__ (language.py:126-127) on post_attention_layernorm(h)
             if ((rc = pie_rms_norm(s->x, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
-            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup))) return rc;
             const size_t n_act = (size_t)M * I;
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
-            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st))) return rc;
+            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown))) return rc;
             if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // out = h + r (language.py:153)
         }
         if (logits_all) {  // lm_head on every position, like the reference (language.py:205-209)

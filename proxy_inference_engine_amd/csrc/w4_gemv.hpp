@@ -50,7 +50,8 @@ struct GemvArgs {
     const u16 *norm_w;    // PRO_RMSNORM
     float eps;
     u16 *y;               // EPI_STORE / EPI_LOGITS [M,N]; EPI_SWIGLU act [N/2]
-    const u16 *lin_bias;  // EPI_STORE, optional
+    const u16 *lin_bias;  // optional nn.Linear / nn.QuantizedLinear bias [N] in PACKED row order (attention_bias / mlp_bias,
+                          // language.py:42-53,117-126): added to the T-rounded product, rounded again; not with EPI_LOGITS
     u16 *resid;           // EPI_RESIDUAL: residual stream, updated in place
     // EPI_ROPE_KV
     const float *freqs;
@@ -165,12 +166,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const bool live = lane < run;
     const int pair = gw + lane * W;
     const int R = 2 * pair;  // packed row index; the pair is rows R, R+1
-    u32 pre_u = 0;           // EPI_RESIDUAL: the residual pair; EPI_STORE: the linear bias pair
+    u32 pre_u = 0;           // EPI_RESIDUAL: the residual pair
+    u32 pre_b = 0;           // the linear bias pair
     float pre_cs = 1.0f, pre_sn = 0.0f;
     int pos = 0, cap = 0;
     u16 *kdst = nullptr, *vdst = nullptr;
     if (EPI == EPI_RESIDUAL && live) pre_u = *reinterpret_cast<const u32 *>(a.resid + R);
-    if (EPI == EPI_STORE && a.lin_bias && live) pre_u = *reinterpret_cast<const u32 *>(a.lin_bias + R);
+    const bool has_bias = EPI != EPI_LOGITS && a.lin_bias != nullptr;  // wave-uniform
+    if (has_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
     if (EPI == EPI_ROPE_KV) {
         pos = a.state->pos, cap = a.state->cap;
         kdst = reinterpret_cast<u16 *>(a.kv_table[a.layer]);
@@ -328,11 +331,15 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         const float2 o = *reinterpret_cast<const float2 *>(outp + 2 * lane);
         va = o.x, vb = o.y;
     }
+    if (has_bias && EPI != EPI_STORE) {  // y = T(T(x W^T) + b): fold the first rounding and the add here, the epilogues round again
+        va = round_T<T>(va) + lo_f32<T>(pre_b);
+        vb = round_T<T>(vb) + hi_f32<T>(pre_b);
+    }
     if (EPI == EPI_STORE || EPI == EPI_LOGITS) {
         float oa = round_T<T>(va), ob = round_T<T>(vb);
-        if (EPI == EPI_STORE && a.lin_bias && live) {
-            oa = round_T<T>(oa + lo_f32<T>(pre_u));
-            ob = round_T<T>(ob + hi_f32<T>(pre_u));
+        if (EPI == EPI_STORE && has_bias && live) {
+            oa = round_T<T>(oa + lo_f32<T>(pre_b));
+            ob = round_T<T>(ob + hi_f32<T>(pre_b));
         }
         if (live) *reinterpret_cast<u32 *>(a.y + (size_t)m * a.N + R) = pack2<T>(oa, ob);
         if (EPI == EPI_LOGITS) {  // per-wave log-softmax partial: max, first argmax, sum exp(x - max)

@@ -48,10 +48,11 @@ class TransformerBlock:
     """One entry of `model.layers` (PromptCache.create_kv_cache counts them, prompt_cache.py:39-41).
     Holds the layer's device weights; the arithmetic of language.py:144-154 runs inside the decoder."""
 
-    def __init__(self, attn_norm, mlp_norm, wqkv, wo, wgateup, wdown):
+    def __init__(self, attn_norm, mlp_norm, wqkv, wo, wgateup, wdown, biases=(None, None, None, None)):
         self.input_layernorm = attn_norm
         self.post_attention_layernorm = mlp_norm
         self.wqkv, self.wo, self.wgateup, self.wdown = wqkv, wo, wgateup, wdown
+        self.bqkv, self.bo, self.bgateup, self.bdown = biases  # attention_bias / mlp_bias (language.py:42-53,117-126), packed row order
 
     def nbytes(self) -> int:
         return sum(w.nbytes for w in (self.wqkv, self.wo, self.wgateup, self.wdown))
@@ -85,8 +86,8 @@ class Model:
         if q and (q.get("group_size") != 64 or q.get("bits") != 4):
             raise ValueError("quantised checkpoints must be int4 group_size=64 (config['quantization']); other MLX "
                              "quantisations are not on the MI355X path")
-        if args.attention_bias or args.mlp_bias or args.rope_traditional:
-            raise NotImplementedError("attention_bias / mlp_bias / rope_traditional are not on this path yet")
+        if args.rope_traditional:
+            raise NotImplementedError("rope_traditional is not on this path (Llama3RoPE uses the rotate-half form, llama/utils.py:42-50)")
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads or self.n_heads
         self.head_dim = args.head_dim or args.hidden_size // self.n_heads
@@ -111,6 +112,14 @@ class Model:
             trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
             return hip_ops.repack_w4s(*trip, row_map=row_map)
 
+        def bias(names: list[str], row_map=None):
+            """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix."""
+            try:
+                b = torch.cat([weights[f"{n}.bias"].reshape(-1) for n in names]).to(self.dtype)
+            except KeyError as e:
+                raise ValueError(f"attention_bias / mlp_bias is set but the checkpoint has no {e.args[0]}") from e
+            return (b[row_map.long()] if row_map is not None else b).contiguous()
+
         self.layers: list[TransformerBlock] = []
         for i in range(args.num_hidden_layers):
             pfx = f"model.layers.{i}"
@@ -121,6 +130,10 @@ class Model:
                 pack([f"{pfx}.self_attn.o_proj"]),
                 pack([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map),
                 pack([f"{pfx}.mlp.down_proj"]),
+                biases=(bias([f"{pfx}.self_attn.{n}_proj" for n in "qkv"], qkv_map) if args.attention_bias else None,
+                        bias([f"{pfx}.self_attn.o_proj"]) if args.attention_bias else None,
+                        bias([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map) if args.mlp_bias else None,
+                        bias([f"{pfx}.mlp.down_proj"]) if args.mlp_bias else None),
             ))
         if self.dense:
             self.embed_tokens = (_dense(weights, "model.embed_tokens", self.dtype).contiguous(), None, None)
@@ -145,7 +158,8 @@ class Model:
         for i, blk in enumerate(self.layers):
             lw = _ffi.pie_layer_weights(blk.input_layernorm.data_ptr(), blk.post_attention_layernorm.data_ptr(),
                                         blk.wqkv.packed.data_ptr(), blk.wo.packed.data_ptr(), blk.wgateup.packed.data_ptr(),
-                                        blk.wdown.packed.data_ptr())
+                                        blk.wdown.packed.data_ptr(),
+                                        *(b.data_ptr() if b is not None else None for b in (blk.bqkv, blk.bo, blk.bgateup, blk.bdown)))
             _ffi.check(lib.pie_decoder_set_layer(self._dec, i, C.byref(lw)))
         gw = _ffi.pie_global_weights(self.embed_tokens[0].data_ptr(), *(t.data_ptr() if t is not None else None for t in self.embed_tokens[1:]),
                                      self.norm.data_ptr(), self.lm_head.packed.data_ptr(), self.rope.freqs.data_ptr())

@@ -409,6 +409,38 @@ def test_llama70b_shaped_layer_on_one_gpu():
         assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="70B-shaped decode")
 
 
+@pytest.mark.parametrize("dtype,quant", [("bfloat16", True), ("float16", False)])
+def test_attention_and_mlp_bias(dtype, quant):
+    """ModelArgs.attention_bias / mlp_bias (language.py:24-25,42-53,117-126): q/k/v/o and gate/up/down carry a bias that
+    is added to the T-rounded product and rounded again -- inside the fused epilogues (before RoPE, before SiLU, before
+    the residual add) at decode, by a row kernel after the GEMM at prefill.  int4 and dense checkpoints."""
+    cfg = dict(po.TINY_CONFIG, attention_bias=True, mlp_bias=True, tie_word_embeddings=False)
+    if not quant:
+        cfg.pop("quantization", None)
+    w = po.synth_checkpoint(cfg, seed=33, dtype=dtype, lm_head_gain=4.0)
+    assert "model.layers.0.self_attn.k_proj.bias" in w and "model.layers.1.mlp.down_proj.bias" in w
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    rng = np.random.default_rng(2)
+    for L in (7, 30):                                                  # iterated decode steps / batched GEMM prefill
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got_all[l], want_all[l], dtype, what=f"bias L={L} position {l}")
+        tok = model.token
+        for _ in range(3):
+            want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"bias decode after L={L}")
+    # the biases matter: dropping them moves the logits far outside the tolerance
+    w0 = {k: v for k, v in w.items() if not k.endswith(".bias")}
+    ref0 = po.OracleLlama(dict(cfg, attention_bias=False, mlp_bias=False), w0, dtype).forward(prompt, [po.OracleKVCache() for _ in orc.layers])
+    assert np.abs(ref0[-1] - want_all[-1]).max() > 16 * EPS[dtype] * np.abs(want_all[-1]).max()
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
