@@ -208,7 +208,8 @@ struct PrefillScratch {
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
     // that is a small share of the free memory (PIE_PREFILL_RESIDENT=0/1 overrides), built on first use.
     std::map<const void *, u16 *> resident;
-    int resident_mode = -1;  // -1 undecided, 0 off, 1 on
+    int resident_mode = -1;   // -1: budget not fixed yet
+    size_t resident_left = 0; // bytes still available for resident copies
 };
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
@@ -217,8 +218,9 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
     const int mode = s->resident_mode;
+    const size_t left = s->resident_left;
     *s = PrefillScratch();
-    s->resident = std::move(keep), s->resident_mode = mode;
+    s->resident = std::move(keep), s->resident_mode = mode, s->resident_left = left;
 }
 
 void prefill_free(pie_decoder *d) {
@@ -277,20 +279,19 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
 // ---------------------------------------------------------------- the batched forward
 int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st);
 
-// Decides once per decoder whether the layer matrices keep a resident T copy: 2 B per parameter of all layers must fit
-// in a quarter of the free device memory.
-static bool resident_enabled(pie_decoder *d) {
+// Byte budget for resident T copies of layer matrices, fixed at the first batched prefill: half of the free device memory
+// (PIE_PREFILL_RESIDENT=0 disables, =<GiB> sets it).  Matrices are admitted in first-use order while the budget lasts
+// (8B model: all 15 GB; 70B: ~7/8 of its 140 GB); the rest keep going through the scratch every chunk.
+static size_t resident_budget(pie_decoder *d) {
     PrefillScratch *s = d->prefill;
     if (s->resident_mode < 0) {
-        const pie_decoder_config &c = d->cfg;
-        const size_t QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
-        const size_t need = 2 * (size_t)c.n_layers * ((QD + 2 * KVD) * c.hidden + (size_t)c.hidden * QD + 3 * (size_t)c.inter * c.hidden);
         size_t free_b = 0, total_b = 0;
         const char *e = getenv("PIE_PREFILL_RESIDENT");
-        if (e) s->resident_mode = atoi(e) != 0;
-        else s->resident_mode = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4;
+        if (e) s->resident_left = (size_t)atol(e) << 30;
+        else s->resident_left = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? free_b / 2 : 0;
+        s->resident_mode = 1;
     }
-    return s->resident_mode == 1;
+    return s->resident_left;
 }
 
 template <class T>
@@ -310,11 +311,14 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     PrefillScratch *s = d->prefill;
     u16 *wT = s->wT;
     bool ready = false;
-    if (keep && resident_enabled(d)) {
+    if (keep) {
+        const size_t bytes = 2 * (size_t)N * K;
         auto it = s->resident.find(packed);
         if (it != s->resident.end()) wT = it->second, ready = true;
-        else if (hipMalloc((void **)&wT, 2 * (size_t)N * K) == hipSuccess) s->resident[packed] = wT;
-        else (void)hipGetLastError(), wT = s->wT, s->resident_mode = 0;  // out of memory: fall back to the scratch from here on
+        else if (resident_budget(d) >= bytes) {
+            if (hipMalloc((void **)&wT, bytes) == hipSuccess) s->resident[packed] = wT, s->resident_left -= bytes;
+            else (void)hipGetLastError(), wT = s->wT, s->resident_left = 0;  // out of memory: scratch from here on
+        }
     }
     if (!ready) {
         const int rc = expand_weights<T>(d, packed, N, K, wT, st);

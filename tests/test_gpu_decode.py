@@ -227,8 +227,9 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
     rng = np.random.default_rng(31)
     prompt, more = rng.integers(0, cfg["vocab_size"], 100), rng.integers(0, cfg["vocab_size"], 40)
     orc = po.OracleLlama(cfg, w, DT)
-    for regime, rows, env in (("batched", 16, {"PIE_PREFILL_CHUNK": "32"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
-        for k in ("PIE_PREFILL_CHUNK", "PIE_PREFILL_MIN"):
+    # PIE_PREFILL_RESIDENT=0: every chunk dequantises into the scratch again (the other prefill tests keep resident copies)
+    for regime, rows, env in (("batched", 16, {"PIE_PREFILL_CHUNK": "32", "PIE_PREFILL_RESIDENT": "0"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
+        for k in ("PIE_PREFILL_CHUNK", "PIE_PREFILL_MIN", "PIE_PREFILL_RESIDENT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -239,9 +240,10 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
             want2 = orc.forward(more, ocache)
         finally:
             po.set_qmm_min_rows(16)
-        cache = model.make_cache()
-        got1 = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
-        got2 = model(torch.from_numpy(more)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        m = build(cfg, w) if regime == "batched" else model        # a fresh decoder: the resident budget is fixed at first use
+        cache = m.make_cache()
+        got1 = m(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        got2 = m(torch.from_numpy(more)[None].cuda(), cache=cache)[0].float().cpu().numpy()
         assert cache[0].offset == 140
         for l in range(100):
             assert_vec_close(got1[l], want1[l], DT, what=f"{regime} position {l}")
