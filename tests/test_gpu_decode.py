@@ -443,6 +443,44 @@ def test_attention_and_mlp_bias(dtype, quant):
     assert np.abs(ref0[-1] - want_all[-1]).max() > 16 * EPS[dtype] * np.abs(want_all[-1]).max()
 
 
+@pytest.mark.parametrize("quant", [True, False])
+def test_load_checkpoint_directory(tmp_path, quant):
+    """models.utils.load (models/utils.py:27-125): config.json + sharded model-*.safetensors in the reference's on-disk
+    layout (HF names; MLX triplets with uint32 codes when config["quantization"] is set, plain 16-bit weights otherwise),
+    through InferenceEngine(model_path) and a greedy generate_step, against the oracle on the same arrays."""
+    from safetensors.numpy import save_file
+
+    from proxy_inference_engine_amd import InferenceEngine
+    dtype = "float16"                                                   # numpy can write f16 shards (bf16 has no numpy dtype)
+    cfg = dict(po.TINY_CONFIG)
+    if not quant:
+        cfg.pop("quantization")
+    w = po.synth_checkpoint(cfg, seed=41, dtype=dtype, lm_head_gain=4.0)
+    arrays = {k: (v if v.dtype == np.uint32 else v.view(np.float16)) for k, v in w.items()}
+    names = sorted(arrays)
+    save_file({k: arrays[k] for k in names[::2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: arrays[k] for k in names[1::2]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(dict(cfg, architectures=["LlamaForCausalLM"], torch_dtype="float16")))
+    eng = InferenceEngine(str(tmp_path))
+    assert eng.model.dense == (not quant) and eng.model.dtype == torch.float16
+    prompt = np.random.default_rng(9).integers(0, cfg["vocab_size"], 20)
+    eng.prepare_engine(prompt, temp=0)
+    gen = eng.generate_step(torch.from_numpy(prompt))
+    orc = po.OracleLlama(cfg, w, dtype)
+    ogen = po.generate_step(orc, po.OraclePromptCache(), prompt)
+    for i in range(4):
+        tok, lp = next(gen)
+        otok, olp = next(ogen)
+        assert_vec_close(lp.cpu().numpy(), olp, dtype, what=f"loaded checkpoint step {i}")
+        top2 = np.sort(olp)[-2:]
+        if top2[1] - top2[0] > margin_bound(olp, dtype):
+            assert int(tok.item()) == otok
+        else:
+            break
+    with pytest.raises(FileNotFoundError):
+        InferenceEngine(str(tmp_path / "nowhere"))
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
