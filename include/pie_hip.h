@@ -113,8 +113,8 @@ int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, i
 /* ---------------------------------------------------------------- fused decode step
  * One forward of Model.__call__ (models/llama/language.py:199-210) for inputs[1,1] over per-layer
  * ReusableKVCache buffers (cache/kv_cache/reusable.py:96-142) followed by the tail of _inference
- * (engine/inference_engine.py:252-271) with the greedy sampler, as ~6 launches per layer:
- *   rmsnorm+qkv GEMV+RoPE+cache append | split-KV attention | combine | o_proj+residual |
+ * (engine/inference_engine.py:252-271) with the greedy sampler, as 5 launches per layer (6 beyond 1024 positions):
+ *   rmsnorm+qkv GEMV+RoPE+cache append | split-KV attention | [combine] | split merge+o_proj+residual |
  *   rmsnorm+gate/up GEMV+SwiGLU | down_proj+residual ; then rmsnorm+lm_head ; log-softmax+argmax.
  * Position and token live in device memory so the captured hipGraph is replayable. */
 typedef struct pie_decoder pie_decoder;

@@ -3,8 +3,8 @@
 // (engine/inference_engine.py:252-271), replayable as a hipGraph because position, token and the KV
 // buffer addresses are read from device memory.
 //
-// Launches per step: embed | per layer { rmsnorm+qkv+rope+append, split-KV attention, combine,
-// o_proj+residual, rmsnorm+gate/up+swiglu, down+residual } | rmsnorm+lm_head(+tile stats) | finish.
+// Launches per step: embed | per layer { rmsnorm+qkv+rope+append, split-KV attention, [combine: caches beyond 1024
+// positions only], merge+o_proj+residual, rmsnorm+gate/up+swiglu, down+residual } | rmsnorm+lm_head(+wave stats) | finish.
 #include <cstring>
 #include <new>
 #include <vector>
