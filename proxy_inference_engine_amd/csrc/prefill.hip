@@ -13,7 +13,7 @@
 //   * hand-written HIP for everything around it: RMSNorm rows, RoPE + cache append from the packed q|k|v rows, causal
 //     attention (the decode kernel with one query row per blockIdx.z: row r attends offset + r + 1 positions), the
 //     split merge, SwiGLU on the interleaved gate/up rows, residual adds.
-// The chunk is bounded (PIE_PREFILL_CHUNK, default 1024 rows) so scratch stays small next to the weights.
+// The chunk is bounded (PIE_PREFILL_CHUNK, default 4096 rows: ~0.6 GB of activation scratch on the 8B model).
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 
@@ -238,8 +238,8 @@ int prefill_min_rows() {  // read per call (not cached): tests and tools switch 
 }
 
 static int prefill_chunk_rows() {
-    const char *e = getenv("PIE_PREFILL_CHUNK");
-    const int n = e ? atoi(e) : 1024;
+    const char *e = getenv("PIE_PREFILL_CHUNK");  // measured on the 8B model, 4096-token prompt: 512 -> 119 ms, 1024 -> 83, 2048 -> 67, 4096 -> 65
+    const int n = e ? atoi(e) : 4096;
     return n < 16 ? 16 : (n > 8192 ? 8192 : n);
 }
 
