@@ -481,6 +481,30 @@ def test_load_checkpoint_directory(tmp_path, quant):
         InferenceEngine(str(tmp_path / "nowhere"))
 
 
+@pytest.mark.parametrize("n_heads,n_kv", [(4, 4), (4, 2), (8, 1)])
+def test_prefill_flash_attention_head_groupings(n_heads, n_kv):
+    """The MFMA prefill attention with 1, 2 and 8 q-heads per kv-head (64 / 128 / 512-thread workgroups; the 8B / 70B
+    tests cover 4 and 8 at full size): small head_dim-128 models, 75-token prompt + 37-token continuation, every position."""
+    cfg = {"model_type": "llama", "hidden_size": n_heads * 128, "num_hidden_layers": 2, "intermediate_size": 768,
+           "num_attention_heads": n_heads, "num_key_value_heads": n_kv, "rms_norm_eps": 1e-5, "vocab_size": 512,
+           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": True,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=50 + n_kv, dtype=DT, lm_head_gain=4.0)
+    model = build(cfg, w)
+    orc = po.OracleLlama(cfg, w, DT)
+    rng = np.random.default_rng(n_heads)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    cache = model.make_cache()
+    off = 0
+    for L in (75, 37):
+        ids = rng.integers(0, cfg["vocab_size"], L)
+        want = orc.forward(ids, ocache)
+        got = model(torch.from_numpy(ids)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got[l], want[l], DT, what=f"{n_heads}/{n_kv} heads position {off + l}")
+        off += L
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
