@@ -344,7 +344,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
     const char *am = getenv("PIE_PREFILL_ATTN");  // "valu" forces the row-per-launch-slice VALU kernel (tests compare the two)
-    const bool mfma_attn = D == 128 && !(am && am[0] == 'v');
+    const bool mfma_attn = !(am && am[0] == 'v');
     for (int c0 = 0; c0 < L; c0 += chunk) {
         const int M = L - c0 < chunk ? L - c0 : chunk;
         // h = embed_tokens(inputs)  (language.py:176)
@@ -365,8 +365,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
                 PrefillAttnArgs pa = {};
                 pa.q = s->q, pa.kv_table = d->kv_table, pa.layer = li, pa.n_layers = c.n_layers, pa.state = d->state;
                 pa.M = M, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
-                if ((rc = prefill_attn_launch_t<T>(pa, st))) return rc;
-            } else {  // head_dim 64: the VALU decode kernel, one query row per blockIdx.z
+                if ((rc = prefill_attn_launch_t<T>(pa, D, st))) return rc;
+            } else {  // PIE_PREFILL_ATTN=valu: the VALU decode kernel, one query row per blockIdx.z (cross-check for the tests)
                 AttnArgs a = {};
                 a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
                 a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.rows = M, a.scale = 1.0f / sqrtf((float)D);

@@ -1,4 +1,4 @@
-// prefill_attn.hpp -- causal flash attention for prompt chunks on the MFMA units (head_dim 128).
+// prefill_attn.hpp -- causal flash attention for prompt chunks on the MFMA units (head_dim 128 or 64).
 //
 // Replaces mx.fast.scaled_dot_product_attention(q, k, v, scale, mask=causal) at models/base.py:111-113 for L > 1
 // (mask built by models/base.py:18-53: query row r at absolute position offset + r sees keys 0 .. offset + r).
@@ -26,13 +26,13 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 struct PrefillAttnArgs {
-    const u16 *q;                        // [M, Hq, 128]
-    const unsigned long long *kv_table;  // K buffers then V buffers, [Hkv, cap, 128] each
+    const u16 *q;                        // [M, Hq, D]
+    const unsigned long long *kv_table;  // K buffers then V buffers, [Hkv, cap, D] each
     int layer, n_layers;
     const DecState *state;               // pos = offset of row 0, cap
     int M, Hq, Hkv;
     float scale;
-    u16 *out;                            // [M, Hq, 128]
+    u16 *out;                            // [M, Hq, D]
 };
 
 template <class T> struct MfmaT;
@@ -47,13 +47,19 @@ template <> struct MfmaT<F16> {
     }
 };
 
-// byte offset of 16-byte chunk `ch` (0..15) of row `row` (0..31) in a [32][128 x 16-bit] LDS tile
-__device__ __forceinline__ int pa_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// byte offset of 16-byte chunk `ch` (0 .. D/8-1) of row `row` (0..31) in a [32][D x 16-bit] LDS tile: the guide's dual-use
+// swizzle (b) for 256-byte rows; for D = 64 the same XOR folded to the row's 8 chunks (a bijection inside the row, which is
+// all correctness needs -- both the writes and the two kinds of reads go through it)
+template <int D>
+__device__ __forceinline__ int pa_off(int row, int ch) {
+    return 2 * D * row + 16 * (ch ^ ((((row & 3) << 2) | ((row >> 2) & 3)) & (D / 8 - 1)));
+}
 
-template <class T, int REP>
+template <class T, int D, int REP>
 __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs a) {
-    constexpr int D = 128, BK = 32, NT = REP * 64, CPT = (BK * 16 + NT - 1) / NT;  // 16-byte chunks per thread and tile
-    __shared__ __attribute__((aligned(16))) char k_lds[BK * 256], v_lds[BK * 256];
+    constexpr int BK = 32, NT = REP * 64, CH = D / 8, KS = D / 16, DT = D / 32;  // chunks per row, k-steps of Q.K^T, 32-dim output tiles
+    constexpr int CPT = (BK * CH + NT - 1) / NT;                                   // 16-byte chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) char k_lds[BK * 2 * D], v_lds[BK * 2 * D];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 32, g = blockIdx.y, hq = g * REP + wave;
@@ -70,20 +76,20 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int x = threadIdx.x + i * NT;
-            x = x < BK * 16 ? x : BK * 16 - 1;
-            int t = b * BK + (x >> 4);
+            x = x < BK * CH ? x : BK * CH - 1;
+            int t = b * BK + x / CH;
             t = t < t_last ? t : t_last;
-            kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x & 15) * 8);
-            vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x & 15) * 8);
+            kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x % CH) * 8);
+            vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x % CH) * 8);
         }
     };
     auto publish = [&]() {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int x = threadIdx.x + i * NT;
-            if (x < BK * 16) {
-                *reinterpret_cast<uint4 *>(k_lds + pa_off(x >> 4, x & 15)) = kreg[i];
-                *reinterpret_cast<uint4 *>(v_lds + pa_off(x >> 4, x & 15)) = vreg[i];
+            if (x < BK * CH) {
+                *reinterpret_cast<uint4 *>(k_lds + pa_off<D>(x / CH, x % CH)) = kreg[i];
+                *reinterpret_cast<uint4 *>(v_lds + pa_off<D>(x / CH, x % CH)) = vreg[i];
             }
         }
     };
@@ -91,15 +97,15 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
 
     // Q fragments (B operand of K . Q^T): lane (row c, half h), k-step s holds Q[r0 + c][hq][16 s + 8 h .. + 8]
     const int qrow = r0 + c < a.M ? r0 + c : a.M - 1;
-    uint4 qf[8];
+    uint4 qf[KS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const uint4 *>(a.q + ((size_t)qrow * a.Hq + hq) * D + 16 * s + 8 * h);
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const uint4 *>(a.q + ((size_t)qrow * a.Hq + hq) * D + 16 * s + 8 * h);
     const int t_row = pos0 + r0 + c;  // last key this lane's query row attends (rows past M are padding: never stored)
     const float sl2 = a.scale * ATTN_LOG2E;
 
-    f32x16_t oacc[4];
+    f32x16_t oacc[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.0f;
     float m_run = ATTN_NEG, l_run = 0.0f;
@@ -119,8 +125,8 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[i] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const uint4 kf = *reinterpret_cast<const uint4 *>(k_lds + pa_off(c, 2 * s + h));
+        for (int s = 0; s < KS; ++s) {
+            const uint4 kf = *reinterpret_cast<const uint4 *>(k_lds + pa_off<D>(c, 2 * s + h));
             sacc = MfmaT<T>::run(kf, qf[s], sacc);
         }
         // online softmax over keys: register i <-> key t0 + (i & 3) + 8 (i >> 2) + 4 h
@@ -138,7 +144,7 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
             const float alpha = attn_exp2(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
             m_run = m_new;
@@ -160,12 +166,12 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
             const uint4 bh = make_uint4(phi[4 * s], phi[4 * s + 1], phi[4 * s + 2], phi[4 * s + 3]);
             const uint4 bl = make_uint4(plo[4 * s], plo[4 * s + 1], plo[4 * s + 2], plo[4 * s + 3]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 const int ch = 4 * dt + 2 * (grp & 1) + (tp >> 1);
                 const v4i16_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off(16 * s + 4 * h + tq, ch) + 8 * (tp & 1)));
+                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off<D>(16 * s + 4 * h + tq, ch) + 8 * (tp & 1)));
                 const v4i16_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off(16 * s + 8 + 4 * h + tq, ch) + 8 * (tp & 1)));
+                    (__attribute__((address_space(3))) v4i16_t *)(v_lds + pa_off<D>(16 * s + 8 + 4 * h + tq, ch) + 8 * (tp & 1)));
                 const uint2 a0 = __builtin_bit_cast(uint2, lo4), a1 = __builtin_bit_cast(uint2, hi4);
                 const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
                 oacc[dt] = MfmaT<T>::run(vf, bh, oacc[dt]);
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     if (r0 + c < a.M) {
         u16 *orow = a.out + ((size_t)(r0 + c) * a.Hq + hq) * D;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // registers 4k .. 4k+3 <-> dims 32 dt + 8 k + 4 h + {0..3}
                 const uint2 o = make_uint2(pack2<T>(oacc[dt][4 * k] * inv, oacc[dt][4 * k + 1] * inv),
@@ -188,16 +194,20 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     }
 }
 
-template <class T>
-static int prefill_attn_launch_t(const PrefillAttnArgs &a, hipStream_t st) {
+template <class T, int D>
+static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
     const dim3 grid((a.M + 31) / 32, a.Hkv);
     switch (a.Hq / a.Hkv) {
-        case 1: hipLaunchKernelGGL((k_prefill_attn<T, 1>), grid, dim3(64), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_prefill_attn<T, 2>), grid, dim3(128), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_prefill_attn<T, 4>), grid, dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_prefill_attn<T, 8>), grid, dim3(512), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_prefill_attn<T, D, 1>), grid, dim3(64), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_prefill_attn<T, D, 2>), grid, dim3(128), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_prefill_attn<T, D, 4>), grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_prefill_attn<T, D, 8>), grid, dim3(512), 0, st, a); break;
         default: return pie::fail(PIE_E_SHAPE, "prefill attention: n_heads / n_kv_heads must be 1, 2, 4 or 8");
     }
     PIE_LAUNCH_CHECK();
     return PIE_OK;
+}
+template <class T>
+static int prefill_attn_launch_t(const PrefillAttnArgs &a, int D, hipStream_t st) {
+    return D == 128 ? prefill_attn_launch_d<T, 128>(a, st) : prefill_attn_launch_d<T, 64>(a, st);
 }
