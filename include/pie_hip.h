@@ -90,6 +90,9 @@ int pie_rms_norm(const void *x, const void *w, float eps, int rows, int H, int d
  * base=None, scale=1.0, offset, freqs) (K4).  Call site: models/llama/utils.py:42-50.
  * x,y [heads,L,D] T; freqs device fp32 [D/2]; position of row l = offset + l. */
 int pie_rope(const void *x, int heads, int L, int D, const float *freqs, int offset, int dtype, void *y, void *stream);
+/* the same with mx.fast.rope's `traditional` flag: non-zero rotates the interleaved pairs (2i, 2i+1) */
+int pie_rope_ex(const void *x, int heads, int L, int D, const float *freqs, int offset, int traditional, int dtype, void *y,
+                void *stream);
 
 /* ---------------------------------------------------------------- mx.fast.scaled_dot_product_attention (K2)
  * Call site: models/base.py:111-113 <- models/llama/language.py:98-105.  Decode form (L = 1, mask = None):
@@ -127,6 +130,8 @@ typedef struct {
     int kv_splits;      /* split-KV factor of the attention kernel (0 = default) */
     int weight_format;  /* PIE_W_INT4_G64 (MLX int4 group-64 triplets, W4S units) or PIE_W_DENSE (16-bit nn.Linear
                            weights, W16S units; embed_codes is then the T [vocab, hidden] table, scales/biases NULL) */
+    int rope_traditional; /* ModelArgs.rope_traditional (language.py:27,69): rotate the interleaved pairs (2i, 2i+1); wqkv is
+                             then the plain q|k|v concatenation (row_map NULL), not pie_qkv_row_map's order */
 } pie_decoder_config;
 enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1 };
 

@@ -265,8 +265,10 @@ void orc_rms_norm(const float *x, int rows, int H, const void *w, float eps, int
  * Call site: models/llama/utils.py:42-50 <- models/llama/language.py:91-92 (offset = cache.offset).
  * x [heads, L, D]; position p = offset + l; theta_i = p * (1/freqs[i]); rotate-half pairs (i, i+D/2).
  */
-void orc_rope(const float *x, int heads, int L, int D, const float *freqs, int offset, int dtype,
-              float *y) {
+/* traditional != 0: mx.fast.rope(traditional=True), ModelArgs.rope_traditional (language.py:27,69): the rotated pairs are
+ * the interleaved (2i, 2i+1) instead of (i, i+D/2); same angles. */
+void orc_rope_ex(const float *x, int heads, int L, int D, const float *freqs, int offset, int dtype,
+                 int traditional, float *y) {
     const int half = D / 2;
     for (int h = 0; h < heads; ++h)
         for (int l = 0; l < L; ++l) {
@@ -276,11 +278,16 @@ void orc_rope(const float *x, int heads, int L, int D, const float *freqs, int o
             for (int i = 0; i < half; ++i) {
                 float theta = p * (1.0f / freqs[i]);
                 float c = cosf(theta), s = sinf(theta);
-                float a = xr[i], b = xr[i + half];
-                yr[i] = rnd(a * c - b * s, dtype);
-                yr[i + half] = rnd(a * s + b * c, dtype);
+                const int i0 = traditional ? 2 * i : i, i1 = traditional ? 2 * i + 1 : i + half;
+                float a = xr[i0], b = xr[i1];
+                yr[i0] = rnd(a * c - b * s, dtype);
+                yr[i1] = rnd(a * s + b * c, dtype);
             }
         }
+}
+void orc_rope(const float *x, int heads, int L, int D, const float *freqs, int offset, int dtype,
+              float *y) {
+    orc_rope_ex(x, heads, L, D, freqs, offset, dtype, 0, y);
 }
 
 /* Llama3RoPE.__init__ (models/llama/utils.py:22-39): scaled frequency table, fp32 like mx.arange math.
@@ -422,6 +429,7 @@ typedef struct {
     orc_linear_t embed;               /* [vocab, hidden] */
     const void *final_norm;
     orc_linear_t lm_head;             /* unused when tied */
+    int rope_traditional;             /* ModelArgs.rope_traditional (language.py:27,69) */
 } orc_llama_t;
 
 /* mx.quantized_matmul has two regimes in MLX (mlx/backend/metal/quantized.cpp + kernels/quantized.h, dependency pinned
@@ -528,8 +536,8 @@ int orc_llama_forward(const orc_llama_t *m, const int32_t *ids, int L, float *co
         to_heads(q, L, nh, D, qh);
         to_heads(kk, L, nkv, D, kh);
         to_heads(vv, L, nkv, D, vh);
-        orc_rope(qh, nh, L, D, m->rope_freqs, offset, dt, q);   /* q now [nh, L, D] */
-        orc_rope(kh, nkv, L, D, m->rope_freqs, offset, dt, kk); /* kk now [nkv, L, D] */
+        orc_rope_ex(qh, nh, L, D, m->rope_freqs, offset, dt, m->rope_traditional, q);   /* q now [nh, L, D] */
+        orc_rope_ex(kh, nkv, L, D, m->rope_freqs, offset, dt, m->rope_traditional, kk); /* kk now [nkv, L, D] */
         /* cache.update_and_fetch, reusable.py:134-142 */
         for (int g = 0; g < nkv; ++g)
             for (int l = 0; l < L; ++l) {

@@ -48,6 +48,7 @@ class orc_llama_t(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
         ("gate", C.c_void_p), ("up", C.c_void_p), ("down", C.c_void_p),
         ("embed", orc_linear_t), ("final_norm", C.c_void_p), ("lm_head", orc_linear_t),
+        ("rope_traditional", C.c_int),
     ]
 
 
@@ -180,14 +181,14 @@ def rms_norm(x, w_bits, eps, dtype="bfloat16"):
     return y
 
 
-def rope(x, freqs, offset=0, dtype="bfloat16"):
-    """mx.fast.rope(x[..., heads, L, D], D, traditional=False, base=None, scale=1.0, offset, freqs)."""
+def rope(x, freqs, offset=0, dtype="bfloat16", traditional=False):
+    """mx.fast.rope(x[..., heads, L, D], D, traditional, base=None, scale=1.0, offset, freqs)."""
     x = _f32(x)
     L, D = x.shape[-2:]
     heads = x.size // (L * D)
     freqs = _f32(freqs)
     y = np.empty_like(x)
-    lib().orc_rope(_p(x), heads, L, D, _p(freqs), int(offset), _dt(dtype), _p(y))
+    lib().orc_rope_ex(_p(x), heads, L, D, _p(freqs), int(offset), _dt(dtype), int(traditional), _p(y))
     return y
 
 
@@ -297,6 +298,7 @@ class OracleLlama:
         m.group_size, m.bits, m.quantized, m.tie_word_embeddings = self.group_size, self.bits, int(self.quantized), int(self.tie)
         m.eps = float(self.config["rms_norm_eps"])
         m.rope_freqs = self.freqs.ctypes.data
+        m.rope_traditional = int(bool(self.config.get("rope_traditional", False)))
         L = self.n_layers
         ptr_arr = C.c_void_p * L
         an = ptr_arr(*[self.weights[f"model.layers.{i}.input_layernorm.weight"].ctypes.data for i in range(L)])

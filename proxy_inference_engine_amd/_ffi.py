@@ -19,7 +19,7 @@ KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5
 EXPORTS = [
     "pie_hello", "pie_version", "pie_last_error", "pie_device_info",
     "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64",
-    "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode",
+    "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode",
     "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_qkv_row_map", "pie_gateup_row_map",
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
     "pie_decoder_set_kv", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill",
@@ -31,7 +31,7 @@ EXPORTS = [
 class pie_decoder_config(C.Structure):
     _fields_ = [("dtype", C.c_int), ("hidden", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
                 ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("inter", C.c_int), ("vocab", C.c_int),
-                ("rms_eps", C.c_float), ("tie_word_embeddings", C.c_int), ("kv_splits", C.c_int), ("weight_format", C.c_int)]
+                ("rms_eps", C.c_float), ("tie_word_embeddings", C.c_int), ("kv_splits", C.c_int), ("weight_format", C.c_int), ("rope_traditional", C.c_int)]
 
 
 class pie_layer_weights(C.Structure):

@@ -88,7 +88,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
             a.freqs = d->glob.rope_freqs, a.rope_cs = dense ? nullptr : d->rope_cs /* filled by the int4 embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
-            a.lin_bias = (const u16 *)w.bqkv;
+            a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_rms_norm(const u16 *x, const u16 *w, fl
 
 // ---------------------------------------------------------------- mx.fast.rope (rotate-half), one thread per pair
 template <class T>
-__global__ void k_rope(const u16 *x, int heads, int L, int D, const float *freqs, int offset, u16 *y) {
+__global__ void k_rope(const u16 *x, int heads, int L, int D, const float *freqs, int offset, int traditional, u16 *y) {
     const int half = D >> 1;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)heads * L * half) return;
@@ -80,9 +80,10 @@ __global__ void k_rope(const u16 *x, int heads, int L, int D, const float *freqs
     const float theta = (float)(offset + l) * (1.0f / freqs[i]);
     float sn, cs;
     sincosf(theta, &sn, &cs);
-    const float a = T::to_f32(x[row * D + i]), b = T::to_f32(x[row * D + i + half]);
-    y[row * D + i] = T::from_f32(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, sn)));
-    y[row * D + i + half] = T::from_f32(__fadd_rn(__fmul_rn(a, sn), __fmul_rn(b, cs)));
+    const int i0 = traditional ? 2 * i : i, i1 = traditional ? 2 * i + 1 : i + half;
+    const float a = T::to_f32(x[row * D + i0]), b = T::to_f32(x[row * D + i1]);
+    y[row * D + i0] = T::from_f32(__fsub_rn(__fmul_rn(a, cs), __fmul_rn(b, sn)));
+    y[row * D + i1] = T::from_f32(__fadd_rn(__fmul_rn(a, sn), __fmul_rn(b, cs)));
 }
 
 // ---------------------------------------------------------------- nn.silu(a) * b and a + b, 8 elements per thread
@@ -158,14 +159,19 @@ int pie_rms_norm(const void *x, const void *w, float eps, int rows, int H, int d
 }
 
 int pie_rope(const void *x, int heads, int L, int D, const float *freqs, int offset, int dtype, void *y, void *stream) {
+    return pie_rope_ex(x, heads, L, D, freqs, offset, 0, dtype, y, stream);
+}
+
+int pie_rope_ex(const void *x, int heads, int L, int D, const float *freqs, int offset, int traditional, int dtype, void *y,
+                void *stream) {
     PIE_REQUIRE(x && freqs && y, PIE_E_ARG, "pie_rope: null pointer");
     PIE_REQUIRE(heads > 0 && L > 0 && D > 0 && D % 2 == 0 && offset >= 0, PIE_E_SHAPE, "pie_rope: bad shape");
     const size_t n = (size_t)heads * L * (D / 2);
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     return by_dtype(
-        dtype, [&] { hipLaunchKernelGGL(k_rope<F16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, (u16 *)y); },
-        [&] { hipLaunchKernelGGL(k_rope<BF16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, (u16 *)y); }, "pie_rope");
+        dtype, [&] { hipLaunchKernelGGL(k_rope<F16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, traditional, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_rope<BF16>, grid, block, 0, st, (const u16 *)x, heads, L, D, freqs, offset, traditional, (u16 *)y); }, "pie_rope");
 }
 
 static int binary(int op, const void *a, const void *b, size_t n, int dtype, void *y, void *stream, const char *who) {

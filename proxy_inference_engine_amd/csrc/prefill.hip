@@ -56,7 +56,7 @@ __global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out)
 template <class T>
 __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
-                                                         int n_kv_heads, int HD, u16 *q_out) {
+                                                         int n_kv_heads, int HD, int traditional, u16 *q_out) {
     const int m = blockIdx.x, pos = state->pos + m, cap = state->cap, half = HD >> 1;
     const int q_cols = n_heads * HD, k_cols = n_kv_heads * HD;
     u16 *kdst = reinterpret_cast<u16 *>(kv_table[layer]), *vdst = reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             float sn, cs;
             sincosf((float)pos * (1.0f / freqs[ii]), &sn, &cs);
             u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + pos) * HD;
-            dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
-            dst[ii + half] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
+            const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
+            dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
+            dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
         } else {
             const int rr = R - q_cols - k_cols;
             *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + pos) * HD + rr % HD) = pr;
@@ -359,7 +360,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
             if ((rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
-                               c.n_layers, c.n_heads, c.n_kv_heads, D, s->q);
+                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q);
             PIE_LAUNCH_CHECK();
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
                 PrefillAttnArgs pa = {};

@@ -60,6 +60,7 @@ struct GemvArgs {
     u16 *q_out;
     const unsigned long long *kv_table;  // [2*n_layers] device pointers: K buffers then V buffers
     int layer, n_layers, n_heads, n_kv_heads, head_dim;
+    int rope_traditional;  // EPI_ROPE_KV: packed q/k rows (2i, 2i+1) are the interleaved pair itself (mx.fast.rope traditional=True)
     LogitStat *stats;     // EPI_LOGITS: one entry per wave of the grid
     const float *part_acc, *part_ml;  // PRO_ATTN: split-KV partials [Hq, splits, D] / [Hq, splits, 2]
     int splits;
@@ -378,8 +379,9 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const int rr = R < q_rows ? R : R - q_rows;
                 const int head = rr / HD, ii = (rr % HD) >> 1;
                 u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD : kdst + ((size_t)head * cap + pos) * HD;
-                dst[ii] = T::from_f32(__fsub_rn(__fmul_rn(ra, pre_cs), __fmul_rn(rb, pre_sn)));
-                dst[ii + half] = T::from_f32(__fadd_rn(__fmul_rn(ra, pre_sn), __fmul_rn(rb, pre_cs)));
+                const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + half;
+                dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, pre_cs), __fmul_rn(rb, pre_sn)));
+                dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, pre_sn), __fmul_rn(rb, pre_cs)));
             } else {
                 const int rr = R - q_rows - k_rows;
                 const int head = rr / HD, dd2 = rr % HD;

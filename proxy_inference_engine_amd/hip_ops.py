@@ -183,14 +183,14 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
 
 def rope(x: torch.Tensor, dims: int, traditional: bool = False, base=None, scale: float = 1.0, offset: int = 0,
          freqs: torch.Tensor | None = None) -> torch.Tensor:
-    """mx.fast.rope(x[..., heads, L, D], dims, traditional=False, base=None, scale=1.0, offset, freqs)."""
-    if traditional or base is not None or scale != 1.0 or freqs is None or dims != x.shape[-1]:
-        raise ValueError("only the Llama3RoPE form is implemented: traditional=False, base=None, scale=1.0, freqs given, dims=D")
+    """mx.fast.rope(x[..., heads, L, D], dims, traditional, base=None, scale=1.0, offset, freqs)."""
+    if base is not None or scale != 1.0 or freqs is None or dims != x.shape[-1]:
+        raise ValueError("only the Llama3RoPE form is implemented: base=None, scale=1.0, freqs given, dims=D")
     _dev(x), _dev(freqs)
     L, D = x.shape[-2:]
     y = torch.empty_like(x)
-    _ffi.check(_ffi.load().pie_rope(_ffi.p(x), x.numel() // (L * D), L, D, _ffi.p(freqs), int(offset),
-                                    _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    _ffi.check(_ffi.load().pie_rope_ex(_ffi.p(x), x.numel() // (L * D), L, D, _ffi.p(freqs), int(offset), int(bool(traditional)),
+                                       _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
     return y
 
 

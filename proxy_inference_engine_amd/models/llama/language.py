@@ -86,8 +86,6 @@ class Model:
         if q and (q.get("group_size") != 64 or q.get("bits") != 4):
             raise ValueError("quantised checkpoints must be int4 group_size=64 (config['quantization']); other MLX "
                              "quantisations are not on the MI355X path")
-        if args.rope_traditional:
-            raise NotImplementedError("rope_traditional is not on this path (Llama3RoPE uses the rotate-half form, llama/utils.py:42-50)")
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads or self.n_heads
         self.head_dim = args.head_dim or args.hidden_size // self.n_heads
@@ -101,7 +99,9 @@ class Model:
         self.rope = Llama3RoPE(max_len, max_len, self.head_dim, args.rope_theta, float(rs.get("factor", 1.0)),
                                float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 1.0)), device=device)
 
-        qkv_map = hip_ops.qkv_row_map(self.n_heads, self.n_kv_heads, self.head_dim).to(device)
+        # rotate-half RoPE wants partners (i, i + D/2) on adjacent packed rows; the traditional form rotates (2i, 2i+1), which
+        # already are adjacent in the plain q|k|v concatenation
+        qkv_map = None if args.rope_traditional else hip_ops.qkv_row_map(self.n_heads, self.n_kv_heads, self.head_dim).to(device)
         gu_map = hip_ops.gateup_row_map(I).to(device)
 
         def pack(names: list[str], row_map=None):
@@ -152,7 +152,7 @@ class Model:
         lib = _ffi.load()
         cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
                                       self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits),
-                                      1 if self.dense else 0)
+                                      1 if self.dense else 0, int(bool(args.rope_traditional)))
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
         for i, blk in enumerate(self.layers):

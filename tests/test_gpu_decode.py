@@ -505,6 +505,38 @@ def test_prefill_flash_attention_head_groupings(n_heads, n_kv):
         off += L
 
 
+def test_rope_traditional():
+    """ModelArgs.rope_traditional (language.py:27,69 -> mx.fast.rope(traditional=True)): the interleaved pairs (2i, 2i+1)
+    rotate.  q|k|v are then streamed in their natural row order; op level and through the fused decode / prefill paths."""
+    from proxy_inference_engine_amd import hip_ops
+    rng = np.random.default_rng(77)
+    x = po.round_T(rng.standard_normal((3, 5, 64)), DT)
+    f = po.llama3_rope_freqs(64, 10000.0)
+    got = hip_ops.rope(to_dev(po.to_bits(x, DT), DT), 64, traditional=True, offset=9, freqs=torch.from_numpy(f).cuda())
+    want = po.rope(x, f, 9, DT, traditional=True)
+    assert np.array_equal(to_bits(got), po.to_bits(want, DT))
+    assert not np.array_equal(po.to_bits(want, DT), po.to_bits(po.rope(x, f, 9, DT), DT))
+    cfg = dict(po.TINY_CONFIG, rope_traditional=True)
+    w = po.synth_checkpoint(cfg, seed=8, dtype=DT, lm_head_gain=4.0)
+    model = build(cfg, w)
+    orc = po.OracleLlama(cfg, w, DT)
+    for L in (6, 33):
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got_all[l], want_all[l], DT, what=f"traditional rope L={L} position {l}")
+        tok = model.token
+        for _ in range(2):
+            want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, DT, what="traditional rope decode")
+    ref = po.OracleLlama(dict(cfg, rope_traditional=False), w, DT).forward(prompt, [po.OracleKVCache() for _ in orc.layers])
+    assert np.abs(ref[-1] - want_all[-1]).max() > 16 * EPS[DT] * np.abs(want_all[-1]).max()   # the flag matters
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
