@@ -114,6 +114,18 @@ int main(int argc, char **argv) {
             a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
             if (w4s_gemv_launch(PIE_BF16, PRO_RMSNORM, EPI_SWIGLU, a, 1, 0)) { printf("launch failed: %s\n", pie_last_error()); exit(1); }
         }
+        // the other per-layer shapes (distinct template instantiations, so their per-kernel averages stay separate):
+        // down (NONE, RESIDUAL, K = 14336), o_proj-sized (NONE, RESIDUAL, K = 4096 -> NPT 1), q|k|v-sized (RMSNORM, STORE)
+        struct PmcCase { int pro, epi, N, K; } pc[] = {{PRO_NONE, EPI_RESIDUAL, 4096, 14336}, {PRO_NONE, EPI_RESIDUAL, 4096, 4096}, {PRO_NONE, EPI_STORE, 6144, 4096}};
+        for (auto &c : pc) {
+            size_t cb = (size_t)(c.N / 2) * w4s_slices(c.K) * W4S_UNIT_BYTES;
+            int csl = (int)(W_BYTES / cb);
+            for (int i = 0; i < 64; ++i) {
+                GemvArgs a = {};
+                a.w = w + (size_t)(i % csl) * cb, a.K = c.K, a.N = c.N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
+                if (w4s_gemv_launch(PIE_BF16, c.pro, c.epi, a, 1, 0)) { printf("launch failed: %s\n", pie_last_error()); exit(1); }
+            }
+        }
         CK(hipDeviceSynchronize());
         return 0;
     }
