@@ -9,12 +9,16 @@ template <class T, int D>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
     dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
-    switch (rep) {
+    switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
         case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7>), grid, block, 0, st, a); break;
         case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8>), grid, block, 0, st, a); break;
-        default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+        default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be between 1 and 8");
     }
     PIE_LAUNCH_CHECK();
     if (combine) {

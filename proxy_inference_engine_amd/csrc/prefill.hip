@@ -402,6 +402,6 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
 
 int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
-    PIE_REQUIRE(rep == 1 || rep == 2 || rep == 4 || rep == 8, PIE_E_SHAPE, "prefill: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+    PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "prefill: n_heads / n_kv_heads must be between 1 and 8");
     return d->cfg.dtype == PIE_BF16 ? prefill_t<BF16>(d, ids, L, logits_all, st) : prefill_t<F16>(d, ids, L, logits_all, st);
 }

@@ -200,9 +200,13 @@ static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
     switch (a.Hq / a.Hkv) {
         case 1: hipLaunchKernelGGL((k_prefill_attn<T, D, 1>), grid, dim3(64), 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_prefill_attn<T, D, 2>), grid, dim3(128), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_prefill_attn<T, D, 3>), grid, dim3(192), 0, st, a); break;
         case 4: hipLaunchKernelGGL((k_prefill_attn<T, D, 4>), grid, dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_prefill_attn<T, D, 5>), grid, dim3(320), 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_prefill_attn<T, D, 6>), grid, dim3(384), 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_prefill_attn<T, D, 7>), grid, dim3(448), 0, st, a); break;
         case 8: hipLaunchKernelGGL((k_prefill_attn<T, D, 8>), grid, dim3(512), 0, st, a); break;
-        default: return pie::fail(PIE_E_SHAPE, "prefill attention: n_heads / n_kv_heads must be 1, 2, 4 or 8");
+        default: return pie::fail(PIE_E_SHAPE, "prefill attention: n_heads / n_kv_heads must be between 1 and 8");
     }
     PIE_LAUNCH_CHECK();
     return PIE_OK;
