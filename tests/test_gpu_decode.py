@@ -384,6 +384,31 @@ def test_dense_checkpoint_prefill_and_decode(dtype):
     assert model.step_bytes(100) > 2 * sum(v.size for k, v in w.items() if k.endswith("proj.weight"))  # 2 B per parameter
 
 
+def test_llama32_3b_shaped_layer():
+    """Llama-3.2-3B geometry: H = 3072 (1.5 K-slices of 2048: ragged), I = 8192, 24/8 heads (3 q-heads per kv-head), D = 128,
+    tied embeddings; one layer, f16."""
+    dtype = "float16"
+    cfg = {"model_type": "llama", "hidden_size": 3072, "num_hidden_layers": 1, "intermediate_size": 8192,
+           "num_attention_heads": 24, "num_key_value_heads": 8, "head_dim": 128, "rms_norm_eps": 1e-5, "vocab_size": 2048,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": True,
+           "rope_scaling": {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "rope_type": "llama3",
+                            "original_max_position_embeddings": 8192},
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=15, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(4).integers(0, cfg["vocab_size"], 20)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache, last_only=True)
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="3B-shaped prefill logits")
+    for _ in range(3):
+        want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+        tok, lp, logits = model.step(None, cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="3B-shaped decode")
+
+
 def test_llama70b_shaped_layer_on_one_gpu():
     """BASELINE.json configs[4] geometry (Llama-3-70B: H=8192, I=28672, 64/8 heads -> 8 q-heads per kv-head, D=128),
     one layer, int4 g=64.  The 70B int4 model is 40 GB and fits one 288 GB card, so it runs on the single-GPU path:
