@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
     ap.add_argument("--model", choices=["8b", "70b"], default="8b", help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); not the metric's workload")
+    ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
 
@@ -93,8 +94,10 @@ def main():
         cfg["num_hidden_layers"] = args.layers
     if args.dense:
         cfg["quantization"] = None
+    elif args.bits != 4:
+        cfg["quantization"] = {"group_size": 64, "bits": args.bits}
     weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b"
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b" and args.bits == 4
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
         weights_host = {k: (v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.view(torch.int16).cpu().numpy().view(np.uint16))
@@ -155,7 +158,7 @@ def main():
 
     traffic = None
     tf = ROOT / "profiles" / "r01_traffic.json"  # PMC passes (separate rocprofv3 runs), see profiles/README.md
-    if tf.exists() and not args.layers and not args.dense and args.model == "8b":
+    if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
         traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
 
     out = {
@@ -163,7 +166,7 @@ def main():
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "dtype_detail": "uint4 g=64 weights x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
-        "config": {"workload": f"Llama-3-{args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else 'int4 g=64'} greedy decode, batch 1, "
+        "config": {"workload": f"Llama-3-{args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
                    "hipgraph": True},

@@ -67,6 +67,21 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
 int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y,
                     int dtype, void *stream);
 
+/* ---------------------------------------------------------------- MLX int8 group-64 checkpoints (config "quantization":
+ * {"group_size": 64, "bits": 8}): weight uint32 [N, K/4] (byte i of word w = code 4w+i), scales/biases T [N, K/64].
+ * Same call sites and kernel as the int4 path on "W8S" units of 4352 B (row pair x 2048-wide K slice, four 16-byte code
+ * pieces per lane).  pie_quantize_g64 / pie_dequantize_g64 / pie_embedding_g64 are the bits-generic forms (bits = 4 | 8)
+ * of the w4g64 entry points above. */
+size_t pie_w8s_bytes(int N_out, int K);
+int pie_repack_w8g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map,
+                     int N_out, void *packed, void *stream);
+int pie_qgemv_w8g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
+int pie_quantize_g64(const void *w, int N, int K, int bits, int dtype, uint32_t *codes, void *scales, void *biases, void *stream);
+int pie_dequantize_g64(const uint32_t *codes, const void *scales, const void *biases, int N, int K, int bits, int dtype, void *w_out,
+                       void *stream);
+int pie_embedding_g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
+                      int bits, int dtype, void *out, void *stream);
+
 /* ---------------------------------------------------------------- dense checkpoints (no "quantization" entry in
  * config.json, models/utils.py:96-97): nn.Linear / nn.Embedding with 16-bit weights.  Same streaming kernel as the int4
  * path on "W16S" units of 2048 B = one ROW PAIR x one 512-wide K slice (2 x [64 lanes x 16 B]); row_map as for
@@ -133,7 +148,7 @@ typedef struct {
     int rope_traditional; /* ModelArgs.rope_traditional (language.py:27,69): rotate the interleaved pairs (2i, 2i+1); wqkv is
                              then the plain q|k|v concatenation (row_map NULL), not pie_qkv_row_map's order */
 } pie_decoder_config;
-enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1 };
+enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1, PIE_W_INT8_G64 = 2 /* W8S units, embed_codes uint32 [vocab, hidden/4] */ };
 
 typedef struct {
     const void *attn_norm, *mlp_norm;   /* T [hidden] */

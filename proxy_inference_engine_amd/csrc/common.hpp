@@ -49,6 +49,7 @@ struct BF16 {
     // per word instead of three.
     static constexpr float ODD_SCALE = 0.0625f;
     static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]);
+    static __device__ __forceinline__ u32 bytes2(u32 masked) { return masked; }  // two 8-bit codes in the 16-bit halves, as operands
     static __device__ __forceinline__ float to_f32(u16 b) { return __builtin_bit_cast(float, (u32)b << 16); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // v_cvt_pk_bf16_f32, RNE
     static __device__ __forceinline__ float dot2(u32 a, u32 b, float c) {
@@ -72,6 +73,7 @@ struct F16 {
         return __builtin_bit_cast(u32, v);
     }
     static constexpr float ODD_SCALE = 1.0f;
+    static __device__ __forceinline__ u32 bytes2(u32 masked) { return codes2(masked); }  // 0x6400|q = 1024+q is exact up to q = 1023
     static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]) {
         d[0] = dot2(codes2(w & 0x000F000Fu), x0, d[0]);
         d[1] = dot2(codes2((w >> 4) & 0x000F000Fu), x1, d[1]);
@@ -163,4 +165,10 @@ static inline __host__ __device__ int w4s_slices(int K) { return (K + W4S_SLICE_
 constexpr int W16S_UNIT_BYTES = 2048;
 constexpr int W16S_SLICE_K = 512;
 static inline __host__ __device__ int w16s_slices(int K) { return (K + W16S_SLICE_K - 1) / W16S_SLICE_K; }
-enum { FMT_W4S = 0, FMT_W16S = 1 };
+// W8S (MLX int8 group-64 triplets): like W4S one unit = row pair x 2048-wide K slice, lane l owns group 32 s + (l & 31) of row
+// l >> 5, but its 64 codes are FOUR 16-byte pieces: [4 x 64 lanes x 16 B] codes + [64 x 4 B] {scale | bias << 16} = 4352 B.
+// The bytes of every word are reordered to (c0, c2, c1, c3) so that w & 0x00FF00FF = codes (0, 1) and (w >> 8) & 0x00FF00FF =
+// codes (2, 3) in the two 16-bit halves: a bare byte 0x00qq IS the bf16 number q * 2^-133 for every q <= 255 (denormal below
+// 128, exponent field 1 above: gradual underflow is continuous), so the int4 path's operand trick carries over unchanged.
+constexpr int W8S_UNIT_BYTES = 4352;
+enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2 };

@@ -15,7 +15,7 @@
 #include "decoder.hpp"
 
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
-                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st, int bits);
 
 namespace {
 thread_local std::string g_last_error;
@@ -76,12 +76,13 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
     const pie_layer_weights &w = d->layers[li];
     const bool dense = c.weight_format == PIE_W_DENSE;
-    const int fmt = dense ? FMT_W16S : FMT_W4S;
+    const bool int8 = c.weight_format == PIE_W_INT8_G64;
+    const int fmt = dense ? FMT_W16S : (int8 ? FMT_W8S : FMT_W4S);
     switch (which) {
         case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
             if (dense) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, c.vocab, H, c.dtype, d->h, st);
             return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, d->h,
-                                    d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st);
+                                    d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st, int8 ? 8 : 4);
         case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
             GemvArgs a = {};
             a.fmt = fmt, a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
@@ -98,7 +99,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
             // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
-            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : pie_w4s_bytes(H, QD);
+            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : (int8 ? pie_w8s_bytes(H, QD) : pie_w4s_bytes(H, QD));
             a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
@@ -181,7 +182,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_REQUIRE(c.n_layers > 0 && c.n_heads > 0 && c.n_kv_heads > 0 && c.n_heads % c.n_kv_heads == 0, PIE_E_SHAPE, "pie_decoder_create: bad head counts");
     PIE_REQUIRE(c.vocab > 0 && c.vocab % 2 == 0, PIE_E_SHAPE, "pie_decoder_create: vocab must be even");
     PIE_REQUIRE(c.hidden <= 32768 && c.inter <= 32768 && c.n_heads * c.head_dim <= 32768, PIE_E_SHAPE, "pie_decoder_create: K > 32768 not supported");
-    PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE, PIE_E_ARG, "pie_decoder_create: unknown weight_format");
+    PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE || c.weight_format == PIE_W_INT8_G64, PIE_E_ARG,
+                "pie_decoder_create: unknown weight_format");
     pie_decoder *d = new (std::nothrow) pie_decoder();
     PIE_REQUIRE(d, PIE_E_HIP, "pie_decoder_create: out of host memory");
     d->cfg = c;
@@ -205,7 +207,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)
         const long mb = e ? atol(e) : 0;
-        const size_t gu = c.weight_format == PIE_W_DENSE ? pie_w16s_bytes(2 * c.inter, c.hidden) : pie_w4s_bytes(2 * c.inter, c.hidden);
+        const size_t gu = c.weight_format == PIE_W_DENSE ? pie_w16s_bytes(2 * c.inter, c.hidden)
+                          : (c.weight_format == PIE_W_INT8_G64 ? pie_w8s_bytes(2 * c.inter, c.hidden) : pie_w4s_bytes(2 * c.inter, c.hidden));
         d->pf_gateup_bytes = mb <= 0 ? 0 : ((size_t)mb << 20 < gu ? (size_t)mb << 20 : gu);
         d->pf_enable = mb >= 0;
     }
@@ -379,7 +382,8 @@ size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T) {
     const pie_decoder_config &c = d->cfg;
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
     const bool dense = c.weight_format == PIE_W_DENSE;
-    auto lin = [dense](size_t n, size_t k) { return dense ? n * k * 2 : n * k / 2 + 2 * (n * k / 64) * 2; };
+    const size_t code_div = c.weight_format == PIE_W_INT8_G64 ? 1 : 2;  // codes: 1 B / parameter (int8) or 0.5 (int4)
+    auto lin = [dense, code_div](size_t n, size_t k) { return dense ? n * k * 2 : n * k / code_div + 2 * (n * k / 64) * 2; };
     switch (which) {
         case PIE_K_QKV: return lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2;
         case PIE_K_ATTN: return 2 * KVD * 2 * (size_t)T;
@@ -398,7 +402,8 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits) {
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
     // int4 codes + 16-bit scale and bias per group of 64 = 0.5625 B / parameter  (SURVEY.md 8d); dense: 2 B / parameter
     const bool dense = c.weight_format == PIE_W_DENSE;
-    auto lin = [dense](size_t n, size_t k) { return dense ? n * k * 2 : n * k / 2 + 2 * (n * k / 64) * 2; };
+    const size_t code_div = c.weight_format == PIE_W_INT8_G64 ? 1 : 2;
+    auto lin = [dense, code_div](size_t n, size_t k) { return dense ? n * k * 2 : n * k / code_div + 2 * (n * k / 64) * 2; };
     size_t per_layer = lin(QD + 2 * KVD, H) + lin(H, QD) + lin(2 * I, H) + lin(H, I);
     size_t bytes = (size_t)c.n_layers * (per_layer + 2 * H * 2 /* norm weights */ + 2 * KVD * 2 * (size_t)T /* KV read */ + 2 * KVD * 2 /* KV write */);
     if (with_logits) bytes += lin(c.vocab, H) + H * 2 + (size_t)c.vocab * 4 /* fp32 logprobs */;

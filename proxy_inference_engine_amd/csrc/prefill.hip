@@ -26,7 +26,7 @@
 #include "prefill_attn.hpp"
 
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
-                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st, int bits);
 
 // ---------------------------------------------------------------- kernels
 // W4S -> T row-major [N, K]; one thread per code word (8 weights, 16 B out).  Same arithmetic as k_dequantize_w4g64.
@@ -48,6 +48,23 @@ __global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out)
         o[i] = pack2<T>(lo, hi);
     }
     *reinterpret_cast<uint4 *>(out + (size_t)r * K + (size_t)wk * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// W8S -> T row-major [N, K]; one thread per code word (4 weights, 8 B out).
+template <class T>
+__global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = K >> 2;
+    if (idx >= (size_t)N * wpr) return;
+    const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
+    const int g = wk >> 4, lane = (r & 1) * 32 + (g & 31), j = (wk & 15) >> 2, t = wk & 3;
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W8S_UNIT_BYTES / 4);
+    const u32 word = unit[j * 256 + lane * 4 + t], sb = unit[1024 + lane];
+    const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
+    // stored byte order (c0, c2, c1, c3)
+    const float q0 = __fadd_rn(__fmul_rn(s, (float)(word & 0xFFu)), b), q2 = __fadd_rn(__fmul_rn(s, (float)((word >> 8) & 0xFFu)), b);
+    const float q1 = __fadd_rn(__fmul_rn(s, (float)((word >> 16) & 0xFFu)), b), q3 = __fadd_rn(__fmul_rn(s, (float)(word >> 24)), b);
+    *reinterpret_cast<uint2 *>(out + (size_t)r * K + (size_t)wk * 4) = make_uint2(pack2<T>(q0, q1), pack2<T>(q2, q3));
 }
 
 // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:134-137) for M rows of the packed
@@ -298,6 +315,12 @@ static size_t resident_budget(pie_decoder *d) {
 template <class T>
 static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 *dst, hipStream_t st) {
     if (d->cfg.weight_format == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
+    if (d->cfg.weight_format == PIE_W_INT8_G64) {
+        const size_t w8 = (size_t)N * (K >> 2);
+        hipLaunchKernelGGL(k_dequant_w8s<T>, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
     const size_t words = (size_t)N * (K >> 3);
     hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
     PIE_LAUNCH_CHECK();
@@ -352,7 +375,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
         rc = c.weight_format == PIE_W_DENSE
                  ? pie_embedding_dense(ids + c0, M, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
                  : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
-                                    nullptr, nullptr, 0, st);
+                                    nullptr, nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
         if (rc) return rc;
         for (int li = 0; li < c.n_layers; ++li) {
             const pie_layer_weights &w = d->layers[li];

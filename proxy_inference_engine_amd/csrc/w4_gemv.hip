@@ -8,8 +8,10 @@
 // One thread per group of 64 (load-time utility, not on the decode path).  Same operation order as the
 // published algorithm with IEEE fp32 division, so codes/scales/biases are
 // bit-identical to the oracle's.  Built with -ffp-contract=off.
-template <class T>
+template <class T, int BITS>
 __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *scales, u16 *biases) {
+    constexpr float LEVELS = (float)((1 << BITS) - 1);
+    constexpr int PER_WORD = 32 / BITS, WORDS = 64 / PER_WORD;
     const int G = K >> 6;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)N * G) return;
@@ -32,7 +34,7 @@ __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *sc
         w_min = v[i] < w_min ? v[i] : w_min;
     }
     const bool side = fabsf(w_min) > fabsf(w_max);
-    float scale = fmaxf(__fdiv_rn(__fsub_rn(w_max, w_min), 15.0f), 1e-7f);
+    float scale = fmaxf(__fdiv_rn(__fsub_rn(w_max, w_min), LEVELS), 1e-7f);
     scale = side ? scale : -scale;
     const float edge = side ? w_min : w_max;
     const float q0 = rintf(__fdiv_rn(edge, scale));
@@ -41,15 +43,15 @@ __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *sc
     const float bias = at_zero ? 0.0f : edge;
     scales[gid] = T::from_f32(scale);
     biases[gid] = T::from_f32(bias);
-    u32 *dst = codes + gid * 8;
+    u32 *dst = codes + gid * WORDS;
 #pragma unroll
-    for (int wd = 0; wd < 8; ++wd) {
+    for (int wd = 0; wd < WORDS; ++wd) {
         u32 word = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float c = rintf(__fdiv_rn(__fsub_rn(v[8 * wd + j], bias), scale));
-            c = c < 0.0f ? 0.0f : (c > 15.0f ? 15.0f : c);
-            word |= ((u32)c) << (4 * j);
+        for (int j = 0; j < PER_WORD; ++j) {
+            float c = rintf(__fdiv_rn(__fsub_rn(v[PER_WORD * wd + j], bias), scale));
+            c = c < 0.0f ? 0.0f : (c > LEVELS ? LEVELS : c);
+            word |= ((u32)c) << (BITS * j);
         }
         dst[wd] = word;
     }
@@ -68,15 +70,24 @@ __device__ __forceinline__ void dequant_word(u32 word, float s, float b, u16 *ou
     *reinterpret_cast<uint4 *>(out8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// 8-bit codes: 4 per word (byte i = code 4w + i), 16 words per group of 64.
 template <class T>
+__device__ __forceinline__ void dequant_word8(u32 word, float s, float b, u16 *out4) {
+    const float q0 = __fadd_rn(__fmul_rn(s, (float)(word & 0xFFu)), b), q1 = __fadd_rn(__fmul_rn(s, (float)((word >> 8) & 0xFFu)), b);
+    const float q2 = __fadd_rn(__fmul_rn(s, (float)((word >> 16) & 0xFFu)), b), q3 = __fadd_rn(__fmul_rn(s, (float)(word >> 24)), b);
+    *reinterpret_cast<uint2 *>(out4) = make_uint2(pack2<T>(q0, q1), pack2<T>(q2, q3));
+}
+
+template <class T, int BITS>
 __global__ void k_dequantize_w4g64(const u32 *codes, const u16 *scales, const u16 *biases, size_t n_words, u16 *out) {
     const size_t wid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wid >= n_words) return;
-    dequant_word<T>(codes[wid], T::to_f32(scales[wid >> 3]), T::to_f32(biases[wid >> 3]), out + wid * 8);
+    if (BITS == 4) dequant_word<T>(codes[wid], T::to_f32(scales[wid >> 3]), T::to_f32(biases[wid >> 3]), out + wid * 8);
+    else dequant_word8<T>(codes[wid], T::to_f32(scales[wid >> 4]), T::to_f32(biases[wid >> 4]), out + wid * 4);
 }
 
 // nn.QuantizedEmbedding.__call__ (language.py:176): out[l,:] = dequantize(row ids[l]).
-template <class T>
+template <class T, int BITS>
 __global__ void k_embedding_w4g64(const int *ids, const u32 *codes, const u16 *scales, const u16 *biases, int V, int H,
                                   u16 *out, const float *freqs, const DecState *state, float *rope_cs, int half) {
     // decoder only: the step's RoPE table (cos, sin of pos / freqs[i], llama/utils.py:42-50) is computed once here
@@ -90,11 +101,13 @@ __global__ void k_embedding_w4g64(const int *ids, const u32 *codes, const u16 *s
     const int l = blockIdx.x;
     int id = ids[l];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const int words = H >> 3;
+    const int words = BITS == 4 ? H >> 3 : H >> 2;
     const u32 *row = codes + (size_t)id * words;
     const u16 *srow = scales + (size_t)id * (H >> 6), *brow = biases + (size_t)id * (H >> 6);
-    for (int wd = threadIdx.x; wd < words; wd += blockDim.x)
-        dequant_word<T>(row[wd], T::to_f32(srow[wd >> 3]), T::to_f32(brow[wd >> 3]), out + (size_t)l * H + (size_t)wd * 8);
+    for (int wd = threadIdx.x; wd < words; wd += blockDim.x) {
+        if (BITS == 4) dequant_word<T>(row[wd], T::to_f32(srow[wd >> 3]), T::to_f32(brow[wd >> 3]), out + (size_t)l * H + (size_t)wd * 8);
+        else dequant_word8<T>(row[wd], T::to_f32(srow[wd >> 4]), T::to_f32(brow[wd >> 4]), out + (size_t)l * H + (size_t)wd * 4);
+    }
 }
 
 // ---------------------------------------------------------------- W4S repack
@@ -134,6 +147,34 @@ __global__ void k_repack_w4s(const u32 *codes, const u16 *scales, const u16 *bia
                 out |= ((src >> (8 * i)) & 0xFu) << (4 * i);
                 out |= ((src >> (8 * i + 4)) & 0xFu) << (16 + 4 * i);
             }
+        }
+    }
+    packed[idx] = out;
+}
+
+// MLX int8 g=64 triplet -> W8S (common.hpp).  One thread per output dword: dwords [0,1024) = four code pieces (piece j: lane l ->
+// dwords 256 j + 4 l .. + 3), [1024,1088) = {scale | bias << 16} per lane.  Piece j, dword t of lane l = source word
+// 16*group + 4j + t with its bytes reordered (c0, c2, c1, c3).
+__global__ void k_repack_w8s(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs,
+                             int ns, u32 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 1088;
+    if (idx >= total) return;
+    const size_t unit = idx / 1088;
+    const int dw = (int)(idx % 1088);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    const bool is_sb = dw >= 1024;
+    const int lane = is_sb ? dw - 1024 : (dw & 255) >> 2, j = dw >> 8, t = dw & 3;
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int g = 32 * s + (lane & 31), G = K >> 6;
+    u32 out = 0;
+    if (g < G && row >= 0 && row < N_src) {
+        if (is_sb) {
+            out = (u32)scales[(size_t)row * G + g] | ((u32)biases[(size_t)row * G + g] << 16);
+        } else {
+            const u32 src = codes[(size_t)row * (K >> 2) + 16 * g + 4 * j + t];
+            out = (src & 0xFF0000FFu) | ((src & 0x0000FF00u) << 8) | ((src & 0x00FF0000u) >> 8);
         }
     }
     packed[idx] = out;
@@ -202,7 +243,9 @@ static int launch_f(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
 }
 template <class T>
 static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
-    return a.fmt == FMT_W16S ? launch_f<T, FMT_W16S>(pro, epi, a, grid, lds, st) : launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
+    if (a.fmt == FMT_W16S) return launch_f<T, FMT_W16S>(pro, epi, a, grid, lds, st);
+    if (a.fmt == FMT_W8S) return launch_f<T, FMT_W8S>(pro, epi, a, grid, lds, st);
+    return launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
 }
 
 // Persistent grid: one wave per row pair until the chip is full (16 waves per CU), then longer runs per wave.
@@ -223,7 +266,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
     PIE_REQUIRE(a.K <= 32768, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
-    PIE_REQUIRE(a.fmt == FMT_W4S || a.fmt == FMT_W16S, PIE_E_ARG, "w4s_gemv: unknown weight format");
+    PIE_REQUIRE(a.fmt == FMT_W4S || a.fmt == FMT_W16S || a.fmt == FMT_W8S, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
     a.n_slices = a.fmt == FMT_W16S ? w16s_slices(a.K) : w4s_slices(a.K);
@@ -239,7 +282,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
 
 // ---------------------------------------------------------------- C ABI
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
-                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st);
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st, int bits);
 
 extern "C" {
 
@@ -249,16 +292,25 @@ size_t pie_w4s_bytes(int N_out, int K) {
 }
 
 int pie_quantize_w4g64(const void *w, int N, int K, int dtype, uint32_t *codes, void *scales, void *biases, void *stream) {
+    return pie_quantize_g64(w, N, K, 4, dtype, codes, scales, biases, stream);
+}
+
+int pie_quantize_g64(const void *w, int N, int K, int bits, int dtype, uint32_t *codes, void *scales, void *biases, void *stream) {
     PIE_REQUIRE(w && codes && scales && biases, PIE_E_ARG, "pie_quantize_w4g64: null pointer");
+    PIE_REQUIRE(bits == 4 || bits == 8, PIE_E_ARG, "pie_quantize_g64: bits must be 4 or 8");
     PIE_REQUIRE(N > 0 && K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_quantize_w4g64: K must be a multiple of 64");
     PIE_REQUIRE(pie_aligned(w, 16) && pie_aligned(codes, 16), PIE_E_ALIGN, "pie_quantize_w4g64: 16-byte alignment required");
     const size_t groups = (size_t)N * (K / 64);
     dim3 grid((unsigned)((groups + 127) / 128)), block(128);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PIE_BF16)
-        hipLaunchKernelGGL(k_quantize_w4g64<BF16>, grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    if (dtype == PIE_BF16 && bits == 4)
+        hipLaunchKernelGGL((k_quantize_w4g64<BF16, 4>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_F16 && bits == 4)
+        hipLaunchKernelGGL((k_quantize_w4g64<F16, 4>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_BF16)
+        hipLaunchKernelGGL((k_quantize_w4g64<BF16, 8>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
     else if (dtype == PIE_F16)
-        hipLaunchKernelGGL(k_quantize_w4g64<F16>, grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+        hipLaunchKernelGGL((k_quantize_w4g64<F16, 8>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
     else
         return pie::fail(PIE_E_ARG, "pie_quantize_w4g64: bad dtype");
     PIE_LAUNCH_CHECK();
@@ -267,16 +319,26 @@ int pie_quantize_w4g64(const void *w, int N, int K, int dtype, uint32_t *codes, 
 
 int pie_dequantize_w4g64(const uint32_t *codes, const void *scales, const void *biases, int N, int K, int dtype, void *w_out,
                          void *stream) {
+    return pie_dequantize_g64(codes, scales, biases, N, K, 4, dtype, w_out, stream);
+}
+
+int pie_dequantize_g64(const uint32_t *codes, const void *scales, const void *biases, int N, int K, int bits, int dtype, void *w_out,
+                       void *stream) {
     PIE_REQUIRE(codes && scales && biases && w_out, PIE_E_ARG, "pie_dequantize_w4g64: null pointer");
+    PIE_REQUIRE(bits == 4 || bits == 8, PIE_E_ARG, "pie_dequantize_g64: bits must be 4 or 8");
     PIE_REQUIRE(N > 0 && K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_dequantize_w4g64: K must be a multiple of 64");
     PIE_REQUIRE(pie_aligned(w_out, 16), PIE_E_ALIGN, "pie_dequantize_w4g64: output must be 16-byte aligned");
-    const size_t n_words = (size_t)N * (K / 8);
+    const size_t n_words = (size_t)N * (K / (32 / bits));
     dim3 grid((unsigned)((n_words + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PIE_BF16)
-        hipLaunchKernelGGL(k_dequantize_w4g64<BF16>, grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+    if (dtype == PIE_BF16 && bits == 4)
+        hipLaunchKernelGGL((k_dequantize_w4g64<BF16, 4>), grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+    else if (dtype == PIE_F16 && bits == 4)
+        hipLaunchKernelGGL((k_dequantize_w4g64<F16, 4>), grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+    else if (dtype == PIE_BF16)
+        hipLaunchKernelGGL((k_dequantize_w4g64<BF16, 8>), grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
     else if (dtype == PIE_F16)
-        hipLaunchKernelGGL(k_dequantize_w4g64<F16>, grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
+        hipLaunchKernelGGL((k_dequantize_w4g64<F16, 8>), grid, block, 0, st, codes, (const u16 *)scales, (const u16 *)biases, n_words, (u16 *)w_out);
     else
         return pie::fail(PIE_E_ARG, "pie_dequantize_w4g64: bad dtype");
     PIE_LAUNCH_CHECK();
@@ -297,6 +359,39 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
                        row_map, n_pairs, ns, (u32 *)packed);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
+}
+
+size_t pie_w8s_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w4s_slices(K) * W8S_UNIT_BYTES;
+}
+
+int pie_repack_w8g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream) {
+    PIE_REQUIRE(codes && scales && biases && packed, PIE_E_ARG, "pie_repack_w8g64: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_w8g64: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0 && K <= 32768, PIE_E_SHAPE, "pie_repack_w8g64: K must be a multiple of 64, at most 32768");
+    PIE_REQUIRE(pie_aligned(packed, 256), PIE_E_ALIGN, "pie_repack_w8g64: packed must be 256-byte aligned");
+    const int n_pairs = N_out / 2, ns = w4s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 1088;
+    hipLaunchKernelGGL(k_repack_w8s, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes, (const u16 *)scales,
+                       (const u16 *)biases, N_src, K, row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qgemv_w8g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w8g64: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w8g64: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w8g64: misaligned pointer");
+    GemvArgs a = {};
+    a.fmt = FMT_W8S;
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
 }
 
 size_t pie_w16s_bytes(int N_out, int K) {
@@ -357,22 +452,29 @@ int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, cons
 
 int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
                         int dtype, void *out, void *stream) {
-    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, 4);
+}
+int pie_embedding_g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int bits,
+                      int dtype, void *out, void *stream) {
+    PIE_REQUIRE(bits == 4 || bits == 8, PIE_E_ARG, "pie_embedding_g64: bits must be 4 or 8");
+    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, bits);
 }
 }  // extern "C"
 
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
-                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st) {
+                     void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st, int bits) {
     PIE_REQUIRE(ids && codes && scales && biases && out, PIE_E_ARG, "pie_embedding_w4g64: null pointer");
     PIE_REQUIRE(L > 0 && V > 0 && H > 0 && H % 64 == 0, PIE_E_SHAPE, "pie_embedding_w4g64: H must be a multiple of 64");
     PIE_REQUIRE(pie_aligned(out, 16), PIE_E_ALIGN, "pie_embedding_w4g64: out must be 16-byte aligned");
     PIE_REQUIRE(half <= 256, PIE_E_SHAPE, "embedding: head_dim too large for the RoPE table");
-    if (dtype == PIE_BF16)
-        hipLaunchKernelGGL(k_embedding_w4g64<BF16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out,
-                           freqs, state, rope_cs, half);
-    else if (dtype == PIE_F16)
-        hipLaunchKernelGGL(k_embedding_w4g64<F16>, dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out,
-                           freqs, state, rope_cs, half);
+#define PIE_EMB(TT, BB)                                                                                                            \
+    hipLaunchKernelGGL((k_embedding_w4g64<TT, BB>), dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, \
+                       (u16 *)out, freqs, state, rope_cs, half)
+    if (dtype == PIE_BF16 && bits == 8) PIE_EMB(BF16, 8);
+    else if (dtype == PIE_F16 && bits == 8) PIE_EMB(F16, 8);
+    else if (dtype == PIE_BF16) PIE_EMB(BF16, 4);
+    else if (dtype == PIE_F16) PIE_EMB(F16, 4);
+#undef PIE_EMB
     else
         return pie::fail(PIE_E_ARG, "pie_embedding_w4g64: bad dtype");
     PIE_LAUNCH_CHECK();

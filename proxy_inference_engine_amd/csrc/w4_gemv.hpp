@@ -91,6 +91,19 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
     return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
 }
 
+// W8S: 16 code words (4 codes each) against the group's 32 packed activation pairs; word i covers pairs 2i, 2i+1.
+template <class T>
+__device__ __forceinline__ float w8s_unit_dot(const uint4 &c0, const uint4 &c1, const uint4 &c2, const uint4 &c3, const u32 (&xr)[32]) {
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const u32 w[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        d[(2 * i) & 3] = T::dot2(T::bytes2(w[i] & 0x00FF00FFu), xr[2 * i], d[(2 * i) & 3]);
+        d[(2 * i + 1) & 3] = T::dot2(T::bytes2((w[i] >> 8) & 0x00FF00FFu), xr[2 * i + 1], d[(2 * i + 1) & 3]);
+    }
+    return (d[0] + d[2]) + (d[1] + d[3]);
+}
+
 // 8 packed activations times the trait's exact power-of-two pre-scale (identity for f16)
 template <class T>
 __device__ __forceinline__ uint4 scale8(const uint4 &v) {
@@ -118,7 +131,7 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs a) {
     constexpr int D = GEMV_DEPTH;
-    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : W4S_UNIT_BYTES;
+    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : W4S_UNIT_BYTES);
     constexpr int NT = GEMV_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -186,6 +199,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
     uint4 c0[D], c1[D];
+    uint4 c2[FMT == FMT_W8S ? D : 1], c3[FMT == FMT_W8S ? D : 1];  // W8S: a lane's 64 codes are four pieces
     u32 sb[D];
     // Weight loads go through a buffer descriptor over the whole matrix: a ring slot that has no unit left to fetch is
     // given an out-of-range offset, which the hardware bounds check drops (no memory traffic, no branch around a load).
@@ -211,6 +225,13 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
             c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
             if (FMT == FMT_W4S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
+            if (FMT == FMT_W8S) {
+                const u32x4_t v2 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 2048, 0, AUX);
+                const u32x4_t v3 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 3072, 0, AUX);
+                c2[d] = make_uint4(v2.x, v2.y, v2.z, v2.w);
+                c3[d] = make_uint4(v3.x, v3.y, v3.z, v3.w);
+                sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 4096 - lane * 12, 0, AUX);
+            }
         }
     };
 #pragma unroll
@@ -269,7 +290,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x141, 0xF, 0xF, true);  // row_half_mirror: 8-lane sums
             if (ok) {
-                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = FMT == FMT_W4S ? scale8<T>(xv[i]) : xv[i];
+                *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = FMT != FMT_W16S ? scale8<T>(xv[i]) : xv[i];
                 if ((j & 7) == 0) sxs[j >> 3] = ps;
             }
         }
@@ -310,8 +331,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                     xr[4 * r + 0] = v.x, xr[4 * r + 1] = v.y, xr[4 * r + 2] = v.z, xr[4 * r + 3] = v.w;
                 }
                 const float sx = (ABL & 4) ? 64.0f : sxs[gc];
-                const float dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
-                                           : w4s_unit_dot<T>(c0[d], c1[d], xr);
+                float dd;
+                if (FMT == FMT_W8S) dd = w8s_unit_dot<T>(c0[d], c1[d], c2[d], c3[d], xr);
+                else dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
+                                    : w4s_unit_dot<T>(c0[d], c1[d], xr);
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
                 const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
                 acc += gvalid ? pr : 0.0f;  // padded groups carry zero codes and zero {scale,bias}; the select keeps a NaN x out

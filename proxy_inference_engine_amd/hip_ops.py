@@ -28,30 +28,30 @@ def _dev(t: torch.Tensor) -> None:
 
 
 def quantize(w: torch.Tensor, group_size: int = 64, bits: int = 4):
-    """mx.quantize(w, group_size=64, bits=4): w [N,K] -> (codes [N,K/8] uint32-in-int32, scales, biases [N,K/64])."""
-    if group_size != 64 or bits != 4:
-        raise ValueError("only group_size=64, bits=4 (the reference's checkpoint format) is implemented")
+    """mx.quantize(w, group_size=64, bits=4|8): w [N,K] -> (codes [N,K*bits/32] uint32-in-int32, scales, biases [N,K/64])."""
+    if group_size != 64 or bits not in (4, 8):
+        raise ValueError("only group_size=64 with bits=4 or 8 is implemented")
     _dev(w)
     N, K = w.shape
     if K % 64:
         raise ValueError(f"last dimension must be a multiple of 64, got {K}")
-    codes = torch.empty((N, K // 8), dtype=U32, device=w.device)
+    codes = torch.empty((N, K * bits // 32), dtype=U32, device=w.device)
     scales = torch.empty((N, K // 64), dtype=w.dtype, device=w.device)
     biases = torch.empty_like(scales)
-    _ffi.check(_ffi.load().pie_quantize_w4g64(_ffi.p(w), N, K, _ffi.dtype_code(w.dtype), _ffi.p(codes), _ffi.p(scales),
-                                              _ffi.p(biases), _ffi.stream()))
+    _ffi.check(_ffi.load().pie_quantize_g64(_ffi.p(w), N, K, bits, _ffi.dtype_code(w.dtype), _ffi.p(codes), _ffi.p(scales),
+                                            _ffi.p(biases), _ffi.stream()))
     return codes, scales, biases
 
 
 def dequantize(codes: torch.Tensor, scales: torch.Tensor, biases: torch.Tensor, group_size: int = 64, bits: int = 4):
-    if group_size != 64 or bits != 4:
-        raise ValueError("only group_size=64, bits=4 is implemented")
+    if group_size != 64 or bits not in (4, 8):
+        raise ValueError("only group_size=64 with bits=4 or 8 is implemented")
     for t in (codes, scales, biases):
         _dev(t)
-    N, K = codes.shape[0], codes.shape[1] * 8
+    N, K = codes.shape[0], codes.shape[1] * 32 // bits
     out = torch.empty((N, K), dtype=scales.dtype, device=codes.device)
-    _ffi.check(_ffi.load().pie_dequantize_w4g64(_ffi.p(codes), _ffi.p(scales), _ffi.p(biases), N, K,
-                                                _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
+    _ffi.check(_ffi.load().pie_dequantize_g64(_ffi.p(codes), _ffi.p(scales), _ffi.p(biases), N, K, bits,
+                                              _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
     return out
 
 
@@ -67,6 +67,37 @@ class W4SWeight:
     @property
     def nbytes(self) -> int:
         return self.packed.numel()
+
+
+@dataclass
+class W8SWeight:
+    """One MLX int8 g=64 Linear in the W8S streaming layout (include/pie_hip.h)."""
+    packed: torch.Tensor          # uint8 [pie_w8s_bytes(N, K)]
+    N: int
+    K: int
+    dtype: torch.dtype
+    lin_bias: torch.Tensor | None = None
+
+    @property
+    def nbytes(self) -> int:
+        return self.packed.numel()
+
+
+def repack_w8s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8SWeight:
+    """Load-time repack of an MLX 8-bit triplet (weight [N_src, K/4], scales, biases) into W8S; row_map as for repack_w4s."""
+    for t in (codes, scales, biases):
+        _dev(t)
+    N_src, K = codes.shape[0], codes.shape[1] * 4
+    N_out = N_src if row_map is None else int(row_map.numel())
+    nbytes = _ffi.load().pie_w8s_bytes(N_out, K)
+    if nbytes == 0:
+        raise ValueError(f"unsupported shape for W8S: N={N_out} (must be even), K={K} (multiple of 64)")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+    if row_map is not None:
+        row_map = row_map.to(device=codes.device, dtype=torch.int32).contiguous()
+    _ffi.check(_ffi.load().pie_repack_w8g64(_ffi.p(codes), _ffi.p(scales), _ffi.p(biases), N_src, K, _ffi.p(row_map), N_out,
+                                            _ffi.p(packed), _ffi.stream()))
+    return W8SWeight(packed, N_out, K, scales.dtype, lin_bias)
 
 
 def repack_w4s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W4SWeight:
@@ -145,29 +176,30 @@ def embedding_dense(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def quantized_matmul(x: torch.Tensor, w: W4SWeight, transpose: bool = True, group_size: int = 64, bits: int = 4):
-    """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4) on a W4S weight:
+def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight", transpose: bool = True, group_size: int = 64, bits: int | None = None):
+    """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64, bits=4|8) on a W4S / W8S weight:
     x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""
-    if not transpose or group_size != 64 or bits != 4:
-        raise ValueError("only transpose=True, group_size=64, bits=4 is implemented (the nn.QuantizedLinear form)")
+    w_bits = 8 if isinstance(w, W8SWeight) else 4
+    if not transpose or group_size != 64 or (bits is not None and bits != w_bits):
+        raise ValueError("only transpose=True, group_size=64 and the weight's own bit width is implemented (the nn.QuantizedLinear form)")
     _dev(x)
     if x.shape[-1] != w.K or x.dtype != w.dtype:
         raise ValueError(f"x [..., {x.shape[-1]}] {x.dtype} does not match weight K={w.K} {w.dtype}")
     M = x.numel() // w.K
     y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
-    _ffi.check(_ffi.load().pie_qgemv_w4g64(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y),
-                                           _ffi.dtype_code(x.dtype), _ffi.stream()))
+    fn = _ffi.load().pie_qgemv_w8g64 if w_bits == 8 else _ffi.load().pie_qgemv_w4g64
+    _ffi.check(fn(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y), _ffi.dtype_code(x.dtype), _ffi.stream()))
     return y
 
 
-def embedding(ids: torch.Tensor, codes, scales, biases) -> torch.Tensor:
+def embedding(ids: torch.Tensor, codes, scales, biases, bits: int = 4) -> torch.Tensor:
     """nn.QuantizedEmbedding.__call__: ids int32 [L] -> [L, H]."""
     _dev(ids)
     ids = ids.to(torch.int32).contiguous().view(-1)
-    V, H = codes.shape[0], codes.shape[1] * 8
+    V, H = codes.shape[0], codes.shape[1] * 32 // bits
     out = torch.empty((ids.numel(), H), dtype=scales.dtype, device=codes.device)
-    _ffi.check(_ffi.load().pie_embedding_w4g64(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H,
-                                               _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
+    _ffi.check(_ffi.load().pie_embedding_g64(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H, bits,
+                                             _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
     return out
 
 

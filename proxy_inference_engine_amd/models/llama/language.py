@@ -83,9 +83,10 @@ class Model:
         device = _ffi.require_gpu()
         q = args.quantization or {}
         self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
-        if q and (q.get("group_size") != 64 or q.get("bits") != 4):
-            raise ValueError("quantised checkpoints must be int4 group_size=64 (config['quantization']); other MLX "
+        if q and (q.get("group_size") != 64 or q.get("bits") not in (4, 8)):
+            raise ValueError("quantised checkpoints must be group_size=64 with 4 or 8 bits (config['quantization']); other MLX "
                              "quantisations are not on the MI355X path")
+        self.bits = int(q["bits"]) if q else 16
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads or self.n_heads
         self.head_dim = args.head_dim or args.hidden_size // self.n_heads
@@ -110,7 +111,7 @@ class Model:
                 ws = [_dense(weights, n, self.dtype) for n in names]
                 return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map)
             trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
-            return hip_ops.repack_w4s(*trip, row_map=row_map)
+            return (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s)(*trip, row_map=row_map)
 
         def bias(names: list[str], row_map=None):
             """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix."""
@@ -152,7 +153,7 @@ class Model:
         lib = _ffi.load()
         cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
                                       self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits),
-                                      1 if self.dense else 0, int(bool(args.rope_traditional)))
+                                      1 if self.dense else (2 if self.bits == 8 else 0), int(bool(args.rope_traditional)))
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
         for i, blk in enumerate(self.layers):

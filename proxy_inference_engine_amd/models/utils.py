@@ -102,7 +102,7 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
     def put_linear(name: str, N: int, K: int, gain: float = 1.0) -> None:
         w = (torch.randn((N, K), generator=gen, device=device, dtype=torch.float32) * (0.02 * gain)).to(dtype)
         if config.get("quantization"):
-            out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w)
+            out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w, bits=int(config["quantization"]["bits"]))
         else:
             out[f"{name}.weight"] = w
 

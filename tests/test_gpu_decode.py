@@ -536,6 +536,34 @@ def test_attention_head_groupings(n_heads, n_kv, D):
         assert_vec_close(logits.float().cpu().numpy(), want, DT, what=f"{n_heads}/{n_kv} heads D={D} decode")
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_int8_checkpoint_prefill_and_decode(dtype):
+    """An MLX 8-bit checkpoint (config "quantization": {"group_size": 64, "bits": 8}) end to end: the tiny Llama with int8
+    triplets for every Linear and the embedding, iterated and batched prompts, greedy decode, against the oracle."""
+    cfg = dict(po.TINY_CONFIG, quantization={"group_size": 64, "bits": 8}, tie_word_embeddings=True)
+    w = po.synth_checkpoint(cfg, seed=61, dtype=dtype, lm_head_gain=4.0)
+    assert w["model.layers.0.mlp.down_proj.weight"].shape[1] == cfg["intermediate_size"] // 4       # 4 codes per word
+    model = build(cfg, w, dtype)
+    assert model.bits == 8
+    orc = po.OracleLlama(cfg, w, dtype)
+    rng = np.random.default_rng(10)
+    for L in (5, 50):
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got_all[l], want_all[l], dtype, what=f"int8 L={L} position {l}")
+        tok = model.token
+        for _ in range(3):
+            want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"int8 decode after L={L}")
+    assert model.step_bytes(64) > 1.8 * build(dict(cfg, quantization={"group_size": 64, "bits": 4}),
+                                              po.synth_checkpoint(dict(cfg, quantization={"group_size": 64, "bits": 4}), seed=61, dtype=dtype), dtype).step_bytes(64) * 0.9
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
@@ -549,6 +577,6 @@ def test_tied_embeddings_and_errors(tiny):
     with pytest.raises(ValueError):
         build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
     with pytest.raises(ValueError):
-        build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other MLX quantisations are not on this path
+        build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other group sizes / bit widths are not on this path
     with pytest.raises(ValueError):
         model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])

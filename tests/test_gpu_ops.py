@@ -199,3 +199,26 @@ def test_dense_gemv_and_embedding_vs_oracle(ops, dt, N, K, M):
         ids = torch.tensor([0, N - 1, 5, 5], dtype=torch.int32, device="cuda")
         rows = ops.embedding_dense(ids, wd)
         assert np.array_equal(to_bits(rows), po.to_bits(w[[0, N - 1, 5, 5]], dt))
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_int8_g64_quantize_gemv_embedding_vs_oracle(ops, dt):
+    """MLX 8-bit group-64 triplets (config "quantization": {"bits": 8}): the HIP quantiser is bit-identical to the oracle's
+    mx.quantize restatement (codes, scales, biases), dequantise and the embedding gather are exact, and the W8S streaming
+    GEMV (bytes fed to v_dot2 as bf16 numbers q * 2^-133 / f16 1024+q) is within one ulp of orc_quantized_matmul_t."""
+    rng = np.random.default_rng(88)
+    for N, K, M in ((96, 256, 2), (4096, 4096, 1), (130, 704, 3)):
+        w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+        x = po.round_T(rng.standard_normal((M, K)), dt)
+        wq, sc, bi = po.quantize(w, 64, 8, dt)
+        codes, scales, biases = ops.quantize(to_dev(po.to_bits(w, dt), dt), bits=8)
+        assert np.array_equal(codes.cpu().numpy().view(np.uint32), wq) and np.array_equal(to_bits(scales), sc) and np.array_equal(to_bits(biases), bi)
+        deq = ops.dequantize(codes, scales, biases, bits=8)
+        assert np.array_equal(to_bits(deq), po.to_bits(po.dequantize(wq, sc, bi, 64, 8, dt), dt))
+        want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=8, dtype=dt)
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), ops.repack_w8s(codes, scales, biases))
+        assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"int8 gemv {N}x{K} M={M} {dt}")
+        if N >= 96:
+            ids = torch.tensor([1, N - 1, 7], dtype=torch.int32, device="cuda")
+            rows = ops.embedding(ids, codes, scales, biases, bits=8)
+            assert np.array_equal(to_bits(rows), to_bits(deq[[1, N - 1, 7]]))
