@@ -162,8 +162,9 @@ int lt_init() {
         if ((g_lt.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     for (const char *n : names)
         if (!g_lt.lib) g_lt.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    const char *dl_msg = g_lt.lib ? nullptr : dlerror();  // dlerror() clears itself: read it once
     PIE_REQUIRE(g_lt.lib, PIE_E_STATE,
-                std::string("prefill: cannot load hipBLASLt (") + (dlerror() ? dlerror() : "not found") +
+                std::string("prefill: cannot load hipBLASLt (") + (dl_msg ? dl_msg : "not found") +
                     "); put libhipblaslt.so on the loader path, or set PIE_PREFILL_MIN=1000000 to process prompts as iterated decode steps");
 #define LT_SYM(field, name)                                                        \
     g_lt.field = reinterpret_cast<decltype(g_lt.field)>(dlsym(g_lt.lib, #name)); \
