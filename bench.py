@@ -78,12 +78,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(n_dev, 1))  # one rank per GPU; PIE_BENCH_BACKEND=gloo lets ranks share a card (rehearsal)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PIE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from proxy_inference_engine_amd import InferenceEngine
     from proxy_inference_engine_amd.models.llama import Model, ModelArgs
