@@ -121,5 +121,34 @@ int main() {
                1e3 * ms / reps, N, 1e3 * ms / reps / N, err[0], err[1]);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
+    // Without a graph: host launches running ahead of the GPU, one stream vs two alternating streams (atomics protocol).
+    for (int two = 0; two < 2; ++two) {
+        CK(hipMemset(counters, 0, N * 4)); CK(hipMemset(epoch, 0, 4)); CK(hipMemset(errors, 0, 8));
+        auto step = [&]() {
+            if (two) { hipEventRecord(fork, s[0]); hipStreamWaitEvent(s[1], fork, 0); }
+            size_t off = 0;
+            for (int i = 0; i < N; ++i) {
+                Args a;
+                const size_t bytes = mb[i % per] << 20;
+                if (off + bytes > BIG) off = 0;
+                a.w = big + off / 16, a.n16 = bytes / 16, off += bytes;
+                a.counters = counters, a.epoch = epoch, a.idx = i, a.wait = 1, a.proto = 4;
+                a.xin = x[(i + 1) & 1], a.xout = x[i & 1], a.errors = errors, a.sink = sink;
+                hipLaunchKernelGGL(k_stage, dim3(WG), dim3(512), 0, s[two ? (i & 1) : 0], a);
+            }
+            if (two) { hipEventRecord(join, s[1]); hipStreamWaitEvent(s[0], join, 0); }
+            hipLaunchKernelGGL(k_epoch, dim3(1), dim3(1), 0, s[0], epoch);
+        };
+        for (int i = 0; i < 3; ++i) step();
+        CK(hipDeviceSynchronize());
+        const int reps = 20;
+        CK(hipEventRecord(e0, s[0]));
+        for (int i = 0; i < reps; ++i) step();
+        CK(hipEventRecord(e1, s[0])); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned err[2]; CK(hipMemcpy(err, errors, 8, hipMemcpyDeviceToHost));
+        printf("%-10s %8.1f us per step (%d kernels, %.2f us each)  ordering errors %u  spin timeouts %u\n", two ? "direct-2s" : "direct-1s",
+               1e3 * ms / reps, N, 1e3 * ms / reps / N, err[0], err[1]);
+    }
     return 0;
 }
