@@ -200,6 +200,33 @@ def test_tinyllama_shaped_layers_vs_oracle(dtype):
     assert cache[0].keys.shape == (1, 4, 256, 64) and cache[0].offset == 74 and matched >= 1
 
 
+def test_long_generation_across_growth_and_plan_switch(tiny):
+    """1300 graph-replayed decode steps after a 12-token prompt: the cache re-allocates 256 -> 512 -> 768 -> 1280 -> 2048
+    (x1.5 rounded up to the 256 step, reusable.py:167-203) and past capacity 1024 the attention plan moves from 4 merged
+    splits to 20 splits + combine, so
+    the graph is re-captured mid-stream.  Teacher-forced with the oracle's greedy tokens; logits compared around every
+    boundary and every 100 steps."""
+    g, cfg, w, model = tiny
+    orc = po.OracleLlama(cfg, w, DT)
+    prompt = np.random.default_rng(44).integers(0, cfg["vocab_size"], 12)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache, last_only=True)
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(logits.float().cpu().numpy(), want, DT, what="prompt")
+    check = set(range(0, 1300, 100)) | {o - 12 + d for o in (256, 512, 768, 1024, 1280) for d in (-2, -1, 0, 1)}
+    caps = set()
+    for i in range(1300):
+        t = int(np.argmax(want))                                        # the oracle's greedy token feeds both sides
+        want = orc.forward(np.array([t]), ocache)[0]
+        tok, lp, logits = model.step(torch.tensor([t], dtype=torch.int32, device="cuda"), cache)
+        caps.add(cache[0].capacity)
+        if i in check:
+            assert_vec_close(logits.float().cpu().numpy(), want, DT, what=f"step {i} offset {cache[0].offset} capacity {cache[0].capacity}")
+    assert caps == {256, 512, 768, 1280, 2048} and cache[0].offset == 12 + 1300 == ocache[0].offset
+    assert ocache[0].keys.shape[2] == cache[0].capacity             # the oracle's ReusableKVCache restatement grew the same way
+
+
 def test_forced_split_counts_match_oracle(tiny):
     """kv_splits pins the attention plan: 1 and 4 (merged in the o_proj prologue), 8 and 32 (k_attn_combine launch)."""
     g, cfg, w, _ = tiny
