@@ -89,8 +89,39 @@ def tiny_llama_fixture():
     print("tiny llama: tokens", toks, "min margin", float(min(margins)))
 
 
+def variant_fixture(name, overrides, dtype, seed):
+    """One-layer tiny Llama variants for the other checkpoint formats / ModelArgs flags: 24-token prompt (batched prefill
+    regime), 8 greedy tokens with their log-probabilities."""
+    cfg = dict(po.TINY_CONFIG, num_hidden_layers=1, vocab_size=256, **overrides)
+    if cfg.get("quantization") is None:
+        cfg.pop("quantization", None)
+    w = po.synth_checkpoint(cfg, seed=seed, dtype=dtype, lm_head_gain=8.0)
+    model = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(seed + 1).integers(0, cfg["vocab_size"], 24)
+    gen = po.generate_step(model, po.OraclePromptCache(), prompt)
+    toks, lps, margins = [], [], []
+    for _ in range(8):
+        t, lp = next(gen)
+        toks.append(t), lps.append(lp.copy())
+        top2 = np.sort(lp)[-2:]
+        margins.append(top2[1] - top2[0])
+    d = {"source": "oracle", "dtype": dtype, "config_json": np.array(__import__("json").dumps(cfg)), "prompt": prompt.astype(np.int32),
+         "tokens": np.array(toks, np.int32), "logprobs": np.stack(lps), "margins": np.array(margins, np.float32)}
+    for k_, v_ in w.items():
+        d["w:" + k_] = v_
+    np.savez_compressed(OUT / f"{name}.npz", **d)
+    print(name, "tokens", toks, "min margin", float(min(margins)))
+
+
+VARIANTS = [
+    ("tiny_dense_f16_bias", {"quantization": None, "attention_bias": True, "mlp_bias": True, "tie_word_embeddings": True}, "float16", 122),
+    ("tiny_w8_bf16_trad", {"quantization": {"group_size": 64, "bits": 8}, "rope_traditional": True, "tie_word_embeddings": False}, "bfloat16", 202),
+]
+
 if __name__ == "__main__":
     ops_fixture()
     tiny_llama_fixture()
+    for v in VARIANTS:
+        variant_fixture(*v)
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")

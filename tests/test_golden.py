@@ -3,6 +3,7 @@ tests/golden/make_golden.py).  Guards the oracle against drift; the same files d
 import json
 
 import numpy as np
+import pytest
 
 from oracle import pie_oracle as po
 
@@ -44,3 +45,17 @@ def test_tiny_llama_fixture_reproduced(golden_dir):
     # prefix reuse: the same prompt again re-processes exactly one token and lands on the same first token
     pc2_first = next(po.generate_step(model, pc, g["prompt"]))[0]
     assert pc2_first == int(g["tokens"][0]) and pc.cache[0].offset == len(g["prompt"])
+
+
+@pytest.mark.parametrize("name", ["tiny_dense_f16_bias", "tiny_w8_bf16_trad"])
+def test_variant_fixtures_reproduced(golden_dir, name):
+    """Dense f16 + Linear biases, and int8 g=64 + traditional RoPE: the oracle reproduces its committed tokens / log-probs."""
+    g = np.load(golden_dir / f"{name}.npz")
+    dt = str(g["dtype"])
+    cfg = json.loads(str(g["config_json"]))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    gen = po.generate_step(po.OracleLlama(cfg, w, dt), po.OraclePromptCache(), g["prompt"])
+    for i, want in enumerate(g["tokens"]):
+        tok, lp = next(gen)
+        assert tok == int(want), f"{name} step {i}"
+        assert np.allclose(lp, g["logprobs"][i], atol=1e-6)

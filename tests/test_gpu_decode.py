@@ -591,6 +591,28 @@ def test_int8_checkpoint_prefill_and_decode(dtype):
                                               po.synth_checkpoint(dict(cfg, quantization={"group_size": 64, "bits": 4}), seed=61, dtype=dtype), dtype).step_bytes(64) * 0.9
 
 
+@pytest.mark.parametrize("name", ["tiny_dense_f16_bias", "tiny_w8_bf16_trad"])
+def test_variant_golden_fixtures(golden_dir, name):
+    """The committed oracle vectors for the other checkpoint formats (dense f16 with Linear biases; int8 g=64 with traditional
+    RoPE) through InferenceEngine.generate_step: tokens on the safe prefix, log-probabilities within tolerance."""
+    from proxy_inference_engine_amd import InferenceEngine
+    g = np.load(golden_dir / f"{name}.npz")
+    dt = str(g["dtype"])
+    cfg = json.loads(str(g["config_json"]))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    eng = InferenceEngine(model=build(cfg, w, dt))
+    eng.prepare_engine(g["prompt"], temp=0)
+    gen = eng.generate_step(torch.from_numpy(g["prompt"]))
+    mb = margin_bound(g["logprobs"][0], dt)
+    safe = int(np.argmax(g["margins"] < mb)) if (g["margins"] < mb).any() else len(g["tokens"])
+    for i in range(len(g["tokens"])):
+        tok, lp = next(gen)
+        if i < safe:
+            assert int(tok.item()) == int(g["tokens"][i]), f"{name} step {i}"
+            assert_vec_close(lp.cpu().numpy(), g["logprobs"][i], dt, what=f"{name} logprobs step {i}")
+    assert safe >= 1
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
