@@ -20,6 +20,8 @@
 #include "attention.hpp"
 #include "common.hpp"
 
+#include <type_traits>
+
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -50,6 +52,14 @@ template <> struct MfmaT<F16> {
 // byte offset of 16-byte chunk `ch` (0 .. D/8-1) of row `row` (0..31) in a [32][D x 16-bit] LDS tile: the guide's dual-use
 // swizzle (b) for 256-byte rows; for D = 64 the same XOR folded to the row's 8 chunks (a bijection inside the row, which is
 // all correctness needs -- both the writes and the two kinds of reads go through it)
+template <int I, int N, class F>
+__device__ __forceinline__ void pa_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pa_static_for<I + 1, N>(f);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ int pa_off(int row, int ch) {
     return 2 * D * row + 16 * (ch ^ ((((row & 3) << 2) | ((row >> 2) & 3)) & (D / 8 - 1)));
@@ -70,29 +80,38 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     const u16 *kbase = reinterpret_cast<const u16 *>(a.kv_table[a.layer]) + (size_t)g * cap * D;
     const u16 *vbase = reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]) + (size_t)g * cap * D;
 
-    // staging: chunk id x = threadIdx.x + i*NT -> (row = x / 16, ch = x % 16); keys past t_last are clamped (masked later)
-    uint4 kreg[CPT], vreg[CPT];
+    // staging: chunk id x = threadIdx.x + i*NT -> (row = x / CH, ch = x % CH); keys past t_last are clamped (masked later).
+    // Eight NAMED register pairs, used up to CPT: as arrays (even with compile-time indices) the compiler parked them in
+    // scratch memory and reloaded them every block (80-272 B per lane).
+    uint4 k0, k1, k2, k3, k4, k5, k6, k7, v0, v1, v2, v3, v4, v5, v6, v7;
+#define PA_FETCH1(i, kr, vr)                                                                   \
+    if constexpr (i < CPT) {                                                                     \
+        int x = threadIdx.x + i * NT;                                                            \
+        x = x < BK * CH ? x : BK * CH - 1;                                                       \
+        int t = b * BK + x / CH;                                                                 \
+        t = t < t_last ? t : t_last;                                                             \
+        kr = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x % CH) * 8);             \
+        vr = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x % CH) * 8);             \
+    }
+#define PA_PUBLISH1(i, kr, vr)                                                                 \
+    if constexpr (i < CPT) {                                                                     \
+        const int x = threadIdx.x + i * NT;                                                      \
+        if (x < BK * CH) {                                                                       \
+            *reinterpret_cast<uint4 *>(k_lds + pa_off<D>(x / CH, x % CH)) = kr;                  \
+            *reinterpret_cast<uint4 *>(v_lds + pa_off<D>(x / CH, x % CH)) = vr;                  \
+        }                                                                                        \
+    }
     auto fetch = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            int x = threadIdx.x + i * NT;
-            x = x < BK * CH ? x : BK * CH - 1;
-            int t = b * BK + x / CH;
-            t = t < t_last ? t : t_last;
-            kreg[i] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x % CH) * 8);
-            vreg[i] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x % CH) * 8);
-        }
+        PA_FETCH1(0, k0, v0) PA_FETCH1(1, k1, v1) PA_FETCH1(2, k2, v2) PA_FETCH1(3, k3, v3)
+        PA_FETCH1(4, k4, v4) PA_FETCH1(5, k5, v5) PA_FETCH1(6, k6, v6) PA_FETCH1(7, k7, v7)
     };
     auto publish = [&]() {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int x = threadIdx.x + i * NT;
-            if (x < BK * CH) {
-                *reinterpret_cast<uint4 *>(k_lds + pa_off<D>(x / CH, x % CH)) = kreg[i];
-                *reinterpret_cast<uint4 *>(v_lds + pa_off<D>(x / CH, x % CH)) = vreg[i];
-            }
-        }
+        PA_PUBLISH1(0, k0, v0) PA_PUBLISH1(1, k1, v1) PA_PUBLISH1(2, k2, v2) PA_PUBLISH1(3, k3, v3)
+        PA_PUBLISH1(4, k4, v4) PA_PUBLISH1(5, k5, v5) PA_PUBLISH1(6, k6, v6) PA_PUBLISH1(7, k7, v7)
     };
+#undef PA_FETCH1
+#undef PA_PUBLISH1
+    static_assert(CPT <= 8, "staging registers");
     fetch(0);
 
     // Q fragments (B operand of K . Q^T): lane (row c, half h), k-step s holds Q[r0 + c][hq][16 s + 8 h .. + 8]
