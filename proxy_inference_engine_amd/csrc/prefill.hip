@@ -202,11 +202,36 @@ int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int
         PIE_REQUIRE(g_lt.LayoutCreate(&p.la, dt, K, N, K) == HIPBLAS_STATUS_SUCCESS && g_lt.LayoutCreate(&p.lb, dt, K, M, K) == HIPBLAS_STATUS_SUCCESS &&
                         g_lt.LayoutCreate(&p.lc, dt, N, M, N) == HIPBLAS_STATUS_SUCCESS,
                     PIE_E_HIP, "prefill: matrix layouts");
-        hipblasLtMatmulHeuristicResult_t res[1];
+        constexpr int MAX_ALGOS = 8;
+        hipblasLtMatmulHeuristicResult_t res[MAX_ALGOS];
         int n_res = 0;
-        const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, 1, res, &n_res);
+        const char *te = getenv("PIE_PREFILL_TUNE");  // 0: take the heuristic's first choice without timing the candidates
+        const int want = (te && te[0] == '0') || M < 64 ? 1 : MAX_ALGOS;
+        const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, want, res, &n_res);
         PIE_REQUIRE(hs == HIPBLAS_STATUS_SUCCESS && n_res > 0, PIE_E_HIP, "prefill: hipBLASLt has no kernel for this GEMM shape");
-        p.algo = res[0].algo;
+        int best = 0;
+        if (n_res > 1) {  // first use of this shape: time the candidates on the real operands (the product is idempotent, beta = 0)
+            const float one = 1.0f, zero = 0.0f;
+            hipEvent_t e0, e1;
+            PIE_HIP_TRY(hipEventCreate(&e0));
+            PIE_HIP_TRY(hipEventCreate(&e1));
+            float best_ms = 1e30f;
+            for (int i = 0; i < n_res; ++i) {
+                bool ok = true;
+                for (int rep = 0; rep < 3 && ok; ++rep) {  // one warm-up, two timed
+                    if (rep == 1) (void)hipEventRecord(e0, st);
+                    ok = g_lt.Matmul(g_lt.handle, p.desc, &one, w, p.la, x, p.lb, &zero, y, p.lc, y, p.lc, &res[i].algo, g_lt.workspace, g_lt.ws_bytes,
+                                     st) == HIPBLAS_STATUS_SUCCESS;
+                }
+                (void)hipEventRecord(e1, st);
+                (void)hipEventSynchronize(e1);
+                float ms = 1e30f;
+                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) best_ms = ms, best = i;
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        p.algo = res[best].algo;
         it = g_lt.plans.emplace(key, p).first;
     }
     const float alpha = 1.0f, beta = 0.0f;
