@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
-    ap.add_argument("--model", choices=["8b", "70b"], default="8b", help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); not the metric's workload")
+    ap.add_argument("--model", choices=["8b", "70b", "qv"], default="8b",
+                    help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; not the metric's workload")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
@@ -92,9 +93,9 @@ def main():
 
     from proxy_inference_engine_amd import InferenceEngine
     from proxy_inference_engine_amd.models.llama import Model, ModelArgs
-    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, LLAMA3_70B, synthetic_checkpoint
+    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, LLAMA3_70B, QWEN2VL_7B_TEXT, synthetic_checkpoint
 
-    cfg = dict(LLAMA3_70B if args.model == "70b" else LLAMA3_8B)
+    cfg = dict({"70b": LLAMA3_70B, "qv": QWEN2VL_7B_TEXT}.get(args.model, LLAMA3_8B))
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
     if args.dense:
@@ -171,7 +172,7 @@ def main():
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "dtype_detail": "uint4 g=64 weights x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
-        "config": {"workload": f"Llama-3-{args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
+        "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
                    "hipgraph": True},

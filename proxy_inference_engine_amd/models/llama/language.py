@@ -114,11 +114,14 @@ class Model:
             return (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s)(*trip, row_map=row_map)
 
         def bias(names: list[str], row_map=None):
-            """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix."""
-            try:
-                b = torch.cat([weights[f"{n}.bias"].reshape(-1) for n in names]).to(self.dtype)
-            except KeyError as e:
-                raise ValueError(f"attention_bias / mlp_bias is set but the checkpoint has no {e.args[0]}") from e
+            """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix; a Linear without a
+            `.bias` entry contributes zeros (Qwen2-style checkpoints carry q/k/v biases but none for o_proj), None if none has one."""
+            if not any(f"{n}.bias" in weights for n in names):
+                return None
+            rows = [int((weights[f"{n}.weight"]).shape[0]) for n in names]
+            parts = [weights[f"{n}.bias"].reshape(-1).to(self.dtype) if f"{n}.bias" in weights
+                     else torch.zeros(r, dtype=self.dtype, device=device) for n, r in zip(names, rows)]
+            b = torch.cat(parts)
             return (b[row_map.long()] if row_map is not None else b).contiguous()
 
         self.layers: list[TransformerBlock] = []

@@ -85,6 +85,16 @@ LLAMA3_70B = {
 }
 
 
+# Qwen2-VL-7B's TEXT tower (BASELINE.json configs[3]) expressed in the Llama ModelArgs: q/k/v biases (attention_bias; the
+# synthetic checkpoint also gets an o_proj bias, which the real model lacks -- 7 KB per layer), 7 q-heads per kv-head.
+QWEN2VL_7B_TEXT = {
+    "model_type": "llama", "hidden_size": 3584, "num_hidden_layers": 28, "intermediate_size": 18944,
+    "num_attention_heads": 28, "num_key_value_heads": 4, "rms_norm_eps": 1e-6, "vocab_size": 152064,
+    "rope_theta": 1000000.0, "max_position_embeddings": 32768, "tie_word_embeddings": False, "attention_bias": True,
+    "quantization": {"group_size": 64, "bits": 4},
+}
+
+
 def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch.bfloat16, device=None,
                          lm_head_gain: float = 1.0) -> dict[str, torch.Tensor]:
     """Random-weight checkpoint in the reference's on-disk layout, generated and quantised ON the GPU
@@ -99,7 +109,9 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
     D = config.get("head_dim") or H // nh
     out: dict[str, torch.Tensor] = {}
 
-    def put_linear(name: str, N: int, K: int, gain: float = 1.0) -> None:
+    def put_linear(name: str, N: int, K: int, gain: float = 1.0, bias: bool = False) -> None:
+        if bias:
+            out[f"{name}.bias"] = (torch.randn(N, generator=gen, device=device, dtype=torch.float32) * 0.1).to(dtype)
         w = (torch.randn((N, K), generator=gen, device=device, dtype=torch.float32) * (0.02 * gain)).to(dtype)
         if config.get("quantization"):
             out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w, bits=int(config["quantization"]["bits"]))
@@ -114,13 +126,14 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
         p = f"model.layers.{i}"
         out[f"{p}.input_layernorm.weight"] = norm_w()
         out[f"{p}.post_attention_layernorm.weight"] = norm_w()
-        put_linear(f"{p}.self_attn.q_proj", nh * D, H)
-        put_linear(f"{p}.self_attn.k_proj", nkv * D, H)
-        put_linear(f"{p}.self_attn.v_proj", nkv * D, H)
-        put_linear(f"{p}.self_attn.o_proj", H, nh * D)
-        put_linear(f"{p}.mlp.gate_proj", I, H)
-        put_linear(f"{p}.mlp.up_proj", I, H)
-        put_linear(f"{p}.mlp.down_proj", H, I)
+        ab, mb = bool(config.get("attention_bias")), bool(config.get("mlp_bias"))
+        put_linear(f"{p}.self_attn.q_proj", nh * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.k_proj", nkv * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.v_proj", nkv * D, H, bias=ab)
+        put_linear(f"{p}.self_attn.o_proj", H, nh * D, bias=ab)
+        put_linear(f"{p}.mlp.gate_proj", I, H, bias=mb)
+        put_linear(f"{p}.mlp.up_proj", I, H, bias=mb)
+        put_linear(f"{p}.mlp.down_proj", H, I, bias=mb)
     out["model.norm.weight"] = norm_w()
     if not config.get("tie_word_embeddings", True):
         put_linear("lm_head", V, H, gain=lm_head_gain)

@@ -20,12 +20,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--prompts", default="128,1024,4096")
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--dense", action="store_true", help="unquantised bf16 weights (BASELINE.json configs[2])")
     ap.add_argument("--iterated-max", type=int, default=1024, help="longest prompt also timed through iterated decode steps")
     args = ap.parse_args()
     from proxy_inference_engine_amd.models.llama import Model, ModelArgs
     from proxy_inference_engine_amd.models.utils import LLAMA3_8B, synthetic_checkpoint
 
     cfg = dict(LLAMA3_8B, num_hidden_layers=args.layers)
+    if args.dense:
+        cfg["quantization"] = None
     model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16))
     torch.cuda.empty_cache()
     for L in [int(x) for x in args.prompts.split(",")]:

@@ -436,6 +436,32 @@ def test_llama32_3b_shaped_layer():
         assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="3B-shaped decode")
 
 
+def test_qwen2vl_text_tower_shaped_layer():
+    """BASELINE.json configs[3]'s text tower geometry (Qwen2-VL-7B: H = 3584, I = 18944 = 9.25 K-slices, 28/4 heads -> 7 q-heads
+    per kv-head, D = 128) with q/k/v biases and NO o_proj bias, one layer, int4: batched prompt + decode vs the oracle.
+    (The vision tower and image-token scatter are SURVEY 8f-3, not built.)"""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 3584, "num_hidden_layers": 1, "intermediate_size": 18944,
+           "num_attention_heads": 28, "num_key_value_heads": 4, "rms_norm_eps": 1e-6, "vocab_size": 2048,
+           "rope_theta": 1000000.0, "max_position_embeddings": 32768, "tie_word_embeddings": False, "attention_bias": True,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=19, dtype=dtype, lm_head_gain=4.0)
+    del w["model.layers.0.self_attn.o_proj.bias"]
+    model = build(cfg, w, dtype)
+    assert model.layers[0].bo is None and model.layers[0].bqkv is not None
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(6).integers(0, cfg["vocab_size"], 24)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache, last_only=True)
+    cache = model.make_cache()
+    tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+    assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="QV-shaped prefill logits")
+    for _ in range(3):
+        want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+        tok, lp, logits = model.step(None, cache)
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="QV-shaped decode")
+
+
 def test_llama70b_shaped_layer_on_one_gpu():
     """BASELINE.json configs[4] geometry (Llama-3-70B: H=8192, I=28672, 64/8 heads -> 8 q-heads per kv-head, D=128),
     one layer, int4 g=64.  The 70B int4 model is 40 GB and fits one 288 GB card, so it runs on the single-GPU path:
