@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
-    ap.add_argument("--model", choices=["8b", "70b", "qv"], default="8b",
-                    help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; not the metric's workload")
+    ap.add_argument("--model", choices=["8b", "70b", "qv", "3b"], default="8b",
+                    help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; 3b: Llama-3.2-3B; not the metric's workload")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
@@ -93,9 +93,9 @@ def main():
 
     from proxy_inference_engine_amd import InferenceEngine
     from proxy_inference_engine_amd.models.llama import Model, ModelArgs
-    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, LLAMA3_70B, QWEN2VL_7B_TEXT, synthetic_checkpoint
+    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, LLAMA3_70B, LLAMA32_3B, QWEN2VL_7B_TEXT, synthetic_checkpoint
 
-    cfg = dict({"70b": LLAMA3_70B, "qv": QWEN2VL_7B_TEXT}.get(args.model, LLAMA3_8B))
+    cfg = dict({"70b": LLAMA3_70B, "qv": QWEN2VL_7B_TEXT, "3b": LLAMA32_3B}.get(args.model, LLAMA3_8B))
     if args.layers:
         cfg["num_hidden_layers"] = args.layers
     if args.dense:

@@ -210,8 +210,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const unsigned woff0 = (unsigned)((size_t)gw * ns * UB) + lane * 16;  // this wave's first unit, this lane's piece
     const unsigned pstride32 = (unsigned)pstride;
     int iss_sl = 0, iss_pl = 0;  // slice / local pair of the next unit to issue
+    // K that is not a multiple of the slice width leaves zero-padded lanes in every row's last unit (Llama-3.2-3B: H = 3072 ->
+    // 1.5 slices, a third more bytes than the checkpoint holds).  Those lanes get the out-of-range offset too: the padding is
+    // 128-byte aligned runs of 8+ lanes, so whole cache lines are never fetched; the lane then computes on zeros, as before.
+    const int my_chunks = FMT == FMT_W16S ? (a.K + 15) >> 4 : (a.K + 63) >> 6;  // valid per-lane column chunks (16 weights / one 64-group)
+    const bool ragged = (my_chunks & 31) != 0;                                    // wave-uniform
     auto issue = [&](int d, int) {  // ring slot d <- next unit of this wave
-        const unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
+        unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
+        if (ragged && iss_sl * 32 + (lane & 31) >= my_chunks) off = 0xFFFFF000u;
         if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
         if (ABL & 1) {
             c0[d] = c1[d] = make_uint4(lane, off, d, 7);

@@ -85,6 +85,13 @@ LLAMA3_70B = {
 }
 
 
+LLAMA32_3B = {
+    "model_type": "llama", "hidden_size": 3072, "num_hidden_layers": 28, "intermediate_size": 8192,
+    "num_attention_heads": 24, "num_key_value_heads": 8, "head_dim": 128, "rms_norm_eps": 1e-5, "vocab_size": 128256,
+    "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": True,
+    "quantization": {"group_size": 64, "bits": 4},
+}
+
 # Qwen2-VL-7B's TEXT tower (BASELINE.json configs[3]) expressed in the Llama ModelArgs: q/k/v biases (attention_bias; the
 # synthetic checkpoint also gets an o_proj bias, which the real model lacks -- 7 KB per layer), 7 q-heads per kv-head.
 QWEN2VL_7B_TEXT = {
