@@ -154,3 +154,19 @@ def test_prompt_cache_persistence_round_trip(tmp_path):
     assert torch.equal(fresh.cache[1].keys.cpu(), pc.cache[1].keys.cpu()) and float(fresh.cache[2].values[0, 0, 9, 0]) == -3.0
     todo = fresh(ids)                                                   # ... until the prefix match trims it
     assert list(todo) == ids[-1:] and fresh.cache[0].offset == 9
+
+
+def test_reference_import_paths_resolve_to_the_same_modules():
+    """Code written against the reference imports `proxy_inference_engine.<module>` (src/proxy_inference_engine/...): every
+    such path must give the very module object of the implementation (shared sampler RNG state, one loaded library)."""
+    import importlib
+    for m in ("engine.inference_engine", "samplers", "samplers.top_p", "samplers.min_p", "samplers.top_k", "samplers.categorical",
+              "cache", "cache.prompt_cache", "cache.kv_cache", "cache.kv_cache.reusable", "logits_processors",
+              "logits_processors.repetition", "models", "models.base", "models.utils", "models.llama", "models.llama.language",
+              "models.llama.utils", "pie_core"):
+        assert importlib.import_module(f"proxy_inference_engine.{m}") is importlib.import_module(f"proxy_inference_engine_amd.{m}"), m
+    from proxy_inference_engine import InferenceEngine, pie_core
+    from proxy_inference_engine.engine.inference_engine import InferenceEngine as IE2
+    assert InferenceEngine is IE2 and pie_core.hello() == "pie_core \u2713"
+    with pytest.raises(ImportError):
+        importlib.import_module("proxy_inference_engine.server")       # the HTTP server is out of scope: absent, not stubbed
