@@ -222,3 +222,53 @@ def test_int8_g64_quantize_gemv_embedding_vs_oracle(ops, dt):
             ids = torch.tensor([1, N - 1, 7], dtype=torch.int32, device="cuda")
             rows = ops.embedding(ids, codes, scales, biases, bits=8)
             assert np.array_equal(to_bits(rows), to_bits(deq[[1, N - 1, 7]]))
+
+
+def test_gemv_random_shape_sweep_all_formats(ops):
+    """Seeded sweep over irregular shapes for the three weight formats of the streaming GEMV: N any even number (incl. fewer
+    row pairs than waves and non-multiples of the wave geometry), K any multiple of 64 up to 9 slices (ragged last slice:
+    the zero-padded lanes are not fetched), M 1..3, both dtypes.  Against the oracle's exact qmv / dense forms."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        dt = ("bfloat16", "float16")[case % 2]
+        fmt = ("int4", "int8", "dense")[case % 3]
+        N = 2 * int(rng.integers(1, 700))
+        K = 64 * int(rng.integers(1, 150))
+        M = int(rng.integers(1, 4))
+        w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+        x = po.round_T(rng.standard_normal((M, K)), dt)
+        xd = to_dev(po.to_bits(x, dt), dt)
+        if fmt == "dense":
+            got = ops.linear(xd, ops.repack_dense(to_dev(po.to_bits(w, dt), dt)))
+            want = po.linear(x, po.to_bits(w, dt), dt)
+        else:
+            bits = 4 if fmt == "int4" else 8
+            wq, sc, bi = po.quantize(w, 64, bits, dt)
+            repack = ops.repack_w4s if bits == 4 else ops.repack_w8s
+            got = ops.quantized_matmul(xd, repack(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt)))
+            want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=bits, dtype=dt)
+        assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"case {case}: {fmt} N={N} K={K} M={M} {dt}")
+
+
+def test_sdpa_decode_random_sweep(ops):
+    """Seeded sweep over the decode attention: every GQA ratio 1..8, head_dim 64 / 128, T from 1 to 3000 (1, 4, 16 and 32
+    splits), capacity above T with poisoned rows past T, both dtypes."""
+    rng = np.random.default_rng(77)
+    for case in range(18):
+        dt = ("bfloat16", "float16")[case % 2]
+        rep = int(rng.integers(1, 9))
+        Hkv = int(rng.integers(1, 5))
+        D = (64, 128)[case % 3 == 0]
+        T = int(rng.choice([1, 2, 31, 33, 127, 129, 500, 1025, 2100, 3000]))
+        cap = ((T + 255) // 256) * 256 + 256 * int(rng.integers(0, 2))
+        Hq = rep * Hkv
+        q = po.round_T(rng.standard_normal((Hq, 1, D)), dt)
+        k = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+        v = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+        k[:, T:] = 1e4
+        v[:, T:] = -1e4
+        want = po.sdpa(q, k, v, D ** -0.5, None, dt, True, T=T)
+        got = ops.scaled_dot_product_attention(to_dev(po.to_bits(q, dt), dt).view(1, Hq, 1, D), to_dev(po.to_bits(k, dt), dt).view(1, Hkv, cap, D),
+                                               to_dev(po.to_bits(v, dt), dt).view(1, Hkv, cap, D), D ** -0.5, T=T)
+        assert_bits_close(to_bits(got), po.to_bits(want, dt), max_ulp=2 if dt == "bfloat16" else 4, max_frac=0.05,
+                          what=f"case {case}: sdpa {Hq}/{Hkv} D{D} T{T} cap{cap} {dt}")
