@@ -119,6 +119,12 @@ size_t pie_sdpa_decode_workspace_bytes(int Hq, int D);
 int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv, int T, int cap, int D, float scale,
                     int dtype, void *out, void *workspace, void *stream);
 
+/* The same call site at L > 1 with the causal mask of models/base.py:37-53 (query row l at absolute position offset + l sees
+ * keys 0 .. offset + l): q, out [L, Hq, D] T (the [B, L, h, D] order of language.py:86 before its transpose); k, v
+ * [Hkv, cap, D] with rows [0, offset + L) valid.  MFMA flash kernel; P kept as hi + lo halves of T (~fp32 contract). */
+int pie_sdpa_prefill(const void *q, const void *k, const void *v, int Hq, int Hkv, int L, int offset, int cap, int D,
+                     float scale, int dtype, void *out, void *stream);
+
 /* nn.silu(a) * b (models/llama/language.py:127) and the residual adds (:151,:153) (K6, K7). */
 int pie_silu_mul(const void *a, const void *b, size_t n, int dtype, void *y, void *stream);
 int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *stream);

@@ -451,6 +451,22 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
     return enqueue_kernel(d, PIE_K_TAIL, 0, nullptr, d->logits, st);
 }
 
+// mx.fast.scaled_dot_product_attention(q, k, v, scale, mask=causal) for L > 1 (models/base.py:37-53,111-113), op level.
+extern "C" int pie_sdpa_prefill(const void *q, const void *k, const void *v, int Hq, int Hkv, int L, int offset, int cap, int D, float scale,
+                                int dtype, void *out, void *stream) {
+    PIE_REQUIRE(q && k && v && out, PIE_E_ARG, "pie_sdpa_prefill: null pointer");
+    PIE_REQUIRE(L >= 1 && offset >= 0 && offset + L <= cap, PIE_E_SHAPE, "pie_sdpa_prefill: need offset + L <= cap");
+    PIE_REQUIRE(D == 64 || D == 128, PIE_E_SHAPE, "pie_sdpa_prefill: head_dim must be 64 or 128");
+    PIE_REQUIRE(Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, PIE_E_SHAPE, "pie_sdpa_prefill: n_heads / n_kv_heads must be between 1 and 8");
+    PIE_REQUIRE(pie_aligned(q, 16) && pie_aligned(k, 16) && pie_aligned(v, 16) && pie_aligned(out, 8), PIE_E_ALIGN, "pie_sdpa_prefill: misaligned pointer");
+    PrefillAttnArgs a = {};
+    a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v, a.offset = offset, a.cap = cap;
+    a.M = L, a.Hq = Hq, a.Hkv = Hkv, a.scale = scale, a.out = (u16 *)out;
+    if (dtype == PIE_BF16) return prefill_attn_launch_t<BF16>(a, D, (hipStream_t)stream);
+    if (dtype == PIE_F16) return prefill_attn_launch_t<F16>(a, D, (hipStream_t)stream);
+    return pie::fail(PIE_E_ARG, "pie_sdpa_prefill: dtype must be PIE_BF16 or PIE_F16");
+}
+
 int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
     PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "prefill: n_heads / n_kv_heads must be between 1 and 8");

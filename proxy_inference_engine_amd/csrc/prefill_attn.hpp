@@ -31,7 +31,9 @@ struct PrefillAttnArgs {
     const u16 *q;                        // [M, Hq, D]
     const unsigned long long *kv_table;  // K buffers then V buffers, [Hkv, cap, D] each
     int layer, n_layers;
-    const DecState *state;               // pos = offset of row 0, cap
+    const DecState *state;               // pos = offset of row 0, cap  (decoder) ...
+    const u16 *k, *v;                    // ... or direct [Hkv, cap, D] buffers with host-side offset / capacity (op-level, state == nullptr)
+    int offset, cap;
     int M, Hq, Hkv;
     float scale;
     u16 *out;                            // [M, Hq, D]
@@ -73,12 +75,12 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 32, g = blockIdx.y, hq = g * REP + wave;
-    const int pos0 = a.state->pos, cap = a.state->cap;
+    const int pos0 = a.state ? a.state->pos : a.offset, cap = a.state ? a.state->cap : a.cap;
     const int r_last = (r0 + 31 < a.M ? r0 + 31 : a.M - 1);
     const int t_last = pos0 + r_last;            // last key any row of this tile attends
     const int n_blocks = t_last / BK + 1;
-    const u16 *kbase = reinterpret_cast<const u16 *>(a.kv_table[a.layer]) + (size_t)g * cap * D;
-    const u16 *vbase = reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]) + (size_t)g * cap * D;
+    const u16 *kbase = (a.state ? reinterpret_cast<const u16 *>(a.kv_table[a.layer]) : a.k) + (size_t)g * cap * D;
+    const u16 *vbase = (a.state ? reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]) : a.v) + (size_t)g * cap * D;
 
     // staging: chunk id x = threadIdx.x + i*NT -> (row = x / CH, ch = x % CH); keys past t_last are clamped (masked later).
     // Eight NAMED register pairs, used up to CPT: as arrays (even with compile-time indices) the compiler parked them in

@@ -232,8 +232,23 @@ _sdpa_ws: dict = {}
 def scaled_dot_product_attention(q, k, v, scale: float, mask=None, T: int | None = None) -> torch.Tensor:
     """mx.fast.scaled_dot_product_attention for the decode step: q [1,Hq,1,D]; k,v [1,Hkv,cap,D] buffers whose
     first T positions are attended (default: all); mask must be None (L == 1: models/base.py:39-53)."""
-    if mask is not None or q.shape[-2] != 1 or q.shape[0] != 1:
-        raise NotImplementedError("decode form only: batch 1, one query position, mask=None")
+    if q.shape[0] != 1:
+        raise NotImplementedError("batch 1 only")
+    if q.shape[-2] != 1:  # prompt form: mask must be the causal one ("causal"; models/base.py:37-53 builds exactly that)
+        if not (isinstance(mask, str) and mask == "causal"):
+            raise NotImplementedError("L > 1 needs mask='causal' (the additive causal mask of models/base.py:18-53)")
+        for t in (q, k, v):
+            _dev(t)
+        _, Hq, L, D = q.shape
+        Hkv, cap = k.shape[1], k.shape[2]
+        total = cap if T is None else int(T)
+        qt = q[0].transpose(0, 1).contiguous()                      # [L, Hq, D]
+        out = torch.empty_like(qt)
+        _ffi.check(_ffi.load().pie_sdpa_prefill(_ffi.p(qt), _ffi.p(k), _ffi.p(v), Hq, Hkv, L, total - L, cap, D, float(scale),
+                                                _ffi.dtype_code(q.dtype), _ffi.p(out), _ffi.stream()))
+        return out.transpose(0, 1).unsqueeze(0).contiguous()         # [1, Hq, L, D]
+    if mask is not None and not (isinstance(mask, str) and mask == "causal"):  # one query row: the causal mask hides nothing
+        raise NotImplementedError("decode form: one query position, mask=None")
     for t in (q, k, v):
         _dev(t)
     Hq, D = q.shape[1], q.shape[3]

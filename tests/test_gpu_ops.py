@@ -272,3 +272,20 @@ def test_sdpa_decode_random_sweep(ops):
                                                to_dev(po.to_bits(v, dt), dt).view(1, Hkv, cap, D), D ** -0.5, T=T)
         assert_bits_close(to_bits(got), po.to_bits(want, dt), max_ulp=2 if dt == "bfloat16" else 4, max_frac=0.05,
                           what=f"case {case}: sdpa {Hq}/{Hkv} D{D} T{T} cap{cap} {dt}")
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("Hq,Hkv,D,L,off,cap", [(8, 2, 128, 70, 0, 256), (6, 2, 128, 33, 100, 256), (8, 1, 64, 45, 19, 256), (4, 4, 64, 1, 200, 256)])
+def test_sdpa_prefill_vs_oracle(ops, dt, Hq, Hkv, D, L, off, cap):
+    """mx.fast.scaled_dot_product_attention with the causal mask at L > 1 (op level, pie_sdpa_prefill): MFMA flash kernel vs
+    the oracle's masked fp32 softmax; stale rows past offset + L are poisoned."""
+    rng = np.random.default_rng(Hq * L + off)
+    T = off + L
+    q = po.round_T(rng.standard_normal((Hq, L, D)), dt)
+    k = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+    v = po.round_T(rng.standard_normal((Hkv, cap, D)), dt)
+    k[:, T:] = 1e4
+    want = po.sdpa(q, k, v, D ** -0.5, po.causal_mask(L, off, dt), dt, True, T=T)
+    got = ops.scaled_dot_product_attention(to_dev(po.to_bits(q, dt), dt).view(1, Hq, L, D), to_dev(po.to_bits(k, dt), dt).view(1, Hkv, cap, D),
+                                           to_dev(po.to_bits(v, dt), dt).view(1, Hkv, cap, D), D ** -0.5, mask="causal", T=T)
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.05, what=f"sdpa prefill {Hq}/{Hkv} D{D} L{L} off{off} {dt}")
