@@ -74,7 +74,11 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     __shared__ __attribute__((aligned(16))) char k_lds[BK * 2 * D], v_lds[BK * 2 * D];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int r0 = blockIdx.x * 32, g = blockIdx.y, hq = g * REP + wave;
+    // XCD-aware tile mapping: workgroups go round-robin over the 8 XCDs by linear id, so the kv-head group is the FASTEST
+    // index (id % Hkv): with 8 kv-heads every XCD's L2 only ever holds one group's K/V (4 MB at 4096 tokens) instead of all
+    // of them.  Query tiles longest first (a tile's work grows with its position: causal).
+    const int g = (int)blockIdx.x % a.Hkv, tile = (int)blockIdx.x / a.Hkv;
+    const int r0 = ((a.M + 31) / 32 - 1 - tile) * 32, hq = g * REP + wave;
     const int pos0 = a.state ? a.state->pos : a.offset, cap = a.state ? a.state->cap : a.cap;
     const int r_last = (r0 + 31 < a.M ? r0 + 31 : a.M - 1);
     const int t_last = pos0 + r_last;            // last key any row of this tile attends
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
 
 template <class T, int D>
 static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
-    const dim3 grid((a.M + 31) / 32, a.Hkv);
+    const dim3 grid(((a.M + 31) / 32) * a.Hkv);
     switch (a.Hq / a.Hkv) {
         case 1: hipLaunchKernelGGL((k_prefill_attn<T, D, 1>), grid, dim3(64), 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_prefill_attn<T, D, 2>), grid, dim3(128), 0, st, a); break;
