@@ -67,9 +67,13 @@ __device__ __forceinline__ int pa_off(int row, int ch) {
     return 2 * D * row + 16 * (ch ^ ((((row & 3) << 2) | ((row >> 2) & 3)) & (D / 8 - 1)));
 }
 
-template <class T, int D, int REP>
-__global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs a) {
-    constexpr int BK = 32, NT = REP * 64, CH = D / 8, KS = D / 16, DT = D / 32;  // chunks per row, k-steps of Q.K^T, 32-dim output tiles
+// QT: 32-row query tiles per workgroup (1 or 2).  With QT = 2 the workgroup has 2*REP waves -- waves [0, REP) own the first
+// tile, [REP, 2 REP) the second -- and one staged K/V block serves 64 query rows: half the L2 -> LDS traffic and barriers per
+// unit of work, at the same number of waves per CU (one 8-wave workgroup instead of two 4-wave ones for REP = 4).
+template <class T, int D, int REP, int QT>
+__global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAttnArgs a) {
+    constexpr int BK = 32, NT = REP * QT * 64, CH = D / 8, KS = D / 16, DT = D / 32;  // chunks per row, k-steps of Q.K^T, 32-dim output tiles
+    constexpr int BM = 32 * QT;
     constexpr int CPT = (BK * CH + NT - 1) / NT;                                   // 16-byte chunks per thread and tile
     __shared__ __attribute__((aligned(16))) char k_lds[BK * 2 * D], v_lds[BK * 2 * D];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,9 +82,10 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
     // index (id % Hkv): with 8 kv-heads every XCD's L2 only ever holds one group's K/V (4 MB at 4096 tokens) instead of all
     // of them.  Query tiles longest first (a tile's work grows with its position: causal).
     const int g = (int)blockIdx.x % a.Hkv, tile = (int)blockIdx.x / a.Hkv;
-    const int r0 = ((a.M + 31) / 32 - 1 - tile) * 32, hq = g * REP + wave;
+    const int wg_r0 = ((a.M + BM - 1) / BM - 1 - tile) * BM;                  // first query row of the workgroup
+    const int r0 = wg_r0 + 32 * (wave / REP), hq = g * REP + wave % REP;     // this wave's 32-row tile and q-head
     const int pos0 = a.state ? a.state->pos : a.offset, cap = a.state ? a.state->cap : a.cap;
-    const int r_last = (r0 + 31 < a.M ? r0 + 31 : a.M - 1);
+    const int r_last = (wg_r0 + BM - 1 < a.M ? wg_r0 + BM - 1 : a.M - 1);
     const int t_last = pos0 + r_last;            // last key any row of this tile attends
     const int n_blocks = t_last / BK + 1;
     const u16 *kbase = (a.state ? reinterpret_cast<const u16 *>(a.kv_table[a.layer]) : a.k) + (size_t)g * cap * D;
@@ -221,18 +226,28 @@ __global__ void __launch_bounds__(REP * 64) k_prefill_attn(const PrefillAttnArgs
 
 template <class T, int D>
 static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
-    const dim3 grid(((a.M + 31) / 32) * a.Hkv);
-    switch (a.Hq / a.Hkv) {
-        case 1: hipLaunchKernelGGL((k_prefill_attn<T, D, 1>), grid, dim3(64), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_prefill_attn<T, D, 2>), grid, dim3(128), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_prefill_attn<T, D, 3>), grid, dim3(192), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_prefill_attn<T, D, 4>), grid, dim3(256), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_prefill_attn<T, D, 5>), grid, dim3(320), 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_prefill_attn<T, D, 6>), grid, dim3(384), 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_prefill_attn<T, D, 7>), grid, dim3(448), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_prefill_attn<T, D, 8>), grid, dim3(512), 0, st, a); break;
+    const int rep = a.Hq / a.Hkv;
+    const char *e = getenv("PIE_PREFILL_QT");  // tuning knob: 1 forces one 32-row query tile per workgroup
+    // 2 tiles need 2*rep <= 8 waves of up to 256 registers, and only pay while the halved grid still fills the 256 CUs
+    // (8B model: 4096 tokens 54.9 -> 53.9 ms, 8000 tokens 126.3 -> 125.0 ms; at 1024 tokens it would idle half the chip)
+    const bool two = rep <= 4 && ((a.M + 63) / 64) * a.Hkv >= 256 && !(e && e[0] == '1');
+    const dim3 grid(((a.M + (two ? 63 : 31)) / (two ? 64 : 32)) * a.Hkv);
+#define PA_LAUNCH(R)                                                                                         \
+    if (two && R <= 4) hipLaunchKernelGGL((k_prefill_attn<T, D, R, (R <= 4 ? 2 : 1)>), grid, dim3(R * 128), 0, st, a); \
+    else hipLaunchKernelGGL((k_prefill_attn<T, D, R, 1>), grid, dim3(R * 64), 0, st, a);                     \
+    break
+    switch (rep) {
+        case 1: PA_LAUNCH(1);
+        case 2: PA_LAUNCH(2);
+        case 3: PA_LAUNCH(3);
+        case 4: PA_LAUNCH(4);
+        case 5: PA_LAUNCH(5);
+        case 6: PA_LAUNCH(6);
+        case 7: PA_LAUNCH(7);
+        case 8: PA_LAUNCH(8);
         default: return pie::fail(PIE_E_SHAPE, "prefill attention: n_heads / n_kv_heads must be between 1 and 8");
     }
+#undef PA_LAUNCH
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
