@@ -92,6 +92,11 @@ int pie_repack_dense(const void *w, int N_src, int K, const int32_t *row_map, in
 int pie_gemv_dense(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
 int pie_embedding_dense(const int32_t *ids, int L, const void *table, int V, int H, int dtype, void *out, void *stream);
 
+/* The same product WITHOUT the final rounding: y fp32 [M,N] = the fp32 row sums.  For the row-parallel Linears (o_proj,
+ * down_proj) of a tensor-parallel shard, whose partial sums are all-reduced over the ranks before the one rounding to T
+ * (proxy_inference_engine_amd/tp.py; the reference has no parallelism). */
+int pie_qgemv_w4g64_f32(const void *x, int M, const void *packed, int N, int K, float *y, int dtype, void *stream);
+
 /* nn.QuantizedEmbedding.__call__ (models/llama/language.py:176): dequantise gathered rows of the
  * MLX-layout table.  ids device int32 [L] -> out [L,H] T. */
 int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases,

@@ -19,7 +19,7 @@ KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5
 EXPORTS = [
     "pie_hello", "pie_version", "pie_last_error", "pie_device_info",
     "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_w8s_bytes", "pie_repack_w8g64", "pie_qgemv_w8g64", "pie_quantize_g64", "pie_dequantize_g64", "pie_embedding_g64",
-    "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64",
+    "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64", "pie_qgemv_w4g64_f32",
     "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode", "pie_sdpa_prefill",
     "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_qkv_row_map", "pie_gateup_row_map",
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",

@@ -222,7 +222,8 @@ __global__ void k_embedding_dense(const int *ids, const uint4 *table, int V, int
 template <class T, int NPT, int FMT>
 static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
     const dim3 block(GEMV_WAVES * 64);
-    if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT, 0, FMT>), grid, block, lds, st, a);
+    if (pro == PRO_NONE && epi == EPI_PARTIAL_F32) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_PARTIAL_F32, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
@@ -359,6 +360,18 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
                        row_map, n_pairs, ns, (u32 *)packed);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
+}
+
+int pie_qgemv_w4g64_f32(const void *x, int M, const void *packed, int N, int K, float *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w4g64_f32: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w4g64_f32: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "pie_qgemv_w4g64_f32: misaligned pointer");
+    GemvArgs a = {};
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y32 = y;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_PARTIAL_F32, a, M, (hipStream_t)stream);
 }
 
 size_t pie_w8s_bytes(int N_out, int K) {

@@ -29,7 +29,8 @@
 // PRO_ATTN: x is the merge of the split-KV attention partials (o_proj input, language.py:107-108)
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
 constexpr int GEMV_ATTN_SPLITS = 4;  // split-KV factor the PRO_ATTN prologue merges (register budget: 10 floats per split and piece)
-enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4 };
+// EPI_PARTIAL_F32: the un-rounded fp32 row sums (row-parallel Linear of a tensor-parallel shard: summed over ranks, THEN rounded)
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4, EPI_PARTIAL_F32 = 5 };
 
 constexpr int GEMV_WAVES = 8;        // waves per workgroup
 constexpr int GEMV_DEPTH = 2;        // units in flight per wave (swept 2..12 on MI355X: 2-3 best, deeper rings are slower)
@@ -50,6 +51,7 @@ struct GemvArgs {
     const u16 *norm_w;    // PRO_RMSNORM
     float eps;
     u16 *y;               // EPI_STORE / EPI_LOGITS [M,N]; EPI_SWIGLU act [N/2]
+    float *y32;           // EPI_PARTIAL_F32 [M,N] fp32
     const u16 *lin_bias;  // optional nn.Linear / nn.QuantizedLinear bias [N] in PACKED row order (attention_bias / mlp_bias,
                           // language.py:42-53,117-126): added to the T-rounded product, rounded again; not with EPI_LOGITS
     u16 *resid;           // EPI_RESIDUAL: residual stream, updated in place
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     int pos = 0, cap = 0;
     u16 *kdst = nullptr, *vdst = nullptr;
     if (EPI == EPI_RESIDUAL && live) pre_u = *reinterpret_cast<const u32 *>(a.resid + R);
-    const bool has_bias = EPI != EPI_LOGITS && a.lin_bias != nullptr;  // wave-uniform
+    const bool has_bias = EPI != EPI_LOGITS && EPI != EPI_PARTIAL_F32 && a.lin_bias != nullptr;  // wave-uniform
     if (has_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
     if (EPI == EPI_ROPE_KV) {
         pos = a.state->pos, cap = a.state->cap;
@@ -387,6 +389,8 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 a.stats[(size_t)m * a.n_waves + gw] = st;
             }
         }
+    } else if (EPI == EPI_PARTIAL_F32) {
+        if (live) *reinterpret_cast<float2 *>(a.y32 + (size_t)m * a.N + R) = make_float2(va, vb);
     } else if (EPI == EPI_RESIDUAL) {
         // h = x + r (language.py:151,153): Linear output rounded to T, then the add rounded to T
         if (live) *reinterpret_cast<u32 *>(a.resid + R) = pack2<T>(lo_f32<T>(pre_u) + round_T<T>(va), hi_f32<T>(pre_u) + round_T<T>(vb));

@@ -192,6 +192,18 @@ def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight", transpose: boo
     return y
 
 
+def quantized_matmul_partial(x: torch.Tensor, w: W4SWeight) -> torch.Tensor:
+    """The fp32 row sums of quantized_matmul before their rounding to T: x [..., K] -> fp32 [..., N].  Row-parallel shards of a
+    tensor-parallel Linear are summed over the ranks in this form (tp.py)."""
+    _dev(x)
+    if not isinstance(w, W4SWeight) or x.shape[-1] != w.K or x.dtype != w.dtype:
+        raise ValueError("quantized_matmul_partial takes a W4S weight matching x's last dimension and dtype")
+    M = x.numel() // w.K
+    y = torch.empty((*x.shape[:-1], w.N), dtype=torch.float32, device=x.device)
+    _ffi.check(_ffi.load().pie_qgemv_w4g64_f32(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(y), _ffi.dtype_code(x.dtype), _ffi.stream()))
+    return y
+
+
 def embedding(ids: torch.Tensor, codes, scales, biases, bits: int = 4) -> torch.Tensor:
     """nn.QuantizedEmbedding.__call__: ids int32 [L] -> [L, H]."""
     _dev(ids)

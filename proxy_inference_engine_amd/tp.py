@@ -103,3 +103,79 @@ class TPGroup:
         lse = M + torch.log((stats[:, 1] * torch.exp(stats[:, 0] - M)).sum())
         cand = stats[stats[:, 0] == M]
         return float(lse), int(cand[:, 2].min().item())  # ties: the lowest vocabulary index wins (mx.argmax)
+
+
+class TPLlama:
+    """One rank of a tensor-parallel Llama decode step ON THE DEVICE: this rank's shard of an int4 g=64 checkpoint through the
+    op-level HIP kernels (hip_ops), the two row-parallel Linears as un-rounded fp32 partials (pie_qgemv_w4g64_f32) summed with
+    one all-reduce each, then the single rounding to T and the residual add -- the rounding points of the unsharded graph.
+    Functional form of the plan above (one launch per op, no fused epilogues, no graph): it exists for models that do not
+    fit one 288 GB card, which none of BASELINE.json's configurations is."""
+
+    def __init__(self, config: dict, weights: dict, tp: TPGroup, device=None):
+        from . import hip_ops
+        from .cache.kv_cache import ReusableKVCache
+        from .models.llama.utils import Llama3RoPE
+        self.ops, self.tp = hip_ops, tp
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        w, c = shard_checkpoint(weights, config, tp.rank, tp.world)
+        w = {k: v.to(self.device) for k, v in w.items()}
+        self.cfg, self.full_cfg = c, config
+        self.dtype = w["model.norm.weight"].dtype
+        self.nh, self.nkv, self.D = c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"]
+        trip = lambda n: (w[f"{n}.weight"], w[f"{n}.scales"], w[f"{n}.biases"])  # noqa: E731
+        cat = lambda names: [torch.cat(t, dim=0) for t in zip(*(trip(n) for n in names))]  # noqa: E731
+        self.layers = []
+        for i in range(config["num_hidden_layers"]):
+            p = f"model.layers.{i}"
+            self.layers.append(dict(
+                attn_norm=w[f"{p}.input_layernorm.weight"], mlp_norm=w[f"{p}.post_attention_layernorm.weight"],
+                qkv=hip_ops.repack_w4s(*cat([f"{p}.self_attn.{n}_proj" for n in "qkv"])),      # natural row order: op-level RoPE
+                o=hip_ops.repack_w4s(*trip(f"{p}.self_attn.o_proj")),                           # K = local q width
+                gate=hip_ops.repack_w4s(*trip(f"{p}.mlp.gate_proj")), up=hip_ops.repack_w4s(*trip(f"{p}.mlp.up_proj")),
+                down=hip_ops.repack_w4s(*trip(f"{p}.mlp.down_proj"))))                          # K = local intermediate width
+        self.embed = trip("model.embed_tokens")
+        self.norm = w["model.norm.weight"]
+        self.lm_head = hip_ops.repack_w4s(*trip("lm_head"))                                     # this rank's vocabulary rows
+        self.vocab_offset = tp.rank * c["tp_vocab_shard"]
+        rs = config.get("rope_scaling") or {}
+        max_len = config.get("max_position_embeddings") or 8192
+        self.rope = Llama3RoPE(max_len, max_len, self.D, config.get("rope_theta", 10000.0), float(rs.get("factor", 1.0)),
+                               float(rs.get("low_freq_factor", 1.0)), float(rs.get("high_freq_factor", 1.0)), device=self.device)
+        self.cache = [ReusableKVCache() for _ in self.layers]
+        self.eps = float(config["rms_norm_eps"])
+
+    def _row_parallel(self, x: torch.Tensor, wmat) -> torch.Tensor:
+        part = self.ops.quantized_matmul_partial(x, wmat)          # fp32 [1, H], this rank's K slice
+        self.tp.all_reduce_partial(part)                           # RCCL / gloo sum over the ranks
+        return part.to(self.dtype)                                 # the Linear's one rounding to T
+
+    def step(self, token: int) -> tuple[int, float, torch.Tensor]:
+        """One decode step of Model.__call__(inputs[1,1]) + greedy tail; returns (next token, logsumexp, hidden [1, H])."""
+        ops, D = self.ops, self.D
+        ids = torch.tensor([int(token)], dtype=torch.int32, device=self.device)
+        x = ops.embedding(ids, *self.embed)                                                     # [1, H] replicated
+        offset = self.cache[0].offset
+        for lw, kv in zip(self.layers, self.cache):
+            xn = ops.rms_norm(x, lw["attn_norm"], self.eps)
+            qkv = ops.quantized_matmul(xn, lw["qkv"])[0]
+            q, k, v = qkv[:self.nh * D], qkv[self.nh * D:(self.nh + self.nkv) * D], qkv[(self.nh + self.nkv) * D:]
+            q = ops.rope(q.reshape(self.nh, 1, D).contiguous(), D, offset=offset, freqs=self.rope.freqs)
+            k = ops.rope(k.reshape(self.nkv, 1, D).contiguous(), D, offset=offset, freqs=self.rope.freqs)
+            keys, values = kv.update_and_fetch(k[None], v.reshape(1, self.nkv, 1, D))
+            att = ops.scaled_dot_product_attention(q[None], kv.keys, kv.values, D ** -0.5, T=kv.offset)   # local heads only
+            x = ops.add(x, self._row_parallel(att.reshape(1, self.nh * D), lw["o"]))
+            hn = ops.rms_norm(x, lw["mlp_norm"], self.eps)
+            act = ops.silu_mul(ops.quantized_matmul(hn, lw["gate"]), ops.quantized_matmul(hn, lw["up"]))
+            x = ops.add(x, self._row_parallel(act, lw["down"]))
+        xn = ops.rms_norm(x, self.norm, self.eps)
+        logits = ops.quantized_matmul(xn, self.lm_head)[0].float()                              # this rank's vocabulary shard
+        m = logits.max()
+        stats = torch.zeros((self.tp.world, 3), dtype=torch.float64, device=self.device)
+        stats[self.tp.rank] = torch.stack([m.double(), torch.exp(logits - m).sum().double(),
+                                           (torch.nonzero(logits == m)[0, 0] + self.vocab_offset).double()])
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.tp.group)                       # all-gather of 3 numbers per rank
+        M = stats[:, 0].max()
+        lse = M + torch.log((stats[:, 1] * torch.exp(stats[:, 0] - M)).sum())
+        tok = int(stats[stats[:, 0] == M][:, 2].min().item())                                   # ties: lowest vocabulary index
+        return tok, float(lse), x

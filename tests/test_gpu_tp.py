@@ -1,0 +1,84 @@
+"""-m gpu: the tensor-parallel decode step ON THE DEVICE (proxy_inference_engine_amd/tp.py: TPLlama), world_size 2.
+
+The one-GPU box has one card, so both ranks share cuda:0 and the collectives run over gloo (the code path is
+torch.distributed's; on an 8-GPU node the backend is "nccl" = RCCL over xGMI).  Each rank shards the same int4 checkpoint,
+decodes a short sequence greedily with one all-reduce per row-parallel Linear, and rank 0 compares every step with the
+oracle on the UNSHARDED checkpoint: same tokens where the margin allows, hidden state within the end-to-end tolerance."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pie_oracle as po
+from tests._util import EPS, assert_vec_close, codes_dev, to_dev
+
+pytestmark = pytest.mark.gpu
+DT = "bfloat16"
+CFG = {"model_type": "llama", "hidden_size": 512, "num_hidden_layers": 2, "intermediate_size": 1024,
+       "num_attention_heads": 8, "num_key_value_heads": 4, "rms_norm_eps": 1e-5, "vocab_size": 1024,
+       "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": False,
+       "quantization": {"group_size": 64, "bits": 4}}
+PROMPT_SEED, STEPS = 3, 10
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from proxy_inference_engine_amd.tp import TPGroup, TPLlama
+        torch.cuda.set_device(0)
+        w = po.synth_checkpoint(CFG, seed=71, dtype=DT, lm_head_gain=4.0)
+        dev_w = {k: (codes_dev(v) if v.dtype == np.uint32 else to_dev(v, DT)) for k, v in w.items()}
+        model = TPLlama(CFG, dev_w, TPGroup())
+        prompt = np.random.default_rng(PROMPT_SEED).integers(0, CFG["vocab_size"], 6)
+        out = []
+        tok = None
+        for t in prompt:                                               # prompt by iterated steps, then greedy decode
+            tok, lse, hid = model.step(int(t))
+        for _ in range(STEPS):
+            out.append((tok, lse, hid.float().cpu().numpy().copy()))
+            tok, lse, hid = model.step(tok)
+        if rank == 0:
+            ret["tokens"] = [o[0] for o in out]
+            ret["lse"] = [o[1] for o in out]
+            ret["hidden"] = [o[2] for o in out]
+        ret[f"rank{rank}_tokens"] = [o[0] for o in out]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_decode_matches_unsharded_oracle():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["rank0_tokens"] == ret["rank1_tokens"]                 # both ranks decode the same sequence
+    w = po.synth_checkpoint(CFG, seed=71, dtype=DT, lm_head_gain=4.0)
+    orc = po.OracleLlama(CFG, w, DT)
+    prompt = np.random.default_rng(PROMPT_SEED).integers(0, CFG["vocab_size"], 6)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    po.set_qmm_min_rows(0)
+    try:
+        logits, hid = orc.forward(prompt, ocache, want_hidden=True)
+        logits, hid = logits[-1], hid[-1]
+        checked = 0
+        for i in range(STEPS):
+            assert_vec_close(ret["hidden"][i][0], hid, DT, what=f"TP hidden step {i}")
+            otok, olp = po.logprobs_argmax(logits)
+            lse_ref = float(np.log(np.exp(logits.astype(np.float64) - logits.max()).sum()) + logits.max())
+            assert abs(ret["lse"][i] - lse_ref) <= 4 * EPS[DT] * np.abs(logits).max()
+            top2 = np.sort(olp)[-2:]
+            if top2[1] - top2[0] > 2 * 4 * EPS[DT] * np.abs(logits).max():
+                assert ret["tokens"][i] == otok, f"step {i}"
+                checked += 1
+            logits, hid = orc.forward(np.array([ret["tokens"][i]]), ocache, want_hidden=True)   # teacher-forced with the TP tokens
+            logits, hid = logits[0], hid[0]
+        assert checked >= 3
+    finally:
+        po.set_qmm_min_rows(16)
