@@ -171,7 +171,7 @@ def main():
         "metric": "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s",
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "dtype_detail": "uint4 g=64 weights x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
+        "dtype": "bf16", "dtype_detail": ("bf16 weights" if args.dense else f"uint{args.bits} g=64 weights") + " x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
         "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
