@@ -289,3 +289,28 @@ def test_sdpa_prefill_vs_oracle(ops, dt, Hq, Hkv, D, L, off, cap):
     got = ops.scaled_dot_product_attention(to_dev(po.to_bits(q, dt), dt).view(1, Hq, L, D), to_dev(po.to_bits(k, dt), dt).view(1, Hkv, cap, D),
                                            to_dev(po.to_bits(v, dt), dt).view(1, Hkv, cap, D), D ** -0.5, mask="causal", T=T)
     assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.05, what=f"sdpa prefill {Hq}/{Hkv} D{D} L{L} off{off} {dt}")
+
+
+def test_qgemv_partial_fp32_and_row_parallel_sum(ops):
+    """pie_qgemv_w4g64_f32 (the un-rounded fp32 row sums of a Linear): two K-halves of an int4 weight, summed and rounded once,
+    reproduce the unsharded product -- the row-parallel identity the tensor-parallel step relies on -- and each partial is
+    within fp32 summation error of the float64 reference."""
+    rng = np.random.default_rng(9)
+    N, K, dt = 512, 2048, DT
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    x = po.round_T(rng.standard_normal((1, K)), dt)
+    wq, sc, bi = po.quantize(w, 64, 4, dt)
+    full = po.quantized_matmul(x, wq, sc, bi, dtype=dt)
+    q = ((wq[:, :, None] >> (4 * np.arange(8, dtype=np.uint32))) & 15).reshape(N, K).astype(np.float64)
+    deq = np.repeat(po.from_bits(sc, dt).astype(np.float64), 64, axis=1) * q + np.repeat(po.from_bits(bi, dt).astype(np.float64), 64, axis=1)  # exact affine values
+    xd = to_dev(po.to_bits(x, dt), dt)
+    total = None
+    for k0, k1 in ((0, K // 2), (K // 2, K)):
+        wsh = ops.repack_w4s(codes_dev(wq[:, k0 // 8:k1 // 8].copy()), to_dev(sc[:, k0 // 64:k1 // 64].copy(), dt), to_dev(bi[:, k0 // 64:k1 // 64].copy(), dt))
+        part = ops.quantized_matmul_partial(xd[:, k0:k1].contiguous(), wsh)
+        assert part.dtype == torch.float32 and part.shape == (1, N)
+        ref = x[:, k0:k1].astype(np.float64) @ deq[:, k0:k1].astype(np.float64).T
+        assert np.abs(part.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-6
+        total = part if total is None else total + part
+    got = total.to(torch.bfloat16)
+    assert_dot_close(got.float().cpu().numpy(), full, dt, what="sum of row-parallel partials")
