@@ -273,6 +273,9 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     a.n_slices = a.fmt == FMT_W16S ? w16s_slices(a.K) : w4s_slices(a.K);
     a.n_pairs = a.N / 2;
     a.n_waves = w4s_gemv_waves(a.N, a.K);
+    const size_t unit_bytes = a.fmt == FMT_W16S ? W16S_UNIT_BYTES : (a.fmt == FMT_W8S ? W8S_UNIT_BYTES : W4S_UNIT_BYTES);
+    PIE_REQUIRE((size_t)a.n_pairs * a.n_slices * unit_bytes < ((size_t)1 << 32) - 8192, PIE_E_SHAPE,
+                "w4s_gemv: one matrix must stay below 4 GiB (32-bit buffer offsets)");
     const unsigned lds = (unsigned)gemv_lds(a.K).total;
     PIE_REQUIRE(lds <= 65536u, PIE_E_SHAPE, "w4s_gemv: activation vector does not fit the 64 KB LDS image");
     dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, M);
