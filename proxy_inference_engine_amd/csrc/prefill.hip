@@ -127,6 +127,65 @@ __global__ void k_bias_rows(u16 *y, const u16 *b, size_t n8, int N8) {
     reinterpret_cast<uint4 *>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// h = x + r (language.py:151,153) fused with the RMSNorm that follows it (language.py:137-141): x <- T(x + r) in place,
+// xn <- w * T(h * rsqrt(mean(h^2) + eps)).  One workgroup per row; the row stays in registers between the two passes.
+template <class T>
+__global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn) {
+    __shared__ float red[4];
+    u16 *xr = x + (size_t)blockIdx.x * H;
+    const u16 *rr = r + (size_t)blockIdx.x * H;
+    u16 *yr = xn + (size_t)blockIdx.x * H;
+    constexpr int MAXP = 4;  // 8-element pieces per thread: H <= 8192
+    uint4 hv[MAXP];
+    float ssq = 0.0f;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = (threadIdx.x + p * 256) * 8;
+        if (i < H) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(xr + i), b = *reinterpret_cast<const uint4 *>(rr + i);
+            const u32 av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+            u32 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = pack2<T>(lo_f32<T>(av[j]) + lo_f32<T>(bv[j]), hi_f32<T>(av[j]) + hi_f32<T>(bv[j]));
+                const float lo = lo_f32<T>(o[j]), hi = hi_f32<T>(o[j]);
+                ssq = fmaf(lo, lo, ssq);
+                ssq = fmaf(hi, hi, ssq);
+            }
+            hv[p] = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(xr + i) = hv[p];
+        }
+    }
+    ssq = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = (threadIdx.x + p * 256) * 8;
+        if (i < H) {
+            const uint4 g = *reinterpret_cast<const uint4 *>(w + i);
+            const u32 vv[4] = {hv[p].x, hv[p].y, hv[p].z, hv[p].w}, gg[4] = {g.x, g.y, g.z, g.w};
+            u32 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack2<T>(round_T<T>(lo_f32<T>(vv[j]) * inv) * lo_f32<T>(gg[j]), round_T<T>(hi_f32<T>(vv[j]) * inv) * hi_f32<T>(gg[j]));
+            *reinterpret_cast<uint4 *>(yr + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <class T>
+static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int M, int H, int dtype, u16 *xn, hipStream_t st) {
+    if (H > 8192) {  // wider than the register-resident row: the two separate kernels
+        const int rc = pie_add(x, r, (size_t)M * H, dtype, x, st);
+        return rc ? rc : pie_rms_norm(x, w, eps, M, H, dtype, xn, st);
+    }
+    hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
 __global__ void k_add_pos(DecState *s, int delta) { s->pos += delta; }
 
 // ---------------------------------------------------------------- hipBLASLt through dlopen
@@ -408,7 +467,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
         for (int li = 0; li < c.n_layers; ++li) {
             const pie_layer_weights &w = d->layers[li];
             // Attention.__call__ (language.py:75-108) on input_layernorm(x)
-            if ((rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            // input_layernorm: layer 0 here; for the later layers it was fused with the previous block's residual add
+            if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q);
@@ -426,15 +486,17 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
             }
             if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo))) return rc;
-            if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // h = x + r (language.py:151)
-            // MLP.__call__ (language.py:126-127) on post_attention_layernorm(h)
-            if ((rc = pie_rms_norm(s->x, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            // h = x + r (language.py:151) + post_attention_layernorm(h) for MLP.__call__ (language.py:126-127)
+            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup))) return rc;
             const size_t n_act = (size_t)M * I;
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
             if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown))) return rc;
-            if ((rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st))) return rc;  // out = h + r (language.py:153)
+            // out = h + r (language.py:153), fused with the next block's input_layernorm when there is one
+            if (li + 1 < c.n_layers) rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st);
+            else rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st);
+            if (rc) return rc;
         }
         if (logits_all) {  // lm_head on every position, like the reference (language.py:205-209)
             if ((rc = pie_rms_norm(s->x, d->glob.final_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
