@@ -201,7 +201,7 @@ int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);
 enum { PIE_STEP_LOGITS = 1, PIE_STEP_GRAPH = 2 };
 int pie_decoder_step(pie_decoder *d, int flags, void *stream);
 /* Prompt processing: Model.__call__(inputs[1, L]) from the current device-side offset, ids[0..L) device int32, all
- * launches queued back to back with no host round trip.  L >= 16 (env PIE_PREFILL_MIN): batched, in chunks of
+ * launches queued back to back with no host round trip.  L >= 6 (env PIE_PREFILL_MIN): batched, in chunks of
  * PIE_PREFILL_CHUNK (4096) rows -- per layer the W4S weights are dequantised to T and multiplied by hipBLASLt (MLX's
  * qmm regime: nn.QuantizedLinear at L > 1 dequantises to T before a T x T -> fp32 MMA), with HIP kernels for RMSNorm,
  * RoPE + cache append, causal attention, SwiGLU and residuals; needs libhipblaslt.so at run time (PIE_E_STATE if it

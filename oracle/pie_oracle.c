@@ -436,8 +436,8 @@ typedef struct {
  * only as "mlx" in pyproject.toml:29): few rows -> qmv kernels, the exact fp32 affine sum of orc_quantized_matmul_t;
  * many rows (prompt processing) -> qmm kernels, whose block loader DEQUANTISES the weights to T (dequantize<T>) and feeds
  * a T x T -> fp32 MMA.  g_qmm_min_rows is the row count from which the second form is used (MLX's own switch-over is
- * device dependent; 16 mirrors the product's prefill threshold; 0 = always the exact form). */
-static int g_qmm_min_rows = 16;
+ * device dependent, 6..32 rows; 6 mirrors the product's prefill threshold; 0 = always the exact form). */
+static int g_qmm_min_rows = 6;
 void orc_set_qmm_min_rows(int n) { g_qmm_min_rows = n < 0 ? 0 : n; }
 int orc_get_qmm_min_rows(void) { return g_qmm_min_rows; }
 

@@ -90,7 +90,7 @@ def max_threads() -> int:
 
 def set_qmm_min_rows(n: int) -> None:
     """Row count from which quantised Linears use MLX's qmm form (weights dequantised to T, then a T x T -> fp32
-    matmul) instead of the exact fp32 affine sum of the qmv kernels; 0 = never.  Default 16 (pie_oracle.c)."""
+    matmul) instead of the exact fp32 affine sum of the qmv kernels; 0 = never.  Default 6 (pie_oracle.c)."""
     lib().orc_set_qmm_min_rows(C.c_int(n))
 
 

@@ -246,8 +246,8 @@ def test_forced_split_counts_match_oracle(tiny):
 
 
 def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
-    """Prompt processing.  Prompts of >= PIE_PREFILL_MIN (16) tokens run as batched GEMMs on weights
-    dequantised to T (MLX's qmm regime, oracle qmm_min_rows = 16), in chunks of PIE_PREFILL_CHUNK rows; shorter ones as
+    """Prompt processing.  Prompts of >= PIE_PREFILL_MIN (6) tokens run as batched GEMMs on weights
+    dequantised to T (MLX's qmm regime, oracle qmm_min_rows = 6), in chunks of PIE_PREFILL_CHUNK rows; shorter ones as
     iterated decode steps (qmv regime: exact fp32 affine sums).  Both against the oracle in the matching regime, every
     position, with a ragged last chunk (100 = 3 x 32 + 4) and a second call that continues at a non-zero offset."""
     g, cfg, w, model = tiny
@@ -255,7 +255,7 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
     prompt, more = rng.integers(0, cfg["vocab_size"], 100), rng.integers(0, cfg["vocab_size"], 40)
     orc = po.OracleLlama(cfg, w, DT)
     # PIE_PREFILL_RESIDENT=0: every chunk dequantises into the scratch again (the other prefill tests keep resident copies)
-    for regime, rows, env in (("batched", 16, {"PIE_PREFILL_CHUNK": "32", "PIE_PREFILL_RESIDENT": "0"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
+    for regime, rows, env in (("batched", 6, {"PIE_PREFILL_CHUNK": "32", "PIE_PREFILL_RESIDENT": "0"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
         for k in ("PIE_PREFILL_CHUNK", "PIE_PREFILL_MIN", "PIE_PREFILL_RESIDENT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -266,7 +266,7 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
             want1 = orc.forward(prompt, ocache)
             want2 = orc.forward(more, ocache)
         finally:
-            po.set_qmm_min_rows(16)
+            po.set_qmm_min_rows(6)
         m = build(cfg, w) if regime == "batched" else model        # a fresh decoder: the resident budget is fixed at first use
         cache = m.make_cache()
         got1 = m(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()

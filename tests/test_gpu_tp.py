@@ -81,4 +81,4 @@ def test_tp2_decode_matches_unsharded_oracle():
             logits, hid = logits[0], hid[0]
         assert checked >= 3
     finally:
-        po.set_qmm_min_rows(16)
+        po.set_qmm_min_rows(6)
