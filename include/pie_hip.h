@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-enum { PIE_OK = 0, PIE_E_ARG = -1, PIE_E_SHAPE = -2, PIE_E_ALIGN = -3, PIE_E_HIP = -4, PIE_E_STATE = -5, PIE_E_ARCH = -6 };
+enum { PIE_OK = 0, PIE_E_ARG = -1, PIE_E_SHAPE = -2, PIE_E_ALIGN = -3, PIE_E_HIP = -4, PIE_E_STATE = -5, PIE_E_ARCH = -6, PIE_E_RANGE = -7,
+       PIE_EXHAUSTED = 1 /* pie_page_alloc: no free page (the reference's std::nullopt); not an error */ };
 enum { PIE_BF16 = 1, PIE_F16 = 2 };
 
 /* pie_core.hello()  (src/pie_core/src/bindings.cpp:8; asserted by tests/python/test_basic.py:16). */
@@ -229,6 +230,35 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
 /* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
 size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
+
+/* ---------------------------------------------------------------- KV page pool
+ * Replaces pie_core's PageAllocator / KVPage: src/pie_core/include/engine/page_allocator.hpp:17-72,
+ * include/engine/page.hpp:14-123, src/engine/page_allocator.cpp:8-157 (contract pinned by
+ * tests/cpp/test_page_allocator.cpp, restated in tests/test_page_pool.py).  A page holds PIE_PAGE_TOKENS token slots
+ * (page.hpp:20): a K block then a V block, each T [64, n_kv_heads, head_dim].  All pages live in ONE caller-owned
+ * device slab of pie_page_pool_slab_bytes() bytes (page p at byte offset p * slab_bytes / num_pages); `slab` may be
+ * NULL for bookkeeping only.  The free list is lock-free (tagged index stack) and LIFO, seeded so a fresh pool hands
+ * out 0, 1, 2, ... (page_allocator.cpp:52-63).  Every entry point is thread-safe.
+ *   create: PIE_E_ARG for num_pages == 0, n_kv_heads <= 0 or head_dim <= 0 (std::invalid_argument, page_allocator.cpp:21-29)
+ *   alloc:  PIE_OK and *page_id with ref count 1 and num_tokens 0 (page_allocator.cpp:68-79), or PIE_EXHAUSTED
+ *   free:   drops one reference; the page returns to the pool when the count reaches 0 (page_allocator.cpp:81-87)
+ *   any id >= size: PIE_E_RANGE (std::out_of_range of check_page_id, page_allocator.cpp:110-117)
+ * The reference's page stores int8 K/V with per-head scales (page.hpp:25-32) that nothing in the reference reads yet;
+ * these pages hold T (bf16 / f16) rows, the layout the decode attention of this library consumes. */
+enum { PIE_PAGE_TOKENS = 64 };
+typedef struct pie_page_pool pie_page_pool;
+size_t pie_page_pool_slab_bytes(size_t num_pages, int n_kv_heads, int head_dim, int dtype);
+int pie_page_pool_create(size_t num_pages, int n_kv_heads, int head_dim, int dtype, void *slab, pie_page_pool **out);
+int pie_page_pool_destroy(pie_page_pool *pool);
+size_t pie_page_pool_size(const pie_page_pool *pool);
+size_t pie_page_pool_num_free(const pie_page_pool *pool);
+int pie_page_alloc(pie_page_pool *pool, uint32_t *page_id);
+int pie_page_free(pie_page_pool *pool, uint32_t page_id);
+int pie_page_add_ref(pie_page_pool *pool, uint32_t page_id);
+int pie_page_ref_count(const pie_page_pool *pool, uint32_t page_id, uint32_t *count);
+int pie_page_num_tokens(const pie_page_pool *pool, uint32_t page_id, size_t *n);
+int pie_page_set_num_tokens(pie_page_pool *pool, uint32_t page_id, size_t n);
+int pie_page_ptrs(const pie_page_pool *pool, uint32_t page_id, void **k, void **v);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,9 @@ EXPORTS = [
     "pie_decoder_set_kv", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill",
     "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
     "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes",
+    "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
+    "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
+    "pie_page_ptrs",
 ]
 
 
@@ -79,6 +82,17 @@ def load() -> C.CDLL:
     lib.pie_add.argtypes = lib.pie_silu_mul.argtypes
     lib.pie_decoder_step_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for name in ("pie_page_pool_slab_bytes", "pie_page_pool_size", "pie_page_pool_num_free"):
+        getattr(lib, name).restype = C.c_size_t
+    lib.pie_page_pool_slab_bytes.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int]
+    lib.pie_page_pool_create.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.pie_page_pool_destroy.argtypes = lib.pie_page_pool_size.argtypes = lib.pie_page_pool_num_free.argtypes = [C.c_void_p]
+    lib.pie_page_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.pie_page_free.argtypes = lib.pie_page_add_ref.argtypes = [C.c_void_p, C.c_uint32]
+    lib.pie_page_ref_count.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.pie_page_num_tokens.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]
+    lib.pie_page_set_num_tokens.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t]
+    lib.pie_page_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib
 
@@ -89,6 +103,8 @@ def check(rc: int) -> None:
     msg = load().pie_last_error().decode("utf-8", "replace")
     if rc in (-1, -2, -3):  # PIE_E_ARG / SHAPE / ALIGN: the caller's fault
         raise ValueError(f"pie_hip: {msg} (code {rc})")
+    if rc == -7:  # PIE_E_RANGE: std::out_of_range in the reference
+        raise IndexError(f"pie_hip: {msg} (code {rc})")
     raise RuntimeError(f"pie_hip: {msg} (code {rc})")
 
 

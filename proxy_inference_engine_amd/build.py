@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libpie_hip.so"
-SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "prefill.hip"]
+SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "prefill.hip", "page_pool.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
@@ -33,7 +33,7 @@ def _stale() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "pie_hip.h"]
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.cpp")) + [PKG.parent / "include" / "pie_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
