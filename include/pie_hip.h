@@ -235,7 +235,8 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
  * Replaces pie_core's PageAllocator / KVPage: src/pie_core/include/engine/page_allocator.hpp:17-72,
  * include/engine/page.hpp:14-123, src/engine/page_allocator.cpp:8-157 (contract pinned by
  * tests/cpp/test_page_allocator.cpp, restated in tests/test_page_pool.py).  A page holds PIE_PAGE_TOKENS token slots
- * (page.hpp:20): a K block then a V block, each T [64, n_kv_heads, head_dim].  All pages live in ONE caller-owned
+ * (page.hpp:14): a K block then a V block, each T [n_kv_heads, 64, head_dim] (the reference's logical shape is
+ * [64, heads, head_dim], page.hpp:29-30; head-major storage keeps one head's rows of a page contiguous).  All pages live in ONE caller-owned
  * device slab of pie_page_pool_slab_bytes() bytes (page p at byte offset p * slab_bytes / num_pages); `slab` may be
  * NULL for bookkeeping only.  The free list is lock-free (tagged index stack) and LIFO, seeded so a fresh pool hands
  * out 0, 1, 2, ... (page_allocator.cpp:52-63).  Every entry point is thread-safe.
@@ -259,6 +260,24 @@ int pie_page_ref_count(const pie_page_pool *pool, uint32_t page_id, uint32_t *co
 int pie_page_num_tokens(const pie_page_pool *pool, uint32_t page_id, size_t *n);
 int pie_page_set_num_tokens(pie_page_pool *pool, uint32_t page_id, size_t n);
 int pie_page_ptrs(const pie_page_pool *pool, uint32_t page_id, void **k, void **v);
+
+/* Paged decode attention over a batch of sequences: what the reference's placeholder
+ * Attention::invoke_paged_attention_kernel (src/pie_core/src/layers/attention.cpp:71-83) and its dummy Metal kernel
+ * (src/kernels/paged_attention.metal:6-23) stand for, with the inputs BatchDetails names
+ * (include/engine/batch_details.hpp:42-66): block_table int32 [B, max_blocks] = consolidated_block_table (logical block
+ * j of sequence s -> page id), context_lens int32 [B] = positions each query attends INCLUDING its own (0 = idle slot,
+ * output row zeroed).  q, out: T [B, n_heads, head_dim]; slab: one layer's page slab (page p at p * page bytes; inside a
+ * page K then V, each T [n_kv_heads, 64, head_dim] -- head-major so one head's rows of a page are one 16 KB burst).
+ * Same arithmetic contract as pie_sdpa_decode: results equal attention over the gathered contiguous rows.
+ * Both tables live in device memory, so a captured graph can replay the launch while the host edits them. */
+size_t pie_paged_attn_workspace_bytes(int B, int n_heads, int head_dim);
+int pie_paged_attn_decode(const void *q, const void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                          const int32_t *context_lens, int B, int n_heads, int n_kv_heads, int head_dim, float scale, int dtype,
+                          void *out, void *workspace, void *stream);
+/* Writes the new K / V rows (T [B, n_kv_heads, head_dim], after RoPE) of B sequences into their pages: sequence s at
+ * position positions[s] (< 0 = idle slot) -> page block_table[s][positions[s] / 64], row positions[s] % 64. */
+int pie_paged_kv_append(const void *k, const void *v, void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                        const int32_t *positions, int B, int n_kv_heads, int head_dim, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes",
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
-    "pie_page_ptrs",
+    "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
 ]
 
 
@@ -92,6 +92,10 @@ def load() -> C.CDLL:
     lib.pie_page_ref_count.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.pie_page_num_tokens.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.pie_page_set_num_tokens.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t]
+    lib.pie_paged_attn_workspace_bytes.restype = C.c_size_t
+    lib.pie_paged_attn_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [
+        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pie_paged_kv_append.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     lib.pie_page_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib

@@ -44,27 +44,30 @@ class KVPage:
     def set_num_tokens(self, n: int) -> None:
         _f.check(_f.load().pie_page_set_num_tokens(self._pool._h, self._id, n))
 
-    def _block(self, which: int) -> torch.Tensor:
+    def _block(self, which: int, layer: int) -> torch.Tensor:
         p = self._pool
         if p.slab is None:
             raise RuntimeError("this PageAllocator was created without device storage (device=None)")
         half = p.page_bytes // 2
-        raw = p.slab[self._id * p.page_bytes + which * half: self._id * p.page_bytes + (which + 1) * half]
-        return raw.view(p.dtype).view(TOKEN_CAPACITY_PER_PAGE, p.num_heads, p.head_dim)
+        raw = p.slab[layer, self._id * p.page_bytes + which * half: self._id * p.page_bytes + (which + 1) * half]
+        # stored head-major [heads, 64, head_dim]; presented in the reference's logical order
+        return raw.view(p.dtype).view(p.num_heads, TOKEN_CAPACITY_PER_PAGE, p.head_dim).permute(1, 0, 2)
 
-    def key_cache(self) -> torch.Tensor:
+    def key_cache(self, layer: int = 0) -> torch.Tensor:
         """[64, num_heads, head_dim] view into the slab (page.hpp:29)."""
-        return self._block(0)
+        return self._block(0, layer)
 
-    def value_cache(self) -> torch.Tensor:
-        return self._block(1)
+    def value_cache(self, layer: int = 0) -> torch.Tensor:
+        return self._block(1, layer)
 
 
 class PageAllocator:
     """Fixed pool of KV pages with a lock-free LIFO free list (page_allocator.hpp:17-72)."""
 
     def __init__(self, num_pages: int, num_heads: int, head_dim: int, dtype: torch.dtype = torch.bfloat16,
-                 device: torch.device | str | None = None):
+                 device: torch.device | str | None = None, num_layers: int = 1):
+        """num_layers > 1: one slab plane per decoder layer ([num_layers, slab bytes]); a page id names the same slice
+        of every plane, so one block table serves all layers."""
         self._h = C.c_void_p()
         lib = _f.load()
         code = _f.dtype_code(dtype)
@@ -73,10 +76,10 @@ class PageAllocator:
         self.slab = None
         nbytes = lib.pie_page_pool_slab_bytes(num_pages, num_heads, head_dim, code)
         if device is not None and nbytes:
-            self.slab = torch.zeros(nbytes, dtype=torch.uint8, device=device)  # mx::zeros pages (page.hpp:29-30)
+            self.slab = torch.zeros(num_layers, nbytes, dtype=torch.uint8, device=device)  # mx::zeros pages (page.hpp:29-30)
         _f.check(lib.pie_page_pool_create(num_pages, num_heads, head_dim, code,
                                           C.c_void_p(self.slab.data_ptr() if self.slab is not None else None), C.byref(self._h)))
-        self.num_heads, self.head_dim, self.dtype = num_heads, head_dim, dtype
+        self.num_heads, self.head_dim, self.dtype, self.num_layers = num_heads, head_dim, dtype, num_layers
         self.page_bytes = nbytes // num_pages
 
     def __del__(self):

@@ -57,6 +57,12 @@ struct AttnArgs {
     u16 *out;         // [Hq, D]
     // Infinity-Cache warm-up riding on the idle CUs of this launch: blocks with blockIdx.y >= splits stream these
     // byte ranges (the next kernels' weights) and discard them, so the small GEMVs that follow start from MALL hits.
+    // Paged KV (PAGED instantiation): blockIdx.z = sequence, sequence s attends ctx_len[s] positions
+    // (0 = idle slot), its token t lives in page block_table[s * bt_stride + t / 64] of the slab at row t % 64.  Page layout:
+    // K block then V block, each [Hkv, 64, D] (one kv-head's 64 rows contiguous: 16 KB bursts at D = 128).
+    const u16 *slab;
+    const int *block_table, *ctx_len;
+    int bt_stride, n_pages;
     const char *pf_ptr[2];
     unsigned long long pf_bytes[2];
     int pf_rows;      // extra blockIdx.y rows doing prefetch (0 = none)
@@ -65,7 +71,7 @@ struct AttnArgs {
 
 constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VALU scoring overlaps the other's loads)
 
-template <class T, int D, int REP>
+template <class T, int D, int REP, bool PAGED = false>
 __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs a) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
     constexpr int TPW = 64 / LPT;  // token rows per wave-load
@@ -95,28 +101,48 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;
     const int row = blockIdx.z;  // query row of a prefill chunk (0 at decode)
-    const int Ttot = (a.state ? a.state->pos + 1 : a.T) + row;
-    const int cap = a.state ? a.state->cap : a.cap;
+    const int Ttot = PAGED ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
+    const int cap = PAGED ? 64 : a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
     if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
     const int t_begin = split * sp.chunk;
     const int t_end = min(Ttot, t_begin + sp.chunk);
 
-    const u16 *kbase = a.k ? a.k : reinterpret_cast<const u16 *>(a.kv_table[a.layer]);
-    const u16 *vbase = a.k ? a.v : reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]);
+    const u16 *kbase = PAGED ? a.slab : a.k ? a.k : reinterpret_cast<const u16 *>(a.kv_table[a.layer]);
+    const u16 *vbase = PAGED ? a.slab + (size_t)a.Hkv * 64 * D : a.k ? a.v : reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]);
     kbase += (size_t)g * cap * D + dc * 8;
     vbase += (size_t)g * cap * D + dc * 8;
+    const int *bt = PAGED ? a.block_table + (size_t)row * a.bt_stride : nullptr;
+    const size_t page_elems = (size_t)2 * 64 * a.Hkv * D;
+    const unsigned last_page = (unsigned)a.n_pages - 1u;
 
     // row-blocks of this wave: block b covers tokens t_begin + (NSUB*b + wave)*TPW + [0, TPW)
     const int first = t_begin + wave * TPW;
     const int n_blk = first < t_end ? (t_end - first + NSUB * TPW - 1) / (NSUB * TPW) : 0;
     uint4 kq[DA], vq[DA];
+    unsigned pgq[DA];  // PAGED: page id of the block ring slot d loads next, fetched one ring turn ahead of its use
+    auto page_of = [&](int b) {
+        int t = first + b * NSUB * TPW + ts;
+        t = t < t_end ? t : t_end - 1;
+        return min((unsigned)bt[t >> 6], last_page);  // a corrupt table must not become a wild address
+    };
     auto issue = [&](int d, int b) {
         int t = first + b * NSUB * TPW + ts;
         t = t < t_end ? t : t_end - 1;  // clamp, never branch around a load
-        kq[d] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D);
-        vq[d] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D);
+        if constexpr (PAGED) {
+            const size_t off = (size_t)pgq[d] * page_elems + (size_t)(t & 63) * D;
+            kq[d] = *reinterpret_cast<const uint4 *>(kbase + off);
+            vq[d] = *reinterpret_cast<const uint4 *>(vbase + off);
+            pgq[d] = page_of(b + DA);
+        } else {
+            kq[d] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D);
+            vq[d] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D);
+        }
     };
+    if constexpr (PAGED) {
+#pragma unroll
+        for (int d = 0; d < DA; ++d) pgq[d] = page_of(d);
+    }
 #pragma unroll
     for (int d = 0; d < DA; ++d) issue(d, d);
 
@@ -299,8 +325,8 @@ __global__ void __launch_bounds__(256) k_attn_combine(const AttnArgs a, int D) {
     const int row = blockIdx.y, PPH = D >> 3, NG = 256 / PPH;
     const size_t h = (size_t)row * a.Hq + blockIdx.x;
     const int pc = threadIdx.x % PPH, grp = threadIdx.x / PPH, d0 = pc * 8, lane = threadIdx.x & 63;
-    const int Ttot = (a.state ? a.state->pos + 1 : a.T) + row;
-    const int active = attn_split(Ttot, a.splits).active;  // <= ATTN_MAX_SPLITS <= 64
+    const int Ttot = a.ctx_len ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
+    const int active = attn_split(Ttot, a.splits).active;  // <= ATTN_MAX_SPLITS <= 64; 0 for an idle paged slot
     const float *ml = a.part_ml + h * a.splits * 2;
     const float *pa = a.part_acc + h * a.splits * D + d0;
     const float M = wave_max(lane < active ? ml[2 * lane] : ATTN_NEG);
@@ -326,7 +352,7 @@ __global__ void __launch_bounds__(256) k_attn_combine(const AttnArgs a, int D) {
         }
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = A[i] / Lsum;
+        for (int i = 0; i < 8; ++i) o[i] = active ? A[i] / Lsum : 0.0f;
         *reinterpret_cast<uint4 *>(a.out + h * D + d0) =
             make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
     }

@@ -6,7 +6,28 @@
 
 // ---------------------------------------------------------------- attention launch
 template <class T, int D>
+static int attn_launch_paged(int rep, const AttnArgs &a, hipStream_t st) {
+    dim3 grid(a.Hkv, a.splits, a.rows), block(ATTN_WAVES * 64);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, true>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, true>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, true>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, true>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, true>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, true>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, true>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, true>), grid, block, 0, st, a); break;
+        default: return pie::fail(PIE_E_SHAPE, "paged_attn_decode: n_heads / n_kv_heads must be between 1 and 8");
+    }
+    PIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, a.rows), dim3(256), 0, st, a, D);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+template <class T, int D>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
+    if (a.slab) return attn_launch_paged<T, D>(rep, a, st);
     const int rows = a.rows > 0 ? a.rows : 1;
     dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
     switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
@@ -147,6 +168,62 @@ int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv
     a.splits = T >= 2048 ? ATTN_MAX_SPLITS : (T >= 512 ? 16 : (T >= 128 ? 4 : 1));
     a.part_acc = (float *)workspace;
     a.part_ml = a.part_acc + (size_t)Hq * ATTN_MAX_SPLITS * D;
+    a.out = (u16 *)out;
+    return attn_decode_launch(dtype, D, a, true, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- paged KV
+// One thread per 16-byte piece of the new K and V rows: row (sequence s, kv-head g) goes to page
+// block_table[s][positions[s] / 64], slot positions[s] % 64.  positions[s] < 0 = idle slot.
+__global__ void __launch_bounds__(256) k_paged_kv_append(const uint4 *k, const uint4 *v, u16 *slab, const int *block_table, int bt_stride,
+                                                          const int *positions, int B, int Hkv, int D, int n_pages) {
+    const int ppr = D >> 3, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Hkv * ppr) return;
+    const int s = i / (Hkv * ppr), g = (i / ppr) % Hkv, pc = i % ppr;
+    const int pos = positions[s];
+    if (pos < 0 || (pos >> 6) >= bt_stride) return;
+    const unsigned pg = min((unsigned)block_table[(size_t)s * bt_stride + (pos >> 6)], (unsigned)n_pages - 1u);
+    u16 *kd = slab + (size_t)pg * 2 * 64 * Hkv * D + ((size_t)g * 64 + (pos & 63)) * D + pc * 8;
+    *reinterpret_cast<uint4 *>(kd) = k[i];
+    *reinterpret_cast<uint4 *>(kd + (size_t)Hkv * 64 * D) = v[i];
+}
+
+size_t pie_paged_attn_workspace_bytes(int B, int Hq, int D) {
+    if (B <= 0 || Hq <= 0 || D <= 0) return 0;
+    return (size_t)B * Hq * ATTN_MAX_SPLITS * (D + 2) * sizeof(float);
+}
+
+int pie_paged_kv_append(const void *k, const void *v, void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                        const int32_t *positions, int B, int Hkv, int D, int dtype, void *stream) {
+    PIE_REQUIRE(k && v && slab && block_table && positions, PIE_E_ARG, "pie_paged_kv_append: null pointer");
+    PIE_REQUIRE(B > 0 && Hkv > 0 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_paged_kv_append: bad shape");
+    PIE_REQUIRE(D == 64 || D == 128, PIE_E_SHAPE, "pie_paged_kv_append: head_dim must be 64 or 128");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_paged_kv_append: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE(pie_aligned(k, 16) && pie_aligned(v, 16) && pie_aligned(slab, 16), PIE_E_ALIGN, "pie_paged_kv_append: 16-byte alignment required");
+    const int n = B * Hkv * (D >> 3);
+    hipLaunchKernelGGL(k_paged_kv_append, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const uint4 *)k, (const uint4 *)v, (u16 *)slab,
+                       block_table, max_blocks, positions, B, Hkv, D, (int)n_pages);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_paged_attn_decode(const void *q, const void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                          const int32_t *context_lens, int B, int Hq, int Hkv, int D, float scale, int dtype, void *out, void *workspace,
+                          void *stream) {
+    PIE_REQUIRE(q && slab && block_table && context_lens && out && workspace, PIE_E_ARG, "pie_paged_attn_decode: null pointer");
+    PIE_REQUIRE(B > 0 && B <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_paged_attn_decode: bad shape");
+    PIE_REQUIRE(pie_aligned(q, 16) && pie_aligned(slab, 16) && pie_aligned(out, 16), PIE_E_ALIGN, "pie_paged_attn_decode: 16-byte alignment required");
+    AttnArgs a = {};
+    a.q = (const u16 *)q, a.slab = (const u16 *)slab, a.block_table = block_table, a.ctx_len = context_lens;
+    a.bt_stride = max_blocks, a.n_pages = (int)n_pages, a.rows = B;
+    a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
+    // enough workgroups for two per CU across the batch, never more splits than pages per sequence
+    int splits = Hkv > 0 ? (512 + B * Hkv - 1) / (B * Hkv) : 1;
+    splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : splits;
+    splits = splits > max_blocks ? max_blocks : splits;
+    a.splits = splits < 1 ? 1 : splits;
+    a.part_acc = (float *)workspace;
+    a.part_ml = a.part_acc + (size_t)B * Hq * a.splits * D;
     a.out = (u16 *)out;
     return attn_decode_launch(dtype, D, a, true, (hipStream_t)stream);
 }

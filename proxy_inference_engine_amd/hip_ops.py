@@ -277,6 +277,49 @@ def scaled_dot_product_attention(q, k, v, scale: float, mask=None, T: int | None
     return out
 
 
+def paged_kv_append(k: torch.Tensor, v: torch.Tensor, slab: torch.Tensor, n_pages: int, block_table: torch.Tensor,
+                    positions: torch.Tensor) -> None:
+    """Stores the new K / V rows [B, Hkv, D] of B sequences in their pages (sequence s at positions[s]; < 0 = idle).
+    slab: one layer's page slab (cache/kv_cache/paged.py); block_table int32 [B, max_blocks]; positions int32 [B]."""
+    for t in (k, v, slab, block_table, positions):
+        _dev(t)
+    if block_table.dtype != torch.int32 or positions.dtype != torch.int32:
+        raise TypeError("block_table and positions must be int32")
+    B, Hkv, D = k.shape
+    if v.shape != k.shape or block_table.shape[0] != B or positions.shape[0] != B:
+        raise ValueError("paged_kv_append: k, v [B, Hkv, D]; block_table [B, max_blocks]; positions [B]")
+    if slab.numel() * slab.element_size() < n_pages * 2 * 64 * Hkv * D * 2:
+        raise ValueError("paged_kv_append: slab smaller than n_pages pages")
+    _ffi.check(_ffi.load().pie_paged_kv_append(_ffi.p(k), _ffi.p(v), _ffi.p(slab), n_pages, _ffi.p(block_table), block_table.shape[1],
+                                               _ffi.p(positions), B, Hkv, D, _ffi.dtype_code(k.dtype), _ffi.stream()))
+
+
+def paged_attention_decode(q: torch.Tensor, slab: torch.Tensor, n_pages: int, block_table: torch.Tensor, context_lens: torch.Tensor,
+                           n_kv_heads: int, scale: float) -> torch.Tensor:
+    """One decode query per sequence against its paged KV: q [B, Hq, D]; block_table int32 [B, max_blocks];
+    context_lens int32 [B] = positions attended including the current one (0 = idle slot -> zeros).  What the
+    reference's Attention::invoke_paged_attention_kernel placeholder stands for (src/layers/attention.cpp:71-83)."""
+    for t in (q, slab, block_table, context_lens):
+        _dev(t)
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise TypeError("block_table and context_lens must be int32")
+    B, Hq, D = q.shape
+    if block_table.shape[0] != B or context_lens.shape[0] != B:
+        raise ValueError("paged_attention_decode: block_table [B, max_blocks]; context_lens [B]")
+    if slab.numel() * slab.element_size() < n_pages * 2 * 64 * n_kv_heads * D * 2:
+        raise ValueError("paged_attention_decode: slab smaller than n_pages pages")
+    key = ("paged", q.device, B, Hq, D)
+    ws = _sdpa_ws.get(key)
+    if ws is None:
+        ws = torch.empty(_ffi.load().pie_paged_attn_workspace_bytes(B, Hq, D), dtype=torch.uint8, device=q.device)
+        _sdpa_ws[key] = ws
+    out = torch.empty_like(q)
+    _ffi.check(_ffi.load().pie_paged_attn_decode(_ffi.p(q), _ffi.p(slab), n_pages, _ffi.p(block_table), block_table.shape[1],
+                                                 _ffi.p(context_lens), B, Hq, n_kv_heads, D, float(scale), _ffi.dtype_code(q.dtype),
+                                                 _ffi.p(out), _ffi.p(ws), _ffi.stream()))
+    return out
+
+
 def silu_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """nn.silu(a) * b (models/llama/language.py:127)."""
     _dev(a), _dev(b)
