@@ -192,6 +192,14 @@ int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w);
 /* Per-layer cache buffers [n_kv_heads, capacity, head_dim] T (ReusableKVCache.keys/values with B=1);
  * call again whenever a cache re-allocates (reusable.py:167-203).  k_ptrs/v_ptrs: HOST arrays of device pointers. */
 int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *const *v_ptrs, int capacity, void *stream);
+/* Paged alternative to pie_decoder_set_kv (the role of the reference's stub PagedKVCache,
+ * cache/kv_cache/paged.py:1-14, over its PageAllocator): slabs = HOST array [n_layers] of device slab pointers (one
+ * pie_page_pool geometry each, the same page ids valid in all of them), block_table = DEVICE int32 [max_blocks], caller-owned
+ * and editable between steps (logical block j of the sequence -> page id).  Position p is stored in / read from page
+ * block_table[p / 64], row p % 64; the caller must have filled the table for every position a step or prefill touches.
+ * Capacity = max_blocks * 64.  Steps, prefill, graphs and outputs behave exactly as with contiguous buffers. */
+int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_pages, const int32_t *block_table, int max_blocks,
+                             void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);

@@ -34,7 +34,8 @@ class BaseCache(ABC):
                 if t is not None:
                     arrays[f"{i}.{j}"] = t.detach().to("cpu").contiguous()
             meta[f"0.{i}"] = str(c.meta_state)
-            meta[f"2.{i}"] = type(c).__name__
+            # a paged cache is stored as its gathered rows, the layout a ReusableKVCache restores from
+            meta[f"2.{i}"] = "ReusableKVCache" if type(c).__name__ == "PagedKVCache" else type(c).__name__
         for k, v in (metadata or {}).items():
             meta[f"1.{k}"] = str(v)
         save_file(arrays, file_name, metadata=meta)
@@ -92,5 +93,6 @@ class BaseCache(ABC):
 
 
 from .reusable import ReusableKVCache  # noqa: E402
+from .paged import PageAllocator, PagedKVCache, PagedSequence  # noqa: E402
 
-__all__ = ["BaseCache", "ReusableKVCache"]
+__all__ = ["BaseCache", "ReusableKVCache", "PagedKVCache", "PagedSequence", "PageAllocator"]

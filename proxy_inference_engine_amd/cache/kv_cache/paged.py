@@ -13,6 +13,7 @@ import ctypes as C
 import torch
 
 from ... import _ffi as _f
+from . import BaseCache
 
 TOKEN_CAPACITY_PER_PAGE = 64  # page.hpp:14
 
@@ -120,3 +121,176 @@ def _id(page_id: int) -> int:
     if page_id < 0 or page_id > 0xFFFFFFFF:
         raise IndexError(f"Page ID {page_id} is out of range")
     return int(page_id)
+
+
+class PagedSequence:
+    """One sequence's view of the page pool: its block table (logical block j -> page id), kept on the host and mirrored
+    in a device int32 tensor the kernels read (BatchDetails.consolidated_block_table, batch_details.hpp:52-66), and its
+    length.  Shared by the per-layer PagedKVCache objects of a model: a page id names the same slice of every layer's
+    slab plane.  Growing takes pages from the allocator -- nothing is copied, unlike ReusableKVCache's reallocation."""
+
+    def __init__(self, allocator: PageAllocator, max_blocks: int = 16):
+        if allocator.slab is None:
+            raise ValueError("PagedSequence needs a PageAllocator with device storage")
+        self.allocator = allocator
+        self.pages: list[int] = []
+        self.offset = 0
+        self.table = torch.zeros(max(1, max_blocks), dtype=torch.int32, device=allocator.slab.device)
+
+    @property
+    def max_blocks(self) -> int:
+        return self.table.numel()
+
+    @property
+    def capacity(self) -> int:
+        return self.max_blocks * TOKEN_CAPACITY_PER_PAGE
+
+    def reserve(self, needed: int) -> None:
+        """Pages (and table room) for `needed` more positions; raises RuntimeError when the pool is exhausted."""
+        blocks = (self.offset + needed + TOKEN_CAPACITY_PER_PAGE - 1) // TOKEN_CAPACITY_PER_PAGE
+        if blocks > self.max_blocks:  # a longer table is a new device buffer: the decoder re-plans its attention launch
+            table = torch.zeros(max(blocks, 2 * self.max_blocks), dtype=torch.int32, device=self.table.device)
+            table[:self.max_blocks] = self.table
+            self.table = table
+        first = len(self.pages)
+        while len(self.pages) < blocks:
+            pid = self.allocator.allocate_page()
+            if pid is None:
+                for p in self.pages[first:]:
+                    self.allocator.free_page(p)
+                del self.pages[first:]
+                raise RuntimeError(f"KV page pool exhausted ({self.allocator.size()} pages of {TOKEN_CAPACITY_PER_PAGE} tokens)")
+            self.pages.append(pid)
+        if len(self.pages) > first:
+            self.table[first:len(self.pages)] = torch.tensor(self.pages[first:], dtype=torch.int32)
+            self._mark_tokens()
+
+    def advance(self, n: int) -> None:
+        self.offset += n
+        self._mark_tokens()
+
+    def _mark_tokens(self) -> None:
+        for j, pid in enumerate(self.pages):  # KVPage.num_tokens (page.hpp:69,100-103)
+            self.allocator.get_page(pid).set_num_tokens(max(0, min(TOKEN_CAPACITY_PER_PAGE, self.offset - j * TOKEN_CAPACITY_PER_PAGE)))
+
+    def truncate(self, length: int) -> None:
+        """Keeps the first `length` positions and returns the pages behind them to the pool."""
+        length = max(0, min(length, self.offset))
+        keep = (length + TOKEN_CAPACITY_PER_PAGE - 1) // TOKEN_CAPACITY_PER_PAGE
+        for pid in self.pages[keep:]:
+            self.allocator.free_page(pid)
+        del self.pages[keep:]
+        self.offset = length
+        self._mark_tokens()
+
+    def release(self) -> None:
+        self.truncate(0)
+
+    def fork(self) -> "PagedSequence":
+        """A second sequence with the same history: full pages are shared by reference count (add_ref,
+        page_allocator.cpp:89-92), the partly filled last page is copied so both can keep appending."""
+        other = PagedSequence(self.allocator, self.max_blocks)
+        full = self.offset // TOKEN_CAPACITY_PER_PAGE
+        for pid in self.pages[:full]:
+            self.allocator.add_ref(pid)
+            other.pages.append(pid)
+        if self.offset % TOKEN_CAPACITY_PER_PAGE:
+            pid = self.allocator.allocate_page()
+            if pid is None:
+                other.release()
+                raise RuntimeError("KV page pool exhausted")
+            pb, src = self.allocator.page_bytes, self.pages[full]
+            self.allocator.slab[:, pid * pb:(pid + 1) * pb] = self.allocator.slab[:, src * pb:(src + 1) * pb]
+            other.pages.append(pid)
+        other.offset = self.offset
+        if other.pages:
+            other.table[:len(other.pages)] = torch.tensor(other.pages, dtype=torch.int32)
+        other._mark_tokens()
+        return other
+
+    def __del__(self):
+        try:
+            if getattr(self, "allocator", None) is not None and getattr(self.allocator, "_h", None):
+                self.release()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+class PagedKVCache(BaseCache):
+    """Per-layer cache object over a PagedSequence: what the reference's stub stands for ("a key-value cache that uses
+    blocks of memory ... and a page manager", cache/kv_cache/paged.py:6-14).  `page_manager` is the shared PagedSequence;
+    the decode kernels append and read the rows themselves through the block table, this class carries the protocol the
+    engine and PromptCache use (offset, reuse, trim, state for persistence)."""
+
+    def __init__(self, page_manager: PagedSequence, layer: int = 0):
+        self.page_manager = page_manager
+        self.layer = layer
+        self.step = TOKEN_CAPACITY_PER_PAGE
+
+    @property
+    def offset(self) -> int:
+        return self.page_manager.offset
+
+    @property
+    def capacity(self) -> int:
+        return self.page_manager.capacity
+
+    def reuse(self, new_prompt_length: int, common_prefix_length: int) -> None:
+        """Trim to the common prefix (reusable.py:44-94); room for the new prompt is taken page by page later."""
+        if self.layer == 0:
+            self.page_manager.truncate(common_prefix_length)
+
+    def is_trimmable(self) -> bool:
+        return True
+
+    def trim(self, n: int) -> int:
+        n = min(self.offset, n)
+        if self.layer == 0:
+            self.page_manager.truncate(self.offset - n)
+        return n
+
+    def _rows(self, which: int) -> torch.Tensor:
+        seq, a = self.page_manager, self.page_manager.allocator
+        half = a.page_bytes // 2
+        if not seq.pages:
+            return torch.zeros((1, a.num_heads, 0, a.head_dim), dtype=a.dtype, device=a.slab.device)
+        blocks = [a.slab[self.layer, p * a.page_bytes + which * half: p * a.page_bytes + (which + 1) * half].view(a.dtype).view(
+            a.num_heads, TOKEN_CAPACITY_PER_PAGE, a.head_dim) for p in seq.pages]
+        return torch.cat(blocks, dim=1)[:, :seq.offset].unsqueeze(0).contiguous()
+
+    @property
+    def state(self):
+        """(keys, values) [1, n_kv_heads, offset, head_dim], gathered from the pages (the layout save_cache stores)."""
+        return self._rows(0), self._rows(1)
+
+    @state.setter
+    def state(self, v):
+        keys, values = v
+        seq, a = self.page_manager, self.page_manager.allocator
+        n = keys.shape[2]
+        if self.layer == 0 or seq.offset != n:
+            seq.truncate(0)
+            seq.reserve(n)
+            seq.offset = n
+            seq._mark_tokens()
+        half = a.page_bytes // 2
+        for j, p in enumerate(seq.pages):
+            rows = min(TOKEN_CAPACITY_PER_PAGE, n - j * TOKEN_CAPACITY_PER_PAGE)
+            for which, src in ((0, keys), (1, values)):
+                dst = a.slab[self.layer, p * a.page_bytes + which * half: p * a.page_bytes + (which + 1) * half].view(a.dtype).view(
+                    a.num_heads, TOKEN_CAPACITY_PER_PAGE, a.head_dim)
+                dst[:, :rows] = src[0, :, j * TOKEN_CAPACITY_PER_PAGE: j * TOKEN_CAPACITY_PER_PAGE + rows].to(a.slab.device)
+
+    @property
+    def meta_state(self):
+        return ""
+
+    @meta_state.setter
+    def meta_state(self, v):
+        pass
+
+    def update_and_fetch(self, keys: torch.Tensor, values: torch.Tensor):
+        raise NotImplementedError("the decode kernels append to the pages themselves (pie_decoder_set_paged_kv)")
+
+    def to_quantized(self, group_size: int = 64, bits: int = 4):
+        return self

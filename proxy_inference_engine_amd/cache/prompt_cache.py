@@ -20,7 +20,7 @@ import torch
 
 logger = logging.getLogger(__name__)
 
-from .kv_cache import BaseCache, ReusableKVCache
+from .kv_cache import BaseCache, PagedKVCache, ReusableKVCache
 
 
 def _as_list(ids) -> list[int]:
@@ -80,7 +80,7 @@ class PromptCache:
         if common == 0:
             return prompt_ids
         for layer_cache in self.cache:
-            assert isinstance(layer_cache, ReusableKVCache)
+            assert isinstance(layer_cache, (ReusableKVCache, PagedKVCache))
             layer_cache.reuse(len(ids), common)
         # Like the reference, computed_ids is NOT truncated here; update() appends the processed suffix.
         return prompt_ids[common:]

@@ -57,9 +57,11 @@ struct AttnArgs {
     u16 *out;         // [Hq, D]
     // Infinity-Cache warm-up riding on the idle CUs of this launch: blocks with blockIdx.y >= splits stream these
     // byte ranges (the next kernels' weights) and discard them, so the small GEMVs that follow start from MALL hits.
-    // Paged KV (PAGED instantiation): blockIdx.z = sequence, sequence s attends ctx_len[s] positions
-    // (0 = idle slot), its token t lives in page block_table[s * bt_stride + t / 64] of the slab at row t % 64.  Page layout:
-    // K block then V block, each [Hkv, 64, D] (one kv-head's 64 rows contiguous: 16 KB bursts at D = 128).
+    // Paged KV (PAGED instantiation, block_table != nullptr): token t of row / sequence r lives in page
+    // block_table[r * bt_stride + t / 64] at row t % 64.  Page layout: K block then V block, each [Hkv, 64, D] (one kv-head's
+    // 64 rows contiguous: 16 KB bursts at D = 128).  Op level: `slab` = the layer's slab, blockIdx.z = sequence, sequence s
+    // attends ctx_len[s] positions (0 = idle slot).  Decoder: slab == nullptr, kv_table holds the layers' K / V slab bases,
+    // T from `state` as in the contiguous case, bt_stride = 0 (one sequence).
     const u16 *slab;
     const int *block_table, *ctx_len;
     int bt_stride, n_pages;
@@ -101,15 +103,15 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;
     const int row = blockIdx.z;  // query row of a prefill chunk (0 at decode)
-    const int Ttot = PAGED ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
+    const int Ttot = PAGED && a.ctx_len ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
     const int cap = PAGED ? 64 : a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
     if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
     const int t_begin = split * sp.chunk;
     const int t_end = min(Ttot, t_begin + sp.chunk);
 
-    const u16 *kbase = PAGED ? a.slab : a.k ? a.k : reinterpret_cast<const u16 *>(a.kv_table[a.layer]);
-    const u16 *vbase = PAGED ? a.slab + (size_t)a.Hkv * 64 * D : a.k ? a.v : reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]);
+    const u16 *kbase = PAGED && a.slab ? a.slab : a.k ? a.k : reinterpret_cast<const u16 *>(a.kv_table[a.layer]);
+    const u16 *vbase = PAGED && a.slab ? a.slab + (size_t)a.Hkv * 64 * D : a.k ? a.v : reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]);
     kbase += (size_t)g * cap * D + dc * 8;
     vbase += (size_t)g * cap * D + dc * 8;
     const int *bt = PAGED ? a.block_table + (size_t)row * a.bt_stride : nullptr;

@@ -90,6 +90,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.freqs = d->glob.rope_freqs, a.rope_cs = dense ? nullptr : d->rope_cs /* filled by the int4 embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
+            a.block_table = d->block_table, a.n_pages = d->n_pages;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
@@ -97,6 +98,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
+            a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
             // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
             a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : (int8 ? pie_w8s_bytes(H, QD) : pie_w4s_bytes(H, QD));
@@ -274,7 +276,36 @@ int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *co
     PIE_LAUNCH_CHECK();
     d->kv_set = true;
     d->kv_cap = capacity;
-    if (plan_attention(d)) drop_graphs(d);  // the launch sequence changed: captured graphs are stale
+    const bool was_paged = d->block_table != nullptr;
+    d->block_table = nullptr, d->n_pages = 0;
+    if (plan_attention(d) || was_paged) drop_graphs(d);  // the launch sequence changed: captured graphs are stale
+    return PIE_OK;
+}
+
+int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_pages, const int32_t *block_table, int max_blocks,
+                             void *stream) {
+    PIE_REQUIRE(d && slabs && block_table, PIE_E_ARG, "pie_decoder_set_paged_kv: null pointer");
+    PIE_REQUIRE(n_pages > 0 && n_pages < 0x7FFFFFFFu && max_blocks > 0 && max_blocks <= (1 << 24), PIE_E_SHAPE,
+                "pie_decoder_set_paged_kv: n_pages and max_blocks must be positive");
+    const int L = d->cfg.n_layers;
+    const size_t v_off = (size_t)d->cfg.n_kv_heads * PIE_PAGE_TOKENS * d->cfg.head_dim * 2;  // bytes: K block, then V block
+    std::vector<unsigned long long> tab(2 * (size_t)L);
+    for (int i = 0; i < L; ++i) {
+        PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_set_paged_kv: null or misaligned slab");
+        tab[i] = (unsigned long long)(uintptr_t)slabs[i];
+        tab[L + i] = tab[i] + v_off;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int capacity = max_blocks * PIE_PAGE_TOKENS;
+    PIE_HIP_TRY(hipMemcpyAsync(d->kv_table, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, st, d->state, -1, -1, capacity);
+    PIE_LAUNCH_CHECK();
+    d->kv_set = true;
+    d->kv_cap = capacity;
+    // kernel arguments are baked into captured graphs: a new table pointer or pool size invalidates them
+    const bool changed = d->block_table != block_table || d->n_pages != (int)n_pages;
+    d->block_table = block_table, d->n_pages = (int)n_pages;
+    if (plan_attention(d) || changed) drop_graphs(d);
     return PIE_OK;
 }
 

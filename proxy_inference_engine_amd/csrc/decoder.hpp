@@ -15,6 +15,10 @@ struct pie_decoder {
     // device-side state and scratch (owned)
     DecState *state = nullptr;
     unsigned long long *kv_table = nullptr;  // [2*n_layers]
+    // paged KV (pie_decoder_set_paged_kv): kv_table holds the layers' slab K / V bases, the caller-owned device block table
+    // maps position p to page block_table[p / 64]; nullptr = contiguous per-layer buffers (pie_decoder_set_kv)
+    const int *block_table = nullptr;
+    int n_pages = 0;
     u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     unsigned *pf_sink = nullptr;

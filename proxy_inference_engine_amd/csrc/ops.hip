@@ -5,40 +5,19 @@
 #include "tail.hpp"
 
 // ---------------------------------------------------------------- attention launch
-template <class T, int D>
-static int attn_launch_paged(int rep, const AttnArgs &a, hipStream_t st) {
-    dim3 grid(a.Hkv, a.splits, a.rows), block(ATTN_WAVES * 64);
-    switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, true>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, true>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, true>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, true>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, true>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, true>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, true>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, true>), grid, block, 0, st, a); break;
-        default: return pie::fail(PIE_E_SHAPE, "paged_attn_decode: n_heads / n_kv_heads must be between 1 and 8");
-    }
-    PIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, a.rows), dim3(256), 0, st, a, D);
-    PIE_LAUNCH_CHECK();
-    return PIE_OK;
-}
-
-template <class T, int D>
+template <class T, int D, bool PAGED>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
-    if (a.slab) return attn_launch_paged<T, D>(rep, a, st);
     const int rows = a.rows > 0 ? a.rows : 1;
     dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
     switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
-        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED>), grid, block, 0, st, a); break;
         default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be between 1 and 8");
     }
     PIE_LAUNCH_CHECK();
@@ -49,14 +28,19 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
     return PIE_OK;
 }
 
+template <class T, int D>
+static int attn_launch_d(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
+    return a.block_table ? attn_launch_rep<T, D, true>(rep, a, combine, st) : attn_launch_rep<T, D, false>(rep, a, combine, st);
+}
+
 int attn_decode_launch(int dtype, int D, AttnArgs &a, bool combine, hipStream_t stream) {
     PIE_REQUIRE(a.Hkv > 0 && a.Hq % a.Hkv == 0, PIE_E_SHAPE, "sdpa_decode: Hq must be a multiple of Hkv");
     PIE_REQUIRE(a.splits >= 1 && a.splits <= ATTN_MAX_SPLITS, PIE_E_ARG, "sdpa_decode: bad split count");
     const int rep = a.Hq / a.Hkv;
-    if (dtype == PIE_BF16 && D == 128) return attn_launch_rep<BF16, 128>(rep, a, combine, stream);
-    if (dtype == PIE_BF16 && D == 64) return attn_launch_rep<BF16, 64>(rep, a, combine, stream);
-    if (dtype == PIE_F16 && D == 128) return attn_launch_rep<F16, 128>(rep, a, combine, stream);
-    if (dtype == PIE_F16 && D == 64) return attn_launch_rep<F16, 64>(rep, a, combine, stream);
+    if (dtype == PIE_BF16 && D == 128) return attn_launch_d<BF16, 128>(rep, a, combine, stream);
+    if (dtype == PIE_BF16 && D == 64) return attn_launch_d<BF16, 64>(rep, a, combine, stream);
+    if (dtype == PIE_F16 && D == 128) return attn_launch_d<F16, 128>(rep, a, combine, stream);
+    if (dtype == PIE_F16 && D == 64) return attn_launch_d<F16, 64>(rep, a, combine, stream);
     return pie::fail(PIE_E_SHAPE, "sdpa_decode: head_dim must be 64 or 128 and dtype bf16/f16");
 }
 

@@ -73,10 +73,16 @@ __global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out)
 template <class T>
 __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
-                                                         int n_kv_heads, int HD, int traditional, u16 *q_out) {
-    const int m = blockIdx.x, pos = state->pos + m, cap = state->cap, half = HD >> 1;
+                                                         int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
+                                                         int n_pages) {
+    const int m = blockIdx.x, pos = state->pos + m, half = HD >> 1;
+    int cap = state->cap, kvrow = pos;
     const int q_cols = n_heads * HD, k_cols = n_kv_heads * HD;
     u16 *kdst = reinterpret_cast<u16 *>(kv_table[layer]), *vdst = reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
+    if (block_table) {  // paged KV: the row goes to slot pos % 64 of page block_table[pos / 64]
+        const size_t pg_off = (size_t)min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u) * 2 * 64 * n_kv_heads * HD;
+        kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
+    }
     const u16 *row = qkv + (size_t)m * n_cols;
     for (int p = threadIdx.x; p < (n_cols >> 1); p += blockDim.x) {
         const int R = 2 * p;
@@ -87,13 +93,13 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             const int head = rr / HD, ii = (rr % HD) >> 1;
             float sn, cs;
             sincosf((float)pos * (1.0f / freqs[ii]), &sn, &cs);
-            u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + pos) * HD;
+            u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
             const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
             dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
             dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
         } else {
             const int rr = R - q_cols - k_cols;
-            *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + pos) * HD + rr % HD) = pr;
+            *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pr;
         }
     }
 }
@@ -471,16 +477,18 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
             if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
-                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q);
+                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages);
             PIE_LAUNCH_CHECK();
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
                 PrefillAttnArgs pa = {};
                 pa.q = s->q, pa.kv_table = d->kv_table, pa.layer = li, pa.n_layers = c.n_layers, pa.state = d->state;
+                pa.block_table = d->block_table, pa.n_pages = d->n_pages;
                 pa.M = M, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
                 if ((rc = prefill_attn_launch_t<T>(pa, D, st))) return rc;
             } else {  // PIE_PREFILL_ATTN=valu: the VALU decode kernel, one query row per blockIdx.z (cross-check for the tests)
                 AttnArgs a = {};
                 a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
+                a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;  // every row reads the one sequence's table
                 a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.rows = M, a.scale = 1.0f / sqrtf((float)D);
                 a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;

@@ -37,6 +37,8 @@ struct PrefillAttnArgs {
     int M, Hq, Hkv;
     float scale;
     u16 *out;                            // [M, Hq, D]
+    const int *block_table;              // paged KV (nullable, decoder only): kv_table holds the layers' slab K / V bases; key t
+    int n_pages;                         //   lives in page block_table[t / 64] (each [Hkv, 64, D]) at row t % 64
 };
 
 template <class T> struct MfmaT;
@@ -84,7 +86,12 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
     const int g = (int)blockIdx.x % a.Hkv, tile = (int)blockIdx.x / a.Hkv;
     const int wg_r0 = ((a.M + BM - 1) / BM - 1 - tile) * BM;                  // first query row of the workgroup
     const int r0 = wg_r0 + 32 * (wave / REP), hq = g * REP + wave % REP;     // this wave's 32-row tile and q-head
-    const int pos0 = a.state ? a.state->pos : a.offset, cap = a.state ? a.state->cap : a.cap;
+    // paged KV: a key block (BK = 32 rows) never straddles a 64-row page, so its page is one scalar table lookup per fetch;
+    // the contiguous case is the same code with one "page" of `cap` rows (mask keeps every row bit, page offset 0)
+    const bool paged = a.block_table != nullptr;
+    const int pos0 = a.state ? a.state->pos : a.offset, cap = paged ? 64 : a.state ? a.state->cap : a.cap;
+    const int row_mask = paged ? 63 : 0x7FFFFFFF;
+    const size_t page_elems = (size_t)2 * 64 * a.Hkv * D;
     const int r_last = (wg_r0 + BM - 1 < a.M ? wg_r0 + BM - 1 : a.M - 1);
     const int t_last = pos0 + r_last;            // last key any row of this tile attends
     const int n_blocks = t_last / BK + 1;
@@ -101,8 +108,8 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
         x = x < BK * CH ? x : BK * CH - 1;                                                       \
         int t = b * BK + x / CH;                                                                 \
         t = t < t_last ? t : t_last;                                                             \
-        kr = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D + (x % CH) * 8);             \
-        vr = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D + (x % CH) * 8);             \
+        kr = *reinterpret_cast<const uint4 *>(kbase + pg_off + (size_t)(t & row_mask) * D + (x % CH) * 8); \
+        vr = *reinterpret_cast<const uint4 *>(vbase + pg_off + (size_t)(t & row_mask) * D + (x % CH) * 8); \
     }
 #define PA_PUBLISH1(i, kr, vr)                                                                 \
     if constexpr (i < CPT) {                                                                     \
@@ -113,6 +120,7 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
         }                                                                                        \
     }
     auto fetch = [&](int b) {
+        const size_t pg_off = paged ? (size_t)min((unsigned)a.block_table[(b * BK) >> 6], (unsigned)a.n_pages - 1u) * page_elems : 0;
         PA_FETCH1(0, k0, v0) PA_FETCH1(1, k1, v1) PA_FETCH1(2, k2, v2) PA_FETCH1(3, k3, v3)
         PA_FETCH1(4, k4, v4) PA_FETCH1(5, k5, v5) PA_FETCH1(6, k6, v6) PA_FETCH1(7, k7, v7)
     };

@@ -61,6 +61,8 @@ struct GemvArgs {
     const DecState *state;
     u16 *q_out;
     const unsigned long long *kv_table;  // [2*n_layers] device pointers: K buffers then V buffers
+    const int *block_table;              // paged KV (nullable): kv_table holds the layers' slab K / V bases, position p lives in
+    int n_pages;                         //   page block_table[p / 64] (K then V block, each [n_kv_heads, 64, head_dim]) at row p % 64
     int layer, n_layers, n_heads, n_kv_heads, head_dim;
     int rope_traditional;  // EPI_ROPE_KV: packed q/k rows (2i, 2i+1) are the interleaved pair itself (mx.fast.rope traditional=True)
     LogitStat *stats;     // EPI_LOGITS: one entry per wave of the grid
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     u32 pre_u = 0;           // EPI_RESIDUAL: the residual pair
     u32 pre_b = 0;           // the linear bias pair
     float pre_cs = 1.0f, pre_sn = 0.0f;
-    int pos = 0, cap = 0;
+    int pos = 0, cap = 0, kvrow = 0;
     u16 *kdst = nullptr, *vdst = nullptr;
     if (EPI == EPI_RESIDUAL && live) pre_u = *reinterpret_cast<const u32 *>(a.resid + R);
     const bool has_bias = EPI != EPI_LOGITS && EPI != EPI_PARTIAL_F32 && a.lin_bias != nullptr;  // wave-uniform
@@ -194,6 +196,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         pos = a.state->pos, cap = a.state->cap;
         kdst = reinterpret_cast<u16 *>(a.kv_table[a.layer]);
         vdst = reinterpret_cast<u16 *>(a.kv_table[a.n_layers + a.layer]);
+        kvrow = pos;
+        if (a.block_table) {  // paged: the page of this position is one more "buffer" of 64 rows per head
+            const size_t pg_off = (size_t)min((unsigned)a.block_table[pos >> 6], (unsigned)a.n_pages - 1u) * 2 * 64 * a.n_kv_heads * a.head_dim;
+            kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
+        }
         if (live && R < (a.n_heads + a.n_kv_heads) * a.head_dim) {
             const int ii = (R % a.head_dim) >> 1;
             if (a.rope_cs) pre_cs = a.rope_cs[2 * ii], pre_sn = a.rope_cs[2 * ii + 1];
@@ -411,14 +418,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             if (R < q_rows + k_rows) {
                 const int rr = R < q_rows ? R : R - q_rows;
                 const int head = rr / HD, ii = (rr % HD) >> 1;
-                u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD : kdst + ((size_t)head * cap + pos) * HD;
+                u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD : kdst + ((size_t)head * cap + kvrow) * HD;
                 const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + half;
                 dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, pre_cs), __fmul_rn(rb, pre_sn)));
                 dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, pre_sn), __fmul_rn(rb, pre_cs)));
             } else {
                 const int rr = R - q_rows - k_rows;
                 const int head = rr / HD, dd2 = rr % HD;
-                *reinterpret_cast<u32 *>(vdst + ((size_t)head * cap + pos) * HD + dd2) = pack2<T>(ra, rb);
+                *reinterpret_cast<u32 *>(vdst + ((size_t)head * cap + kvrow) * HD + dd2) = pack2<T>(ra, rb);
             }
         }
     }

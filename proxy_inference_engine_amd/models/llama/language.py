@@ -19,7 +19,7 @@ import torch
 
 from .. import base
 from ... import _ffi, hip_ops
-from ...cache.kv_cache import BaseCache, ReusableKVCache
+from ...cache.kv_cache import BaseCache, PageAllocator, PagedKVCache, PagedSequence, ReusableKVCache
 from .utils import Llama3RoPE
 
 
@@ -173,6 +173,8 @@ class Model:
         _ffi.check(lib.pie_decoder_bind_outputs(self._dec, _ffi.p(self.logits), _ffi.p(self.logprobs), _ffi.p(self.token), _ffi.p(self.hidden),
                                                 _ffi.p(self.history), self.history.numel()))
         self._kv_key = None      # (pointers, capacity) currently in the decoder's device table
+        self._kv_hold = None
+        self._page_pool, self._page_blocks = None, 16
         self._dev_offset = None  # device-side cache offset the decoder believes in
         torch.cuda.synchronize(device)
 
@@ -187,13 +189,56 @@ class Model:
 
     # ------------------------------------------------------------------ cache plumbing
     def make_cache(self) -> list[BaseCache]:
+        if self._page_pool is not None:
+            return self.make_paged_cache(self._page_pool, max_blocks=self._page_blocks)
         return [ReusableKVCache() for _ in self.layers]
+
+    def enable_paged_kv(self, num_pages: int = 512, max_blocks: int = 16) -> PageAllocator:
+        """From now on make_cache() (PromptCache.create_kv_cache, prompt_cache.py:34-41) hands out paged caches drawing
+        on one pool of `num_pages` 64-token pages (all layers).  Returns the pool."""
+        self._page_pool = PageAllocator(num_pages, self.n_kv_heads, self.head_dim, dtype=self.dtype, device=self.device,
+                                        num_layers=len(self.layers))
+        self._page_blocks = max_blocks
+        return self._page_pool
+
+    def make_paged_cache(self, allocator: PageAllocator | None = None, num_pages: int = 512, max_blocks: int = 16) -> list[BaseCache]:
+        """Per-layer PagedKVCache objects over one PagedSequence: KV rows live in 64-token pages of
+        the allocator's slab (one plane per layer) instead of per-layer contiguous buffers; growth takes pages, never
+        copies.  Pass a shared `allocator` to keep several sequences in one pool."""
+        if allocator is None:
+            allocator = PageAllocator(num_pages, self.n_kv_heads, self.head_dim, dtype=self.dtype, device=self.device,
+                                      num_layers=len(self.layers))
+        if (allocator.num_layers, allocator.num_heads, allocator.head_dim, allocator.dtype) != (
+                len(self.layers), self.n_kv_heads, self.head_dim, self.dtype) or allocator.slab is None:
+            raise ValueError("the allocator's geometry does not match this model")
+        seq = PagedSequence(allocator, max_blocks)
+        return [PagedKVCache(seq, i) for i in range(len(self.layers))]
+
+    def _sync_paged(self, cache: list[PagedKVCache], n_new: int) -> None:
+        seq = cache[0].page_manager
+        if any(not isinstance(c, PagedKVCache) or c.page_manager is not seq for c in cache):
+            raise TypeError("the layers of a paged cache must share one PagedSequence")
+        seq.reserve(n_new)
+        a = seq.allocator
+        key = ("paged", a.slab.data_ptr(), a.size(), seq.table.data_ptr(), seq.max_blocks)
+        lib = _ffi.load()
+        if key != self._kv_key:
+            n = len(cache)
+            slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
+            _ffi.check(lib.pie_decoder_set_paged_kv(self._dec, slabs, a.size(), _ffi.p(seq.table), seq.max_blocks, _ffi.stream()))
+            self._kv_key = key
+            self._kv_hold = (a, seq.table)  # keeps the slab and the table alive while the decoder points at them
+        if self._dev_offset != seq.offset:
+            _ffi.check(lib.pie_decoder_set_state(self._dec, seq.offset, -1, _ffi.stream()))
+            self._dev_offset = seq.offset
 
     def _sync_cache(self, cache: list[ReusableKVCache], n_new: int) -> None:
         """The host half of cache.update_and_fetch for every layer (reusable.py:113-131), then make the decoder's
         device-side view (buffer addresses, capacity, offset) match the Python objects."""
         if len(cache) != len(self.layers):
             raise ValueError(f"expected {len(self.layers)} layer caches, got {len(cache)}")
+        if isinstance(cache[0], PagedKVCache):
+            return self._sync_paged(cache, n_new)
         off = cache[0].offset
         for c in cache:
             if not isinstance(c, ReusableKVCache):
@@ -215,8 +260,11 @@ class Model:
             self._dev_offset = off
 
     def _advance(self, cache, n: int) -> None:
-        for c in cache:
-            c.advance(n)  # reusable.py:139
+        if isinstance(cache[0], PagedKVCache):
+            cache[0].page_manager.advance(n)
+        else:
+            for c in cache:
+                c.advance(n)  # reusable.py:139
         self._dev_offset += n
 
     # ------------------------------------------------------------------ reference calling convention

@@ -152,3 +152,134 @@ def test_paged_argument_errors(ops):
         ops.paged_attention_decode(q, alloc.slab[0], 3, bt, torch.ones(1, dtype=torch.int32, device="cuda"), 2, 1.0)   # slab too small
     with pytest.raises(ValueError):
         ops.paged_attention_decode(q, alloc.slab[0], 2, bt, torch.ones(2, dtype=torch.int32, device="cuda"), 2, 1.0)
+
+
+# ---------------------------------------------------------------------------- the decoder on paged KV
+import json  # noqa: E402
+
+
+def _tiny(golden_dir, **kw):
+    from tests.test_gpu_decode import build
+    g = np.load(golden_dir / "tiny_llama_w4_bf16.npz")
+    cfg = json.loads(str(g["config_json"]))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    return g, cfg, build(cfg, w, **kw)
+
+
+def _run(model, cache, prompt, steps):
+    """Prompt (batched prefill) then `steps` greedy steps; returns the tokens and every step's logits bits."""
+    tok, _, logits = model.step(torch.from_numpy(prompt.astype(np.int32)).cuda(), cache)
+    toks, bits = [int(tok.item())], [to_bits(logits).copy()]
+    for _ in range(steps):
+        tok, _, logits = model.step(None, cache)
+        toks.append(int(tok.item()))
+        bits.append(to_bits(logits).copy())
+    return toks, bits
+
+
+def test_decoder_on_pages_is_bitwise_the_contiguous_decoder(golden_dir):
+    """Same model, same prompt: KV in scattered 64-token pages vs per-layer contiguous buffers.  Both run the same
+    kernels on the same rows with the same split geometry (capacity <= 1024 either way), so prompt logits and 200 greedy
+    steps -- crossing three page boundaries and one block-table growth (2 -> 4 blocks) -- must agree bit for bit."""
+    g, cfg, model = _tiny(golden_dir)
+    prompt = g["prompt"]
+    want_t, want_b = _run(model, model.make_cache(), prompt, 200)
+    pool = model.enable_paged_kv(num_pages=24, max_blocks=2)
+    for _ in range(5):                       # scatter: the sequence's pages will not be 0, 1, 2, ...
+        pool.allocate_page()
+    pool.free_page(1), pool.free_page(3)
+    cache = model.make_cache()
+    got_t, got_b = _run(model, cache, prompt, 200)
+    assert got_t == want_t
+    for i, (a, b) in enumerate(zip(got_b, want_b)):
+        assert np.array_equal(a, b), f"logits differ at step {i}"
+    seq = cache[0].page_manager
+    n = len(prompt) + 200
+    assert seq.offset == n and len(seq.pages) == (n + 63) // 64 and seq.pages[:2] == [3, 1]
+    assert seq.max_blocks >= len(seq.pages) > 2
+    assert [pool.get_page(p).num_tokens() for p in seq.pages] == [64] * (n // 64) + ([n % 64] if n % 64 else [])
+    # the reference's protocol on top: state gathers the rows, trim / reuse give pages back
+    k0, v0 = cache[0].state
+    assert k0.shape == (1, cfg["num_key_value_heads"], n, cfg["hidden_size"] // cfg["num_attention_heads"])
+    free = pool.get_num_free_pages()
+    assert cache[0].trim(n - 70) == n - 70 and seq.offset == 70 and len(seq.pages) == 2
+    assert pool.get_num_free_pages() == free + (n + 63) // 64 - 2
+
+
+def test_decoder_on_pages_long_context_forced_splits(golden_dir):
+    """Past capacity 1024 the attention plan switches to many splits + the combine launch; with the split count pinned
+    (kv_splits) the paged and contiguous decoders still see identical geometry: 1100 positions, bitwise."""
+    g, cfg, model = _tiny(golden_dir, kv_splits=8)
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(0, cfg["vocab_size"], 1050).astype(np.int32)
+    want_t, want_b = _run(model, model.make_cache(), prompt, 50)
+    model.enable_paged_kv(num_pages=40, max_blocks=4)
+    got_t, got_b = _run(model, model.make_cache(), prompt, 50)
+    assert got_t == want_t
+    assert all(np.array_equal(a, b) for a, b in zip(got_b, want_b))
+
+
+def test_engine_generates_on_pages_with_prefix_reuse(golden_dir):
+    """InferenceEngine end to end on the paged cache: golden greedy tokens, then a second request sharing the prompt:
+    PromptCache.reuse_cache trims to the common prefix (pages behind it return to the pool) and one token is re-processed."""
+    from proxy_inference_engine_amd import InferenceEngine
+    from tests.test_gpu_decode import margin_bound
+    g, cfg, model = _tiny(golden_dir)
+    pool = model.enable_paged_kv(num_pages=16)
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(g["prompt"], temp=0)
+    gen = eng.generate_step(torch.from_numpy(g["prompt"]))
+    mb = margin_bound(po.from_bits(g["prefill_last_logits"], "bfloat16"))
+    n = len(g["tokens"])
+    safe = int(np.argmax(g["margins"] < mb)) if (g["margins"] < mb).any() else n
+    first = None
+    for i in range(n):
+        tok, _ = next(gen)
+        first = int(tok.item()) if i == 0 else first
+        if i < safe:
+            assert int(tok.item()) == int(g["tokens"][i]), f"step {i}"
+    from proxy_inference_engine_amd.cache.kv_cache import PagedKVCache
+    assert isinstance(eng.prompt_cache.cache[0], PagedKVCache)
+    used = pool.size() - pool.get_num_free_pages()
+    assert used == (len(g["prompt"]) + n - 1 + 63) // 64
+    again = next(eng.generate_step(torch.from_numpy(g["prompt"])))[0]
+    assert int(again.item()) == first
+    assert eng.prompt_cache.cache[0].offset == len(g["prompt"])
+    assert pool.size() - pool.get_num_free_pages() == (len(g["prompt"]) + 63) // 64
+
+
+def test_pool_exhaustion_is_an_error_not_a_fault(golden_dir):
+    g, cfg, model = _tiny(golden_dir)
+    model.enable_paged_kv(num_pages=2)
+    cache = model.make_cache()
+    with pytest.raises(RuntimeError, match="exhausted"):
+        model.step(torch.zeros(200, dtype=torch.int32, device="cuda"), cache)
+    assert cache[0].offset == 0 and cache[0].page_manager.allocator.get_num_free_pages() == 2
+
+
+def test_forked_sequence_shares_full_pages(golden_dir):
+    """fork(): full pages shared by reference count, the partial page copied; both continuations produce what an
+    unshared sequence with the same history produces."""
+    from proxy_inference_engine_amd.cache.kv_cache import PagedKVCache
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(9)
+    prompt = rng.integers(0, cfg["vocab_size"], 150).astype(np.int32)            # 2 full pages + 22 rows
+    pool = model.enable_paged_kv(num_pages=16)
+    a = model.make_cache()
+    model.step(torch.from_numpy(prompt).cuda(), a)
+    seq_b = a[0].page_manager.fork()
+    b = [PagedKVCache(seq_b, i) for i in range(len(a))]
+    assert seq_b.pages[:2] == a[0].page_manager.pages[:2] and seq_b.pages[2] != a[0].page_manager.pages[2]
+    assert all(pool.get_page(p).get_ref_count() == 2 for p in seq_b.pages[:2])
+    nxt_a = torch.tensor([5], dtype=torch.int32, device="cuda")
+    nxt_b = torch.tensor([9], dtype=torch.int32, device="cuda")
+    la = to_bits(model.step(nxt_a, a)[2]).copy()
+    lb = to_bits(model.step(nxt_b, b)[2]).copy()
+    for tail, got in ((5, la), (9, lb)):
+        ref = model.make_cache()
+        model.step(torch.from_numpy(prompt).cuda(), ref)
+        want = to_bits(model.step(torch.tensor([tail], dtype=torch.int32, device="cuda"), ref)[2]).copy()
+        assert np.array_equal(got, want)
+        ref[0].page_manager.release()
+    seq_b.release()
+    assert all(pool.get_page(p).get_ref_count() == 1 for p in a[0].page_manager.pages[:2])
