@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32)
     ap.add_argument("--kv-splits", type=int, default=0)
+    ap.add_argument("--paged", action="store_true", help="KV cache in 64-token pages of one slab (PagedKVCache) instead of contiguous per-layer buffers")
     ap.add_argument("--model", choices=["8b", "70b", "qv", "3b"], default="8b",
                     help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; 3b: Llama-3.2-3B; not the metric's workload")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
@@ -112,6 +113,8 @@ def main():
     del weights
     torch.cuda.empty_cache()
 
+    if args.paged:
+        model.enable_paged_kv(num_pages=(args.prompt + args.warmup + args.steps + 2) // 64 + 2)
     eng = InferenceEngine(model=model)
     prompt = torch.randint(0, cfg["vocab_size"], (args.prompt,), generator=torch.Generator().manual_seed(1 + rank))
     eng.prepare_engine(prompt, temp=0)
@@ -175,7 +178,7 @@ def main():
         "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
-                   "hipgraph": True},
+                   "hipgraph": True, "kv": "paged (64-token pages)" if args.paged else "contiguous"},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,
                      "ms_per_launch": k_ms,
