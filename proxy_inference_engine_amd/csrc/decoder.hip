@@ -99,6 +99,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
             a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
+            a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
             // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
             a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : (int8 ? pie_w8s_bytes(H, QD) : pie_w4s_bytes(H, QD));

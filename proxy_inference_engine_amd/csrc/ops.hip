@@ -5,19 +5,19 @@
 #include "tail.hpp"
 
 // ---------------------------------------------------------------- attention launch
-template <class T, int D, bool PAGED>
+template <class T, int D, bool PAGED, bool NT>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
     dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
     switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
-        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED, NT>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED, NT>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED, NT>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED, NT>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED, NT>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED, NT>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED, NT>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED, NT>), grid, block, 0, st, a); break;
         default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be between 1 and 8");
     }
     PIE_LAUNCH_CHECK();
@@ -30,7 +30,8 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
 
 template <class T, int D>
 static int attn_launch_d(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
-    return a.block_table ? attn_launch_rep<T, D, true>(rep, a, combine, st) : attn_launch_rep<T, D, false>(rep, a, combine, st);
+    if (a.nt_kv) return a.block_table ? attn_launch_rep<T, D, true, true>(rep, a, combine, st) : attn_launch_rep<T, D, false, true>(rep, a, combine, st);
+    return a.block_table ? attn_launch_rep<T, D, true, false>(rep, a, combine, st) : attn_launch_rep<T, D, false, false>(rep, a, combine, st);
 }
 
 int attn_decode_launch(int dtype, int D, AttnArgs &a, bool combine, hipStream_t stream) {
@@ -150,6 +151,7 @@ int pie_sdpa_decode(const void *q, const void *k, const void *v, int Hq, int Hkv
     a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v;
     a.T = T, a.cap = cap, a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
     a.splits = T >= 2048 ? ATTN_MAX_SPLITS : (T >= 512 ? 16 : (T >= 128 ? 4 : 1));
+    a.nt_kv = T >= 2048;
     a.part_acc = (float *)workspace;
     a.part_ml = a.part_acc + (size_t)Hq * ATTN_MAX_SPLITS * D;
     a.out = (u16 *)out;
@@ -200,6 +202,7 @@ int pie_paged_attn_decode(const void *q, const void *slab, size_t n_pages, const
     AttnArgs a = {};
     a.q = (const u16 *)q, a.slab = (const u16 *)slab, a.block_table = block_table, a.ctx_len = context_lens;
     a.bt_stride = max_blocks, a.n_pages = (int)n_pages, a.rows = B;
+    a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;  // more rows than stay cached between steps
     a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
     // enough workgroups for two per CU across the batch, never more splits than pages per sequence
     int splits = Hkv > 0 ? (512 + B * Hkv - 1) / (B * Hkv) : 1;

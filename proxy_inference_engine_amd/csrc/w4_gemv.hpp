@@ -23,6 +23,9 @@
 //     and the epilogue runs once after the stream, one lane per row pair (coalesced stores, vectorised RoPE/SiLU):
 //     global stores inside the loop would share vmcnt with the loads and make the compiler drain the ring.
 #pragma once
+#ifndef PIE_GEMV_NT
+#define PIE_GEMV_NT 1  // non-temporal loads on every weight stream (0: only lm_head); A/B in DESIGN.md 2
+#endif
 #include "attention.hpp"
 #include "common.hpp"
 
@@ -232,9 +235,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             c0[d] = c1[d] = make_uint4(lane, off, d, 7);
             sb[d] = 0x3c003c00u;
         } else {
-            // lm_head (295 MB) exceeds the 256 MiB Infinity Cache: non-temporal loads (aux = 2) measured 53.6 -> 48.3 us;
-            // on the per-layer matrices (<= 66 MB) nt was 8-15 % SLOWER, so they keep the default policy
-            constexpr int AUX = EPI == EPI_LOGITS ? 2 : 0;
+            // Weights are read once per step and a step streams 4.2 GB through the 256 MiB Infinity Cache: non-temporal
+            // loads (aux = 2).  lm_head alone: 53.6 -> 48.3 us.  The per-layer matrices looked 8-15 % SLOWER with nt when one
+            // kernel was replayed back to back (its <= 66 MB then hit the cache); inside the real step, where nothing is ever
+            // re-read, nt on every stream measured 761 -> 780 tok/s (two A/B rounds in one session), gate/up 13.1 -> 12.7 us
+            constexpr int AUX = (EPI == EPI_LOGITS || PIE_GEMV_NT) ? 2 : 0;
             const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, AUX);
             const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, AUX);
             c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
