@@ -218,6 +218,10 @@ int pie_decoder_step(pie_decoder *d, int flags, void *stream);
  * reads logits[:, -1, :], engine/inference_engine.py:254).  logits_all != NULL: T [L, vocab], lm_head on every
  * position like the reference's Model.__call__ (language.py:205-209). */
 int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream);
+/* The same with the input embeddings given instead of token ids: embeds T [L, hidden] replaces embed_tokens(ids) --
+ * `h = inputs_embeds` of the VLM text tower (models/intern/language.py:155-158), fed by the ensemble's merged text and image
+ * features (models/intern/ensemble.py:33-91, :106-108).  Always the batched path, whatever L. */
+int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *logits_all, void *stream);
 /* Output buffers of the step, allocated by the caller (device): logits T [vocab], logprobs fp32 [vocab],
  * token int32 [1] (the greedy choice), hidden T [hidden] (the residual stream; after a step it holds the
  * output of the last block, the input of the final norm).  history (optional, int32 [history_len]): the tail

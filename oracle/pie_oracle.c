@@ -503,9 +503,21 @@ static void from_heads(const float *x, int L, int heads, int D, float *y) {
  * the residual stream after the last block (before the final norm) for layer-wise checks.
  * Returns 0, or -1 on allocation failure / capacity overflow.
  */
+int orc_llama_forward_ex(const orc_llama_t *m, const int32_t *ids, const float *embeds, int L, float *const *kcache,
+                         float *const *vcache, int cap, int offset, int last_only, int sdpa_fused,
+                         float *logits, float *hidden_out);
+
 int orc_llama_forward(const orc_llama_t *m, const int32_t *ids, int L, float *const *kcache,
                       float *const *vcache, int cap, int offset, int last_only, int sdpa_fused,
                       float *logits, float *hidden_out) {
+    return orc_llama_forward_ex(m, ids, NULL, L, kcache, vcache, cap, offset, last_only, sdpa_fused, logits, hidden_out);
+}
+
+/* embeds != NULL: [L, hidden] input embeddings used instead of embed_tokens(ids) -- `h = inputs_embeds`,
+ * models/intern/language.py:155-158 (the VLM ensemble's merged text + image features, intern/ensemble.py:106-108). */
+int orc_llama_forward_ex(const orc_llama_t *m, const int32_t *ids, const float *embeds, int L, float *const *kcache,
+                         float *const *vcache, int cap, int offset, int last_only, int sdpa_fused,
+                         float *logits, float *hidden_out) {
     const int H = m->hidden, D = m->head_dim, nh = m->n_heads, nkv = m->n_kv_heads, I = m->inter;
     const int dt = m->dtype, T = offset + L;
     if (T > cap) return -1;
@@ -519,8 +531,12 @@ int orc_llama_forward(const orc_llama_t *m, const int32_t *ids, int L, float *co
     float *mask = NULL;
     if (!h || !xn || !q || !qh || !kk || !vv || !kh || !vh || !t1 || !t2 || !r) return -1;
 
-    orc_embedding(ids, L, m->embed.w, m->embed.scales, m->embed.biases, m->quantized && m->embed.scales != NULL,
-                  H, m->group_size, m->bits, dt, h); /* language.py:176 */
+    if (embeds) {
+        for (size_t i = 0; i < (size_t)L * H; ++i) h[i] = rnd(embeds[i], dt);
+    } else {
+        orc_embedding(ids, L, m->embed.w, m->embed.scales, m->embed.biases, m->quantized && m->embed.scales != NULL,
+                      H, m->group_size, m->bits, dt, h); /* language.py:176 */
+    }
     if (L > 1) { /* language.py:178-179 -> base.py:37-53 */
         mask = malloc(sizeof(float) * (size_t)L * T);
         if (!mask) return -1;

@@ -315,8 +315,13 @@ class OracleLlama:
             m.lm_head = self._lin("lm_head")
         return m
 
-    def forward(self, ids, cache: list["OracleKVCache"], last_only=False, sdpa_fused=True, want_hidden=False):
-        """Model.__call__(inputs[None], cache=cache) for batch 1: returns logits [L, V] (or [V] if last_only)."""
+    def forward(self, ids, cache: list["OracleKVCache"], last_only=False, sdpa_fused=True, want_hidden=False, inputs_embeds=None):
+        """Model.__call__(inputs[None], cache=cache) for batch 1: returns logits [L, V] (or [V] if last_only).
+        inputs_embeds [L, hidden] (ids then ignored): LanguageModel(None, inputs_embeds=...), models/intern/language.py:155-158."""
+        emb = None
+        if inputs_embeds is not None:
+            emb = _f32(inputs_embeds).reshape(-1, self.hidden)
+            ids = np.zeros(emb.shape[0], np.int32)
         ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
         L = ids.size
         offset = cache[0].offset
@@ -327,8 +332,8 @@ class OracleLlama:
         vp = (C.c_void_p * self.n_layers)(*[c.values.ctypes.data for c in cache])
         logits = np.empty((self.vocab,) if last_only else (L, self.vocab), np.float32)
         hidden = np.empty((L, self.hidden), np.float32) if want_hidden else None
-        rc = lib().orc_llama_forward(C.byref(self._struct), _p(ids), L, kp, vp, cap, offset, int(last_only),
-                                     int(sdpa_fused), _p(logits), _p(hidden))
+        rc = lib().orc_llama_forward_ex(C.byref(self._struct), _p(ids), _p(emb), L, kp, vp, cap, offset, int(last_only),
+                                        int(sdpa_fused), _p(logits), _p(hidden))
         if rc != 0:
             raise RuntimeError("orc_llama_forward failed")
         for c in cache:

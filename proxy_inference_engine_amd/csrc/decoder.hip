@@ -369,7 +369,7 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     if (rc) return rc;
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
-    if (L >= prefill_min_rows()) return prefill_batched(d, ids, L, logits_all, st);  // MLX's qmm regime: dequantise-to-T GEMMs
+    if (L >= prefill_min_rows()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime: dequantise-to-T GEMMs
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
         u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;
@@ -379,6 +379,14 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
         PIE_HIP_TRY(hipMemcpyAsync(d->logits, (u16 *)logits_all + (size_t)(L - 1) * d->cfg.vocab, 2 * (size_t)d->cfg.vocab,
                                    hipMemcpyDeviceToDevice, st));
     return PIE_OK;
+}
+
+int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *logits_all, void *stream) {
+    int rc = ready(d);
+    if (rc) return rc;
+    PIE_REQUIRE(embeds && L > 0, PIE_E_ARG, "pie_decoder_prefill_embeds: need at least one row");
+    PIE_REQUIRE(pie_aligned(embeds, 16), PIE_E_ALIGN, "pie_decoder_prefill_embeds: 16-byte alignment required");
+    return prefill_batched(d, nullptr, embeds, L, logits_all, (hipStream_t)stream);
 }
 
 int pie_decoder_bind_outputs(pie_decoder *d, void *logits, float *logprobs, int32_t *token, void *hidden, int32_t *history,

@@ -45,6 +45,6 @@ struct pie_decoder {
 // prefill.hip: batched prompt processing (L >= prefill_min_rows() tokens): per layer the W4S weights are dequantised to T
 // and multiplied by hipBLASLt, with hand-written HIP kernels for RoPE + cache append, causal attention and SwiGLU.
 int prefill_min_rows();
-int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st);
+int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st);
 void prefill_free(pie_decoder *d);
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st);

@@ -450,7 +450,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
 }
 
 template <class T>
-static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
+static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
     const int chunk = prefill_chunk_rows() < L ? prefill_chunk_rows() : L;
@@ -465,7 +465,11 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, int L, void *logits_all
     for (int c0 = 0; c0 < L; c0 += chunk) {
         const int M = L - c0 < chunk ? L - c0 : chunk;
         // h = embed_tokens(inputs)  (language.py:176)
-        rc = c.weight_format == PIE_W_DENSE
+        if (embeds) {  // h = inputs_embeds (models/intern/language.py:155-158)
+            PIE_HIP_TRY(hipMemcpyAsync(s->x, (const u16 *)embeds + (size_t)c0 * H, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
+            rc = PIE_OK;
+        } else
+            rc = c.weight_format == PIE_W_DENSE
                  ? pie_embedding_dense(ids + c0, M, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
                  : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
                                     nullptr, nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
@@ -537,8 +541,8 @@ extern "C" int pie_sdpa_prefill(const void *q, const void *k, const void *v, int
     return pie::fail(PIE_E_ARG, "pie_sdpa_prefill: dtype must be PIE_BF16 or PIE_F16");
 }
 
-int prefill_batched(pie_decoder *d, const int32_t *ids, int L, void *logits_all, hipStream_t st) {
+int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st) {
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
     PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "prefill: n_heads / n_kv_heads must be between 1 and 8");
-    return d->cfg.dtype == PIE_BF16 ? prefill_t<BF16>(d, ids, L, logits_all, st) : prefill_t<F16>(d, ids, L, logits_all, st);
+    return d->cfg.dtype == PIE_BF16 ? prefill_t<BF16>(d, ids, embeds, L, logits_all, st) : prefill_t<F16>(d, ids, embeds, L, logits_all, st);
 }

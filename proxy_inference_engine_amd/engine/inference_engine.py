@@ -78,8 +78,10 @@ class InferenceEngine:
         """Yields (next_token_id[1] int32, logprobs[V] fp32) per step, forever (inference_engine.py:228-297).
         Prefill of the non-cached prompt suffix, then one forward per token; all device work is queued
         asynchronously, the consumer synchronises when it reads a token (generate() does, like `.tolist()` :202)."""
-        if pixel_values is not None or mask is not None:
-            raise NotImplementedError("pixel_values / mask: the VLM prefill path is SURVEY.md 8f-3")
+        if mask is not None:
+            raise NotImplementedError("explicit masks are not supported: the causal mask of models/base.py:37-53 is implicit")
+        if pixel_values is not None and not hasattr(self.model, "get_input_embeddings"):
+            raise TypeError("pixel_values need a VLM ensemble (models/intern/ensemble.py: Model) as the engine's model")
         if "root" not in self.samplers:
             self.prepare_engine(prompt_ids, temp=0)
         dev = self.model.device
@@ -94,6 +96,26 @@ class InferenceEngine:
                     state = "root"
             sampler = self.samplers[state]
             procs = self.logits_processors.get(state) or []
+            if pixel_values is not None and not fed_back:
+                # the prompt of a VLM request (:246-252): text embeddings with the image features scattered in, through the
+                # text tower.  The reference passes pixel_values on every later step too, where a single new token holds
+                # no image token and the vision tower's output is discarded (ensemble.py:62-91); those steps skip it here.
+                embeds = self.model.get_input_embeddings(ids.reshape(1, -1), pixel_values)
+                if not procs:
+                    tok, logprobs, _ = self.model.step_embeds(embeds, self.prompt_cache.cache)
+                    self.prompt_cache.update(ids)
+                    if getattr(sampler, "is_greedy", False):
+                        return tok, logprobs
+                    return sampler(logprobs[None]).reshape(1).to(torch.int32), logprobs
+                logits = self.model.language_model(None, cache=self.prompt_cache.cache, inputs_embeds=embeds)
+                last = logits[:, -1, :]
+                self.prompt_cache.update(ids)
+                for proc in procs:
+                    last = proc(self.prompt_cache.computed_ids, last)
+                tok, logprobs = hip_ops.logprobs_argmax(last)
+                if getattr(sampler, "is_greedy", False):
+                    return tok, logprobs
+                return sampler(logprobs[None]), logprobs
             if not procs:
                 # fused step: hipGraph replay for L == 1, log-softmax (+ greedy argmax) in the HIP tail, no host sync
                 greedy_fused = getattr(sampler, "is_greedy", False)

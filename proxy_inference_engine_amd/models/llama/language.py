@@ -268,22 +268,64 @@ class Model:
         self._dev_offset += n
 
     # ------------------------------------------------------------------ reference calling convention
-    def __call__(self, inputs: torch.Tensor, mask=None, cache: list[BaseCache] | None = None) -> torch.Tensor:
+    def __call__(self, inputs: torch.Tensor | None = None, mask=None, cache: list[BaseCache] | None = None,
+                 inputs_embeds: torch.Tensor | None = None) -> torch.Tensor:
         """Model.__call__ (language.py:199-210): inputs [1, L] -> logits [1, L, V] in the activation dtype,
-        lm_head on every position like the reference (the engine's fast path is `step`)."""
+        lm_head on every position like the reference (the engine's fast path is `step`).
+        inputs_embeds [1, L, hidden] replaces embed_tokens(inputs): the VLM text tower's entry
+        (models/intern/language.py:148-158, LanguageModel(None, cache=cache, inputs_embeds=...), intern/ensemble.py:108)."""
         if mask is not None:
             raise NotImplementedError("explicit masks are not supported: the causal mask of models/base.py:37-53 is implicit")
-        if inputs.dim() != 2 or inputs.shape[0] != 1:
-            raise ValueError("batch-1 path: inputs must be [1, L]")
+        if inputs is None and inputs_embeds is None:
+            raise ValueError("Either inputs or inputs_embeds must be provided")  # intern/language.py:188-189
         if cache is None:
             cache = self.make_cache()  # reference: cache=None means no caching; a throw-away cache is equivalent
-        ids = inputs.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
-        L = ids.numel()
-        self._sync_cache(cache, L)
-        out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
-        _ffi.check(_ffi.load().pie_decoder_prefill(self._dec, _ffi.p(ids), L, _ffi.p(out), _ffi.stream()))
+        lib = _ffi.load()
+        if inputs_embeds is not None:
+            emb = self._check_embeds(inputs_embeds)
+            L = emb.shape[0]
+            self._sync_cache(cache, L)
+            out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
+            _ffi.check(lib.pie_decoder_prefill_embeds(self._dec, _ffi.p(emb), L, _ffi.p(out), _ffi.stream()))
+        else:
+            if inputs.dim() != 2 or inputs.shape[0] != 1:
+                raise ValueError("batch-1 path: inputs must be [1, L]")
+            ids = inputs.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+            L = ids.numel()
+            self._sync_cache(cache, L)
+            out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
+            _ffi.check(lib.pie_decoder_prefill(self._dec, _ffi.p(ids), L, _ffi.p(out), _ffi.stream()))
         self._advance(cache, L)
         return out.unsqueeze(0)
+
+    def _check_embeds(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        emb = inputs_embeds
+        if emb.dim() == 3:
+            if emb.shape[0] != 1:
+                raise ValueError("batch-1 path: inputs_embeds must be [1, L, hidden]")
+            emb = emb[0]
+        if emb.dim() != 2 or emb.shape[1] != self.args.hidden_size or emb.shape[0] == 0:
+            raise ValueError(f"inputs_embeds must be [L, {self.args.hidden_size}]")
+        return emb.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def embed(self, ids: torch.Tensor) -> torch.Tensor:
+        """embed_tokens(ids) -> [L, hidden] (language.py:176; the VLM ensemble starts from it, intern/ensemble.py:46)."""
+        from ... import hip_ops
+        ids = ids.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+        if self.embed_tokens[1] is None:
+            return hip_ops.embedding_dense(ids, self.embed_tokens[0])
+        return hip_ops.embedding(ids, *self.embed_tokens, bits=self.bits)
+
+    def step_embeds(self, inputs_embeds: torch.Tensor, cache: list[BaseCache]):
+        """`step` for a prompt given as embeddings: forwards the rows, lm_head + tail on the last one only."""
+        emb = self._check_embeds(inputs_embeds)
+        L = emb.shape[0]
+        self._sync_cache(cache, L)
+        _ffi.check(_ffi.load().pie_decoder_prefill_embeds(self._dec, _ffi.p(emb), L, None, _ffi.stream()))
+        self._advance(cache, L)
+        pos = self._dev_offset
+        token = self.history[pos:pos + 1] if pos < self.history.numel() else self.token.clone()
+        return token, self.logprobs, self.logits
 
     def step(self, ids: torch.Tensor | None, cache: list[BaseCache], graph: bool = True):
         """Fast path of _inference (engine/inference_engine.py:252-271) for the greedy sampler without logits

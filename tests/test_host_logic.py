@@ -170,3 +170,18 @@ def test_reference_import_paths_resolve_to_the_same_modules():
     assert InferenceEngine is IE2 and pie_core.hello() == "pie_core \u2713"
     with pytest.raises(ImportError):
         importlib.import_module("proxy_inference_engine.server")       # the HTTP server is out of scope: absent, not stubbed
+
+
+def test_oracle_forward_from_input_embeddings_equals_forward_from_ids():
+    """`h = inputs_embeds` (models/intern/language.py:155-158): feeding the oracle the embedding rows of the ids must give
+    exactly the logits of feeding the ids."""
+    cfg = {"model_type": "llama", "hidden_size": 128, "num_hidden_layers": 2, "intermediate_size": 256, "num_attention_heads": 4,
+           "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 320, "rope_theta": 10000.0, "tie_word_embeddings": True,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=2, dtype="bfloat16")
+    orc = po.OracleLlama(cfg, w, "bfloat16")
+    ids = np.random.default_rng(0).integers(0, 320, 9)
+    a = orc.forward(ids, [po.OracleKVCache() for _ in orc.layers])
+    rows = po.dequantize(w["model.embed_tokens.weight"], w["model.embed_tokens.scales"], w["model.embed_tokens.biases"], dtype="bfloat16")[ids]
+    b = orc.forward(None, [po.OracleKVCache() for _ in orc.layers], inputs_embeds=rows)
+    assert np.array_equal(a, b)
