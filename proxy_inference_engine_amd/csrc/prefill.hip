@@ -251,7 +251,7 @@ int lt_init() {
 }
 
 // y[M, N] = x[M, K] . w[N, K]^T  (row-major T in, fp32 accumulate, T out).  Column-major view: Y'[N, M] = W'^T . X'.
-int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
+int gemm_xwt_impl(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_lt_mutex);
     int rc = lt_init();
     if (rc) return rc;
@@ -307,6 +307,11 @@ int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int
     return PIE_OK;
 }
 }  // namespace
+
+// also used by vision.hip (pie_linear)
+int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
+    return gemm_xwt_impl(dtype, x, w, y, M, N, K, st);
+}
 
 // ---------------------------------------------------------------- scratch
 struct PrefillScratch {

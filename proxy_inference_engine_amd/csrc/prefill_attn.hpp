@@ -37,6 +37,9 @@ struct PrefillAttnArgs {
     int M, Hq, Hkv;
     float scale;
     u16 *out;                            // [M, Hq, D]
+    // SEG instantiation (vision tower: block-diagonal, non-causal attention -- the mask of models/intern/vision.py:160-167):
+    // query row r attends keys [seg_lo[r], seg_hi[r]); both int32 [M], non-decreasing in r.  Op level only (k, v, cap = M).
+    const int *seg_lo, *seg_hi;
     const int *block_table;              // paged KV (nullable, decoder only): kv_table holds the layers' slab K / V bases; key t
     int n_pages;                         //   lives in page block_table[t / 64] (each [Hkv, 64, D]) at row t % 64
 };
@@ -72,7 +75,7 @@ __device__ __forceinline__ int pa_off(int row, int ch) {
 // QT: 32-row query tiles per workgroup (1 or 2).  With QT = 2 the workgroup has 2*REP waves -- waves [0, REP) own the first
 // tile, [REP, 2 REP) the second -- and one staged K/V block serves 64 query rows: half the L2 -> LDS traffic and barriers per
 // unit of work, at the same number of waves per CU (one 8-wave workgroup instead of two 4-wave ones for REP = 4).
-template <class T, int D, int REP, int QT>
+template <class T, int D, int REP, int QT, bool SEG = false>
 __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAttnArgs a) {
     constexpr int BK = 32, NT = REP * QT * 64, CH = D / 8, KS = D / 16, DT = D / 32;  // chunks per row, k-steps of Q.K^T, 32-dim output tiles
     constexpr int BM = 32 * QT;
@@ -93,7 +96,10 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
     const int row_mask = paged ? 63 : 0x7FFFFFFF;
     const size_t page_elems = (size_t)2 * 64 * a.Hkv * D;
     const int r_last = (wg_r0 + BM - 1 < a.M ? wg_r0 + BM - 1 : a.M - 1);
-    const int t_last = pos0 + r_last;            // last key any row of this tile attends
+    // last / first key any row of this tile attends (segment bounds are non-decreasing in the row index)
+    // (bounds clamped to the buffer: a bad segment table must not become a wild address)
+    const int t_last = SEG ? max(min(a.seg_hi[r_last], a.cap), 1) - 1 : pos0 + r_last;
+    const int b_first = SEG ? min(max(a.seg_lo[wg_r0], 0), t_last) / BK : 0;
     const int n_blocks = t_last / BK + 1;
     const u16 *kbase = (a.state ? reinterpret_cast<const u16 *>(a.kv_table[a.layer]) : a.k) + (size_t)g * cap * D;
     const u16 *vbase = (a.state ? reinterpret_cast<const u16 *>(a.kv_table[a.n_layers + a.layer]) : a.v) + (size_t)g * cap * D;
@@ -131,14 +137,16 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
 #undef PA_FETCH1
 #undef PA_PUBLISH1
     static_assert(CPT <= 8, "staging registers");
-    fetch(0);
+    fetch(b_first);
 
     // Q fragments (B operand of K . Q^T): lane (row c, half h), k-step s holds Q[r0 + c][hq][16 s + 8 h .. + 8]
     const int qrow = r0 + c < a.M ? r0 + c : a.M - 1;
     uint4 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const uint4 *>(a.q + ((size_t)qrow * a.Hq + hq) * D + 16 * s + 8 * h);
-    const int t_row = pos0 + r0 + c;  // last key this lane's query row attends (rows past M are padding: never stored)
+    // last (and, SEG, first) key this lane's query row attends (rows past M are padding: never stored)
+    const int t_row = SEG ? a.seg_hi[qrow] - 1 : pos0 + r0 + c;
+    const int t_lo = SEG ? a.seg_lo[qrow] : 0;
     const float sl2 = a.scale * ATTN_LOG2E;
 
     f32x16_t oacc[DT];
@@ -152,7 +160,7 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
     // 4-row x 16-column block; lane i of the group receives column i, row q in element q
     const int grp = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 
-    for (int b = 0; b < n_blocks; ++b) {
+    for (int b = b_first; b < n_blocks; ++b) {
         __syncthreads();  // every wave is done reading the previous block's image
         publish();
         __syncthreads();
@@ -173,7 +181,7 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int t = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            sc[i] = t <= t_row ? sacc[i] * sl2 : ATTN_NEG;
+            sc[i] = (t <= t_row && (!SEG || t >= t_lo)) ? sacc[i] * sl2 : ATTN_NEG;
             mloc = fmaxf(mloc, sc[i]);
         }
         mloc = xor32_max(mloc);  // the other 16 keys of the block live in the partner lane
@@ -191,8 +199,8 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int ta = t0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float pa = ta <= t_row ? attn_exp2(sc[i] - m_run) : 0.0f;
-            const float pb = ta + 1 <= t_row ? attn_exp2(sc[i + 1] - m_run) : 0.0f;
+            const float pa = (ta <= t_row && (!SEG || ta >= t_lo)) ? attn_exp2(sc[i] - m_run) : 0.0f;
+            const float pb = (ta + 1 <= t_row && (!SEG || ta + 1 >= t_lo)) ? attn_exp2(sc[i + 1] - m_run) : 0.0f;
             l_run += pa + pb;
             const float ha = round_T<T>(pa), hb = round_T<T>(pb);
             phi[i >> 1] = pack2<T>(ha, hb);
@@ -259,6 +267,23 @@ static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
+// block-diagonal attention (SEG): multi-head only (Hq == Hkv, the vision tower), two query tiles per workgroup while the
+// halved grid still fills the chip
+template <class T, int D>
+static int segment_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
+    if (a.Hq != a.Hkv) return pie::fail(PIE_E_SHAPE, "segment attention: n_heads must equal n_kv_heads");
+    const bool two = a.M > 32 && ((a.M + 63) / 64) * a.Hkv >= 512;
+    const dim3 grid(((a.M + (two ? 63 : 31)) / (two ? 64 : 32)) * a.Hkv);
+    if (two) hipLaunchKernelGGL((k_prefill_attn<T, D, 1, 2, true>), grid, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((k_prefill_attn<T, D, 1, 1, true>), grid, dim3(64), 0, st, a);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+template <class T>
+static int segment_attn_launch_t(const PrefillAttnArgs &a, int D, hipStream_t st) {
+    return D == 128 ? segment_attn_launch_d<T, 128>(a, st) : segment_attn_launch_d<T, 64>(a, st);
+}
+
 template <class T>
 static int prefill_attn_launch_t(const PrefillAttnArgs &a, int D, hipStream_t st) {
     return D == 128 ? prefill_attn_launch_d<T, 128>(a, st) : prefill_attn_launch_d<T, 64>(a, st);

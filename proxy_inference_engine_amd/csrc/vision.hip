@@ -1,0 +1,132 @@
+// vision.hip -- op-level kernels of the Qwen2.5-VL vision tower (reference models/intern/vision.py:87-442).
+//
+// The tower is dense 16-bit GEMMs (hipBLASLt, through prefill.hip's gemm_xwt: MFMA-bound, 1 k-4 k rows) plus four hand-written
+// pieces: the rotate-half rotary embedding with per-patch (row, column) angles fused with the q / k / v re-layout the attention
+// kernel wants, block-diagonal non-causal attention on the MFMA units (prefill_attn.hpp, SEG instantiation: full-image and
+// 64-patch-window layers are the same kernel with different segment tables), bias add for any column count, and erf-GELU.
+// RMSNorm, SiLU*up and residual adds are the ops the text tower already has (ops.hip).
+#include "prefill_attn.hpp"
+
+int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st);  // prefill.hip
+
+// y[m, n] = T(y[m, n] + b[n]), any N (two columns per thread; rows of odd length end in a single column)
+template <class T>
+__global__ void k_bias_any(u16 *y, const u16 *b, int M, int N) {
+    const int n2 = (N + 1) >> 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * n2) return;
+    const int m = (int)(i / n2), n = (int)(i % n2) * 2;
+    u16 *p = y + (size_t)m * N + n;
+    p[0] = T::from_f32(T::to_f32(p[0]) + T::to_f32(b[n]));
+    if (n + 1 < N) p[1] = T::from_f32(T::to_f32(p[1]) + T::to_f32(b[n + 1]));
+}
+
+// nn.GELU() (exact): x * (1 + erf(x / sqrt 2)) / 2  (PatchMerger.mlp[1], vision.py:130)
+template <class T>
+__global__ void k_gelu(const u16 *x, size_t n, u16 *y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = T::to_f32(x[i]);
+    y[i] = T::from_f32(v * (1.0f + erff(v * 0.70710678118654752440f)) * 0.5f);
+}
+
+// Attention.__call__, vision.py:152-158 + the layout step: qkv [N, 3, H, D] (the qkv Linear's output) ->
+//   q [N, H, DP] = rope(q), k [H, N, DP] = rope(k), v [H, N, DP] = v, head dims D..DP-1 zero (DP = 64 or 128: the MFMA
+//   attention's head sizes; zero columns change neither the scores nor the output's first D dims).
+// rope = apply_rotary_pos_emb_vision (vision.py:55-70): x * cos + rotate_half(x) * sin in fp32, one rounding;
+// cos / sin fp32 [N, D/2] (the row's angles, tiled twice over the head dim).  One thread per (row, head, pair d < D/2).
+template <class T>
+__global__ void k_vision_qkv_rope(const u16 *qkv, const float *cs, const float *sn, int N, int H, int D, int DP, u16 *q, u16 *k, u16 *v) {
+    const int half = D >> 1, hp = DP >> 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * H * hp) return;
+    const int d = (int)(i % hp), hh = (int)((i / hp) % H), n = (int)(i / ((size_t)hp * H));
+    u16 *qo = q + ((size_t)n * H + hh) * DP, *ko = k + ((size_t)hh * N + n) * DP, *vo = v + ((size_t)hh * N + n) * DP;
+    if (d >= half) {  // padding pairs: columns D + 2 (d - half), + 1
+        const int c0 = D + 2 * (d - half);
+        if (c0 + 1 < DP) qo[c0] = qo[c0 + 1] = ko[c0] = ko[c0 + 1] = vo[c0] = vo[c0 + 1] = 0;
+        return;
+    }
+    const u16 *row = qkv + (size_t)n * 3 * H * D + (size_t)hh * D;
+    const float c = cs[(size_t)n * half + d], s = sn[(size_t)n * half + d];
+    {
+        const float a = T::to_f32(row[d]), b = T::to_f32(row[d + half]);
+        qo[d] = T::from_f32(__fadd_rn(__fmul_rn(a, c), __fmul_rn(-b, s)));
+        qo[d + half] = T::from_f32(__fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s)));
+    }
+    {
+        const u16 *kr = row + (size_t)H * D;
+        const float a = T::to_f32(kr[d]), b = T::to_f32(kr[d + half]);
+        ko[d] = T::from_f32(__fadd_rn(__fmul_rn(a, c), __fmul_rn(-b, s)));
+        ko[d + half] = T::from_f32(__fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s)));
+    }
+    const u16 *vr = row + (size_t)2 * H * D;
+    vo[d] = vr[d], vo[d + half] = vr[d + half];
+}
+
+template <class F16F, class BF16F>
+static int by_dt(int dtype, F16F &&f16, BF16F &&bf16, const char *who) {
+    if (dtype == PIE_F16) f16();
+    else if (dtype == PIE_BF16) bf16();
+    else return pie::fail(PIE_E_ARG, std::string(who) + ": dtype must be PIE_BF16 or PIE_F16");
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+extern "C" {
+
+int pie_linear(const void *x, const void *w, const void *bias, int M, int N, int K, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && w && y, PIE_E_ARG, "pie_linear: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0 && K > 0, PIE_E_SHAPE, "pie_linear: empty operand");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_linear: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(w, 16) && pie_aligned(y, 16), PIE_E_ALIGN, "pie_linear: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = gemm_xwt(dtype, x, w, y, M, N, K, st);
+    if (rc || !bias) return rc;
+    const size_t n = (size_t)M * ((N + 1) >> 1);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype, [&] { hipLaunchKernelGGL(k_bias_any<F16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); },
+        [&] { hipLaunchKernelGGL(k_bias_any<BF16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); }, "pie_linear");
+}
+
+int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && y, PIE_E_ARG, "pie_gelu: null pointer");
+    PIE_REQUIRE(n > 0, PIE_E_SHAPE, "pie_gelu: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype, [&] { hipLaunchKernelGGL(k_gelu<F16>, grid, block, 0, st, (const u16 *)x, n, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_gelu<BF16>, grid, block, 0, st, (const u16 *)x, n, (u16 *)y); }, "pie_gelu");
+}
+
+int pie_vision_qkv_rope(const void *qkv, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype, void *q, void *k,
+                        void *v, void *stream) {
+    PIE_REQUIRE(qkv && cos_t && sin_t && q && k && v, PIE_E_ARG, "pie_vision_qkv_rope: null pointer");
+    PIE_REQUIRE(N > 0 && H > 0 && D > 0 && D % 2 == 0 && (DP == 64 || DP == 128) && D <= DP, PIE_E_SHAPE,
+                "pie_vision_qkv_rope: head_dim must be even and fit the padded size 64 or 128");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)N * H * (DP / 2);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype,
+        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<F16>, grid, block, 0, st, (const u16 *)qkv, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<BF16>, grid, block, 0, st, (const u16 *)qkv, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+        "pie_vision_qkv_rope");
+}
+
+int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D, float scale,
+                      int dtype, void *out, void *stream) {
+    PIE_REQUIRE(q && k && v && seg_lo && seg_hi && out, PIE_E_ARG, "pie_sdpa_segments: null pointer");
+    PIE_REQUIRE(N > 0 && H > 0 && (D == 64 || D == 128), PIE_E_SHAPE, "pie_sdpa_segments: head_dim must be 64 or 128");
+    PIE_REQUIRE(pie_aligned(q, 16) && pie_aligned(k, 16) && pie_aligned(v, 16) && pie_aligned(out, 8), PIE_E_ALIGN, "pie_sdpa_segments: misaligned pointer");
+    PrefillAttnArgs a = {};
+    a.q = (const u16 *)q, a.k = (const u16 *)k, a.v = (const u16 *)v, a.offset = 0, a.cap = N;
+    a.seg_lo = seg_lo, a.seg_hi = seg_hi;
+    a.M = N, a.Hq = H, a.Hkv = H, a.scale = scale, a.out = (u16 *)out;
+    if (dtype == PIE_BF16) return segment_attn_launch_t<BF16>(a, D, (hipStream_t)stream);
+    if (dtype == PIE_F16) return segment_attn_launch_t<F16>(a, D, (hipStream_t)stream);
+    return pie::fail(PIE_E_ARG, "pie_sdpa_segments: dtype must be PIE_BF16 or PIE_F16");
+}
+
+}  // extern "C"

@@ -358,3 +358,79 @@ def gateup_row_map(inter: int) -> torch.Tensor:
     arr = (C.c_int32 * (2 * inter))()
     _ffi.check(_ffi.load().pie_gateup_row_map(inter, arr))
     return torch.tensor(list(arr), dtype=torch.int32)
+
+
+# ---------------------------------------------------------------------------- vision tower ops
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """nn.Linear on a block of rows: x [M, K] @ weight [N, K].T (+ bias [N]) -> [M, N]; dense 16-bit weights, hipBLASLt GEMM
+    with fp32 accumulation (models/intern/vision.py:150-151,192-194,129-133; PatchEmbed's Conv3d with stride = kernel is the
+    same product over flattened patches, vision.py:97-121)."""
+    _dev(x), _dev(weight)
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.dtype != weight.dtype:
+        raise ValueError("linear_rows: x [M, K], weight [N, K] of one dtype")
+    if bias is not None and (bias.shape != (weight.shape[0],) or bias.dtype != x.dtype):
+        raise ValueError("linear_rows: bias must be [N] in the activation dtype")
+    x, weight = x.contiguous(), weight.contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _ffi.check(_ffi.load().pie_linear(_ffi.p(x), _ffi.p(weight), _ffi.p(bias.contiguous() if bias is not None else None), M, N, K,
+                                      _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    """nn.GELU() (exact erf form; PatchMerger, vision.py:130)."""
+    _dev(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _ffi.check(_ffi.load().pie_gelu(_ffi.p(x), x.numel(), _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def vision_qkv_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int, padded_head_dim: int | None = None):
+    """qkv [N, 3 * H * D] (the qkv Linear's output, vision.py:152-156) -> (q [N, H, DP], k [H, N, DP], v [H, N, DP]) with
+    apply_rotary_pos_emb_vision (vision.py:55-70) on q and k; cos / sin fp32 [N, D/2]; head dims D..DP-1 are zero."""
+    _dev(qkv), _dev(cos), _dev(sin)
+    N = qkv.shape[0]
+    D = qkv.shape[1] // (3 * num_heads)
+    if qkv.dim() != 2 or qkv.shape[1] != 3 * num_heads * D or D % 2:
+        raise ValueError("vision_qkv_rope: qkv must be [N, 3 * H * D] with even D")
+    DP = padded_head_dim or (64 if D <= 64 else 128)
+    if cos.shape != (N, D // 2) or sin.shape != (N, D // 2) or cos.dtype != torch.float32 or sin.dtype != torch.float32:
+        raise ValueError("vision_qkv_rope: cos / sin must be float32 [N, D/2]")
+    q = torch.empty((N, num_heads, DP), dtype=qkv.dtype, device=qkv.device)
+    k = torch.empty((num_heads, N, DP), dtype=qkv.dtype, device=qkv.device)
+    v = torch.empty((num_heads, N, DP), dtype=qkv.dtype, device=qkv.device)
+    _ffi.check(_ffi.load().pie_vision_qkv_rope(_ffi.p(qkv.contiguous()), _ffi.p(cos.contiguous()), _ffi.p(sin.contiguous()), N, num_heads, D, DP,
+                                               _ffi.dtype_code(qkv.dtype), _ffi.p(q), _ffi.p(k), _ffi.p(v), _ffi.stream()))
+    return q, k, v
+
+
+def segment_bounds(cu_seqlens, device) -> tuple[torch.Tensor, torch.Tensor]:
+    """cu_seqlens (host ints, [0, ..., N]) -> per-row key ranges (seg_lo, seg_hi) int32 [N] on the device: the 0 blocks of the
+    additive mask vision.py:160-167 builds."""
+    import numpy as np
+    cu = np.asarray([int(c) for c in cu_seqlens], dtype=np.int64)
+    if cu.size < 2 or cu[0] != 0 or np.any(np.diff(cu) < 0):
+        raise ValueError("cu_seqlens must start at 0 and be non-decreasing")
+    lens = np.diff(cu)
+    lo = np.repeat(cu[:-1], lens).astype(np.int32)
+    hi = np.repeat(cu[1:], lens).astype(np.int32)
+    return torch.from_numpy(lo).to(device), torch.from_numpy(hi).to(device)
+
+
+def sdpa_segments(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seg_lo: torch.Tensor, seg_hi: torch.Tensor, scale: float) -> torch.Tensor:
+    """mx.fast.scaled_dot_product_attention with the block-diagonal mask of vision.py:160-176: q [N, H, D], k / v [H, N, D]
+    (D = 64 or 128), row r attends keys [seg_lo[r], seg_hi[r]) -> [N, H, D]."""
+    for t in (q, k, v, seg_lo, seg_hi):
+        _dev(t)
+    N, H, D = q.shape
+    if k.shape != (H, N, D) or v.shape != (H, N, D) or seg_lo.shape != (N,) or seg_hi.shape != (N,):
+        raise ValueError("sdpa_segments: q [N, H, D]; k, v [H, N, D]; seg_lo, seg_hi [N]")
+    if seg_lo.dtype != torch.int32 or seg_hi.dtype != torch.int32:
+        raise TypeError("segment bounds must be int32")
+    out = torch.empty_like(q)
+    _ffi.check(_ffi.load().pie_sdpa_segments(_ffi.p(q.contiguous()), _ffi.p(k.contiguous()), _ffi.p(v.contiguous()), _ffi.p(seg_lo), _ffi.p(seg_hi),
+                                             N, H, D, float(scale), _ffi.dtype_code(q.dtype), _ffi.p(out), _ffi.stream()))
+    return out

@@ -1,0 +1,148 @@
+"""-m gpu: the vision tower -- its four op-level kernels and the whole Qwen2.5-VL tower on the HIP ops
+against oracle/vision_oracle.py (the CPU restatement of models/intern/vision.py), then tower -> ensemble -> text tower."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pie_oracle as po
+from oracle import vision_oracle as vo
+from tests._util import assert_bits_close, assert_dot_close, assert_vec_close, to_bits, to_dev
+
+pytestmark = pytest.mark.gpu
+DT = "bfloat16"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from proxy_inference_engine_amd import hip_ops
+    return hip_ops
+
+
+def dev(x, dt=DT):
+    return to_dev(po.to_bits(x, dt), dt)
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K,bias", [(92, 480, 160, True), (23, 96, 640, True), (64, 214, 1176, False), (130, 160, 212, True), (1, 7, 64, True)])
+def test_linear_rows_vs_oracle(ops, dt, M, N, K, bias):
+    rng = np.random.default_rng(M + N)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    w = po.round_T(rng.standard_normal((N, K)) / np.sqrt(K), dt)
+    b = po.round_T(rng.standard_normal(N) * 0.5, dt) if bias else None
+    want = po.linear(x, po.to_bits(w, dt), dt, po.to_bits(b, dt) if bias else None)
+    got = ops.linear_rows(dev(x, dt), dev(w, dt), dev(b, dt) if bias else None)
+    assert got.shape == (M, N)
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, mag=np.abs(want).max() if bias else None, what=f"linear {M}x{N}x{K} {dt}")
+
+
+def test_gelu_vs_oracle(ops):
+    x = po.round_T(np.random.default_rng(0).standard_normal(5003) * 3, DT)
+    assert_bits_close(to_bits(ops.gelu(dev(x))), po.to_bits(vo.gelu(x, DT), DT), max_ulp=1, what="gelu")
+
+
+@pytest.mark.parametrize("D,DP", [(80, 128), (64, 64), (32, 64), (128, 128)])
+def test_vision_qkv_rope_layout_and_values(ops, D, DP):
+    rng = np.random.default_rng(D)
+    N, H = 37, 3
+    qkv = po.round_T(rng.standard_normal((N, 3, H, D)), DT)
+    ang = (rng.standard_normal((N, D // 2)) * 3).astype(np.float32)
+    q, k, v = ops.vision_qkv_rope(dev(qkv).view(N, -1), torch.from_numpy(np.cos(ang)).cuda(), torch.from_numpy(np.sin(ang)).cuda(), H, DP)
+    assert q.shape == (N, H, DP) and k.shape == (H, N, DP) and v.shape == (H, N, DP)
+    wq, wk = vo.rope_vision(qkv[:, 0], ang, DT), vo.rope_vision(qkv[:, 1], ang, DT)
+    assert np.array_equal(to_bits(q[..., :D]), po.to_bits(wq, DT))
+    assert np.array_equal(to_bits(k[..., :D]), po.to_bits(wk.transpose(1, 0, 2), DT))
+    assert np.array_equal(to_bits(v[..., :D]), po.to_bits(qkv[:, 2].transpose(1, 0, 2), DT))
+    for t in (q, k, v):
+        assert not to_bits(t[..., D:]).any(), "padding columns must be zero"
+
+
+def _mask(cu, N, dt):
+    m = np.full((N, N), vo.finfo_min(dt), np.float32)
+    for i in range(1, len(cu)):
+        m[cu[i - 1]:cu[i], cu[i - 1]:cu[i]] = 0.0
+    return m
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("H,D,cu", [
+    (2, 64, [0, 64, 128, 192]),                       # windows aligned with the 32-row tiles
+    (3, 128, [0, 40, 44, 108, 109, 300]),            # ragged: tiles span several segments, a 1-row and a 4-row segment
+    (16, 128, [0, 1024]),                            # one full-image segment (two query tiles per workgroup)
+    (4, 64, [0, 16, 48, 112, 176, 180, 436, 500]),
+])
+def test_sdpa_segments_vs_oracle(ops, dt, H, D, cu):
+    rng = np.random.default_rng(H * D + len(cu))
+    N = cu[-1]
+    q = po.round_T(rng.standard_normal((N, H, D)), dt)
+    k = po.round_T(rng.standard_normal((H, N, D)), dt)
+    v = po.round_T(rng.standard_normal((H, N, D)), dt)
+    lo, hi = ops.segment_bounds(cu, "cuda")
+    got = ops.sdpa_segments(dev(q, dt), dev(k, dt), dev(v, dt), lo, hi, D ** -0.5)
+    want = po.sdpa(np.ascontiguousarray(q.transpose(1, 0, 2)), k, v, D ** -0.5, _mask(cu, N, dt), dt, True).transpose(1, 0, 2)
+    assert_dot_close(got.float().cpu().numpy(), po.round_T(want, dt), dt, max_frac=0.05, what=f"segments H{H} D{D} {dt}")
+
+
+def _tower(cfg, seed, dt=DT):
+    from proxy_inference_engine_amd.models.intern.vision import VisionConfig, VisionModel
+    w = vo.synth_vision_checkpoint(cfg, seed, dt)
+    tw = {k: to_dev(v, dt) for k, v in w.items()}
+    return w, VisionModel(VisionConfig(**cfg), tw, dtype=torch.bfloat16 if dt == "bfloat16" else torch.float16)
+
+
+CFG80 = dict(depth=3, hidden_size=160, intermediate_size=212, out_hidden_size=96, num_heads=2, patch_size=14, in_channels=3,
+             spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])      # head_dim 80, like the 7B tower
+CFG64 = dict(CFG80, hidden_size=128, intermediate_size=344, num_heads=2, fullatt_block_indexes=[0, 2])     # head_dim 64, no padding
+
+
+@pytest.mark.parametrize("cfg,grid", [(CFG80, [(1, 6, 10), (2, 4, 4)]), (CFG64, [(1, 16, 12)]), (CFG80, [(1, 2, 2)])])
+def test_vision_tower_vs_oracle(cfg, grid):
+    w, model = _tower(cfg, seed=4)
+    N = sum(t * h * ww for t, h, ww in grid)
+    pix = po.round_T(np.random.default_rng(7).standard_normal((N, 3 * 2 * 14 * 14)), DT)
+    want, states = vo.vision_forward(cfg, w, pix, grid, DT, want_states=True)
+    got_states = []
+    got = model(dev(pix), torch.tensor(grid), output_hidden_states=False)
+    assert got.shape == (N // 4, cfg["out_hidden_size"])
+    assert_vec_close(got.float().cpu().numpy(), want, DT, c_max=6.0, c_rms=5.0, what=f"tower output {grid}")
+
+
+def test_vision_tower_mlx_ordered_conv_weight_and_errors():
+    from proxy_inference_engine_amd.models.intern.vision import VisionConfig, VisionModel
+    w = vo.synth_vision_checkpoint(CFG80, 1, DT)
+    tw = {k: to_dev(v, DT) for k, v in w.items()}
+    a = VisionModel(VisionConfig(**CFG80), tw)
+    tw2 = dict(tw)
+    tw2["vision_tower.patch_embed.proj.weight"] = tw["vision_tower.patch_embed.proj.weight"].permute(0, 2, 3, 4, 1).contiguous()   # MLX order
+    b = VisionModel(VisionConfig(**CFG80), tw2)
+    assert torch.equal(a.patch_w, b.patch_w)
+    with pytest.raises(ValueError, match="grid_thw must be provided"):
+        a(torch.zeros(4, 1176, device="cuda"))
+    with pytest.raises(ValueError, match="do not match"):
+        a(torch.zeros(5, 1176, device="cuda"), [(1, 2, 2)])
+
+
+def test_image_to_text_logits_end_to_end():
+    """pixels -> vision tower -> image-token scatter -> text tower, all on the device, against the two oracles chained."""
+    from proxy_inference_engine_amd.models.intern import Model as Ensemble, ModelArgs as EnsembleArgs
+    from tests.test_gpu_decode import build
+    tcfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2, "intermediate_size": 704, "num_attention_heads": 4,
+            "num_key_value_heads": 2, "rms_norm_eps": 1e-6, "vocab_size": 512, "rope_theta": 1000000.0, "tie_word_embeddings": False,
+            "attention_bias": True, "quantization": {"group_size": 64, "bits": 4}}
+    vcfg = dict(CFG80, out_hidden_size=256, depth=2)
+    tw = po.synth_checkpoint(tcfg, seed=3, dtype=DT, lm_head_gain=4.0)
+    lm = build(tcfg, tw, DT)
+    vw, tower = _tower(vcfg, seed=6)
+    grid = [(1, 4, 6)]
+    n_img = 4 * 6 // 4
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([rng.integers(10, 500, 5), np.full(n_img, 7), rng.integers(10, 500, 4)]).astype(np.int64)
+    pix = po.round_T(rng.standard_normal((24, 1176)), DT)
+    ens = Ensemble(EnsembleArgs(image_token_id=7, video_token_id=8), lm, vision_tower=tower)
+    logits = ens(torch.from_numpy(ids)[None].cuda(), pixel_values=dev(pix), image_grid_thw=torch.tensor(grid))
+    feats = vo.vision_forward(vcfg, vw, pix, grid, DT)
+    table = po.dequantize(tw["model.embed_tokens.weight"], tw["model.embed_tokens.scales"], tw["model.embed_tokens.biases"], dtype=DT)[ids].copy()
+    table[ids == 7] = feats
+    orc = po.OracleLlama(tcfg, tw, DT)
+    want = orc.forward(None, [po.OracleKVCache() for _ in orc.layers], inputs_embeds=table)
+    # the image rows carry the tower's own rounding noise into the text tower: one more factor on the end-to-end bound
+    assert_vec_close(logits[0, -1].float().cpu().numpy(), want[-1], DT, c_max=8.0, c_rms=6.0, what="image -> text logits")
