@@ -297,15 +297,20 @@ int pie_paged_kv_append(const void *k, const void *v, void *slab, size_t n_pages
  * pie_linear: nn.Linear on M rows -- y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]), T in, fp32 accumulate, T out (rounded
  *   before the bias is added, like the text tower's Linear); hipBLASLt (PIE_E_STATE if it cannot be loaded).
  * pie_gelu: nn.GELU() exact form, fp32 inside, one rounding.
- * pie_vision_qkv_rope: qkv T [N, 3, H, D] -> q T [N, H, DP], k, v T [H, N, DP] with rotate-half rotary on q and k
+ * pie_vision_qkv_rope: qkv T [N, 3, H, D] (+ optional bias T [3 * H * D], the qkv Linear's) -> q T [N, H, DP], k, v T [H, N, DP] with rotate-half rotary on q and k
  *   (apply_rotary_pos_emb_vision, vision.py:55-70; cos / sin fp32 [N, D/2] = the row's angles) and head dims D..DP-1 zeroed
  *   (DP = 64 or 128, the attention kernel's head sizes).
  * pie_sdpa_segments: block-diagonal non-causal attention, the mask of vision.py:160-167: query row r attends keys
  *   [seg_lo[r], seg_hi[r]) (device int32 [N], non-decreasing, lo <= r < hi).  q, out T [N, H, D]; k, v T [H, N, D]. */
 int pie_linear(const void *x, const void *w, const void *bias, int M, int N, int K, int dtype, void *y, void *stream);
 int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream);
-int pie_vision_qkv_rope(const void *qkv, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype, void *q, void *k,
-                        void *v, void *stream);
+int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype,
+                        void *q, void *k, void *v, void *stream);
+/* Bias adds folded into the op that consumes the GEMM output (same values as pie_linear with a bias followed by the op):
+ * pie_bias_silu_mul: y = silu(gate + bias_gate) * (up + bias_up), T [M, N] (MLP, vision.py:196-197);
+ * pie_add_bias: y = x + (r + bias), T [M, N] (the residual adds of vision.py:212-218). */
+int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int dtype, void *y, void *stream);
+int pie_add_bias(const void *x, const void *r, const void *bias, int M, int N, int dtype, void *y, void *stream);
 int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D,
                       float scale, int dtype, void *out, void *stream);
 

@@ -35,8 +35,11 @@ __global__ void k_gelu(const u16 *x, size_t n, u16 *y) {
 //   attention's head sizes; zero columns change neither the scores nor the output's first D dims).
 // rope = apply_rotary_pos_emb_vision (vision.py:55-70): x * cos + rotate_half(x) * sin in fp32, one rounding;
 // cos / sin fp32 [N, D/2] (the row's angles, tiled twice over the head dim).  One thread per (row, head, pair d < D/2).
+// `bias` (nullable, [3 * H * D]): the qkv Linear's bias, added here -- T(x + b), the Linear's own rounding -- instead of in a pass
+// of its own over the GEMM output.
 template <class T>
-__global__ void k_vision_qkv_rope(const u16 *qkv, const float *cs, const float *sn, int N, int H, int D, int DP, u16 *q, u16 *k, u16 *v) {
+__global__ void k_vision_qkv_rope(const u16 *qkv, const u16 *bias, const float *cs, const float *sn, int N, int H, int D, int DP, u16 *q, u16 *k,
+                                  u16 *v) {
     const int half = D >> 1, hp = DP >> 1;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * H * hp) return;
@@ -48,20 +51,54 @@ __global__ void k_vision_qkv_rope(const u16 *qkv, const float *cs, const float *
         return;
     }
     const u16 *row = qkv + (size_t)n * 3 * H * D + (size_t)hh * D;
+    const u16 *brow = bias ? bias + (size_t)hh * D : nullptr;
+    auto ld = [&](int part, int col) {  // element `col` of this head's q (0) / k (1) / v (2) row, bias applied
+        const float x = T::to_f32(row[(size_t)part * H * D + col]);
+        return brow ? round_T<T>(x + T::to_f32(brow[(size_t)part * H * D + col])) : x;
+    };
     const float c = cs[(size_t)n * half + d], s = sn[(size_t)n * half + d];
     {
-        const float a = T::to_f32(row[d]), b = T::to_f32(row[d + half]);
+        const float a = ld(0, d), b = ld(0, d + half);
         qo[d] = T::from_f32(__fadd_rn(__fmul_rn(a, c), __fmul_rn(-b, s)));
         qo[d + half] = T::from_f32(__fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s)));
     }
     {
-        const u16 *kr = row + (size_t)H * D;
-        const float a = T::to_f32(kr[d]), b = T::to_f32(kr[d + half]);
+        const float a = ld(1, d), b = ld(1, d + half);
         ko[d] = T::from_f32(__fadd_rn(__fmul_rn(a, c), __fmul_rn(-b, s)));
         ko[d + half] = T::from_f32(__fadd_rn(__fmul_rn(b, c), __fmul_rn(a, s)));
     }
-    const u16 *vr = row + (size_t)2 * H * D;
-    vo[d] = vr[d], vo[d + half] = vr[d + half];
+    vo[d] = T::from_f32(ld(2, d)), vo[d + half] = T::from_f32(ld(2, d + half));
+}
+
+// MLP.__call__ (vision.py:196-197) between the GEMMs: act = T(T(silu(T(g + bg))) * T(u + bu)); two columns per thread.
+template <class T>
+__global__ void k_bias_silu_mul(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, u16 *y) {
+    const int n2 = (N + 1) >> 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * n2) return;
+    const int n = (int)(i % n2) * 2;
+    const size_t o = (i / n2) * (size_t)N + n;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (n + j >= N) break;
+        const float gv = round_T<T>(T::to_f32(g[o + j]) + T::to_f32(bg[n + j])), uv = round_T<T>(T::to_f32(u[o + j]) + T::to_f32(bu[n + j]));
+        y[o + j] = T::from_f32(round_T<T>(gv / (1.0f + expf(-gv))) * uv);
+    }
+}
+
+// hidden_states + Linear(...) (vision.py:212-218) with the Linear's bias folded in: y = T(x + T(r + b)).
+template <class T>
+__global__ void k_add_bias(const u16 *x, const u16 *r, const u16 *b, int M, int N, u16 *y) {
+    const int n2 = (N + 1) >> 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * n2) return;
+    const int n = (int)(i % n2) * 2;
+    const size_t o = (i / n2) * (size_t)N + n;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (n + j >= N) break;
+        y[o + j] = T::from_f32(T::to_f32(x[o + j]) + round_T<T>(T::to_f32(r[o + j]) + T::to_f32(b[n + j])));
+    }
 }
 
 template <class F16F, class BF16F>
@@ -100,8 +137,8 @@ int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream) {
         [&] { hipLaunchKernelGGL(k_gelu<BF16>, grid, block, 0, st, (const u16 *)x, n, (u16 *)y); }, "pie_gelu");
 }
 
-int pie_vision_qkv_rope(const void *qkv, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype, void *q, void *k,
-                        void *v, void *stream) {
+int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype, void *q,
+                        void *k, void *v, void *stream) {
     PIE_REQUIRE(qkv && cos_t && sin_t && q && k && v, PIE_E_ARG, "pie_vision_qkv_rope: null pointer");
     PIE_REQUIRE(N > 0 && H > 0 && D > 0 && D % 2 == 0 && (DP == 64 || DP == 128) && D <= DP, PIE_E_SHAPE,
                 "pie_vision_qkv_rope: head_dim must be even and fit the padded size 64 or 128");
@@ -110,9 +147,33 @@ int pie_vision_qkv_rope(const void *qkv, const float *cos_t, const float *sin_t,
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     return by_dt(
         dtype,
-        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<F16>, grid, block, 0, st, (const u16 *)qkv, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
-        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<BF16>, grid, block, 0, st, (const u16 *)qkv, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<F16>, grid, block, 0, st, (const u16 *)qkv, (const u16 *)bias, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+        [&] { hipLaunchKernelGGL(k_vision_qkv_rope<BF16>, grid, block, 0, st, (const u16 *)qkv, (const u16 *)bias, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
         "pie_vision_qkv_rope");
+}
+
+int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(gate && up && bias_gate && bias_up && y, PIE_E_ARG, "pie_bias_silu_mul: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0, PIE_E_SHAPE, "pie_bias_silu_mul: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)M * ((N + 1) >> 1);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype,
+        [&] { hipLaunchKernelGGL(k_bias_silu_mul<F16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_bias_silu_mul<BF16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+        "pie_bias_silu_mul");
+}
+
+int pie_add_bias(const void *x, const void *r, const void *bias, int M, int N, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && r && bias && y, PIE_E_ARG, "pie_add_bias: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0, PIE_E_SHAPE, "pie_add_bias: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)M * ((N + 1) >> 1);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype, [&] { hipLaunchKernelGGL(k_add_bias<F16>, grid, block, 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, M, N, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_add_bias<BF16>, grid, block, 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, M, N, (u16 *)y); }, "pie_add_bias");
 }
 
 int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D, float scale,

@@ -388,9 +388,11 @@ def gelu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def vision_qkv_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int, padded_head_dim: int | None = None):
+def vision_qkv_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num_heads: int, padded_head_dim: int | None = None,
+                    bias: torch.Tensor | None = None):
     """qkv [N, 3 * H * D] (the qkv Linear's output, vision.py:152-156) -> (q [N, H, DP], k [H, N, DP], v [H, N, DP]) with
-    apply_rotary_pos_emb_vision (vision.py:55-70) on q and k; cos / sin fp32 [N, D/2]; head dims D..DP-1 are zero."""
+    apply_rotary_pos_emb_vision (vision.py:55-70) on q and k; cos / sin fp32 [N, D/2]; head dims D..DP-1 are zero.
+    bias [3 * H * D]: the qkv Linear's bias when the GEMM was run without it (added here, same values)."""
     _dev(qkv), _dev(cos), _dev(sin)
     N = qkv.shape[0]
     D = qkv.shape[1] // (3 * num_heads)
@@ -402,7 +404,9 @@ def vision_qkv_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, num
     q = torch.empty((N, num_heads, DP), dtype=qkv.dtype, device=qkv.device)
     k = torch.empty((num_heads, N, DP), dtype=qkv.dtype, device=qkv.device)
     v = torch.empty((num_heads, N, DP), dtype=qkv.dtype, device=qkv.device)
-    _ffi.check(_ffi.load().pie_vision_qkv_rope(_ffi.p(qkv.contiguous()), _ffi.p(cos.contiguous()), _ffi.p(sin.contiguous()), N, num_heads, D, DP,
+    if bias is not None and (bias.shape != (qkv.shape[1],) or bias.dtype != qkv.dtype):
+        raise ValueError("vision_qkv_rope: bias must be [3 * H * D] in the activation dtype")
+    _ffi.check(_ffi.load().pie_vision_qkv_rope(_ffi.p(qkv.contiguous()), _ffi.p(bias.contiguous() if bias is not None else None), _ffi.p(cos.contiguous()), _ffi.p(sin.contiguous()), N, num_heads, D, DP,
                                                _ffi.dtype_code(qkv.dtype), _ffi.p(q), _ffi.p(k), _ffi.p(v), _ffi.stream()))
     return q, k, v
 
@@ -434,3 +438,29 @@ def sdpa_segments(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seg_lo: tor
     _ffi.check(_ffi.load().pie_sdpa_segments(_ffi.p(q.contiguous()), _ffi.p(k.contiguous()), _ffi.p(v.contiguous()), _ffi.p(seg_lo), _ffi.p(seg_hi),
                                              N, H, D, float(scale), _ffi.dtype_code(q.dtype), _ffi.p(out), _ffi.stream()))
     return out
+
+
+def bias_silu_mul(gate: torch.Tensor, up: torch.Tensor, bias_gate: torch.Tensor, bias_up: torch.Tensor) -> torch.Tensor:
+    """silu(gate + bias_gate) * (up + bias_up) on [M, N] GEMM outputs (MLP of vision.py:196-197, biases folded in)."""
+    for t in (gate, up, bias_gate, bias_up):
+        _dev(t)
+    M, N = gate.shape
+    if up.shape != (M, N) or bias_gate.shape != (N,) or bias_up.shape != (N,):
+        raise ValueError("bias_silu_mul: gate, up [M, N]; biases [N]")
+    y = torch.empty_like(gate)
+    _ffi.check(_ffi.load().pie_bias_silu_mul(_ffi.p(gate.contiguous()), _ffi.p(up.contiguous()), _ffi.p(bias_gate.contiguous()), _ffi.p(bias_up.contiguous()),
+                                             M, N, _ffi.dtype_code(gate.dtype), _ffi.p(y), _ffi.stream()))
+    return y
+
+
+def add_bias(x: torch.Tensor, r: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x + (r + bias) on [M, N] (residual add with the preceding Linear's bias folded in, vision.py:212-218)."""
+    for t in (x, r, bias):
+        _dev(t)
+    M, N = x.shape
+    if r.shape != (M, N) or bias.shape != (N,):
+        raise ValueError("add_bias: x, r [M, N]; bias [N]")
+    y = torch.empty_like(x)
+    _ffi.check(_ffi.load().pie_add_bias(_ffi.p(x.contiguous()), _ffi.p(r.contiguous()), _ffi.p(bias.contiguous()), M, N, _ffi.dtype_code(x.dtype),
+                                        _ffi.p(y), _ffi.stream()))
+    return y

@@ -85,6 +85,8 @@ class VisionModel:
                 "up_w": get(p + "mlp.up_proj.weight"), "up_b": get(p + "mlp.up_proj.bias"),
                 "down_w": get(p + "mlp.down_proj.weight"), "down_b": get(p + "mlp.down_proj.bias"),
             })
+        self._table_cache: dict = {}
+        self._graphs: dict = {}
         self.merger = {"ln_q": get("merger.ln_q.weight"), "w0": get("merger.mlp.0.weight"), "b0": get("merger.mlp.0.bias"),
                        "w2": get("merger.mlp.2.weight"), "b2": get("merger.mlp.2.bias")}
 
@@ -126,50 +128,90 @@ class VisionModel:
         return np.concatenate(window_index, axis=0), cu
 
     # ------------------------------------------------------------------ vision.py:364-442
-    def __call__(self, hidden_states: torch.Tensor, grid_thw=None, output_hidden_states: bool | None = None) -> torch.Tensor:
-        if grid_thw is None:
-            raise ValueError("grid_thw must be provided for the VisionModel forward pass.")
-        c = self.config
-        grid = [tuple(int(v) for v in row) for row in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
-        x = hidden_states.to(device=self.device, dtype=self.dtype).reshape(-1, self.patch_w.shape[1])
-        seq_len = x.shape[0]
-        if seq_len != sum(t * h * w for t, h, w in grid):
-            raise ValueError("pixel rows do not match grid_thw")
-        x = ops.linear_rows(x, self.patch_w)                                                  # PatchEmbed
+    def _tables(self, grid: tuple) -> dict:
+        """Everything that depends on the grid only (positions, window order, segment tables), computed once per distinct grid
+        and kept on the device."""
+        t = self._table_cache.get(grid)
+        if t is not None:
+            return t
+        unit = self.spatial_merge_unit
+        seq_len = sum(a * h * w for a, h, w in grid)
         angles = self.rot_pos_emb(grid)
         window_index, cu_window = self.get_window_index(grid)
         cu_window = sorted(set(cu_window))                                                     # first occurrences (vision.py:381-390)
-        unit = self.spatial_merge_unit
-        widx = torch.from_numpy(window_index.astype(np.int64)).to(self.device)
-        x = x.view(seq_len // unit, unit, -1)[widx].reshape(seq_len, -1).contiguous()
         angles = angles.reshape(seq_len // unit, unit, -1)[window_index].reshape(seq_len, -1)
-        cos = torch.from_numpy(np.cos(angles).astype(np.float32)).to(self.device)
-        sin = torch.from_numpy(np.sin(angles).astype(np.float32)).to(self.device)
         cu_full = [0]
-        for t, h, w in grid:
-            for _ in range(t):
+        for a, h, w in grid:
+            for _ in range(a):
                 cu_full.append(cu_full[-1] + h * w)
-        seg_full = ops.segment_bounds(cu_full, self.device)
-        seg_win = ops.segment_bounds(cu_window, self.device)
+        t = {"seq_len": seq_len,
+             "widx": torch.from_numpy(window_index.astype(np.int64)).to(self.device),
+             "reverse": torch.from_numpy(np.argsort(window_index, kind="stable").astype(np.int64)).to(self.device),
+             "cos": torch.from_numpy(np.cos(angles).astype(np.float32)).to(self.device),
+             "sin": torch.from_numpy(np.sin(angles).astype(np.float32)).to(self.device),
+             "seg_full": ops.segment_bounds(cu_full, self.device), "seg_win": ops.segment_bounds(cu_window, self.device)}
+        if len(self._table_cache) >= 64:
+            self._table_cache.pop(next(iter(self._table_cache)))
+        self._table_cache[grid] = t
+        return t
+
+    def _forward_device(self, x: torch.Tensor, t: dict, output_hidden_states: bool = False):
+        """The device half: only launches on the current stream (capturable in a hipGraph)."""
+        c = self.config
+        seq_len, unit = t["seq_len"], self.spatial_merge_unit
+        x = ops.linear_rows(x, self.patch_w)                                                  # PatchEmbed
+        x = x.view(seq_len // unit, unit, -1)[t["widx"]].reshape(seq_len, -1).contiguous()
+        cos, sin = t["cos"], t["sin"]
         states = (x,) if output_hidden_states else ()
         scale = self.head_dim ** -0.5
         for i, b in enumerate(self.blocks):
-            lo, hi = seg_full if i in c.fullatt_block_indexes else seg_win
+            lo, hi = t["seg_full"] if i in c.fullatt_block_indexes else t["seg_win"]
             # hidden_states + attn(norm1(hidden_states))  (vision.py:212-217)
             xn = ops.rms_norm(x, b["norm1"], 1e-6)
-            qkv = ops.linear_rows(xn, b["qkv_w"], b["qkv_b"])
-            q, k, v = ops.vision_qkv_rope(qkv, cos, sin, c.num_heads, self.padded_head_dim)
+            qkv = ops.linear_rows(xn, b["qkv_w"])                                           # bias folded into the rotary kernel
+            q, k, v = ops.vision_qkv_rope(qkv, cos, sin, c.num_heads, self.padded_head_dim, bias=b["qkv_b"])
             att = ops.sdpa_segments(q, k, v, lo, hi, scale)
-            x = ops.add(x, ops.linear_rows(att.view(seq_len, -1), b["proj_w"], b["proj_b"]))
+            x = ops.add_bias(x, ops.linear_rows(att.view(seq_len, -1), b["proj_w"]), b["proj_b"])
             # hidden_states + mlp(norm2(hidden_states))  (vision.py:218, :196-197)
             xn = ops.rms_norm(x, b["norm2"], 1e-6)
-            act = ops.silu_mul(ops.linear_rows(xn, b["gate_w"], b["gate_b"]), ops.linear_rows(xn, b["up_w"], b["up_b"]))
-            x = ops.add(x, ops.linear_rows(act, b["down_w"], b["down_b"]))
+            act = ops.bias_silu_mul(ops.linear_rows(xn, b["gate_w"]), ops.linear_rows(xn, b["up_w"]), b["gate_b"], b["up_b"])
+            x = ops.add_bias(x, ops.linear_rows(act, b["down_w"]), b["down_b"])
             if output_hidden_states:
                 states = (*states, x)
         # PatchMerger (vision.py:136-140), then undo the window order (:438-440)
         m = self.merger
         y = ops.rms_norm(x, m["ln_q"], 1e-6).view(seq_len // unit, -1)
         y = ops.linear_rows(ops.gelu(ops.linear_rows(y, m["w0"], m["b0"])), m["w2"], m["b2"])
-        reverse = torch.from_numpy(np.argsort(window_index, kind="stable").astype(np.int64)).to(self.device)
-        return y[reverse].contiguous()
+        y = y[t["reverse"]].contiguous()
+        return (y, states) if output_hidden_states else y
+
+    # ------------------------------------------------------------------ vision.py:364-442
+    def __call__(self, hidden_states: torch.Tensor, grid_thw=None, output_hidden_states: bool | None = None, graph: bool = False):
+        """pixel rows [N, C*T*P*P] + grid_thw [[t, h, w], ...] -> image features [N / merge^2, out_hidden_size].
+        graph=True replays a hipGraph of the ~15 launches per block, captured on first use of a grid (the second call with
+        that grid captures; the features are then a buffer owned by the graph, valid until its next replay)."""
+        if grid_thw is None:
+            raise ValueError("grid_thw must be provided for the VisionModel forward pass.")
+        grid = tuple(tuple(int(v) for v in row) for row in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw))
+        x = hidden_states.to(device=self.device, dtype=self.dtype).reshape(-1, self.patch_w.shape[1]).contiguous()
+        if x.shape[0] != sum(a * h * w for a, h, w in grid):
+            raise ValueError("pixel rows do not match grid_thw")
+        t = self._tables(grid)
+        if not graph or output_hidden_states:
+            return self._forward_device(x, t, bool(output_hidden_states))
+        g = self._graphs.get(grid)
+        if g is None:
+            out = self._forward_device(x, t)                 # first call: eager (also lets hipBLASLt pick its kernels)
+            self._graphs[grid] = "warm"
+            return out
+        if g == "warm":
+            static_in = x.clone()
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                static_out = self._forward_device(static_in, t)
+            g = self._graphs[grid] = (cg, static_in, static_out)
+        cg, static_in, static_out = g
+        static_in.copy_(x)
+        cg.replay()
+        return static_out

@@ -54,6 +54,24 @@ def test_vision_qkv_rope_layout_and_values(ops, D, DP):
     assert np.array_equal(to_bits(v[..., :D]), po.to_bits(qkv[:, 2].transpose(1, 0, 2), DT))
     for t in (q, k, v):
         assert not to_bits(t[..., D:]).any(), "padding columns must be zero"
+    # the qkv Linear's bias folded in: same values as adding it to the GEMM output first
+    b = po.round_T(rng.standard_normal(3 * H * D) * 0.5, DT)
+    qkv_b = po.round_T(qkv.reshape(N, -1) + b, DT).reshape(N, 3, H, D)
+    q2, k2, v2 = ops.vision_qkv_rope(dev(qkv).view(N, -1), torch.from_numpy(np.cos(ang)).cuda(), torch.from_numpy(np.sin(ang)).cuda(), H, DP, bias=dev(b))
+    assert np.array_equal(to_bits(q2[..., :D]), po.to_bits(vo.rope_vision(qkv_b[:, 0], ang, DT), DT))
+    assert np.array_equal(to_bits(k2[..., :D]), po.to_bits(vo.rope_vision(qkv_b[:, 1], ang, DT).transpose(1, 0, 2), DT))
+    assert np.array_equal(to_bits(v2[..., :D]), po.to_bits(qkv_b[:, 2].transpose(1, 0, 2), DT))
+
+
+@pytest.mark.parametrize("M,N", [(33, 212), (5, 3421), (64, 1280)])
+def test_bias_folded_elementwise_ops(ops, M, N):
+    rng = np.random.default_rng(N)
+    g, u, x = (po.round_T(rng.standard_normal((M, N)) * 2, DT) for _ in range(3))
+    bg, bu = (po.round_T(rng.standard_normal(N), DT) for _ in range(2))
+    want = po.silu_mul(po.round_T(g + bg, DT), po.round_T(u + bu, DT), DT)
+    assert_bits_close(to_bits(ops.bias_silu_mul(dev(g), dev(u), dev(bg), dev(bu))), po.to_bits(want, DT), max_ulp=1, max_frac=0.01, what="bias_silu_mul")
+    want = po.add(x, po.round_T(g + bg, DT), DT)
+    assert np.array_equal(to_bits(ops.add_bias(dev(x), dev(g), dev(bg))), po.to_bits(want, DT))
 
 
 def _mask(cu, N, dt):
@@ -104,6 +122,16 @@ def test_vision_tower_vs_oracle(cfg, grid):
     got = model(dev(pix), torch.tensor(grid), output_hidden_states=False)
     assert got.shape == (N // 4, cfg["out_hidden_size"])
     assert_vec_close(got.float().cpu().numpy(), want, DT, c_max=6.0, c_rms=5.0, what=f"tower output {grid}")
+    # per-block hidden states against the oracle's, and the hipGraph replay against the eager run (bit for bit)
+    got2, got_states = model(dev(pix), torch.tensor(grid), output_hidden_states=True)
+    assert torch.equal(got2, got) and len(got_states) == len(states)
+    for i, (a, b) in enumerate(zip(got_states, states)):
+        assert_vec_close(a.float().cpu().numpy(), b, DT, c_max=6.0, c_rms=5.0, what=f"hidden state {i}")
+    for _ in range(3):                                       # eager, capture, replay
+        rep = model(dev(pix), torch.tensor(grid), graph=True)
+        assert torch.equal(rep, got)
+    other = po.round_T(np.random.default_rng(8).standard_normal((N, 3 * 2 * 14 * 14)), DT)
+    assert torch.equal(model(dev(other), torch.tensor(grid), graph=True), model(dev(other), torch.tensor(grid)))
 
 
 def test_vision_tower_mlx_ordered_conv_weight_and_errors():
