@@ -70,6 +70,53 @@ __global__ void k_vision_qkv_rope(const u16 *qkv, const u16 *bias, const float *
     vo[d] = T::from_f32(ld(2, d)), vo[d + half] = T::from_f32(ld(2, d + half));
 }
 
+// The same, four pairs per thread with 8-byte accesses (D % 8 == 0: every head size the tower uses); the scalar kernel above is
+// the fallback.  At 4096 patches: 50 -> see DESIGN.md 2d (the scalar form moved 2 bytes per lane per access).
+template <class T>
+__global__ void k_vision_qkv_rope_v4(const u16 *qkv, const u16 *bias, const float *cs, const float *sn, int N, int H, int D, int DP, u16 *q, u16 *k,
+                                     u16 *v) {
+    const int half = D >> 1, hp4 = DP >> 3;  // groups of 4 pairs per padded head
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * H * hp4) return;
+    const int d0 = (int)(i % hp4) * 4, hh = (int)((i / hp4) % H), n = (int)(i / ((size_t)hp4 * H));
+    u16 *qo = q + ((size_t)n * H + hh) * DP, *ko = k + ((size_t)hh * N + n) * DP, *vo = v + ((size_t)hh * N + n) * DP;
+    if (d0 >= half) {  // 8 padding columns
+        const int c0 = D + 2 * (d0 - half);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(qo + c0) = z, *reinterpret_cast<uint4 *>(ko + c0) = z, *reinterpret_cast<uint4 *>(vo + c0) = z;
+        return;
+    }
+    const u16 *row = qkv + (size_t)n * 3 * H * D + (size_t)hh * D;
+    const u16 *brow = bias ? bias + (size_t)hh * D : nullptr;
+    const float4 c = *reinterpret_cast<const float4 *>(cs + (size_t)n * half + d0), s = *reinterpret_cast<const float4 *>(sn + (size_t)n * half + d0);
+    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+    auto ld4 = [&](int part, int col, float *o) {  // 4 elements of this head's q / k / v row, bias applied
+        const uint2 x = *reinterpret_cast<const uint2 *>(row + (size_t)part * H * D + col);
+        o[0] = lo_f32<T>(x.x), o[1] = hi_f32<T>(x.x), o[2] = lo_f32<T>(x.y), o[3] = hi_f32<T>(x.y);
+        if (brow) {
+            const uint2 b = *reinterpret_cast<const uint2 *>(brow + (size_t)part * H * D + col);
+            o[0] = round_T<T>(o[0] + lo_f32<T>(b.x)), o[1] = round_T<T>(o[1] + hi_f32<T>(b.x));
+            o[2] = round_T<T>(o[2] + lo_f32<T>(b.y)), o[3] = round_T<T>(o[3] + hi_f32<T>(b.y));
+        }
+    };
+    auto st4 = [&](u16 *dst, const float *o) { *reinterpret_cast<uint2 *>(dst) = make_uint2(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])); };
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        float a[4], b[4], lo[4], hi[4];
+        ld4(part, d0, a), ld4(part, d0 + half, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = __fadd_rn(__fmul_rn(a[j], cc[j]), __fmul_rn(-b[j], ss[j]));
+            hi[j] = __fadd_rn(__fmul_rn(b[j], cc[j]), __fmul_rn(a[j], ss[j]));
+        }
+        u16 *dst = part == 0 ? qo : ko;
+        st4(dst + d0, lo), st4(dst + d0 + half, hi);
+    }
+    float a[4], b[4];
+    ld4(2, d0, a), ld4(2, d0 + half, b);
+    st4(vo + d0, a), st4(vo + d0 + half, b);
+}
+
 // MLP.__call__ (vision.py:196-197) between the GEMMs: act = T(T(silu(T(g + bg))) * T(u + bu)); two columns per thread.
 template <class T>
 __global__ void k_bias_silu_mul(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, u16 *y) {
@@ -84,6 +131,29 @@ __global__ void k_bias_silu_mul(const u16 *g, const u16 *u, const u16 *bg, const
         const float gv = round_T<T>(T::to_f32(g[o + j]) + T::to_f32(bg[n + j])), uv = round_T<T>(T::to_f32(u[o + j]) + T::to_f32(bu[n + j]));
         y[o + j] = T::from_f32(round_T<T>(gv / (1.0f + expf(-gv))) * uv);
     }
+}
+
+// four columns per thread, 8-byte accesses (N % 4 == 0)
+template <class T>
+__global__ void k_bias_silu_mul_v4(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, u16 *y) {
+    const int n4 = N >> 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * n4) return;
+    const int n = (int)(i % n4) * 4;
+    const size_t o = (i / n4) * (size_t)N + n;
+    const uint2 gv = *reinterpret_cast<const uint2 *>(g + o), uv = *reinterpret_cast<const uint2 *>(u + o);
+    const uint2 bgv = *reinterpret_cast<const uint2 *>(bg + n), buv = *reinterpret_cast<const uint2 *>(bu + n);
+    const float gg[4] = {lo_f32<T>(gv.x), hi_f32<T>(gv.x), lo_f32<T>(gv.y), hi_f32<T>(gv.y)};
+    const float uu[4] = {lo_f32<T>(uv.x), hi_f32<T>(uv.x), lo_f32<T>(uv.y), hi_f32<T>(uv.y)};
+    const float bgg[4] = {lo_f32<T>(bgv.x), hi_f32<T>(bgv.x), lo_f32<T>(bgv.y), hi_f32<T>(bgv.y)};
+    const float buu[4] = {lo_f32<T>(buv.x), hi_f32<T>(buv.x), lo_f32<T>(buv.y), hi_f32<T>(buv.y)};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = round_T<T>(gg[j] + bgg[j]), b = round_T<T>(uu[j] + buu[j]);
+        r[j] = round_T<T>(a / (1.0f + expf(-a))) * b;
+    }
+    *reinterpret_cast<uint2 *>(y + o) = make_uint2(pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]));
 }
 
 // hidden_states + Linear(...) (vision.py:212-218) with the Linear's bias folded in: y = T(x + T(r + b)).
@@ -143,6 +213,16 @@ int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, c
     PIE_REQUIRE(N > 0 && H > 0 && D > 0 && D % 2 == 0 && (DP == 64 || DP == 128) && D <= DP, PIE_E_SHAPE,
                 "pie_vision_qkv_rope: head_dim must be even and fit the padded size 64 or 128");
     hipStream_t st = (hipStream_t)stream;
+    if (D % 8 == 0 && pie_aligned(qkv, 8) && pie_aligned(q, 16) && pie_aligned(k, 16) && pie_aligned(v, 16) && (!bias || pie_aligned(bias, 8)) &&
+        pie_aligned(cos_t, 16) && pie_aligned(sin_t, 16)) {
+        const size_t n4 = (size_t)N * H * (DP / 8);
+        const dim3 grid4((unsigned)((n4 + 255) / 256)), block4(256);
+        return by_dt(
+            dtype,
+            [&] { hipLaunchKernelGGL(k_vision_qkv_rope_v4<F16>, grid4, block4, 0, st, (const u16 *)qkv, (const u16 *)bias, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+            [&] { hipLaunchKernelGGL(k_vision_qkv_rope_v4<BF16>, grid4, block4, 0, st, (const u16 *)qkv, (const u16 *)bias, cos_t, sin_t, N, H, D, DP, (u16 *)q, (u16 *)k, (u16 *)v); },
+            "pie_vision_qkv_rope");
+    }
     const size_t n = (size_t)N * H * (DP / 2);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     return by_dt(
@@ -156,6 +236,15 @@ int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, c
     PIE_REQUIRE(gate && up && bias_gate && bias_up && y, PIE_E_ARG, "pie_bias_silu_mul: null pointer");
     PIE_REQUIRE(M > 0 && N > 0, PIE_E_SHAPE, "pie_bias_silu_mul: empty input");
     hipStream_t st = (hipStream_t)stream;
+    if (N % 4 == 0 && pie_aligned(gate, 8) && pie_aligned(up, 8) && pie_aligned(bias_gate, 8) && pie_aligned(bias_up, 8) && pie_aligned(y, 8)) {
+        const size_t n4 = (size_t)M * (N / 4);
+        const dim3 grid4((unsigned)((n4 + 255) / 256)), block4(256);
+        return by_dt(
+            dtype,
+            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<F16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<BF16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+            "pie_bias_silu_mul");
+    }
     const size_t n = (size_t)M * ((N + 1) >> 1);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     return by_dt(

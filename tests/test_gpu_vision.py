@@ -40,7 +40,7 @@ def test_gelu_vs_oracle(ops):
     assert_bits_close(to_bits(ops.gelu(dev(x))), po.to_bits(vo.gelu(x, DT), DT), max_ulp=1, what="gelu")
 
 
-@pytest.mark.parametrize("D,DP", [(80, 128), (64, 64), (32, 64), (128, 128)])
+@pytest.mark.parametrize("D,DP", [(80, 128), (64, 64), (32, 64), (128, 128), (36, 64), (2, 64)])   # the last two: scalar fallback kernel
 def test_vision_qkv_rope_layout_and_values(ops, D, DP):
     rng = np.random.default_rng(D)
     N, H = 37, 3
