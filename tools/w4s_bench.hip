@@ -1,6 +1,6 @@
 // tools/w4s_bench.hip -- kernel-level microbenchmark for the W4S GEMV (developer tool, not part of the product).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/w4s_bench.hip proxy_inference_engine_amd/csrc/w4_gemv.hip \
-//        proxy_inference_engine_amd/csrc/decoder.hip proxy_inference_engine_amd/csrc/ops.hip proxy_inference_engine_amd/csrc/prefill.hip -ldl -o tools/w4s_bench
+//        proxy_inference_engine_amd/csrc/{decoder,ops,prefill,vision}.hip proxy_inference_engine_amd/csrc/page_pool.cpp -ldl -o tools/w4s_bench
 #include <cstdio>
 #include <cstdlib>
 #include <string>
