@@ -307,9 +307,15 @@ int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream);
 int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype,
                         void *q, void *k, void *v, void *stream);
 /* Bias adds folded into the op that consumes the GEMM output (same values as pie_linear with a bias followed by the op):
- * pie_bias_silu_mul: y = silu(gate + bias_gate) * (up + bias_up), T [M, N] (MLP, vision.py:196-197);
+ * pie_bias_silu_mul: y = silu(gate + bias_gate) * (up + bias_up), T [M, N] (MLP, vision.py:196-197); gate / up rows are `ld`
+ *   elements apart (0 = N), so both may be column halves of one [M, 2N] GEMM output;
  * pie_add_bias: y = x + (r + bias), T [M, N] (the residual adds of vision.py:212-218). */
-int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int dtype, void *y, void *stream);
+int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int ld, int dtype, void *y,
+                      void *stream);
+/* pie_add_bias_rms_norm: the residual add and the RMSNorm after it in one pass: y = x + (r + bias), xn = rms_norm(y, norm_w, eps);
+ * T [M, N], N % 8 == 0 (the values pie_add_bias followed by pie_rms_norm produce). */
+int pie_add_bias_rms_norm(const void *x, const void *r, const void *bias, const void *norm_w, float eps, int M, int N, int dtype, void *y, void *xn,
+                          void *stream);
 int pie_add_bias(const void *x, const void *r, const void *bias, int M, int N, int dtype, void *y, void *stream);
 int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D,
                       float scale, int dtype, void *out, void *stream);

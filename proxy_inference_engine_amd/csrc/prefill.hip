@@ -271,7 +271,9 @@ int gemm_xwt_impl(int dtype, const void *x, const void *w, void *y, int M, int N
         hipblasLtMatmulHeuristicResult_t res[MAX_ALGOS];
         int n_res = 0;
         const char *te = getenv("PIE_PREFILL_TUNE");  // 0: take the heuristic's first choice without timing the candidates
-        const int want = (te && te[0] == '0') || M < 64 ? 1 : MAX_ALGOS;
+        const char *ts = getenv("PIE_PREFILL_TUNE_MIN_ROWS");  // experiment knob: smallest M whose candidates are timed
+        const int tune_min = ts ? atoi(ts) : 64;
+        const int want = (te && te[0] == '0') || M < tune_min ? 1 : MAX_ALGOS;
         const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, want, res, &n_res);
         PIE_REQUIRE(hs == HIPBLAS_STATUS_SUCCESS && n_res > 0, PIE_E_HIP, "prefill: hipBLASLt has no kernel for this GEMM shape");
         int best = 0;

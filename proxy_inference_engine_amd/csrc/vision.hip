@@ -119,29 +119,29 @@ __global__ void k_vision_qkv_rope_v4(const u16 *qkv, const u16 *bias, const floa
 
 // MLP.__call__ (vision.py:196-197) between the GEMMs: act = T(T(silu(T(g + bg))) * T(u + bu)); two columns per thread.
 template <class T>
-__global__ void k_bias_silu_mul(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, u16 *y) {
+__global__ void k_bias_silu_mul(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, int ld, u16 *y) {
     const int n2 = (N + 1) >> 1;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * n2) return;
     const int n = (int)(i % n2) * 2;
-    const size_t o = (i / n2) * (size_t)N + n;
+    const size_t o = (i / n2) * (size_t)N + n, oi = (i / n2) * (size_t)ld + n;  // output / input (row stride ld) offsets
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (n + j >= N) break;
-        const float gv = round_T<T>(T::to_f32(g[o + j]) + T::to_f32(bg[n + j])), uv = round_T<T>(T::to_f32(u[o + j]) + T::to_f32(bu[n + j]));
+        const float gv = round_T<T>(T::to_f32(g[oi + j]) + T::to_f32(bg[n + j])), uv = round_T<T>(T::to_f32(u[oi + j]) + T::to_f32(bu[n + j]));
         y[o + j] = T::from_f32(round_T<T>(gv / (1.0f + expf(-gv))) * uv);
     }
 }
 
 // four columns per thread, 8-byte accesses (N % 4 == 0)
 template <class T>
-__global__ void k_bias_silu_mul_v4(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, u16 *y) {
+__global__ void k_bias_silu_mul_v4(const u16 *g, const u16 *u, const u16 *bg, const u16 *bu, int M, int N, int ld, u16 *y) {
     const int n4 = N >> 2;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * n4) return;
     const int n = (int)(i % n4) * 4;
-    const size_t o = (i / n4) * (size_t)N + n;
-    const uint2 gv = *reinterpret_cast<const uint2 *>(g + o), uv = *reinterpret_cast<const uint2 *>(u + o);
+    const size_t o = (i / n4) * (size_t)N + n, oi = (i / n4) * (size_t)ld + n;
+    const uint2 gv = *reinterpret_cast<const uint2 *>(g + oi), uv = *reinterpret_cast<const uint2 *>(u + oi);
     const uint2 bgv = *reinterpret_cast<const uint2 *>(bg + n), buv = *reinterpret_cast<const uint2 *>(bu + n);
     const float gg[4] = {lo_f32<T>(gv.x), hi_f32<T>(gv.x), lo_f32<T>(gv.y), hi_f32<T>(gv.y)};
     const float uu[4] = {lo_f32<T>(uv.x), hi_f32<T>(uv.x), lo_f32<T>(uv.y), hi_f32<T>(uv.y)};
@@ -168,6 +168,54 @@ __global__ void k_add_bias(const u16 *x, const u16 *r, const u16 *b, int M, int 
     for (int j = 0; j < 2; ++j) {
         if (n + j >= N) break;
         y[o + j] = T::from_f32(T::to_f32(x[o + j]) + round_T<T>(T::to_f32(r[o + j]) + T::to_f32(b[n + j])));
+    }
+}
+
+// The residual add (with the preceding Linear's bias) and the RMSNorm that follows it in one pass over the row (vision.py:212-218 ->
+// :213 / :218's norm): y = T(x + T(r + b)), xn = w * T(y * rsqrt(mean(y^2) + eps)).  One workgroup per row, H % 8 == 0, H <= 8192.
+template <class T>
+__global__ void __launch_bounds__(256) k_add_bias_rms_norm(const u16 *x, const u16 *r, const u16 *b, const u16 *w, float eps, int H, u16 *y, u16 *xn) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * H;
+    constexpr int MAXP = 4;
+    uint4 hv[MAXP];
+    float ssq = 0.0f;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = (threadIdx.x + p * 256) * 8;
+        if (i < H) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(x + base + i), c = *reinterpret_cast<const uint4 *>(r + base + i);
+            const uint4 bb = *reinterpret_cast<const uint4 *>(b + i);
+            const u32 av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+            u32 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = pack2<T>(lo_f32<T>(av[j]) + round_T<T>(lo_f32<T>(cv[j]) + lo_f32<T>(bv[j])),
+                                hi_f32<T>(av[j]) + round_T<T>(hi_f32<T>(cv[j]) + hi_f32<T>(bv[j])));
+                const float lo = lo_f32<T>(o[j]), hi = hi_f32<T>(o[j]);
+                ssq = fmaf(lo, lo, ssq);
+                ssq = fmaf(hi, hi, ssq);
+            }
+            hv[p] = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(y + base + i) = hv[p];
+        }
+    }
+    ssq = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = (threadIdx.x + p * 256) * 8;
+        if (i < H) {
+            const uint4 g = *reinterpret_cast<const uint4 *>(w + i);
+            const u32 vv[4] = {hv[p].x, hv[p].y, hv[p].z, hv[p].w}, gg[4] = {g.x, g.y, g.z, g.w};
+            u32 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack2<T>(round_T<T>(lo_f32<T>(vv[j]) * inv) * lo_f32<T>(gg[j]), round_T<T>(hi_f32<T>(vv[j]) * inv) * hi_f32<T>(gg[j]));
+            *reinterpret_cast<uint4 *>(xn + base + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -232,25 +280,28 @@ int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, c
         "pie_vision_qkv_rope");
 }
 
-int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int dtype, void *y, void *stream) {
+int pie_bias_silu_mul(const void *gate, const void *up, const void *bias_gate, const void *bias_up, int M, int N, int ld, int dtype, void *y,
+                      void *stream) {
     PIE_REQUIRE(gate && up && bias_gate && bias_up && y, PIE_E_ARG, "pie_bias_silu_mul: null pointer");
     PIE_REQUIRE(M > 0 && N > 0, PIE_E_SHAPE, "pie_bias_silu_mul: empty input");
+    if (ld == 0) ld = N;
+    PIE_REQUIRE(ld >= N, PIE_E_SHAPE, "pie_bias_silu_mul: row stride smaller than the row");
     hipStream_t st = (hipStream_t)stream;
-    if (N % 4 == 0 && pie_aligned(gate, 8) && pie_aligned(up, 8) && pie_aligned(bias_gate, 8) && pie_aligned(bias_up, 8) && pie_aligned(y, 8)) {
+    if (N % 4 == 0 && ld % 4 == 0 && pie_aligned(gate, 8) && pie_aligned(up, 8) && pie_aligned(bias_gate, 8) && pie_aligned(bias_up, 8) && pie_aligned(y, 8)) {
         const size_t n4 = (size_t)M * (N / 4);
         const dim3 grid4((unsigned)((n4 + 255) / 256)), block4(256);
         return by_dt(
             dtype,
-            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<F16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
-            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<BF16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<F16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, ld, (u16 *)y); },
+            [&] { hipLaunchKernelGGL(k_bias_silu_mul_v4<BF16>, grid4, block4, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, ld, (u16 *)y); },
             "pie_bias_silu_mul");
     }
     const size_t n = (size_t)M * ((N + 1) >> 1);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     return by_dt(
         dtype,
-        [&] { hipLaunchKernelGGL(k_bias_silu_mul<F16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
-        [&] { hipLaunchKernelGGL(k_bias_silu_mul<BF16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_bias_silu_mul<F16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, ld, (u16 *)y); },
+        [&] { hipLaunchKernelGGL(k_bias_silu_mul<BF16>, grid, block, 0, st, (const u16 *)gate, (const u16 *)up, (const u16 *)bias_gate, (const u16 *)bias_up, M, N, ld, (u16 *)y); },
         "pie_bias_silu_mul");
 }
 
@@ -263,6 +314,20 @@ int pie_add_bias(const void *x, const void *r, const void *bias, int M, int N, i
     return by_dt(
         dtype, [&] { hipLaunchKernelGGL(k_add_bias<F16>, grid, block, 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, M, N, (u16 *)y); },
         [&] { hipLaunchKernelGGL(k_add_bias<BF16>, grid, block, 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, M, N, (u16 *)y); }, "pie_add_bias");
+}
+
+int pie_add_bias_rms_norm(const void *x, const void *r, const void *bias, const void *norm_w, float eps, int M, int N, int dtype, void *y, void *xn,
+                          void *stream) {
+    PIE_REQUIRE(x && r && bias && norm_w && y && xn, PIE_E_ARG, "pie_add_bias_rms_norm: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && N <= 8192, PIE_E_SHAPE, "pie_add_bias_rms_norm: N must be a multiple of 8, at most 8192");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(r, 16) && pie_aligned(bias, 16) && pie_aligned(norm_w, 16) && pie_aligned(y, 16) && pie_aligned(xn, 16),
+                PIE_E_ALIGN, "pie_add_bias_rms_norm: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    return by_dt(
+        dtype,
+        [&] { hipLaunchKernelGGL(k_add_bias_rms_norm<F16>, dim3(M), dim3(256), 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, (const u16 *)norm_w, eps, N, (u16 *)y, (u16 *)xn); },
+        [&] { hipLaunchKernelGGL(k_add_bias_rms_norm<BF16>, dim3(M), dim3(256), 0, st, (const u16 *)x, (const u16 *)r, (const u16 *)bias, (const u16 *)norm_w, eps, N, (u16 *)y, (u16 *)xn); },
+        "pie_add_bias_rms_norm");
 }
 
 int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D, float scale,

@@ -441,15 +441,19 @@ def sdpa_segments(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seg_lo: tor
 
 
 def bias_silu_mul(gate: torch.Tensor, up: torch.Tensor, bias_gate: torch.Tensor, bias_up: torch.Tensor) -> torch.Tensor:
-    """silu(gate + bias_gate) * (up + bias_up) on [M, N] GEMM outputs (MLP of vision.py:196-197, biases folded in)."""
-    for t in (gate, up, bias_gate, bias_up):
-        _dev(t)
+    """silu(gate + bias_gate) * (up + bias_up) on [M, N] GEMM outputs (MLP of vision.py:196-197, biases folded in).  gate and up
+    may be the two column halves of one [M, 2N] GEMM output (equal row strides, unit column stride)."""
+    _dev(bias_gate), _dev(bias_up)
+    if not (gate.is_cuda and up.is_cuda):
+        raise ValueError("pie_hip ops take device tensors (ROCm); got a CPU tensor")
     M, N = gate.shape
     if up.shape != (M, N) or bias_gate.shape != (N,) or bias_up.shape != (N,):
         raise ValueError("bias_silu_mul: gate, up [M, N]; biases [N]")
-    y = torch.empty_like(gate)
-    _ffi.check(_ffi.load().pie_bias_silu_mul(_ffi.p(gate.contiguous()), _ffi.p(up.contiguous()), _ffi.p(bias_gate.contiguous()), _ffi.p(bias_up.contiguous()),
-                                             M, N, _ffi.dtype_code(gate.dtype), _ffi.p(y), _ffi.stream()))
+    if gate.stride(1) != 1 or up.stride(1) != 1 or gate.stride(0) != up.stride(0):
+        gate, up = gate.contiguous(), up.contiguous()
+    y = torch.empty((M, N), dtype=gate.dtype, device=gate.device)
+    _ffi.check(_ffi.load().pie_bias_silu_mul(_ffi.p(gate), _ffi.p(up), _ffi.p(bias_gate.contiguous()), _ffi.p(bias_up.contiguous()),
+                                             M, N, gate.stride(0) if M > 1 else N, _ffi.dtype_code(gate.dtype), _ffi.p(y), _ffi.stream()))
     return y
 
 
@@ -464,3 +468,16 @@ def add_bias(x: torch.Tensor, r: torch.Tensor, bias: torch.Tensor) -> torch.Tens
     _ffi.check(_ffi.load().pie_add_bias(_ffi.p(x.contiguous()), _ffi.p(r.contiguous()), _ffi.p(bias.contiguous()), M, N, _ffi.dtype_code(x.dtype),
                                         _ffi.p(y), _ffi.stream()))
     return y
+
+
+def add_bias_rms_norm(x: torch.Tensor, r: torch.Tensor, bias: torch.Tensor, norm_weight: torch.Tensor, eps: float):
+    """(y, rms_norm(y)) with y = x + (r + bias): the residual add and the norm after it in one pass over the rows."""
+    for t in (x, r, bias, norm_weight):
+        _dev(t)
+    M, N = x.shape
+    if r.shape != (M, N) or bias.shape != (N,) or norm_weight.shape != (N,):
+        raise ValueError("add_bias_rms_norm: x, r [M, N]; bias, norm_weight [N]")
+    y, xn = torch.empty_like(x), torch.empty_like(x)
+    _ffi.check(_ffi.load().pie_add_bias_rms_norm(_ffi.p(x.contiguous()), _ffi.p(r.contiguous()), _ffi.p(bias.contiguous()), _ffi.p(norm_weight.contiguous()),
+                                                 float(eps), M, N, _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.p(xn), _ffi.stream()))
+    return y, xn

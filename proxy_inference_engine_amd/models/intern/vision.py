@@ -81,8 +81,9 @@ class VisionModel:
                 "norm1": get(p + "norm1.weight"), "norm2": get(p + "norm2.weight"),
                 "qkv_w": get(p + "attn.qkv.weight"), "qkv_b": get(p + "attn.qkv.bias"),
                 "proj_w": proj, "proj_b": get(p + "attn.proj.bias"),
-                "gate_w": get(p + "mlp.gate_proj.weight"), "gate_b": get(p + "mlp.gate_proj.bias"),
-                "up_w": get(p + "mlp.up_proj.weight"), "up_b": get(p + "mlp.up_proj.bias"),
+                # gate_proj and up_proj as one GEMM: [2 * intermediate, hidden]
+                "gateup_w": torch.cat([get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")], dim=0).contiguous(),
+                "gate_b": get(p + "mlp.gate_proj.bias"), "up_b": get(p + "mlp.up_proj.bias"),
                 "down_w": get(p + "mlp.down_proj.weight"), "down_b": get(p + "mlp.down_proj.bias"),
             })
         self._table_cache: dict = {}
@@ -164,23 +165,36 @@ class VisionModel:
         cos, sin = t["cos"], t["sin"]
         states = (x,) if output_hidden_states else ()
         scale = self.head_dim ** -0.5
+        I = c.intermediate_size
+        fuse_norm = c.hidden_size % 8 == 0 and c.hidden_size <= 8192
+        xn = ops.rms_norm(x, self.blocks[0]["norm1"], 1e-6) if self.blocks else None
         for i, b in enumerate(self.blocks):
             lo, hi = t["seg_full"] if i in c.fullatt_block_indexes else t["seg_win"]
-            # hidden_states + attn(norm1(hidden_states))  (vision.py:212-217)
-            xn = ops.rms_norm(x, b["norm1"], 1e-6)
+            # hidden_states + attn(norm1(hidden_states))  (vision.py:212-217); xn = norm1(x) comes from the previous fused pass
             qkv = ops.linear_rows(xn, b["qkv_w"])                                           # bias folded into the rotary kernel
             q, k, v = ops.vision_qkv_rope(qkv, cos, sin, c.num_heads, self.padded_head_dim, bias=b["qkv_b"])
             att = ops.sdpa_segments(q, k, v, lo, hi, scale)
-            x = ops.add_bias(x, ops.linear_rows(att.view(seq_len, -1), b["proj_w"]), b["proj_b"])
+            r = ops.linear_rows(att.view(seq_len, -1), b["proj_w"])
+            if fuse_norm:
+                x, xn = ops.add_bias_rms_norm(x, r, b["proj_b"], b["norm2"], 1e-6)
+            else:
+                x = ops.add_bias(x, r, b["proj_b"])
+                xn = ops.rms_norm(x, b["norm2"], 1e-6)
             # hidden_states + mlp(norm2(hidden_states))  (vision.py:218, :196-197)
-            xn = ops.rms_norm(x, b["norm2"], 1e-6)
-            act = ops.bias_silu_mul(ops.linear_rows(xn, b["gate_w"]), ops.linear_rows(xn, b["up_w"]), b["gate_b"], b["up_b"])
-            x = ops.add_bias(x, ops.linear_rows(act, b["down_w"]), b["down_b"])
+            gu = ops.linear_rows(xn, b["gateup_w"])
+            act = ops.bias_silu_mul(gu[:, :I], gu[:, I:], b["gate_b"], b["up_b"])
+            r = ops.linear_rows(act, b["down_w"])
+            nxt = self.blocks[i + 1]["norm1"] if i + 1 < len(self.blocks) else self.merger["ln_q"]   # the next consumer's norm
+            if fuse_norm:
+                x, xn = ops.add_bias_rms_norm(x, r, b["down_b"], nxt, 1e-6)
+            else:
+                x = ops.add_bias(x, r, b["down_b"])
+                xn = ops.rms_norm(x, nxt, 1e-6)
             if output_hidden_states:
                 states = (*states, x)
         # PatchMerger (vision.py:136-140), then undo the window order (:438-440)
         m = self.merger
-        y = ops.rms_norm(x, m["ln_q"], 1e-6).view(seq_len // unit, -1)
+        y = (xn if self.blocks else ops.rms_norm(x, m["ln_q"], 1e-6)).view(seq_len // unit, -1)
         y = ops.linear_rows(ops.gelu(ops.linear_rows(y, m["w0"], m["b0"])), m["w2"], m["b2"])
         y = y[t["reverse"]].contiguous()
         return (y, states) if output_hidden_states else y

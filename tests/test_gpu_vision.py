@@ -63,15 +63,23 @@ def test_vision_qkv_rope_layout_and_values(ops, D, DP):
     assert np.array_equal(to_bits(v2[..., :D]), po.to_bits(qkv_b[:, 2].transpose(1, 0, 2), DT))
 
 
-@pytest.mark.parametrize("M,N", [(33, 212), (5, 3421), (64, 1280)])
+@pytest.mark.parametrize("M,N", [(33, 212), (5, 3421), (64, 1280), (3, 3424)])
 def test_bias_folded_elementwise_ops(ops, M, N):
     rng = np.random.default_rng(N)
     g, u, x = (po.round_T(rng.standard_normal((M, N)) * 2, DT) for _ in range(3))
     bg, bu = (po.round_T(rng.standard_normal(N), DT) for _ in range(2))
     want = po.silu_mul(po.round_T(g + bg, DT), po.round_T(u + bu, DT), DT)
     assert_bits_close(to_bits(ops.bias_silu_mul(dev(g), dev(u), dev(bg), dev(bu))), po.to_bits(want, DT), max_ulp=1, max_frac=0.01, what="bias_silu_mul")
+    # gate | up as the column halves of one GEMM output
+    gu = dev(np.concatenate([g, u], axis=1))
+    assert torch.equal(ops.bias_silu_mul(gu[:, :N], gu[:, N:], dev(bg), dev(bu)), ops.bias_silu_mul(dev(g), dev(u), dev(bg), dev(bu)))
     want = po.add(x, po.round_T(g + bg, DT), DT)
-    assert np.array_equal(to_bits(ops.add_bias(dev(x), dev(g), dev(bg))), po.to_bits(want, DT))
+    y = ops.add_bias(dev(x), dev(g), dev(bg))
+    assert np.array_equal(to_bits(y), po.to_bits(want, DT))
+    if N % 8 == 0:      # the fused residual + RMSNorm pass gives exactly the two-pass values
+        nw = dev(po.round_T(1 + 0.1 * rng.standard_normal(N), DT))
+        y2, xn = ops.add_bias_rms_norm(dev(x), dev(g), dev(bg), nw, 1e-6)
+        assert torch.equal(y2, y) and torch.equal(xn, ops.rms_norm(y, nw, 1e-6))
 
 
 def _mask(cu, N, dt):
