@@ -672,19 +672,38 @@ def test_random_model_configs_end_to_end(case):
     ocache = [po.OracleKVCache() for _ in orc.layers]
     cache = model.make_cache()
     what = f"case {case}: {fmt} {dtype} H{H} I{I} {nh}/{nkv}xD{D} V{V} L{cfg['num_hidden_layers']}"
+    prompts, prompt_bits = [], None
     for L in (int(rng.integers(17, 90)), int(rng.integers(2, 9))):      # batched (qmm regime), then iterated (qmv regime)
         ids = rng.integers(0, V, L)
+        prompts.append(ids)
         want = orc.forward(ids, ocache)
-        got = model(torch.from_numpy(ids)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        got_t = model(torch.from_numpy(ids)[None].cuda(), cache=cache)[0]
+        prompt_bits = to_bits(got_t).copy()
+        got = got_t.float().cpu().numpy()
         for l in (0, L // 2, L - 1):
             # 6 / 5 instead of 4 / 4: these tiny vocabularies (max |logit| ~ 1.5) and up to 3 layers put the max over a few hundred
             # elements at 2-2.6 eps typically and 3.7-4.0 in 1 of 80 seeded cases (PIE_FUZZ_CASES=80), with no outlier structure
             assert_vec_close(got[l], want[l], dtype, c_max=6.0, c_rms=5.0, what=f"{what} prompt L={L} position {l}")
     tok = model.token
+    first = int(tok.item())
+    dec_bits = []
     for _ in range(3):
         want1 = orc.forward(np.array([int(tok.item())]), ocache)[0]
         tok, lp, logits = model.step(None, cache)
+        dec_bits.append(to_bits(logits).copy())
         assert_vec_close(logits.float().cpu().numpy(), want1, dtype, c_max=6.0, c_rms=5.0, what=f"{what} decode")
+    # the same sequence with the KV cache in scattered 64-token pages: identical kernels on identical rows -> identical bits
+    pool = model.enable_paged_kv(num_pages=8, max_blocks=int(rng.integers(1, 4)))
+    for _ in range(int(rng.integers(0, 4))):
+        pool.allocate_page()
+    if pool.get_num_free_pages() < 8:
+        pool.free_page(0)                                    # LIFO: the sequence's first page is page 0, the rest follow the held ones
+    pcache = model.make_cache()
+    model(torch.from_numpy(prompts[0])[None].cuda(), cache=pcache)
+    got2 = model(torch.from_numpy(prompts[1])[None].cuda(), cache=pcache)[0]
+    assert np.array_equal(to_bits(got2), prompt_bits), f"{what}: paged prompt logits differ from the contiguous cache's"
+    tok2, _, logits2 = model.step(torch.tensor([first], dtype=torch.int32, device="cuda"), pcache)
+    assert np.array_equal(to_bits(logits2), dec_bits[0]), f"{what}: paged decode logits differ"
 
 
 def test_tied_embeddings_and_errors(tiny):
