@@ -320,6 +320,15 @@ int pie_add_bias(const void *x, const void *r, const void *bias, int M, int N, i
 int pie_sdpa_segments(const void *q, const void *k, const void *v, const int32_t *seg_lo, const int32_t *seg_hi, int N, int H, int D,
                       float scale, int dtype, void *out, void *stream);
 
+/* ---------------------------------------------------------------- few-row int4 GEMM (prompts of 2..32 tokens)
+ * mx.quantized_matmul in its many-row regime (weights dequantised to T, T x T products, fp32 accumulation;
+ * models/llama/language.py:83,108,127) without a 16-bit copy of the weights: W4M tiles (32 output rows x 64 columns, 1152 B,
+ * built on the device from the W4S stream of pie_repack_w4g64) are dequantised in registers into MFMA operand fragments.
+ * N % 32 == 0, K % 64 == 0, 1 <= M <= 32.  x T [M, K], y T [M, N] (rows in the packed order of the W4S matrix). */
+size_t pie_w4m_bytes(int N, int K);
+int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream);
+int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@ EXPORTS = [
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
+    "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
 ]
 
 
@@ -105,6 +106,9 @@ def load() -> C.CDLL:
     lib.pie_add_bias_rms_norm.argtypes = [C.c_void_p] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p] * 3
     lib.pie_add_bias.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2
     lib.pie_sdpa_segments.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_w4m_bytes.restype = C.c_size_t
+    lib.pie_repack_w4s_to_w4m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_qgemm_w4m.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_page_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib

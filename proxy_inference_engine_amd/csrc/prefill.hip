@@ -326,6 +326,8 @@ struct PrefillScratch {
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
     // that is a small share of the free memory (PIE_PREFILL_RESIDENT=0/1 overrides), built on first use.
     std::map<const void *, u16 *> resident;
+    // W4M tile copies (w4m_gemm.hip) of int4 layer matrices for prompts of at most small_rows() rows: 0.5625 B per weight each
+    std::map<const void *, void *> resident_w4m;
     int resident_mode = -1;   // -1: budget not fixed yet
     size_t resident_left = 0; // bytes still available for resident copies
 };
@@ -335,16 +337,18 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
+    auto keep_m = std::move(s->resident_w4m);
     const int mode = s->resident_mode;
     const size_t left = s->resident_left;
     *s = PrefillScratch();
-    s->resident = std::move(keep), s->resident_mode = mode, s->resident_left = left;
+    s->resident = std::move(keep), s->resident_w4m = std::move(keep_m), s->resident_mode = mode, s->resident_left = left;
 }
 
 void prefill_free(pie_decoder *d) {
     if (!d->prefill) return;
     scratch_release(d->prefill);
     for (auto &kv : d->prefill->resident) (void)hipFree(kv.second);
+    for (auto &kv : d->prefill->resident_w4m) (void)hipFree(kv.second);
     delete d->prefill;
     d->prefill = nullptr;
 }
@@ -429,10 +433,48 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
 
 // y[M, N] = x[M, K] . W^T for one streaming-layout matrix.  keep: a layer matrix (eligible for the resident copy); the
 // lm_head of a logits-on-every-position call always goes through the scratch.
+// w4m_gemm.hip: the few-row int4 GEMM on W4M tiles
+size_t w4m_bytes(int N, int K);
+int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st);
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st);
+
+// Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
+static int small_rows() {
+    const char *e = getenv("PIE_SMALL_M");
+    const int v = e ? atoi(e) : 32;
+    return v < 0 ? 0 : (v > 32 ? 32 : v);
+}
+
+template <class T>
+static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
+    const size_t n8 = (size_t)M * N / 8;
+    hipLaunchKernelGGL(k_bias_rows<T>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, y, (const u16 *)bias, n8, N / 8);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
                        const void *bias = nullptr) {
     PrefillScratch *s = d->prefill;
+    if (keep && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
+        void *wm = nullptr;
+        auto it = s->resident_w4m.find(packed);
+        if (it != s->resident_w4m.end()) wm = it->second;
+        else if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
+            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K);
+            const int rc = w4m_repack_launch(packed, N, K, wm, st);
+            if (rc) return rc;
+        } else {
+            (void)hipGetLastError();
+            wm = nullptr;  // no room for the tile copy: the T-copy path below
+        }
+        if (wm) {
+            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st);
+            if (rc || !bias) return rc;
+            return bias_rows<T>(y, bias, M, N, st);
+        }
+    }
     u16 *wT = s->wT;
     bool ready = false;
     if (keep) {
@@ -450,10 +492,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     }
     const int rc = gemm_xwt(d->cfg.dtype, x, wT, y, M, N, K, st);
     if (rc || !bias) return rc;
-    const size_t n8 = (size_t)M * N / 8;
-    hipLaunchKernelGGL(k_bias_rows<T>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, y, (const u16 *)bias, n8, N / 8);
-    PIE_LAUNCH_CHECK();
-    return PIE_OK;
+    return bias_rows<T>(y, bias, M, N, st);
 }
 
 template <class T>

@@ -1,0 +1,296 @@
+// w4m_gemm.hip -- int4 g=64 x T GEMM for a FEW rows (2..32 prompt tokens) on the MFMA units, weights read once in 4-bit form.
+//
+// Measured (8B model, whole prompt incl. lm_head and tail): 6..8 tokens 5.1 -> 3.3 ms, 16 tokens 5.2 -> 3.8, 32 tokens 5.1 -> 4.5.
+// tools/w4m_bench ablations at 8 rows (us: qkv / o_proj / gate|up / down): full 8.4 / 8.2 / 26.8 / 20.5; without x loads
+// 7.9 / 7.9 / 22.1 / 17.5; without dequantisation 8.1 / 8.1 / 26.3 / 19.7; stream + reduction only 5.3 / 5.1 / 16.7 / 9.6 -- the
+// arithmetic is nearly free; what is left is the grid shape (N / 32 workgroups of ~74 KB each: 128 workgroups for the two
+// N = 4096 matrices leave half the chip idle) and the x fragments.  Next: a persistent grid with K split across workgroups.
+//
+// Why: a short prompt (a chat turn appended to a cached prefix) sits between the two existing paths -- the GEMV reads the
+// 0.5625 B/weight stream once PER TOKEN, the hipBLASLt path reads a 2 B/weight T copy (and its skinny-GEMM kernels reach
+// ~3 TB/s): 6..32 tokens cost a flat 5.1 ms on the 8B model.  This kernel keeps MLX's qmm contract (weights dequantised to T,
+// T x T products, fp32 accumulation: mx.quantized_matmul for many rows, models/llama/language.py:83,108,127) but dequantises
+// in registers straight into MFMA operand fragments, so a pass over the model moves 4.2 GB instead of 15 GB.
+//
+// W4M layout (derived on the device from the W4S stream, cached next to it; same 0.5625 B/weight): tiles of 32 output rows x
+// 64 columns (one quantisation group per row), 1152 B each, tile (nt, g) at ((nt * K/64) + g) * 1152:
+//   bytes [0, 1024): lane l = 32 * kh + n holds 4 code words (16 B): word s = the 8 codes of row 32 nt + n, columns
+//                    64 g + 16 s + 8 kh .. + 8, in the W4S word format (codes 2i, 2i+1 at nibble i of the low / high half)
+//                    -- after dequantisation exactly the A fragment of v_mfma_f32_32x32x16 k-step s (row n, k-half kh);
+//   bytes [1024, 1152): row n's (scale, bias) as one 32-bit word.
+// One workgroup per 32-row tile strip, 8 waves splitting the K/64 groups round-robin (consecutive groups are consecutive
+// 1152-byte blocks: the 8 waves stream one contiguous range), fp32 partial tiles summed through LDS in fixed order.
+#include <cstdlib>
+
+#include "prefill_attn.hpp"  // MfmaT, f32x16_t
+
+#ifndef W4M_ABL
+#define W4M_ABL 0  // developer ablation mask (tools/w4m_bench): 1 no dequantisation, 2 no x loads, 4 no MFMA; 0 in the product
+#endif
+
+constexpr int W4M_TILE_BYTES = 1152;
+constexpr int W4M_WAVES = 8;
+constexpr int W4M_DEPTH = 3;   // staged kernel: weight tiles in flight per wave
+constexpr int W4M_WDEPTH = 8;  // direct kernel: weight tiles (16 B codes + 4 B scale/bias per lane) in flight per wave
+constexpr int W4M_XDEPTH = 2;  //                x fragment sets (4 x 16 B per lane) in flight per wave
+
+// W4S unit stream -> W4M tiles.  One thread per (tile, lane): pure word shuffle, no nibble work.
+__global__ void __launch_bounds__(256) k_w4s_to_w4m(const u32 *w4s, int N, int K, int ns, u32 *w4m) {
+    const int groups = K >> 6;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)(N >> 5) * groups * 64) return;
+    const int lane = (int)(i & 63), g = (int)((i >> 6) % groups), nt = (int)((i >> 6) / groups);
+    const int n = lane & 31, kh = lane >> 5, r = 32 * nt + n;
+    const u32 *unit = w4s + ((size_t)(r >> 1) * ns + (g >> 5)) * (W4S_UNIT_BYTES / 4);
+    const int src_lane = (r & 1) * 32 + (g & 31);
+    u32 *tile = w4m + ((size_t)nt * groups + g) * (W4M_TILE_BYTES / 4);
+    u32 o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int wk = 2 * s + kh;  // word (8 columns) inside the 64-column group
+        o[s] = unit[(wk >> 2) * 256 + src_lane * 4 + (wk & 3)];
+    }
+    *reinterpret_cast<uint4 *>(tile + lane * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (kh == 0) tile[256 + n] = unit[512 + src_lane];
+}
+
+// two fp32 -> one packed pair of T in a single v_cvt_pk_* (pack2<T> converts each half separately and ORs them: 3 instructions)
+template <class T>
+__device__ __forceinline__ u32 w4m_pack(float lo, float hi);
+template <>
+__device__ __forceinline__ u32 w4m_pack<BF16>(float lo, float hi) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(u32, __builtin_convertvector((f2_t){lo, hi}, b2_t));
+}
+template <>
+__device__ __forceinline__ u32 w4m_pack<F16>(float lo, float hi) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(u32, __builtin_convertvector((f2_t){lo, hi}, h2_t));
+}
+
+// 8 codes of one word -> 8 weights in T, the mx.dequantize arithmetic of k_dequant_w4s: T(fp32(s * q) + b), as the MFMA fragment
+template <class T>
+__device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
+    u32 e = word & 0x0F0F0F0Fu, o = (word >> 4) & 0x0F0F0F0Fu;  // bytes: codes (0, 4, 1, 5) and (2, 6, 3, 7)
+    // keep the two masked words as they are: folded back into per-code shift + and + v_cvt_f32_ubyte0 the conversion cost 4.7
+    // VALU instructions per weight instead of one v_cvt_f32_ubyteN each
+    asm volatile("" : "+v"(e), "+v"(o));
+    const float c0 = (float)(e & 0xFFu), c4 = (float)((e >> 8) & 0xFFu), c1 = (float)((e >> 16) & 0xFFu), c5 = (float)(e >> 24);
+    const float c2 = (float)(o & 0xFFu), c6 = (float)((o >> 8) & 0xFFu), c3 = (float)((o >> 16) & 0xFFu), c7 = (float)(o >> 24);
+    auto dq = [&](float q) { return __fadd_rn(__fmul_rn(s, q), b); };
+    return make_uint4(w4m_pack<T>(dq(c0), dq(c1)), w4m_pack<T>(dq(c2), dq(c3)), w4m_pack<T>(dq(c4), dq(c5)), w4m_pack<T>(dq(c6), dq(c7)));
+}
+
+// y[M, N] = x[M, K] . dequant(W)[N, K]^T, M <= 32.  grid = N / 32 workgroups of 8 waves.
+// Two rings per wave: the weight tiles come from HBM (~2 us away) and cost 5 registers per slot -> W4M_WDEPTH = 8 slots in
+// flight (with depth 3 the 128-workgroup matrices, o_proj and down, had 27 KB in flight per CU on half the chip: 1.7 TB/s);
+// the x fragments come from L2 and cost 16 registers per slot -> 2 slots.
+template <class T>
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y) {
+    __shared__ float s_red[W4M_WAVES][16][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, groups = K >> 6;
+    const int nt = blockIdx.x;
+    const char *strip = w4m + (size_t)nt * groups * W4M_TILE_BYTES;
+    const int m = n < M ? n : M - 1;                          // B-operand column = x row (columns >= M are never stored)
+    const u16 *xrow = x + (size_t)m * K + 8 * kh;
+    const int my_groups = groups > wave ? (groups - wave + W4M_WAVES - 1) / W4M_WAVES : 0;
+
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    uint4 cw[W4M_WDEPTH], xf[W4M_XDEPTH][4];
+    u32 sb[W4M_WDEPTH];
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // iteration `it` of this wave -> tile group (clamped to a valid one: never branch around a load)
+    auto group_of = [&](int it) {
+        it = it < my_groups ? it : my_groups - 1;
+        int g = wave + (it < 0 ? 0 : it) * W4M_WAVES;
+        return g < groups ? g : groups - 1;
+    };
+#define W4M_WISSUE(d, it)                                                                                          \
+    {                                                                                                              \
+        const char *tile_ = strip + (size_t)group_of(it) * W4M_TILE_BYTES;                                          \
+        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);           \
+        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                                \
+        sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);                        \
+    }
+#define W4M_XISSUE(d, it)                                                                                          \
+    {                                                                                                              \
+        const u16 *xp_ = xrow + (size_t)group_of(it) * 64;                                                          \
+        xf[d][0] = *reinterpret_cast<const uint4 *>(xp_), xf[d][1] = *reinterpret_cast<const uint4 *>(xp_ + 16);    \
+        xf[d][2] = *reinterpret_cast<const uint4 *>(xp_ + 32), xf[d][3] = *reinterpret_cast<const uint4 *>(xp_ + 48); \
+    }
+#pragma unroll
+    for (int d = 0; d < W4M_WDEPTH; ++d) W4M_WISSUE(d, d)
+#pragma unroll
+    for (int d = 0; d < W4M_XDEPTH; ++d) W4M_XISSUE(d, d)
+    for (int base = 0; base < my_groups; base += W4M_WDEPTH) {
+#pragma unroll
+        for (int d = 0; d < W4M_WDEPTH; ++d) {
+            const int it = base + d;
+            constexpr int XD = W4M_XDEPTH;
+            if (it < my_groups) {  // wave-uniform
+                const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
+                const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 af = (W4M_ABL & 1) ? make_uint4(words[k], words[k] ^ sb[d], words[k] + 1, sb[d]) : w4m_dequant<T>(words[k], s, b);
+                    if (W4M_ABL & 4) acc[k] += __builtin_bit_cast(float, af.x ^ af.y ^ af.z ^ af.w ^ xf[d % XD][k].x);
+                    else acc = MfmaT<T>::run(af, xf[d % XD][k], acc);
+                }
+            }
+            W4M_WISSUE(d, it + W4M_WDEPTH)
+            if (!(W4M_ABL & 2)) W4M_XISSUE(d % XD, it + XD)
+        }
+    }
+#undef W4M_WISSUE
+#undef W4M_XISSUE
+    // partial tiles -> LDS, summed in wave order (deterministic), rounded once, stored for the M live columns
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
+        const int i = o >> 6, l = o & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
+        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // accumulator register i <-> A row (i & 3) + 8 (i >> 2) + 4 kh
+        if (mm < M) y[(size_t)mm * N + nn] = T::from_f32(v);
+    }
+}
+
+
+// The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
+// row per lane (32 cache lines per load instruction): at 32 rows the address unit, not HBM, sets the pace (5.0 ms per 8B-model
+// prompt, no better than the T-copy path).  Here each round of 8 groups (512 columns) first lands in LDS with row-contiguous
+// 16-byte loads (one x row segment per wave instruction), double-buffered against the MFMA work of the previous round; the
+// fragments are then ds_read_b128 with rows 1040 bytes apart (16 lanes of a quarter-wave hit 16 distinct bank quads).
+constexpr int W4M_XROW = 1024 + 16;  // bytes per staged x row: 512 columns + pad
+template <class T>
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y) {
+    __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, groups = K >> 6;
+    const int nt = blockIdx.x;
+    const char *strip = w4m + (size_t)nt * groups * W4M_TILE_BYTES;
+    const int rounds = (groups + W4M_WAVES - 1) / W4M_WAVES;
+    const int m_read = n < M ? n : M - 1;  // fragment row (columns >= M of the product are never stored)
+
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    uint4 cw[W4M_DEPTH];
+    u32 sb[W4M_DEPTH];
+#define W4M_WLOAD(d, r)                                                                                   \
+    {                                                                                                     \
+        int g_ = wave + ((r) < rounds ? (r) : rounds - 1) * W4M_WAVES;                                    \
+        g_ = g_ < groups ? g_ : groups - 1;                                                               \
+        const char *tile_ = strip + (size_t)g_ * W4M_TILE_BYTES;                                          \
+        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);  \
+        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                       \
+        sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);               \
+    }
+    // x rows of round r: wave w owns rows w, w + 8, w + 16, w + 24; lane l their columns 512 r + 8 l .. + 8
+    uint4 xs[4];
+    auto x_fetch = [&](int r) {
+        const int col = 512 * r + 8 * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wave + 8 * j;
+            xs[j] = (m < M && col < K) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wave + 8 * j;
+            if (m < M) *reinterpret_cast<uint4 *>(s_x[buf] + m * W4M_XROW + lane * 16) = xs[j];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < W4M_DEPTH; ++d) W4M_WLOAD(d, d)
+    x_fetch(0);
+    x_store(0);
+    __syncthreads();
+
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int base = 0; base < rounds; base += W4M_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < W4M_DEPTH; ++d) {
+            const int r = base + d;
+            if (r < rounds) {  // uniform for the workgroup
+                if (r + 1 < rounds) x_fetch(r + 1);
+                if (wave + r * W4M_WAVES < groups) {  // wave-uniform: the last round may be short
+                    const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
+                    const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
+                    const char *xr = s_x[r & 1] + m_read * W4M_XROW + wave * 128 + kh * 16;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc = MfmaT<T>::run(w4m_dequant<T>(words[k], s, b), *reinterpret_cast<const uint4 *>(xr + 32 * k), acc);
+                }
+                W4M_WLOAD(d, r + W4M_DEPTH)
+                if (r + 1 < rounds) x_store((r + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+#undef W4M_WLOAD
+    float(*s_red)[16][64] = reinterpret_cast<float(*)[16][64]>(&s_x[0][0]);  // every wave is past its last fragment read (barrier above)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
+        const int i = o >> 6, l = o & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
+        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+        if (mm < M) y[(size_t)mm * N + nn] = T::from_f32(v);
+    }
+}
+
+size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
+
+int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) {
+    PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M repack: N must be a multiple of 32 and K of 64");
+    const size_t n = (size_t)(N >> 5) * (K >> 6) * 64;
+    hipLaunchKernelGGL(k_w4s_to_w4m, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K), (u32 *)w4m);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st) {
+    PIE_REQUIRE(M >= 1 && M <= 32, PIE_E_SHAPE, "W4M GEMM: 1 to 32 rows");
+    PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M GEMM: N must be a multiple of 32 and K of 64");
+    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 2), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
+    const dim3 grid(N >> 5), block(W4M_WAVES * 64);
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
+    const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
+    const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
+    if (M >= stage_min) {
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
+        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
+    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
+    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+extern "C" {
+
+size_t pie_w4m_bytes(int N, int K) { return N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0 ? w4m_bytes(N, K) : 0; }
+
+int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream) {
+    PIE_REQUIRE(w4s && w4m, PIE_E_ARG, "pie_repack_w4s_to_w4m: null pointer");
+    return w4m_repack_launch(w4s, N, K, w4m, (hipStream_t)stream);
+}
+
+int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
+    PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
+    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -481,3 +481,33 @@ def add_bias_rms_norm(x: torch.Tensor, r: torch.Tensor, bias: torch.Tensor, norm
     _ffi.check(_ffi.load().pie_add_bias_rms_norm(_ffi.p(x.contiguous()), _ffi.p(r.contiguous()), _ffi.p(bias.contiguous()), _ffi.p(norm_weight.contiguous()),
                                                  float(eps), M, N, _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.p(xn), _ffi.stream()))
     return y, xn
+
+
+def quantized_matmul_rows(x: torch.Tensor, w: "W4SWeight", w4m: torch.Tensor | None = None) -> torch.Tensor:
+    """mx.quantized_matmul for a few rows (2..32) in its many-row regime -- weights dequantised to T, T x T products on the
+    MFMA units, fp32 accumulation -- reading the int4 weights once (pie_qgemm_w4m).  x [M, K]; w: the W4S matrix (N % 32 == 0);
+    w4m: its W4M tile copy from `repack_w4m` (built here when absent)."""
+    _dev(x)
+    if not isinstance(w, W4SWeight):
+        raise TypeError("quantized_matmul_rows takes a W4SWeight (int4 g=64)")
+    M, K = x.shape
+    if K != w.K or not 1 <= M <= 32 or w.N % 32:
+        raise ValueError("quantized_matmul_rows: x [M <= 32, K], N % 32 == 0")
+    if w4m is None:
+        w4m = repack_w4m(w)
+    y = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
+    _ffi.check(_ffi.load().pie_qgemm_w4m(_ffi.p(x.contiguous()), _ffi.p(w4m), M, w.N, K, _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    if w.lin_bias is not None:
+        y = add(y, w.lin_bias.expand_as(y).contiguous())
+    return y
+
+
+def repack_w4m(w: "W4SWeight") -> torch.Tensor:
+    """W4S stream -> W4M tiles (32 rows x 64 columns, MFMA operand order; include/pie_hip.h), same bytes per weight."""
+    lib = _ffi.load()
+    n = lib.pie_w4m_bytes(w.N, w.K)
+    if n == 0:
+        raise ValueError("repack_w4m: N must be a multiple of 32 and K of 64")
+    out = torch.empty(n, dtype=torch.uint8, device=w.packed.device)
+    _ffi.check(lib.pie_repack_w4s_to_w4m(_ffi.p(w.packed), w.N, w.K, _ffi.p(out), _ffi.stream()))
+    return out

@@ -281,6 +281,30 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
         assert_vec_close(k_gpu.ravel(), ocache[0].keys[0, :, :140].ravel(), DT, what=f"{regime} layer-0 keys")
 
 
+@pytest.mark.parametrize("L", [6, 9, 16, 24, 32, 33])
+def test_short_prompt_int4_gemm_paths(tiny, monkeypatch, L):
+    """Prompts of 6..32 tokens run the few-row int4 GEMM on W4M tiles (w4m_gemm.hip: direct fragments below 24 rows, x staged
+    through LDS from 24), 33 and PIE_SMALL_M=0 the T copy + hipBLASLt: same qmm contract, every position against the oracle,
+    and the two paths within one rounding of each other."""
+    g, cfg, w, _ = tiny
+    rng = np.random.default_rng(L)
+    prompt = rng.integers(0, cfg["vocab_size"], L)
+    orc = po.OracleLlama(cfg, w, DT)
+    want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
+    outs = {}
+    for small in ("32", "0"):
+        monkeypatch.setenv("PIE_SMALL_M", small)
+        m = build(cfg, w)
+        cache = m.make_cache()
+        got = m(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got[l], want[l], DT, what=f"PIE_SMALL_M={small} L={L} position {l}")
+        tok, _, logits = m.step(None, cache)                           # decode continues on the cache the short prompt filled
+        outs[small] = (got, logits.float().cpu().numpy())
+    assert_vec_close(outs["32"][0][-1], outs["0"][0][-1], DT, what="w4m vs hipBLASLt path")
+    assert_vec_close(outs["32"][1], outs["0"][1], DT, what="decode after w4m vs hipBLASLt prompt")
+
+
 def test_batched_prefill_llama8b_shapes(monkeypatch):
     """The real GEMM shapes (N = 6144 / 4096 / 28672, K = 4096 / 14336) on two Llama-3-8B-shaped layers: 48-token prompt
     through the batched path, then decode steps on the cache it filled."""

@@ -314,3 +314,25 @@ def test_qgemv_partial_fp32_and_row_parallel_sum(ops):
         total = part if total is None else total + part
     got = total.to(torch.bfloat16)
     assert_dot_close(got.float().cpu().numpy(), full, dt, what="sum of row-parallel partials")
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K", [(6, 64, 64), (32, 96, 4096), (17, 4096, 1408), (1, 32, 192), (9, 6144, 4096), (31, 128, 14336)])
+def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
+    """pie_qgemm_w4m (W4M tiles, in-register dequantisation, MFMA) against the oracle's many-row regime of
+    mx.quantized_matmul (weights dequantised to T first); K = 1408 / 192: ragged last W4S slice, fewer groups than waves."""
+    rng = np.random.default_rng(M * 7 + N)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    wq, sc, bi = po.quantize(w, 64, 4, dt)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+    got = ops.quantized_matmul_rows(to_dev(po.to_bits(x, dt), dt), packed)
+    want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w4m {M}x{N}x{K} {dt}")
+    # the tile copy holds exactly the W4S matrix: multiplying the identity recovers the dequantised weights bit for bit
+    if K <= 192:
+        eye = np.zeros((min(32, K), K), np.float32)
+        eye[np.arange(min(32, K)), np.arange(min(32, K))] = 1.0
+        cols = ops.quantized_matmul_rows(to_dev(po.to_bits(eye, dt), dt), packed)          # [32, N]: row j = column j of W
+        deq = po.dequantize(wq, sc, bi, dtype=dt)
+        assert np.array_equal(to_bits(cols), po.to_bits(deq[:, :min(32, K)].T.copy(), dt))
