@@ -15,7 +15,6 @@ as "bits" arrays (uint16 for bfloat16/float16, float32 for float32).
 from __future__ import annotations
 
 import ctypes as C
-import os
 import subprocess
 from pathlib import Path
 

@@ -126,7 +126,6 @@ def test_vision_tower_vs_oracle(cfg, grid):
     N = sum(t * h * ww for t, h, ww in grid)
     pix = po.round_T(np.random.default_rng(7).standard_normal((N, 3 * 2 * 14 * 14)), DT)
     want, states = vo.vision_forward(cfg, w, pix, grid, DT, want_states=True)
-    got_states = []
     got = model(dev(pix), torch.tensor(grid), output_hidden_states=False)
     assert got.shape == (N // 4, cfg["out_hidden_size"])
     assert_vec_close(got.float().cpu().numpy(), want, DT, c_max=6.0, c_rms=5.0, what=f"tower output {grid}")

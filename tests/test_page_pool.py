@@ -5,7 +5,6 @@ the threaded cases do race in the native code; tests/cpp/page_pool_stress.cpp re
 ThreadSanitizer)."""
 import os
 import subprocess
-import sys
 import threading
 from pathlib import Path
 
