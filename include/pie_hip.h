@@ -200,6 +200,16 @@ int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *co
  * Capacity = max_blocks * 64.  Steps, prefill, graphs and outputs behave exactly as with contiguous buffers. */
 int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_pages, const int32_t *block_table, int max_blocks,
                              void *stream);
+/* One decode step for B sequences at once over the paged KV pool (continuous batching): the weights stream once for all rows;
+ * row s is its own sequence -- input token tokens[s], attending context_lens[s] positions INCLUDING the new one (its position is
+ * context_lens[s] - 1; 0 = idle slot), K / V appended to page block_tables[s][pos / 64] of every layer's slab (slabs: HOST array
+ * [n_layers] of device pointers), attention over its own table row.  Outputs per row: logits T [B, vocab], logprobs fp32
+ * [B, vocab], next_tokens int32 [B] (greedy).  What the reference's decode-state batch is meant to be (BatchDetails,
+ * include/engine/batch_details.hpp:10-88; Scheduler and the paged attention kernel are skeletons there).  Independent of
+ * pie_decoder_set_kv / set_state / bind_outputs; all device arrays are caller-owned. */
+int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
+                           const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
+                           void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);

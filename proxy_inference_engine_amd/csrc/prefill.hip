@@ -74,11 +74,16 @@ template <class T>
 __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
-                                                         int n_pages) {
-    const int m = blockIdx.x, pos = state->pos + m, half = HD >> 1;
-    int cap = state->cap, kvrow = pos;
+                                                         int n_pages, const int *ctx_len = nullptr, int bt_stride = 0, u16 *slab = nullptr) {
+    // ctx_len != nullptr (multi-sequence decode step): row m is its own sequence at position ctx_len[m] - 1 with its own block
+    // table row and the layer's slab given directly; otherwise row m continues the decoder's one sequence at state->pos + m
+    const int m = blockIdx.x, pos = ctx_len ? ctx_len[m] - 1 : state->pos + m, half = HD >> 1;
+    if (pos < 0) return;  // idle slot of the batch
+    int cap = ctx_len ? 64 : state->cap, kvrow = pos;
     const int q_cols = n_heads * HD, k_cols = n_kv_heads * HD;
-    u16 *kdst = reinterpret_cast<u16 *>(kv_table[layer]), *vdst = reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
+    u16 *kdst = slab ? slab : reinterpret_cast<u16 *>(kv_table[layer]);
+    u16 *vdst = slab ? slab + (size_t)n_kv_heads * 64 * HD : reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
+    block_table = block_table ? block_table + (size_t)m * bt_stride : nullptr;
     if (block_table) {  // paged KV: the row goes to slot pos % 64 of page block_table[pos / 64]
         const size_t pg_off = (size_t)min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u) * 2 * 64 * n_kv_heads * HD;
         kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
@@ -328,6 +333,8 @@ struct PrefillScratch {
     std::map<const void *, u16 *> resident;
     // W4M tile copies (w4m_gemm.hip) of int4 layer matrices for prompts of at most small_rows() rows: 0.5625 B per weight each
     std::map<const void *, void *> resident_w4m;
+    LogitStat *tail_stats = nullptr;  // multi-sequence step: per-row tail partials
+    int tail_rows = 0;
     int resident_mode = -1;   // -1: budget not fixed yet
     size_t resident_left = 0; // bytes still available for resident copies
 };
@@ -338,10 +345,13 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
     auto keep_m = std::move(s->resident_w4m);
+    LogitStat *keep_ts = s->tail_stats;
+    const int keep_tr = s->tail_rows;
     const int mode = s->resident_mode;
     const size_t left = s->resident_left;
     *s = PrefillScratch();
     s->resident = std::move(keep), s->resident_w4m = std::move(keep_m), s->resident_mode = mode, s->resident_left = left;
+    s->tail_stats = keep_ts, s->tail_rows = keep_tr;
 }
 
 void prefill_free(pie_decoder *d) {
@@ -349,6 +359,7 @@ void prefill_free(pie_decoder *d) {
     scratch_release(d->prefill);
     for (auto &kv : d->prefill->resident) (void)hipFree(kv.second);
     for (auto &kv : d->prefill->resident_w4m) (void)hipFree(kv.second);
+    if (d->prefill->tail_stats) (void)hipFree(d->prefill->tail_stats);
     delete d->prefill;
     d->prefill = nullptr;
 }
@@ -455,9 +466,9 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
-                       const void *bias = nullptr) {
+                       const void *bias = nullptr, bool keep_w4m = false) {
     PrefillScratch *s = d->prefill;
-    if (keep && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
+    if ((keep || keep_w4m) && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
         if (it != s->resident_w4m.end()) wm = it->second;
@@ -585,6 +596,81 @@ extern "C" int pie_sdpa_prefill(const void *q, const void *k, const void *v, int
     if (dtype == PIE_BF16) return prefill_attn_launch_t<BF16>(a, D, (hipStream_t)stream);
     if (dtype == PIE_F16) return prefill_attn_launch_t<F16>(a, D, (hipStream_t)stream);
     return pie::fail(PIE_E_ARG, "pie_sdpa_prefill: dtype must be PIE_BF16 or PIE_F16");
+}
+
+
+// ---------------------------------------------------------------- one decode step for B sequences (continuous batching)
+// The weights stream once for all B rows (few-row int4 GEMM for B <= 32, the T copy + hipBLASLt beyond); each row is its own
+// sequence: RoPE at its own position, K/V appended to its own page, attention over its own block table (k_attn_decode PAGED,
+// one sequence per blockIdx.z), lm_head + tail on every row.  What the reference's Scheduler / BatchDetails / PagedAttention
+// skeleton (src/pie_core/include/engine/batch_details.hpp:10-88, scheduler.hpp) describes for decode-state sequences.
+template <class T>
+static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *ctx_len, const void *const *slabs, int n_pages,
+                          const int32_t *block_tables, int max_blocks, int B, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
+    const pie_decoder_config &c = d->cfg;
+    const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
+    size_t w_elems = (size_t)2 * I * H;
+    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
+    if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    // attention splits: enough workgroups for two per CU across the batch, never more than pages per sequence
+    int splits = (512 + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);
+    splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
+    splits = splits < 1 ? 1 : splits;
+    int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
+    if (rc) return rc;
+    PrefillScratch *s = d->prefill;
+    if (s->tail_rows < B) {
+        if (s->tail_stats) (void)hipFree(s->tail_stats);
+        s->tail_stats = nullptr, s->tail_rows = 0;
+        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)B));
+        s->tail_rows = B;
+    }
+    rc = c.weight_format == PIE_W_DENSE
+             ? pie_embedding_dense(tokens, B, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
+             : embedding_launch(tokens, B, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
+                                nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
+    if (rc) return rc;
+    for (int li = 0; li < c.n_layers; ++li) {
+        const pie_layer_weights &w = d->layers[li];
+        if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv))) return rc;
+        hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+                           c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, ctx_len, max_blocks, (u16 *)slabs[li]);
+        PIE_LAUNCH_CHECK();
+        AttnArgs a = {};
+        a.q = s->q, a.slab = (const u16 *)slabs[li], a.block_table = block_tables, a.ctx_len = ctx_len, a.bt_stride = max_blocks, a.n_pages = n_pages;
+        a.rows = B, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = splits, a.scale = 1.0f / sqrtf((float)D);
+        a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;
+        a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
+        if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup))) return rc;
+        const size_t n_act = (size_t)B * I;
+        hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
+        PIE_LAUNCH_CHECK();
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown))) return rc;
+        const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;  // final norm: language.py:187
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+    }
+    if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, B, logits, st, false, nullptr, true))) return rc;
+    return logits_tail_rows_launch(c.dtype, logits, c.vocab, B, s->tail_stats, logprobs, next_tokens, st);
+}
+
+extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
+                                      const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
+                                      void *stream) {
+    PIE_REQUIRE(d && tokens && context_lens && slabs && block_tables && logits && logprobs && next_tokens, PIE_E_ARG, "pie_decoder_step_batch: null pointer");
+    PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_step_batch: set_globals must be called first");
+    for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_step_batch: a layer has no weights (pie_decoder_set_layer)");
+    PIE_REQUIRE(B >= 1 && B <= 4096 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_step_batch: bad batch shape");
+    const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
+    PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_step_batch: n_heads / n_kv_heads must be between 1 and 8");
+    for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_step_batch: null or misaligned slab");
+    hipStream_t st = (hipStream_t)stream;
+    return d->cfg.dtype == PIE_BF16
+               ? decode_batch_t<BF16>(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st)
+               : decode_batch_t<F16>(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st);
 }
 
 int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st) {

@@ -15,6 +15,7 @@ template <class T>
 __global__ void __launch_bounds__(256) k_logits_stats(const u16 *logits, int V, LogitStat *stats) {
     __shared__ float s_max[4], s_sum[4];
     __shared__ int s_arg[4];
+    logits += (size_t)blockIdx.y * V, stats += (size_t)blockIdx.y * gridDim.x;  // blockIdx.y: row of a batch of logit vectors
     const int tile_len = (V + gridDim.x - 1) / gridDim.x;
     const int begin = blockIdx.x * tile_len, end = min(V, begin + tile_len);
     float mx = -INFINITY;
@@ -53,6 +54,7 @@ __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V,
                                                        int *token, DecState *state, int *history, int hist_cap) {
     __shared__ float s_max[4], s_sum[4];
     __shared__ int s_arg[4];
+    logits += (size_t)blockIdx.y * V, stats += (size_t)blockIdx.y * n_stats, logprobs += (size_t)blockIdx.y * V, token += blockIdx.y;  // batch row
     // every workgroup merges all partials: 16 independent 16-byte loads per thread, then two register passes
     LogitStat st[16];
 #pragma unroll
@@ -109,6 +111,22 @@ __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V,
             state->pos = next_pos;  // cache.offset += 1 (reusable.py:139)
         }
     }
+}
+
+// `rows` logit vectors [rows, V] at once (the multi-sequence decode step): stats_buf = rows * TAIL_STAT_TILES partials of scratch.
+static inline int logits_tail_rows_launch(int dtype, const u16 *logits, int V, int rows, LogitStat *stats_buf, float *logprobs, int *tokens,
+                                          hipStream_t st) {
+    if (dtype != PIE_BF16 && dtype != PIE_F16) return pie::fail(PIE_E_ARG, "logits tail: dtype must be PIE_BF16 or PIE_F16");
+    const dim3 g1(TAIL_STAT_TILES, rows), g2(TAIL_FINISH_BLOCKS, rows);
+    if (dtype == PIE_BF16) {
+        hipLaunchKernelGGL(k_logits_stats<BF16>, g1, dim3(256), 0, st, logits, V, stats_buf);
+        hipLaunchKernelGGL(k_logits_finish<BF16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0);
+    } else {
+        hipLaunchKernelGGL(k_logits_stats<F16>, g1, dim3(256), 0, st, logits, V, stats_buf);
+        hipLaunchKernelGGL(k_logits_finish<F16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0);
+    }
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
 }
 
 // stats == nullptr (op-level API): the per-tile partials are computed from the logits first, into

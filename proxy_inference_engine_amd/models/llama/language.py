@@ -175,6 +175,7 @@ class Model:
         self._kv_key = None      # (pointers, capacity) currently in the decoder's device table
         self._kv_hold = None
         self._page_pool, self._page_blocks = None, 16
+        self._batch_key, self._batch_table = None, None
         self._dev_offset = None  # device-side cache offset the decoder believes in
         torch.cuda.synchronize(device)
 
@@ -353,6 +354,46 @@ class Model:
         pos = self._dev_offset  # position the chosen token will occupy
         token = self.history[pos:pos + 1] if pos < self.history.numel() else self.token.clone()
         return token, self.logprobs, self.logits
+
+    def step_batch(self, tokens: torch.Tensor, caches: list[list[BaseCache]]):
+        """One decode step for several sequences at once (continuous batching over the page pool; pie_decoder_step_batch):
+        tokens [B] = each sequence's input token, caches = their per-layer PagedKVCache lists (model.make_cache() after
+        enable_paged_kv(), all drawing on one PageAllocator, each already holding its prompt -- e.g. through step()).
+        Returns (next_tokens [B] int32 greedy, logprobs [B, V] fp32, logits [B, V]); every cache advances by one position.
+        The weights stream once for the whole batch: int4 models run the few-row MFMA GEMM up to 32 sequences."""
+        seqs = []
+        for c in caches:
+            if len(c) != len(self.layers) or not isinstance(c[0], PagedKVCache):
+                raise TypeError("step_batch runs on paged caches (enable_paged_kv(), then make_cache())")
+            seqs.append(c[0].page_manager)
+        a = seqs[0].allocator
+        if any(s.allocator is not a for s in seqs) or len({id(s) for s in seqs}) != len(seqs):
+            raise ValueError("step_batch: distinct sequences of one page pool")
+        B = len(seqs)
+        tokens = tokens.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+        if tokens.numel() != B:
+            raise ValueError("step_batch: one token per sequence")
+        for s in seqs:
+            s.reserve(1)
+        key = tuple((id(s), len(s.pages)) for s in seqs)
+        if self._batch_key != key:   # the consolidated block table (batch_details.hpp:52-66) changes when a sequence takes a page
+            mb = max(len(s.pages) for s in seqs)
+            table = torch.zeros((B, mb), dtype=torch.int32)
+            for i, s in enumerate(seqs):
+                table[i, :len(s.pages)] = torch.tensor(s.pages, dtype=torch.int32)
+            self._batch_table, self._batch_key = table.to(self.device), key
+        ctx = torch.tensor([s.offset + 1 for s in seqs], dtype=torch.int32).to(self.device)
+        V = self.args.vocab_size
+        logits = torch.empty((B, V), dtype=self.dtype, device=self.device)
+        logprobs = torch.empty((B, V), dtype=torch.float32, device=self.device)
+        nxt = torch.empty(B, dtype=torch.int32, device=self.device)
+        n = len(self.layers)
+        slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
+        _ffi.check(_ffi.load().pie_decoder_step_batch(self._dec, _ffi.p(tokens), _ffi.p(ctx), slabs, a.size(), _ffi.p(self._batch_table),
+                                                      self._batch_table.shape[1], B, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt), _ffi.stream()))
+        for s in seqs:
+            s.advance(1)
+        return nxt, logprobs, logits
 
     def step_bytes(self, T: int, with_logits: bool = True) -> int:
         """Algorithmic HBM bytes of one decode step at context length T."""

@@ -283,3 +283,88 @@ def test_forked_sequence_shares_full_pages(golden_dir):
         ref[0].page_manager.release()
     seq_b.release()
     assert all(pool.get_page(p).get_ref_count() == 1 for p in a[0].page_manager.pages[:2])
+
+
+# ---------------------------------------------------------------------------- multi-sequence decode step (continuous batching)
+def _oracle_seq(cfg, w, prompt, steps, regime_rows):
+    """Oracle run of one sequence: prompt, then `steps` teacher-forced steps along its own greedy choices; the batched step
+    multiplies B rows at once, so its Linears are in MLX's many-row regime from 6 sequences on (oracle qmm_min_rows)."""
+    orc = po.OracleLlama(cfg, w, "bfloat16")
+    cache = [po.OracleKVCache() for _ in orc.layers]
+    logits = [orc.forward(prompt, cache)[-1]]
+    po.set_qmm_min_rows(regime_rows)
+    try:
+        for _ in range(steps):
+            logits.append(orc.forward(np.array([int(np.argmax(logits[-1]))]), cache)[0])
+    finally:
+        po.set_qmm_min_rows(6)
+    return logits
+
+
+@pytest.mark.parametrize("B", [3, 8, 32, 40])
+def test_batched_decode_step_matches_each_sequence_alone(golden_dir, B):
+    """B sequences of different lengths decode together (pie_decoder_step_batch): the weights stream once per step, every row
+    has its own position, pages and attention span.  Each row's logits must be what the oracle gives for that sequence alone
+    (teacher-forced along the oracle's greedy tokens, margins permitting); B = 3: GEMV-regime arithmetic is not used here
+    either (the batch path always multiplies dequantised-to-T weights), so the oracle runs the qmm regime from 1 row.
+    B = 40: beyond the few-row kernel, the T copy + hipBLASLt."""
+    from tests._util import assert_vec_close
+    from tests.test_gpu_decode import margin_bound
+    g, cfg, model = _tiny(golden_dir)
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    rng = np.random.default_rng(B)
+    steps = 4
+    lens = [int(rng.integers(7, 150)) for _ in range(B)]
+    lens[0], lens[-1] = 63, 64                                   # a sequence that crosses a page boundary during the steps, one that just did
+    prompts = [rng.integers(0, cfg["vocab_size"], n).astype(np.int32) for n in lens]
+    pool = model.enable_paged_kv(num_pages=4 * B + 4, max_blocks=2)
+    caches, toks = [], []
+    for p in prompts:
+        c = model.make_cache()
+        tok, _, _ = model.step(torch.from_numpy(p).cuda(), c)
+        caches.append(c)
+        toks.append(int(tok.item()))
+    want = [_oracle_seq(cfg, w, p, steps, 1) for p in prompts[:6]]          # the oracle is slow: check the first six rows
+    alive = [True] * len(want)
+    tokens = torch.tensor(toks, dtype=torch.int32, device="cuda")
+    for st in range(steps):
+        # teacher-force the oracle's greedy token where we compare, the model's own elsewhere
+        feed = tokens.clone()
+        for i in range(len(want)):
+            feed[i] = int(np.argmax(want[i][st]))
+        tokens, logprobs, logits = model.step_batch(feed, caches)
+        assert tokens.shape == (B,) and logprobs.shape == (B, cfg["vocab_size"])
+        got = logits.float().cpu().numpy()
+        for i in range(len(want)):
+            assert_vec_close(got[i], want[i][st + 1], "bfloat16", what=f"B={B} step {st} row {i} (len {lens[i]})")
+            top2 = np.sort(want[i][st + 1])[-2:]
+            if top2[1] - top2[0] > margin_bound(want[i][st + 1]):
+                assert int(tokens[i].item()) == int(np.argmax(want[i][st + 1]))
+        lp = logprobs.double().exp().sum(dim=1).cpu().numpy()
+        assert np.all(np.abs(lp - 1.0) < 1e-4)
+    for c, n in zip(caches, lens):
+        assert c[0].offset == n + steps
+    assert pool.size() - pool.get_num_free_pages() == sum((n + steps + 63) // 64 for n in lens)
+
+
+def test_batched_step_equals_single_sequence_batched_path(golden_dir):
+    """A batch of one sequence against a one-token prompt through the batched path on a contiguous cache (PIE_PREFILL_MIN=1):
+    same Linears, different attention kernel (paged split-KV decode vs the MFMA prompt kernel) -- equal within rounding."""
+    import os
+    from tests._util import assert_vec_close
+    g, cfg, model = _tiny(golden_dir)
+    prompt = g["prompt"].astype(np.int32)
+    ref_cache = model.make_cache()
+    model.step(torch.from_numpy(prompt).cuda(), ref_cache)
+    os.environ["PIE_PREFILL_MIN"] = "1"
+    try:
+        want = model(torch.tensor([[77]]).cuda(), cache=ref_cache)[0, -1]
+    finally:
+        del os.environ["PIE_PREFILL_MIN"]
+    model.enable_paged_kv(num_pages=8)
+    c = model.make_cache()
+    model.step(torch.from_numpy(prompt).cuda(), c)
+    _, _, logits = model.step_batch(torch.tensor([77], dtype=torch.int32), [c])
+    assert_vec_close(logits[0].float().cpu().numpy(), want.float().cpu().numpy(), "bfloat16", what="batch of one")
+    with pytest.raises(TypeError):
+        model.step_batch(torch.tensor([1]), [ref_cache])
