@@ -1,0 +1,72 @@
+"""Aggregate decode throughput of the multi-sequence step (pie_decoder_step_batch) on the 8B int4 model: B sequences share one
+pass over the weights.  Prints ms per step and total tokens/s per batch size, next to the single-sequence graph-replayed step.
+
+    python scripts/bench_batch.py [--batches 1,2,4,8,16,32,64] [--prompt 128] [--steps 32]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from proxy_inference_engine_amd.models.llama import Model, ModelArgs  # noqa: E402
+from proxy_inference_engine_amd.models.utils import LLAMA3_8B, synthetic_checkpoint  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", default="1,2,4,8,16,32,64")
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--layers", type=int, default=0)
+    args = ap.parse_args()
+    cfg = dict(LLAMA3_8B)
+    if args.layers:
+        cfg["num_hidden_layers"] = args.layers
+    model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16))
+    torch.cuda.empty_cache()
+    batches = [int(b) for b in args.batches.split(",")]
+    pages_per_seq = (args.prompt + 8 + 2 * args.steps + 63) // 64 + 1
+    model.enable_paged_kv(num_pages=max(batches) * pages_per_seq + 4, max_blocks=pages_per_seq)
+    # single-sequence baseline: the graph-replayed decode step on a paged cache
+    c0 = model.make_cache()
+    g = torch.Generator().manual_seed(1)
+    model.step(torch.randint(0, cfg["vocab_size"], (args.prompt,), generator=g).cuda(), c0)
+    for _ in range(8):
+        model.step(None, c0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.step(None, c0)
+    torch.cuda.synchronize()
+    single = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"mode": "single sequence, hipGraph step", "ms_per_step": round(single * 1e3, 3), "tokens_per_s": round(1 / single, 1)}), flush=True)
+    c0[0].page_manager.release()
+    for B in batches:
+        caches = []
+        toks = []
+        for i in range(B):
+            c = model.make_cache()
+            tok, _, _ = model.step(torch.randint(0, cfg["vocab_size"], (args.prompt + (i % 7),), generator=g).cuda(), c)
+            caches.append(c)
+            toks.append(tok)
+        tokens = torch.cat(toks)
+        for _ in range(4):
+            tokens, _, _ = model.step_batch(tokens, caches)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tokens, _, _ = model.step_batch(tokens, caches)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"mode": "step_batch", "sequences": B, "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(B / dt, 1),
+                          "vs_single": round(B / dt * single, 2)}), flush=True)
+        for c in caches:
+            c[0].page_manager.release()
+
+
+if __name__ == "__main__":
+    main()
