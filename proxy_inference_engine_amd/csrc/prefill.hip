@@ -67,6 +67,19 @@ __global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out)
     *reinterpret_cast<uint2 *>(out + (size_t)r * K + (size_t)wk * 4) = make_uint2(pack2<T>(q0, q1), pack2<T>(q2, q3));
 }
 
+// (cos, sin) of every row's rotary angles, once per forward: the angle of pair ii at position p is the same for all heads and all
+// layers, and sincosf on arguments up to ~1e5 rad (argument reduction) was most of k_rope_append_rows' 8 us per layer.
+__global__ void k_rope_cs_rows(const float *freqs, const DecState *state, const int *ctx_len, int half, float *cs) {
+    const int m = blockIdx.x;
+    int pos = ctx_len ? ctx_len[m] - 1 : state->pos + m;
+    pos = pos < 0 ? 0 : pos;
+    for (int ii = threadIdx.x; ii < half; ii += blockDim.x) {
+        float sn, c;
+        sincosf((float)pos * (1.0f / freqs[ii]), &sn, &c);
+        cs[((size_t)m * half + ii) * 2] = c, cs[((size_t)m * half + ii) * 2 + 1] = sn;
+    }
+}
+
 // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:134-137) for M rows of the packed
 // q|k|v projection: packed columns (2i, 2i+1) of a q/k head are its dims (i, i + D/2); v columns are natural.
 // grid M, one thread per packed column pair.
@@ -74,7 +87,8 @@ template <class T>
 __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
-                                                         int n_pages, const int *ctx_len = nullptr, int bt_stride = 0, u16 *slab = nullptr) {
+                                                         int n_pages, const float *rope_cs, const int *ctx_len = nullptr, int bt_stride = 0,
+                                                         u16 *slab = nullptr) {
     // ctx_len != nullptr (multi-sequence decode step): row m is its own sequence at position ctx_len[m] - 1 with its own block
     // table row and the layer's slab given directly; otherwise row m continues the decoder's one sequence at state->pos + m
     const int m = blockIdx.x, pos = ctx_len ? ctx_len[m] - 1 : state->pos + m, half = HD >> 1;
@@ -96,8 +110,8 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
         if (R < q_cols + k_cols) {
             const int rr = R < q_cols ? R : R - q_cols;
             const int head = rr / HD, ii = (rr % HD) >> 1;
-            float sn, cs;
-            sincosf((float)pos * (1.0f / freqs[ii]), &sn, &cs);
+            const float2 csn = *reinterpret_cast<const float2 *>(rope_cs + ((size_t)m * half + ii) * 2);  // k_rope_cs_rows
+            const float cs = csn.x, sn = csn.y;
             u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
             const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
             dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
@@ -325,7 +339,7 @@ struct PrefillScratch {
     int rows = 0;           // chunk capacity (rows)
     size_t w_elems = 0;     // capacity of the dequantised-weight buffer (elements)
     u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
-    float *part_acc = nullptr, *part_ml = nullptr;
+    float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     int part_splits = 0;
     // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
@@ -340,7 +354,7 @@ struct PrefillScratch {
 };
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
-    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml};
+    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
@@ -396,6 +410,7 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         PF_ALLOC(s->act, 2 * R * c.inter);
         PF_ALLOC(s->part_acc, 4 * R * c.n_heads * splits * c.head_dim);
         PF_ALLOC(s->part_ml, 4 * R * c.n_heads * splits * 2);
+        PF_ALLOC(s->rope_cs, 4 * R * c.head_dim);
         PF_ALLOC(s->wT, 2 * we);
         s->rows = rows, s->part_splits = splits, s->w_elems = we;
     }
@@ -531,6 +546,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                  : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
                                     nullptr, nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
         if (rc) return rc;
+        hipLaunchKernelGGL(k_rope_cs_rows, dim3(M), dim3(64), 0, st, d->glob.rope_freqs, d->state, nullptr, D / 2, s->rope_cs);
+        PIE_LAUNCH_CHECK();
         for (int li = 0; li < c.n_layers; ++li) {
             const pie_layer_weights &w = d->layers[li];
             // Attention.__call__ (language.py:75-108) on input_layernorm(x)
@@ -538,7 +555,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
-                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages);
+                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs);
             PIE_LAUNCH_CHECK();
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
                 PrefillAttnArgs pa = {};
@@ -630,12 +647,14 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
              : embedding_launch(tokens, B, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
                                 nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_rope_cs_rows, dim3(B), dim3(64), 0, st, d->glob.rope_freqs, nullptr, ctx_len, D / 2, s->rope_cs);
+    PIE_LAUNCH_CHECK();
     for (int li = 0; li < c.n_layers; ++li) {
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
         if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv))) return rc;
         hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
-                           c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, ctx_len, max_blocks, (u16 *)slabs[li]);
+                           c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li]);
         PIE_LAUNCH_CHECK();
         AttnArgs a = {};
         a.q = s->q, a.slab = (const u16 *)slabs[li], a.block_table = block_tables, a.ctx_len = ctx_len, a.bt_stride = max_blocks, a.n_pages = n_pages;
