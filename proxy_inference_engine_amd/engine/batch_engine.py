@@ -1,0 +1,93 @@
+"""Continuous batching on top of the multi-sequence decode step (SURVEY.md 8 row f2's "unlocks multi-sequence batching").
+
+The reference declares this shape -- a `Scheduler` that forms `BatchDetails` from prefill- and decode-state sequences over the
+paged pool (src/pie_core/include/engine/batch_details.hpp:10-88, scheduler.hpp) -- without a body (`Scheduler::step` is
+empty, the Python engine serves one sequence).  This is the smallest complete loop over the pieces that exist here: requests
+wait in a queue, join the batch when a slot and enough pages are free (their prompt runs through the single-sequence prompt
+path), every step decodes all active sequences with one pass over the weights (`Model.step_batch`), finished sequences leave
+and return their pages.  Greedy by default; `sampler` maps a [B, V] log-probability block to B token ids."""
+from __future__ import annotations
+
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Callable, Iterable
+
+import torch
+
+from ..cache.kv_cache.paged import TOKEN_CAPACITY_PER_PAGE
+
+
+@dataclass
+class _Active:
+    request: int
+    cache: list
+    token: torch.Tensor           # [1] int32 on the device: the input of the next step
+    generated: list = field(default_factory=list)
+
+
+class BatchedEngine:
+    def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
+                 sampler: Callable[[torch.Tensor], torch.Tensor] | None = None):
+        self.model = model
+        self.pool = model.enable_paged_kv(num_pages=num_pages)
+        self.max_batch = max_batch
+        self.stop_tokens = set(int(t) for t in stop_tokens)
+        self.sampler = sampler
+        self.steps = 0                # batched decode steps taken (for throughput accounting)
+
+    def _pages_for(self, n_tokens: int) -> int:
+        return (n_tokens + TOKEN_CAPACITY_PER_PAGE - 1) // TOKEN_CAPACITY_PER_PAGE
+
+    def generate(self, prompts: list, max_new_tokens: int) -> list[list[int]]:
+        """Token ids generated for every prompt (in order), at most max_new_tokens each, ending early at a stop token."""
+        if max_new_tokens < 1:
+            return [[] for _ in prompts]
+        for p in prompts:
+            if self._pages_for(len(p) + max_new_tokens) > self.pool.size():
+                raise ValueError("a prompt does not fit the page pool")
+        pending = deque(enumerate(prompts))
+        active: list[_Active] = []
+        out: list[list[int]] = [[] for _ in prompts]
+        reserved = 0                  # pages promised to the active sequences for their full length
+        need = {}
+        while pending or active:
+            # admit while there is a slot and the pool can hold the request to its end
+            while pending and len(active) < self.max_batch:
+                idx, prompt = pending[0]
+                n_pages = self._pages_for(len(prompt) + max_new_tokens)
+                if reserved + n_pages > self.pool.size():
+                    break
+                pending.popleft()
+                cache = self.model.make_cache()
+                ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
+                tok, logprobs, _ = self.model.step(ids.to(self.model.device), cache)
+                if self.sampler is not None:
+                    tok = self.sampler(logprobs[None]).reshape(1).to(torch.int32)
+                a = _Active(idx, cache, tok.reshape(1).clone())
+                need[idx] = n_pages
+                reserved += n_pages
+                active.append(a)
+            if not active:
+                raise RuntimeError("no request fits the page pool")      # unreachable after the check above
+            # every active sequence holds one token not yet recorded (from its prompt or from the last step): record, retire, step
+            tokens = torch.cat([a.token for a in active])
+            host = tokens.tolist()                                        # one read-back per step for the stop / length checks
+            keep = []
+            for a, t in zip(active, host):
+                a.generated.append(int(t))
+                if int(t) in self.stop_tokens or len(a.generated) >= max_new_tokens:
+                    out[a.request] = a.generated
+                    a.cache[0].page_manager.release()
+                    reserved -= need.pop(a.request)
+                else:
+                    keep.append(a)
+            active = keep
+            if not active:
+                continue
+            nxt, logprobs, _ = self.model.step_batch(torch.cat([a.token for a in active]), [a.cache for a in active])
+            self.steps += 1
+            if self.sampler is not None:
+                nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
+            for i, a in enumerate(active):
+                a.token = nxt[i:i + 1]
+        return out

@@ -368,3 +368,31 @@ def test_batched_step_equals_single_sequence_batched_path(golden_dir):
     assert_vec_close(logits[0].float().cpu().numpy(), want.float().cpu().numpy(), "bfloat16", what="batch of one")
     with pytest.raises(TypeError):
         model.step_batch(torch.tensor([1]), [ref_cache])
+
+
+def test_continuous_batching_engine(golden_dir):
+    """BatchedEngine: ten requests, at most four in flight, a pool too small for all of them at once -- requests wait, join as
+    others retire, every one finishes with the tokens it gets when served alone (same kernels; only the attention split
+    geometry varies with the batch, so low-margin steps may differ: first tokens exact, overall agreement high), stop tokens
+    end a request early, and every page returns to the pool."""
+    from proxy_inference_engine_amd.engine import BatchedEngine
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(21)
+    prompts = [rng.integers(0, cfg["vocab_size"], int(n)).tolist() for n in rng.integers(3, 90, 10)]
+    new = 6
+    eng = BatchedEngine(model, num_pages=7, max_batch=4)
+    got = eng.generate(prompts, new)
+    assert [len(t) for t in got] == [new] * 10
+    assert eng.pool.get_num_free_pages() == eng.pool.size()
+    assert 0 < eng.steps < 10 * new                       # fewer batched steps than tokens: sequences really shared steps
+    alone = BatchedEngine(model, num_pages=7, max_batch=1).generate(prompts, new)
+    assert [t[0] for t in got] == [t[0] for t in alone]
+    same = sum(a == b for x, y in zip(got, alone) for a, b in zip(x, y))
+    assert same >= 0.85 * 10 * new, f"{same} of {10 * new} tokens agree"
+    # a stop token ends its request (the token is reported, like the reference's loop does before breaking)
+    stop = got[3][2]
+    got2 = BatchedEngine(model, num_pages=7, max_batch=4, stop_tokens=[stop]).generate(prompts, new)
+    assert got2[3] == got[3][:got[3].index(stop) + 1]
+    assert all(len(t) <= new for t in got2)
+    with pytest.raises(ValueError, match="does not fit"):
+        BatchedEngine(model, num_pages=2, max_batch=2).generate([list(range(200))], 4)
