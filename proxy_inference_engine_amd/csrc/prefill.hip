@@ -154,11 +154,15 @@ __global__ void k_bias_rows(u16 *y, const u16 *b, size_t n8, int N8) {
 
 // h = x + r (language.py:151,153) fused with the RMSNorm that follows it (language.py:137-141): x <- T(x + r) in place,
 // xn <- w * T(h * rsqrt(mean(h^2) + eps)).  One workgroup per row; the row stays in registers between the two passes.
+// r32 != nullptr: the Linear's output arrives as fp32 sums of a K-split few-row GEMM (w4m_gemm.hip): r = T(T(r32) + bias) is formed
+// here (the Linear's own roundings) and the buffer is handed back zeroed for the next GEMM.
 template <class T>
-__global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn) {
+__global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn, float *r32 = nullptr,
+                                                          const u16 *bias = nullptr) {
     __shared__ float red[4];
     u16 *xr = x + (size_t)blockIdx.x * H;
     const u16 *rr = r + (size_t)blockIdx.x * H;
+    float *r32r = r32 ? r32 + (size_t)blockIdx.x * H : nullptr;
     u16 *yr = xn + (size_t)blockIdx.x * H;
     constexpr int MAXP = 4;  // 8-element pieces per thread: H <= 8192
     uint4 hv[MAXP];
@@ -167,7 +171,22 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
     for (int p = 0; p < MAXP; ++p) {
         const int i = (threadIdx.x + p * 256) * 8;
         if (i < H) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(xr + i), b = *reinterpret_cast<const uint4 *>(rr + i);
+            const uint4 a = *reinterpret_cast<const uint4 *>(xr + i);
+            uint4 b;
+            if (r32r) {
+                const float4 f0 = *reinterpret_cast<const float4 *>(r32r + i), f1 = *reinterpret_cast<const float4 *>(r32r + i + 4);
+                *reinterpret_cast<float4 *>(r32r + i) = make_float4(0, 0, 0, 0), *reinterpret_cast<float4 *>(r32r + i + 4) = make_float4(0, 0, 0, 0);
+                float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                if (bias) {
+                    const uint4 bb = *reinterpret_cast<const uint4 *>(bias + i);
+                    const u32 bw[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[2 * j] = round_T<T>(v[2 * j]) + lo_f32<T>(bw[j]), v[2 * j + 1] = round_T<T>(v[2 * j + 1]) + hi_f32<T>(bw[j]);
+                }
+                b = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+            } else {
+                b = *reinterpret_cast<const uint4 *>(rr + i);
+            }
             const u32 av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
             u32 o[4];
 #pragma unroll
@@ -201,12 +220,13 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
 }
 
 template <class T>
-static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int M, int H, int dtype, u16 *xn, hipStream_t st) {
+static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int M, int H, int dtype, u16 *xn, hipStream_t st,
+                             float *r32 = nullptr, const void *bias = nullptr) {
     if (H > 8192) {  // wider than the register-resident row: the two separate kernels
         const int rc = pie_add(x, r, (size_t)M * H, dtype, x, st);
         return rc ? rc : pie_rms_norm(x, w, eps, M, H, dtype, xn, st);
     }
-    hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn);
+    hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, r32, (const u16 *)bias);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -340,6 +360,7 @@ struct PrefillScratch {
     size_t w_elems = 0;     // capacity of the dequantised-weight buffer (elements)
     u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
+    float *y32 = nullptr;  // [rows, hidden] fp32, zero between uses: K-split few-row GEMM sums (o_proj, down), consumed by k_add_rms_norm_rows
     int part_splits = 0;
     // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
@@ -354,7 +375,7 @@ struct PrefillScratch {
 };
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
-    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs};
+    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->y32};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
@@ -411,6 +432,9 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         PF_ALLOC(s->part_acc, 4 * R * c.n_heads * splits * c.head_dim);
         PF_ALLOC(s->part_ml, 4 * R * c.n_heads * splits * 2);
         PF_ALLOC(s->rope_cs, 4 * R * c.head_dim);
+        PF_ALLOC(s->y32, 4 * R * c.hidden);
+        PIE_HIP_TRY(hipMemset(s->y32, 0, 4 * R * c.hidden));
+        PIE_HIP_TRY(hipDeviceSynchronize());  // (re)allocation only: the zeros must be in place whatever stream the GEMMs run on
         PF_ALLOC(s->wT, 2 * we);
         s->rows = rows, s->part_splits = splits, s->w_elems = we;
     }
@@ -462,13 +486,18 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
 // w4m_gemm.hip: the few-row int4 GEMM on W4M tiles
 size_t w4m_bytes(int N, int K);
 int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st);
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st);
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32);
 
 // Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
 static int small_rows() {
     const char *e = getenv("PIE_SMALL_M");
     const int v = e ? atoi(e) : 32;
     return v < 0 ? 0 : (v > 32 ? 32 : v);
+}
+
+static bool split_k_enabled() {  // PIE_W4M_SPLITK=0: never split (tuning / test knob)
+    const char *e = getenv("PIE_W4M_SPLITK");
+    return !(e && e[0] == '0');
 }
 
 template <class T>
@@ -481,8 +510,10 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
-                       const void *bias = nullptr, bool keep_w4m = false) {
+                       const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr) {
+    // y32 / used32: the caller's consumer can take fp32 K-split sums (+ the bias) instead of y; *used32 tells whether it must
     PrefillScratch *s = d->prefill;
+    if (used32) *used32 = false;
     if ((keep || keep_w4m) && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
@@ -496,8 +527,13 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             wm = nullptr;  // no room for the tile copy: the T-copy path below
         }
         if (wm) {
-            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st);
-            if (rc || !bias) return rc;
+            // K split over two workgroups per strip where the strips alone cannot fill the chip (N / 32 < 256) and K is long enough
+            // (measured on the 8B shapes: 32 rows 4.39 -> 4.22 ms per prompt, 16 rows 3.70 -> 3.84: only from ~24 rows, where the
+            // half-occupied chip is VALU-bound on the dequantisation)
+            const bool split = y32 && used32 && N / 32 < 256 && K >= 2048 && M >= 24 && split_k_enabled();
+            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr);
+            if (split) *used32 = rc == PIE_OK;
+            if (rc || !bias || split) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
@@ -571,16 +607,18 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                 a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
             }
-            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo))) return rc;
+            bool r32 = false;
+            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
             // h = x + r (language.py:151) + post_attention_layernorm(h) for MLP.__call__ (language.py:126-127)
-            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
+            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
             if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup))) return rc;
             const size_t n_act = (size_t)M * I;
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
-            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown))) return rc;
+            const bool fused_next = li + 1 < c.n_layers;
+            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, fused_next && H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
             // out = h + r (language.py:153), fused with the next block's input_layernorm when there is one
-            if (li + 1 < c.n_layers) rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st);
+            if (fused_next) rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr);
             else rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st);
             if (rc) return rc;
         }
@@ -662,15 +700,16 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;
         a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
         if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
-        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo))) return rc;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+        bool r32 = false;
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
         if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup))) return rc;
         const size_t n_act = (size_t)B * I;
         hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
         PIE_LAUNCH_CHECK();
-        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown))) return rc;
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;  // final norm: language.py:187
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr))) return rc;
     }
     if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, B, logits, st, false, nullptr, true))) return rc;
     return logits_tail_rows_launch(c.dtype, logits, c.vocab, B, s->tail_stats, logprobs, next_tokens, st);

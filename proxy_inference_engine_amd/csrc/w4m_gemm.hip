@@ -83,19 +83,40 @@ __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
     return make_uint4(w4m_pack<T>(dq(c0), dq(c1)), w4m_pack<T>(dq(c2), dq(c3)), w4m_pack<T>(dq(c4), dq(c5)), w4m_pack<T>(dq(c6), dq(c7)));
 }
 
-// y[M, N] = x[M, K] . dequant(W)[N, K]^T, M <= 32.  grid = N / 32 workgroups of 8 waves.
+// Sum of the 8 waves' partial tiles (fixed order), then either the T result or -- K split over two workgroups (gridDim.y = 2:
+// the N = 4096 matrices have only 128 strips, half the chip) -- an fp32 atomic add into a zeroed [M, N] buffer that the consumer
+// kernel rounds and re-zeroes.  Two addends commute exactly, so the sum does not depend on which workgroup arrives first.
+template <class T>
+__device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int M, int N, u16 *y, float *y32) {
+    for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
+        const int i = o >> 6, l = o & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
+        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // accumulator register i <-> A row (i & 3) + 8 (i >> 2) + 4 kh
+        if (mm < M) {
+            if (y32) atomicAdd(y32 + (size_t)mm * N + nn, v);
+            else y[(size_t)mm * N + nn] = T::from_f32(v);
+        }
+    }
+}
+
+// y[M, N] = x[M, K] . dequant(W)[N, K]^T, M <= 32.  grid = N / 32 workgroups of 8 waves (x 2 K-halves with y32).
 // Two rings per wave: the weight tiles come from HBM (~2 us away) and cost 5 registers per slot -> W4M_WDEPTH = 8 slots in
 // flight (with depth 3 the 128-workgroup matrices, o_proj and down, had 27 KB in flight per CU on half the chip: 1.7 TB/s);
 // the x fragments come from L2 and cost 16 registers per slot -> 2 slots.
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32) {
     __shared__ float s_red[W4M_WAVES][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, groups = K >> 6;
+    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
     const int nt = blockIdx.x;
-    const char *strip = w4m + (size_t)nt * groups * W4M_TILE_BYTES;
+    // this workgroup's share of the K groups: everything, or one half (gridDim.y == 2)
+    const int g_lo = gridDim.y == 2 ? (blockIdx.y ? (all_groups >> 1) : 0) : 0;
+    const int groups = gridDim.y == 2 ? (blockIdx.y ? all_groups - (all_groups >> 1) : (all_groups >> 1)) : all_groups;
+    const char *strip = w4m + ((size_t)nt * all_groups + g_lo) * W4M_TILE_BYTES;
     const int m = n < M ? n : M - 1;                          // B-operand column = x row (columns >= M are never stored)
-    const u16 *xrow = x + (size_t)m * K + 8 * kh;
+    const u16 *xrow = x + (size_t)m * K + 8 * kh + (size_t)g_lo * 64;
     const int my_groups = groups > wave ? (groups - wave + W4M_WAVES - 1) / W4M_WAVES : 0;
 
     typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
@@ -152,16 +173,8 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
-        const int i = o >> 6, l = o & 63;
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
-        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // accumulator register i <-> A row (i & 3) + 8 (i >> 2) + 4 kh
-        if (mm < M) y[(size_t)mm * N + nn] = T::from_f32(v);
-    }
+    w4m_epilogue<T>(s_red, nt, M, N, y, y32);
 }
-
 
 // The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
 // row per lane (32 cache lines per load instruction): at 32 rows the address unit, not HBM, sets the pace (5.0 ms per 8B-model
@@ -170,13 +183,19 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 // fragments are then ds_read_b128 with rows 1040 bytes apart (16 lanes of a quarter-wave hit 16 distinct bank quads).
 constexpr int W4M_XROW = 1024 + 16;  // bytes per staged x row: 512 columns + pad
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32) {
     __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, groups = K >> 6;
+    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
     const int nt = blockIdx.x;
-    const char *strip = w4m + (size_t)nt * groups * W4M_TILE_BYTES;
-    const int rounds = (groups + W4M_WAVES - 1) / W4M_WAVES;
+    // K halves for gridDim.y == 2, cut at a multiple of 8 groups (512 columns) so a staging round never straddles the cut
+    const int half_lo = ((all_groups >> 1) + 7) & ~7;
+    const int g_lo = gridDim.y == 2 && blockIdx.y ? (half_lo < all_groups ? half_lo : all_groups) : 0;
+    const int groups = gridDim.y == 2 ? (blockIdx.y ? all_groups - g_lo : (half_lo < all_groups ? half_lo : all_groups)) : all_groups;
+    const char *strip = w4m + ((size_t)nt * all_groups + g_lo) * W4M_TILE_BYTES;
+    x += (size_t)g_lo * 64;                // this half's first column
+    const int Kx = K - g_lo * 64;          // columns of x from there on (row stride stays K)
+    const int rounds = groups > 0 ? (groups + W4M_WAVES - 1) / W4M_WAVES : 1;  // an empty half still walks one (idle) round
     const int m_read = n < M ? n : M - 1;  // fragment row (columns >= M of the product are never stored)
 
     typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
@@ -198,7 +217,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = wave + 8 * j;
-            xs[j] = (m < M && col < K) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
+            xs[j] = (m < M && col < Kx) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
         }
     };
     auto x_store = [&](int buf) {
@@ -242,14 +261,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
-        const int i = o >> 6, l = o & 63;
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
-        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-        if (mm < M) y[(size_t)mm * N + nn] = T::from_f32(v);
-    }
+    w4m_epilogue<T>(s_red, nt, M, N, y, y32);
 }
 
 size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
@@ -262,19 +274,22 @@ int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) 
     return PIE_OK;
 }
 
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st) {
+// y32 != nullptr: K split over two workgroups per strip, fp32 sums added into y32 [M, N] (zero on entry; the consumer rounds and
+// re-zeroes it); y is then unused.
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32) {
     PIE_REQUIRE(M >= 1 && M <= 32, PIE_E_SHAPE, "W4M GEMM: 1 to 32 rows");
     PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 2), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
-    const dim3 grid(N >> 5), block(W4M_WAVES * 64);
+    PIE_REQUIRE(!y32 || K >= 1024, PIE_E_SHAPE, "W4M GEMM: the K-split form needs K >= 1024 (both halves non-empty)");
+    const dim3 grid(N >> 5, y32 ? 2 : 1), block(W4M_WAVES * 64);
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
     const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
     const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     if (M >= stage_min) {
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
-        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
-    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
-    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y);
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
+        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
+    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
+    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -290,7 +305,7 @@ int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
-    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream);
+    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"
