@@ -206,10 +206,11 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
  * [n_layers] of device pointers), attention over its own table row.  Outputs per row: logits T [B, vocab], logprobs fp32
  * [B, vocab], next_tokens int32 [B] (greedy).  What the reference's decode-state batch is meant to be (BatchDetails,
  * include/engine/batch_details.hpp:10-88; Scheduler and the paged attention kernel are skeletons there).  Independent of
- * pie_decoder_set_kv / set_state / bind_outputs; all device arrays are caller-owned. */
+ * pie_decoder_set_kv / set_state / bind_outputs; all device arrays are caller-owned.  flags: PIE_STEP_GRAPH replays a captured
+ * hipGraph of the step while the caller passes the same buffers (their contents may change) -- captured on the second such call. */
 int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
                            const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
-                           void *stream);
+                           int flags, void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);

@@ -370,6 +370,12 @@ struct PrefillScratch {
     std::map<const void *, void *> resident_w4m;
     LogitStat *tail_stats = nullptr;  // multi-sequence step: per-row tail partials
     int tail_rows = 0;
+    // Captured multi-sequence step (pie_decoder_step_batch with PIE_STEP_GRAPH): valid while the caller's buffers (key) and every
+    // device allocation baked into the launches (alloc_gen) stay what they were at capture time.
+    unsigned alloc_gen = 0;
+    hipGraphExec_t batch_graph = nullptr;
+    std::vector<uintptr_t> batch_key, warm_key;
+    unsigned batch_gen = 0, warm_gen = 0;
     int resident_mode = -1;   // -1: budget not fixed yet
     size_t resident_left = 0; // bytes still available for resident copies
 };
@@ -382,11 +388,13 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
     auto keep_m = std::move(s->resident_w4m);
     LogitStat *keep_ts = s->tail_stats;
     const int keep_tr = s->tail_rows;
+    const unsigned gen = s->alloc_gen + 1;  // the chunk buffers move: captured launches are stale
+    if (s->batch_graph) (void)hipGraphExecDestroy(s->batch_graph);
     const int mode = s->resident_mode;
     const size_t left = s->resident_left;
     *s = PrefillScratch();
     s->resident = std::move(keep), s->resident_w4m = std::move(keep_m), s->resident_mode = mode, s->resident_left = left;
-    s->tail_stats = keep_ts, s->tail_rows = keep_tr;
+    s->tail_stats = keep_ts, s->tail_rows = keep_tr, s->alloc_gen = gen;
 }
 
 void prefill_free(pie_decoder *d) {
@@ -395,6 +403,7 @@ void prefill_free(pie_decoder *d) {
     for (auto &kv : d->prefill->resident) (void)hipFree(kv.second);
     for (auto &kv : d->prefill->resident_w4m) (void)hipFree(kv.second);
     if (d->prefill->tail_stats) (void)hipFree(d->prefill->tail_stats);
+    if (d->prefill->batch_graph) (void)hipGraphExecDestroy(d->prefill->batch_graph);
     delete d->prefill;
     d->prefill = nullptr;
 }
@@ -442,7 +451,7 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         if (s->wT) (void)hipFree(s->wT);
         s->wT = nullptr;
         PF_ALLOC(s->wT, 2 * w_elems);
-        s->w_elems = w_elems;
+        s->w_elems = w_elems, ++s->alloc_gen;
     }
 #undef PF_ALLOC
     return PIE_OK;
@@ -519,7 +528,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
         auto it = s->resident_w4m.find(packed);
         if (it != s->resident_w4m.end()) wm = it->second;
         else if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
-            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K);
+            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K), ++s->alloc_gen;
             const int rc = w4m_repack_launch(packed, N, K, wm, st);
             if (rc) return rc;
         } else {
@@ -544,7 +553,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
         auto it = s->resident.find(packed);
         if (it != s->resident.end()) wT = it->second, ready = true;
         else if (resident_budget(d) >= bytes) {
-            if (hipMalloc((void **)&wT, bytes) == hipSuccess) s->resident[packed] = wT, s->resident_left -= bytes;
+            if (hipMalloc((void **)&wT, bytes) == hipSuccess) s->resident[packed] = wT, s->resident_left -= bytes, ++s->alloc_gen;
             else (void)hipGetLastError(), wT = s->wT, s->resident_left = 0;  // out of memory: scratch from here on
         }
     }
@@ -678,7 +687,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         if (s->tail_stats) (void)hipFree(s->tail_stats);
         s->tail_stats = nullptr, s->tail_rows = 0;
         PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)B));
-        s->tail_rows = B;
+        s->tail_rows = B, ++s->alloc_gen;
     }
     rc = c.weight_format == PIE_W_DENSE
              ? pie_embedding_dense(tokens, B, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
@@ -715,9 +724,16 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     return logits_tail_rows_launch(c.dtype, logits, c.vocab, B, s->tail_stats, logprobs, next_tokens, st);
 }
 
+static int decode_batch(pie_decoder *d, const int32_t *tokens, const int32_t *ctx_len, const void *const *slabs, int n_pages, const int32_t *block_tables,
+                        int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
+    return d->cfg.dtype == PIE_BF16
+               ? decode_batch_t<BF16>(d, tokens, ctx_len, slabs, n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st)
+               : decode_batch_t<F16>(d, tokens, ctx_len, slabs, n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st);
+}
+
 extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
                                       const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
-                                      void *stream) {
+                                      int flags, void *stream) {
     PIE_REQUIRE(d && tokens && context_lens && slabs && block_tables && logits && logprobs && next_tokens, PIE_E_ARG, "pie_decoder_step_batch: null pointer");
     PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_step_batch: set_globals must be called first");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_step_batch: a layer has no weights (pie_decoder_set_layer)");
@@ -726,9 +742,50 @@ extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, con
     PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_step_batch: n_heads / n_kv_heads must be between 1 and 8");
     for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_step_batch: null or misaligned slab");
     hipStream_t st = (hipStream_t)stream;
-    return d->cfg.dtype == PIE_BF16
-               ? decode_batch_t<BF16>(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st)
-               : decode_batch_t<F16>(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st);
+    if (!(flags & PIE_STEP_GRAPH)) return decode_batch(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, logits, logprobs, next_tokens, st);
+    // Graph replay.  The launches bake in the caller's buffers and this library's scratch / resident weight copies, so a graph is
+    // captured only for a call that repeats the previous call's buffers after that call allocated nothing, and is dropped when
+    // either changes.  (First call with new buffers: eager, it may allocate; second: capture; from the third: replay.)
+    std::vector<uintptr_t> key = {(uintptr_t)tokens, (uintptr_t)context_lens, (uintptr_t)block_tables, (uintptr_t)logits, (uintptr_t)logprobs,
+                                  (uintptr_t)next_tokens, (uintptr_t)n_pages, (uintptr_t)max_blocks, (uintptr_t)B};
+    for (int i = 0; i < d->cfg.n_layers; ++i) key.push_back((uintptr_t)slabs[i]);
+    if (!d->prefill) d->prefill = new PrefillScratch();
+    PrefillScratch *s = d->prefill;
+    if (s->batch_graph && s->batch_key == key && s->batch_gen == s->alloc_gen) {
+        PIE_HIP_TRY(hipGraphLaunch(s->batch_graph, st));
+        return PIE_OK;
+    }
+    if (s->warm_key == key && s->warm_gen == s->alloc_gen) {
+        if (s->batch_graph) (void)hipGraphExecDestroy(s->batch_graph), s->batch_graph = nullptr;
+        hipGraph_t g = nullptr;
+        hipStream_t cs = nullptr;
+        PIE_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(cs);
+            return pie::fail(PIE_E_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+        }
+        const unsigned gen = s->alloc_gen;
+        const int rc = decode_batch(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, logits, logprobs, next_tokens, cs);
+        e = hipStreamEndCapture(cs, &g);
+        (void)hipStreamDestroy(cs);
+        if (rc || e != hipSuccess || d->prefill->alloc_gen != gen) {  // something allocated or failed under capture: run this call eagerly instead
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            d->prefill->warm_key.clear();
+            return decode_batch(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, logits, logprobs, next_tokens, st);
+        }
+        s = d->prefill;
+        e = hipGraphInstantiate(&s->batch_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return pie::fail(PIE_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        s->batch_key = key, s->batch_gen = s->alloc_gen;
+        PIE_HIP_TRY(hipGraphLaunch(s->batch_graph, st));
+        return PIE_OK;
+    }
+    const int rc = decode_batch(d, tokens, context_lens, slabs, (int)n_pages, block_tables, max_blocks, B, logits, logprobs, next_tokens, st);
+    d->prefill->warm_key = key, d->prefill->warm_gen = d->prefill->alloc_gen;
+    return rc;
 }
 
 int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st) {

@@ -175,7 +175,7 @@ class Model:
         self._kv_key = None      # (pointers, capacity) currently in the decoder's device table
         self._kv_hold = None
         self._page_pool, self._page_blocks = None, 16
-        self._batch_key, self._batch_table = None, None
+        self._batch_bufs: dict = {}
         self._dev_offset = None  # device-side cache offset the decoder believes in
         torch.cuda.synchronize(device)
 
@@ -355,11 +355,13 @@ class Model:
         token = self.history[pos:pos + 1] if pos < self.history.numel() else self.token.clone()
         return token, self.logprobs, self.logits
 
-    def step_batch(self, tokens: torch.Tensor, caches: list[list[BaseCache]]):
+    def step_batch(self, tokens: torch.Tensor, caches: list[list[BaseCache]], graph: bool = True):
         """One decode step for several sequences at once (continuous batching over the page pool; pie_decoder_step_batch):
         tokens [B] = each sequence's input token, caches = their per-layer PagedKVCache lists (model.make_cache() after
         enable_paged_kv(), all drawing on one PageAllocator, each already holding its prompt -- e.g. through step()).
-        Returns (next_tokens [B] int32 greedy, logprobs [B, V] fp32, logits [B, V]); every cache advances by one position.
+        Returns (next_tokens [B] int32 greedy, logprobs [B, V] fp32, logits [B, V]) -- buffers owned by the model per batch size,
+        valid until the next step_batch of that size; every cache advances by one position.  graph: replay a captured hipGraph
+        of the step while the batch size and table width stay the same (captured on the second such step).
         The weights stream once for the whole batch: int4 models run the few-row MFMA GEMM up to 32 sequences."""
         seqs = []
         for c in caches:
@@ -375,22 +377,34 @@ class Model:
             raise ValueError("step_batch: one token per sequence")
         for s in seqs:
             s.reserve(1)
+        # Persistent device buffers per batch size (the captured graph of the step keeps pointing at them): inputs are copied in,
+        # the block table (batch_details.hpp:52-66) is rewritten in place when a sequence takes a page or the batch changes.
+        mb = max(len(s.pages) for s in seqs)
+        buf = self._batch_bufs.get(B)
+        if buf is None or buf["table"].shape[1] < mb:
+            V = self.args.vocab_size
+            width = max(mb, 2 * buf["table"].shape[1]) if buf is not None else max(mb, 4)
+            buf = {"table": torch.zeros((B, width), dtype=torch.int32, device=self.device),
+                   "tokens": torch.empty(B, dtype=torch.int32, device=self.device), "ctx": torch.empty(B, dtype=torch.int32, device=self.device),
+                   "logits": torch.empty((B, V), dtype=self.dtype, device=self.device),
+                   "logprobs": torch.empty((B, V), dtype=torch.float32, device=self.device),
+                   "next": torch.empty(B, dtype=torch.int32, device=self.device), "key": None}
+            self._batch_bufs[B] = buf
         key = tuple((id(s), len(s.pages)) for s in seqs)
-        if self._batch_key != key:   # the consolidated block table (batch_details.hpp:52-66) changes when a sequence takes a page
-            mb = max(len(s.pages) for s in seqs)
-            table = torch.zeros((B, mb), dtype=torch.int32)
+        if buf["key"] != key:
+            table = torch.zeros(buf["table"].shape, dtype=torch.int32)
             for i, s in enumerate(seqs):
                 table[i, :len(s.pages)] = torch.tensor(s.pages, dtype=torch.int32)
-            self._batch_table, self._batch_key = table.to(self.device), key
-        ctx = torch.tensor([s.offset + 1 for s in seqs], dtype=torch.int32).to(self.device)
-        V = self.args.vocab_size
-        logits = torch.empty((B, V), dtype=self.dtype, device=self.device)
-        logprobs = torch.empty((B, V), dtype=torch.float32, device=self.device)
-        nxt = torch.empty(B, dtype=torch.int32, device=self.device)
+            buf["table"].copy_(table)
+            buf["key"] = key
+        buf["tokens"].copy_(tokens)
+        buf["ctx"].copy_(torch.tensor([s.offset + 1 for s in seqs], dtype=torch.int32))
         n = len(self.layers)
         slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
-        _ffi.check(_ffi.load().pie_decoder_step_batch(self._dec, _ffi.p(tokens), _ffi.p(ctx), slabs, a.size(), _ffi.p(self._batch_table),
-                                                      self._batch_table.shape[1], B, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt), _ffi.stream()))
+        _ffi.check(_ffi.load().pie_decoder_step_batch(self._dec, _ffi.p(buf["tokens"]), _ffi.p(buf["ctx"]), slabs, a.size(), _ffi.p(buf["table"]),
+                                                      buf["table"].shape[1], B, _ffi.p(buf["logits"]), _ffi.p(buf["logprobs"]), _ffi.p(buf["next"]),
+                                                      _ffi.PIE_STEP_GRAPH if graph else 0, _ffi.stream()))
+        nxt, logprobs, logits = buf["next"], buf["logprobs"], buf["logits"]
         for s in seqs:
             s.advance(1)
         return nxt, logprobs, logits
