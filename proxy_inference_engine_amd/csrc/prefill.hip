@@ -495,7 +495,8 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
 // w4m_gemm.hip: the few-row int4 GEMM on W4M tiles
 size_t w4m_bytes(int N, int K);
 int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st);
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32);
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
+                    const void *bias);
 
 // Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
 static int small_rows() {
@@ -519,10 +520,13 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
-                       const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr) {
+                       const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr, u16 *act = nullptr,
+                       bool *used_act = nullptr) {
+    // act / used_act: for the packed gate|up matrix the few-row kernel can apply the SwiGLU itself and write act [M, N / 2]
     // y32 / used32: the caller's consumer can take fp32 K-split sums (+ the bias) instead of y; *used32 tells whether it must
     PrefillScratch *s = d->prefill;
     if (used32) *used32 = false;
+    if (used_act) *used_act = false;
     if ((keep || keep_w4m) && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
@@ -540,7 +544,11 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             // (measured on the 8B shapes: 32 rows 4.39 -> 4.22 ms per prompt, 16 rows 3.70 -> 3.84: only from ~24 rows, where the
             // half-occupied chip is VALU-bound on the dequantisation)
             const bool split = y32 && used32 && N / 32 < 256 && K >= 2048 && M >= 24 && split_k_enabled();
-            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr);
+            if (act && used_act) {
+                *used_act = true;
+                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, st, nullptr, 1, bias);
+            }
+            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr, 0, nullptr);
             if (split) *used32 = rc == PIE_OK;
             if (rc || !bias || split) return rc;
             return bias_rows<T>(y, bias, M, N, st);
@@ -620,10 +628,13 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
             // h = x + r (language.py:151) + post_attention_layernorm(h) for MLP.__call__ (language.py:126-127)
             if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
-            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup))) return rc;
-            const size_t n_act = (size_t)M * I;
-            hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
-            PIE_LAUNCH_CHECK();
+            bool fused_act = false;
+            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+            if (!fused_act) {
+                const size_t n_act = (size_t)M * I;
+                hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
+                PIE_LAUNCH_CHECK();
+            }
             const bool fused_next = li + 1 < c.n_layers;
             if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, fused_next && H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
             // out = h + r (language.py:153), fused with the next block's input_layernorm when there is one
@@ -712,10 +723,13 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         bool r32 = false;
         if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
         if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
-        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup))) return rc;
-        const size_t n_act = (size_t)B * I;
-        hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
-        PIE_LAUNCH_CHECK();
+        bool fused_act = false;
+        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+        if (!fused_act) {
+            const size_t n_act = (size_t)B * I;
+            hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
+            PIE_LAUNCH_CHECK();
+        }
         if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;  // final norm: language.py:187
         if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr))) return rc;

@@ -86,8 +86,22 @@ __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
 // Sum of the 8 waves' partial tiles (fixed order), then either the T result or -- K split over two workgroups (gridDim.y = 2:
 // the N = 4096 matrices have only 128 strips, half the chip) -- an fp32 atomic add into a zeroed [M, N] buffer that the consumer
 // kernel rounds and re-zeroes.  Two addends commute exactly, so the sum does not depend on which workgroup arrives first.
+// ... or (swiglu) the MLP activation: the packed gate|up matrix interleaves its rows (2i, 2i + 1) = (gate_i, up_i), so a strip holds
+// 16 complete pairs and act[m][16 nt + j] = T(T(silu(g)) * u) with g, u the T-rounded (and biased) Linear outputs -- exactly what
+// the GEMM followed by the bias and SwiGLU row kernels produce, without writing and re-reading the [M, 2I] block.
 template <class T>
-__device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int M, int N, u16 *y, float *y32) {
+__device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int M, int N, u16 *y, float *y32, bool swiglu, const u16 *bias) {
+    if (swiglu) {  // one (gate, up) pair per thread: accumulator registers (2p, 2p + 1) of lane l
+        const int i = 2 * (threadIdx.x >> 6), l = threadIdx.x & 63;
+        float g = 0.0f, u = 0.0f;
+#pragma unroll
+        for (int w = 0; w < W4M_WAVES; ++w) g += s_red[w][i][l], u += s_red[w][i + 1][l];
+        const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // even: the gate row; nn + 1: its up row
+        g = round_T<T>(g), u = round_T<T>(u);
+        if (bias) g = round_T<T>(g + T::to_f32(bias[nn])), u = round_T<T>(u + T::to_f32(bias[nn + 1]));
+        if (mm < M) y[(size_t)mm * (N >> 1) + (nn >> 1)] = T::from_f32(round_T<T>(g / (1.0f + expf(-g))) * u);
+        return;
+    }
     for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
         const int i = o >> 6, l = o & 63;
         float v = 0.0f;
@@ -106,7 +120,7 @@ __device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int
 // flight (with depth 3 the 128-workgroup matrices, o_proj and down, had 27 KB in flight per CU on half the chip: 1.7 TB/s);
 // the x fragments come from L2 and cost 16 registers per slot -> 2 slots.
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias) {
     __shared__ float s_red[W4M_WAVES][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    w4m_epilogue<T>(s_red, nt, M, N, y, y32);
+    w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
 // The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
@@ -183,7 +197,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 // fragments are then ds_read_b128 with rows 1040 bytes apart (16 lanes of a quarter-wave hit 16 distinct bank quads).
 constexpr int W4M_XROW = 1024 + 16;  // bytes per staged x row: 512 columns + pad
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias) {
     __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
@@ -261,7 +275,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    w4m_epilogue<T>(s_red, nt, M, N, y, y32);
+    w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
 size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
@@ -276,20 +290,23 @@ int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) 
 
 // y32 != nullptr: K split over two workgroups per strip, fp32 sums added into y32 [M, N] (zero on entry; the consumer rounds and
 // re-zeroes it); y is then unused.
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32) {
+// swiglu: N = 2 * inter interleaved gate|up rows -> y is the activation [M, N / 2] (bias: the Linear's, applied before it).
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
+                    const void *bias) {
     PIE_REQUIRE(M >= 1 && M <= 32, PIE_E_SHAPE, "W4M GEMM: 1 to 32 rows");
     PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 2), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
+    PIE_REQUIRE(!(swiglu && y32), PIE_E_ARG, "W4M GEMM: the SwiGLU epilogue needs the whole K in one workgroup");
     PIE_REQUIRE(!y32 || K >= 1024, PIE_E_SHAPE, "W4M GEMM: the K-split form needs K >= 1024 (both halves non-empty)");
     const dim3 grid(N >> 5, y32 ? 2 : 1), block(W4M_WAVES * 64);
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
     const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
     const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     if (M >= stage_min) {
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
-        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
-    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
-    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32);
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
+        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
+    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
+    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -305,7 +322,7 @@ int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
-    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr);
+    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr, 0, nullptr);
 }
 
 }  // extern "C"
