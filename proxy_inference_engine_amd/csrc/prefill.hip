@@ -495,8 +495,19 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
 // w4m_gemm.hip: the few-row int4 GEMM on W4M tiles
 size_t w4m_bytes(int N, int K);
 int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st);
+struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.hip)
+    const float *rope_cs;
+    const DecState *state;
+    const int *ctx_len;
+    const unsigned long long *kv_table;
+    u16 *slab;
+    const int *block_table;
+    int bt_stride, n_pages, layer, n_layers, n_heads, n_kv_heads, HD, traditional;
+    u16 *q_out;
+    const u16 *bias;
+};
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
-                    const void *bias);
+                    const void *bias, const W4mRope *rope);
 
 // Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
 static int small_rows() {
@@ -521,7 +532,8 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
                        const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr, u16 *act = nullptr,
-                       bool *used_act = nullptr) {
+                       bool *used_act = nullptr, W4mRope *rope = nullptr) {
+    // rope / used_act: for the packed q|k|v matrix the few-row kernel can rotate q / k and append k / v itself
     // act / used_act: for the packed gate|up matrix the few-row kernel can apply the SwiGLU itself and write act [M, N / 2]
     // y32 / used32: the caller's consumer can take fp32 K-split sums (+ the bias) instead of y; *used32 tells whether it must
     PrefillScratch *s = d->prefill;
@@ -544,11 +556,16 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             // (measured on the 8B shapes: 32 rows 4.39 -> 4.22 ms per prompt, 16 rows 3.70 -> 3.84: only from ~24 rows, where the
             // half-occupied chip is VALU-bound on the dequantisation)
             const bool split = y32 && used32 && N / 32 < 256 && K >= 2048 && M >= 24 && split_k_enabled();
+            if (rope && used_act) {
+                *used_act = true;
+                rope->bias = (const u16 *)bias;
+                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, nullptr, st, nullptr, 2, nullptr, rope);
+            }
             if (act && used_act) {
                 *used_act = true;
-                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, st, nullptr, 1, bias);
+                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, st, nullptr, 1, bias, nullptr);
             }
-            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr, 0, nullptr);
+            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr, 0, nullptr, nullptr);
             if (split) *used32 = rc == PIE_OK;
             if (rc || !bias || split) return rc;
             return bias_rows<T>(y, bias, M, N, st);
@@ -606,10 +623,15 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             // Attention.__call__ (language.py:75-108) on input_layernorm(x)
             // input_layernorm: layer 0 here; for the later layers it was fused with the previous block's residual add
             if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
-            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv))) return rc;
-            hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
-                               c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs);
-            PIE_LAUNCH_CHECK();
+            W4mRope re = {s->rope_cs, d->state, nullptr, d->kv_table, nullptr, d->block_table, 0, d->n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads, D,
+                          c.rope_traditional, s->q, nullptr};
+            bool roped = false;
+            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
+            if (!roped) {
+                hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
+                                   c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs);
+                PIE_LAUNCH_CHECK();
+            }
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
                 PrefillAttnArgs pa = {};
                 pa.q = s->q, pa.kv_table = d->kv_table, pa.layer = li, pa.n_layers = c.n_layers, pa.state = d->state;
@@ -710,10 +732,15 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     for (int li = 0; li < c.n_layers; ++li) {
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv))) return rc;
-        hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
-                           c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li]);
-        PIE_LAUNCH_CHECK();
+        W4mRope re = {s->rope_cs, nullptr, ctx_len, nullptr, (u16 *)slabs[li], block_tables, max_blocks, n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads,
+                      D, c.rope_traditional, s->q, nullptr};
+        bool roped = false;
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
+        if (!roped) {
+            hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+                               c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li]);
+            PIE_LAUNCH_CHECK();
+        }
         AttnArgs a = {};
         a.q = s->q, a.slab = (const u16 *)slabs[li], a.block_table = block_tables, a.ctx_len = ctx_len, a.bt_stride = max_blocks, a.n_pages = n_pages;
         a.rows = B, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = splits, a.scale = 1.0f / sqrtf((float)D);

@@ -22,7 +22,7 @@
 // 1152-byte blocks: the 8 waves stream one contiguous range), fp32 partial tiles summed through LDS in fixed order.
 #include <cstdlib>
 
-#include "prefill_attn.hpp"  // MfmaT, f32x16_t
+#include "prefill_attn.hpp"  // MfmaT, f32x16_t, DecState
 
 #ifndef W4M_ABL
 #define W4M_ABL 0  // developer ablation mask (tools/w4m_bench): 1 no dequantisation, 2 no x loads, 4 no MFMA; 0 in the product
@@ -86,6 +86,54 @@ __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
 // Sum of the 8 waves' partial tiles (fixed order), then either the T result or -- K split over two workgroups (gridDim.y = 2:
 // the N = 4096 matrices have only 128 strips, half the chip) -- an fp32 atomic add into a zeroed [M, N] buffer that the consumer
 // kernel rounds and re-zeroes.  Two addends commute exactly, so the sum does not depend on which workgroup arrives first.
+// Arguments of the q|k|v epilogue (rope = 2): RoPE on the q and k pairs and the cache append, exactly k_rope_append_rows (prefill.hip).
+struct W4mRope {
+    const float *rope_cs;               // [M, HD / 2, 2] (cos, sin) of every row's position (k_rope_cs_rows)
+    const DecState *state;              // single sequence: row m sits at state->pos + m, cache capacity state->cap ...
+    const int *ctx_len;                 // ... or a batch of sequences: row m at ctx_len[m] - 1 (< 0: idle slot)
+    const unsigned long long *kv_table; // per-layer K / V buffer (or slab) bases ...
+    u16 *slab;                          // ... or this layer's slab directly (batch)
+    const int *block_table;             // paged KV (nullable): table row m * bt_stride
+    int bt_stride, n_pages, layer, n_layers, n_heads, n_kv_heads, HD, traditional;
+    u16 *q_out;                         // [M, n_heads, HD]
+    const u16 *bias;                    // the Linear's bias (packed order), nullable
+};
+
+template <class T>
+__device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt, int M, const W4mRope &r) {
+    const int i = 2 * (threadIdx.x >> 6), l = threadIdx.x & 63;
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int w = 0; w < W4M_WAVES; ++w) a += s_red[w][i][l], b += s_red[w][i + 1][l];
+    const int m = l & 31, R = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // packed columns (R, R + 1)
+    if (m >= M) return;
+    a = round_T<T>(a), b = round_T<T>(b);
+    if (r.bias) a = round_T<T>(a + T::to_f32(r.bias[R])), b = round_T<T>(b + T::to_f32(r.bias[R + 1]));
+    const int pos = r.ctx_len ? r.ctx_len[m] - 1 : r.state->pos + m, HD = r.HD, half = HD >> 1;
+    if (pos < 0) return;
+    int cap = r.ctx_len ? 64 : r.state->cap, kvrow = pos;
+    u16 *kdst = r.slab ? r.slab : reinterpret_cast<u16 *>(r.kv_table[r.layer]);
+    u16 *vdst = r.slab ? r.slab + (size_t)r.n_kv_heads * 64 * HD : reinterpret_cast<u16 *>(r.kv_table[r.n_layers + r.layer]);
+    if (r.block_table) {
+        const int *bt = r.block_table + (size_t)m * r.bt_stride;
+        const size_t pg_off = (size_t)min((unsigned)bt[pos >> 6], (unsigned)r.n_pages - 1u) * 2 * 64 * r.n_kv_heads * HD;
+        kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
+    }
+    const int q_cols = r.n_heads * HD, k_cols = r.n_kv_heads * HD;
+    if (R < q_cols + k_cols) {
+        const int rr = R < q_cols ? R : R - q_cols;
+        const int head = rr / HD, ii = (rr % HD) >> 1;
+        const float2 csn = *reinterpret_cast<const float2 *>(r.rope_cs + ((size_t)m * half + ii) * 2);
+        u16 *dst = R < q_cols ? r.q_out + ((size_t)m * r.n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
+        const int i0 = r.traditional ? 2 * ii : ii, i1 = r.traditional ? 2 * ii + 1 : ii + half;
+        dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(a, csn.x), __fmul_rn(b, csn.y)));
+        dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(a, csn.y), __fmul_rn(b, csn.x)));
+    } else {
+        const int rr = R - q_cols - k_cols;
+        *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pack2<T>(a, b);
+    }
+}
+
 // ... or (swiglu) the MLP activation: the packed gate|up matrix interleaves its rows (2i, 2i + 1) = (gate_i, up_i), so a strip holds
 // 16 complete pairs and act[m][16 nt + j] = T(T(silu(g)) * u) with g, u the T-rounded (and biased) Linear outputs -- exactly what
 // the GEMM followed by the bias and SwiGLU row kernels produce, without writing and re-reading the [M, 2I] block.
@@ -120,7 +168,7 @@ __device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int
 // flight (with depth 3 the 128-workgroup matrices, o_proj and down, had 27 KB in flight per CU on half the chip: 1.7 TB/s);
 // the x fragments come from L2 and cost 16 registers per slot -> 2 slots.
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias, const W4mRope rope) {
     __shared__ float s_red[W4M_WAVES][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
@@ -187,7 +235,8 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
+    if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt, M, rope);
+    else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
 // The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
@@ -197,7 +246,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
 // fragments are then ds_read_b128 with rows 1040 bytes apart (16 lanes of a quarter-wave hit 16 distinct bank quads).
 constexpr int W4M_XROW = 1024 + 16;  // bytes per staged x row: 512 columns + pad
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias, const W4mRope rope) {
     __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
@@ -275,7 +324,8 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
-    w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
+    if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt, M, rope);
+    else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
 size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
@@ -291,11 +341,14 @@ int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) 
 // y32 != nullptr: K split over two workgroups per strip, fp32 sums added into y32 [M, N] (zero on entry; the consumer rounds and
 // re-zeroes it); y is then unused.
 // swiglu: N = 2 * inter interleaved gate|up rows -> y is the activation [M, N / 2] (bias: the Linear's, applied before it).
+// swiglu == 2 (rope != nullptr): N = packed q|k|v rows; the epilogue rotates q / k and appends k / v to the cache (y unused).
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
-                    const void *bias) {
+                    const void *bias, const W4mRope *rope) {
+    const W4mRope rope_args = rope ? *rope : W4mRope{};
+    PIE_REQUIRE((swiglu == 2) == (rope != nullptr), PIE_E_ARG, "W4M GEMM: the q|k|v epilogue needs its arguments");
     PIE_REQUIRE(M >= 1 && M <= 32, PIE_E_SHAPE, "W4M GEMM: 1 to 32 rows");
     PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M GEMM: N must be a multiple of 32 and K of 64");
-    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 2), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
+    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
     PIE_REQUIRE(!(swiglu && y32), PIE_E_ARG, "W4M GEMM: the SwiGLU epilogue needs the whole K in one workgroup");
     PIE_REQUIRE(!y32 || K >= 1024, PIE_E_SHAPE, "W4M GEMM: the K-split form needs K >= 1024 (both halves non-empty)");
     const dim3 grid(N >> 5, y32 ? 2 : 1), block(W4M_WAVES * 64);
@@ -303,10 +356,10 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
     const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     if (M >= stage_min) {
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
-        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
-    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
-    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias);
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
+        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
+    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
+    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -322,7 +375,7 @@ int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
-    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr, 0, nullptr);
+    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr, 0, nullptr, nullptr);
 }
 
 }  // extern "C"
