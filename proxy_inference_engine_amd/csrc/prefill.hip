@@ -553,9 +553,12 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
         }
         if (wm) {
             // K split over two workgroups per strip where the strips alone cannot fill the chip (N / 32 < 256) and K is long enough
-            // (measured on the 8B shapes: 32 rows 4.39 -> 4.22 ms per prompt, 16 rows 3.70 -> 3.84: only from ~24 rows, where the
-            // half-occupied chip is VALU-bound on the dequantisation)
-            const bool split = y32 && used32 && N / 32 < 256 && K >= 2048 && M >= 24 && split_k_enabled();
+            // (measured on the 8B shapes: down, K = 14336, gains at every row count -- 8 rows 3.05 -> 2.85 ms per prompt, half the
+            // chip is VALU-bound on its dequantisation; o_proj, K = 4096, only from ~24 rows, below that its halves are too short)
+            static const int split_min_k = getenv("PIE_W4M_SPLIT_MIN_K") ? atoi(getenv("PIE_W4M_SPLIT_MIN_K")) : 2048;  // tuning knobs
+            static const int split_min_m = getenv("PIE_W4M_SPLIT_MIN_M") ? atoi(getenv("PIE_W4M_SPLIT_MIN_M")) : 24;
+            static const int split_long_k = getenv("PIE_W4M_SPLIT_LONG_K") ? atoi(getenv("PIE_W4M_SPLIT_LONG_K")) : 8192;  // K from which any M splits
+            const bool split = y32 && used32 && N / 32 < 256 && K >= split_min_k && (M >= split_min_m || K >= split_long_k) && split_k_enabled();
             if (rope && used_act) {
                 *used_act = true;
                 rope->bias = (const u16 *)bias;
