@@ -79,7 +79,9 @@ __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
     asm volatile("" : "+v"(e), "+v"(o));
     const float c0 = (float)(e & 0xFFu), c4 = (float)((e >> 8) & 0xFFu), c1 = (float)((e >> 16) & 0xFFu), c5 = (float)(e >> 24);
     const float c2 = (float)(o & 0xFFu), c6 = (float)((o >> 8) & 0xFFu), c3 = (float)((o >> 16) & 0xFFu), c7 = (float)(o >> 24);
-    auto dq = [&](float q) { return __fadd_rn(__fmul_rn(s, q), b); };
+    // fmaf == fadd(fmul): s * q is exact in fp32 (a 16-bit float's <= 11 significant bits times a 4-bit code), so the separate
+    // rounding of the product that mx.dequantize's fp32(s * q) + b implies never rounds -- one (packed) FMA per weight instead of two ops
+    auto dq = [&](float q) { return __builtin_fmaf(s, q, b); };
     return make_uint4(w4m_pack<T>(dq(c0), dq(c1)), w4m_pack<T>(dq(c2), dq(c3)), w4m_pack<T>(dq(c4), dq(c5)), w4m_pack<T>(dq(c6), dq(c7)));
 }
 
