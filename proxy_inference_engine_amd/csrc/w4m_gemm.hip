@@ -241,6 +241,81 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
     else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
+// Persistent form for matrices with more strips than workgroup slots (gate|up: 896, lm_head: 4008): every workgroup walks
+// several strips (blockIdx.x, + gridDim.x, ...) with ONE load ring running across the strip boundaries, so the next strip's
+// tiles are in flight while this one is reduced.  (One strip per workgroup, every wave issues all its loads up front, waits
+// ~2 us, computes with the other waves of its SIMD all in the same phase, and leaves: SQ counters on gate|up showed waves 45 %
+// of their life in s_waitcnt and the VALU 46 % busy.)  Same arithmetic and summation order as k_w4m_gemm.
+template <class T>
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_p(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias,
+                                                              const W4mRope rope) {
+    __shared__ float s_red[2][W4M_WAVES][16][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, groups = K >> 6, n_strips = N >> 5;
+    const int m = n < M ? n : M - 1;
+    const u16 *xrow = x + (size_t)m * K + 8 * kh;
+    const int my_groups = (groups - wave + W4M_WAVES - 1) / W4M_WAVES;                       // >= 1: the launcher requires K >= 512
+    const int my_strips = ((n_strips - (int)blockIdx.x) + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: gridDim.x <= n_strips
+    const int total = my_strips * my_groups;
+
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    uint4 cw[W4M_WDEPTH], xf[W4M_XDEPTH][4];
+    u32 sb[W4M_WDEPTH];
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // issue-side cursors: (strip, group-iteration) of the next weight tile / x fragment set to fetch; they stop at the last valid one
+    int wj = 0, wit = 0, xit = 0;
+#define W4M_WISSUE(d)                                                                                              \
+    {                                                                                                              \
+        const int nt_ = (int)blockIdx.x + wj * (int)gridDim.x;                                                      \
+        const char *tile_ = w4m + ((size_t)nt_ * groups + wave + wit * W4M_WAVES) * W4M_TILE_BYTES;                  \
+        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);           \
+        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                                \
+        sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);                        \
+        if (!(wj == my_strips - 1 && wit == my_groups - 1)) {                                                       \
+            if (++wit == my_groups) wit = 0, ++wj;                                                                  \
+        }                                                                                                          \
+    }
+#define W4M_XISSUE(d)                                                                                              \
+    {                                                                                                              \
+        const u16 *xp_ = xrow + (size_t)(wave + xit * W4M_WAVES) * 64;                                              \
+        xf[d][0] = *reinterpret_cast<const uint4 *>(xp_), xf[d][1] = *reinterpret_cast<const uint4 *>(xp_ + 16);    \
+        xf[d][2] = *reinterpret_cast<const uint4 *>(xp_ + 32), xf[d][3] = *reinterpret_cast<const uint4 *>(xp_ + 48); \
+        if (++xit == my_groups) xit = 0;                                                                            \
+    }
+#pragma unroll
+    for (int d = 0; d < W4M_WDEPTH; ++d) W4M_WISSUE(d)
+#pragma unroll
+    for (int d = 0; d < W4M_XDEPTH; ++d) W4M_XISSUE(d)
+    int cj = 0, cit = 0;  // compute-side cursor
+    for (int base = 0; base < total; base += W4M_WDEPTH) {
+#pragma unroll
+        for (int d = 0; d < W4M_WDEPTH; ++d) {
+            constexpr int XD = W4M_XDEPTH;
+            if (base + d < total) {  // wave-uniform
+                const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
+                const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = MfmaT<T>::run(w4m_dequant<T>(words[k], s, b), xf[d % XD][k], acc);
+                W4M_WISSUE(d)
+                W4M_XISSUE(d % XD)
+                if (++cit == my_groups) {  // strip done for this wave: all eight waves meet here once per strip
+                    const int buf = cj & 1, nt = (int)blockIdx.x + cj * (int)gridDim.x;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s_red[buf][wave][i][lane] = acc[i], acc[i] = 0.0f;
+                    __syncthreads();  // also orders this buffer's previous use (two strips ago) before these writes: one barrier per strip
+                    if (swiglu == 2) w4m_epilogue_rope<T>(s_red[buf], nt, M, rope);
+                    else w4m_epilogue<T>(s_red[buf], nt, M, N, y, nullptr, swiglu != 0, bias);
+                    cit = 0, ++cj;
+                }
+            }
+        }
+    }
+#undef W4M_WISSUE
+#undef W4M_XISSUE
+}
+
 // The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
 // row per lane (32 cache lines per load instruction): at 32 rows the address unit, not HBM, sets the pace (5.0 ms per 8B-model
 // prompt, no better than the T-copy path).  Here each round of 8 groups (512 columns) first lands in LDS with row-contiguous
@@ -357,6 +432,18 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
     const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
     const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
+    const int n_strips = N >> 5;
+    const char *pe = getenv("PIE_W4M_PERSIST");  // 0: never use the persistent form (tuning / test knob)
+    if (M < stage_min && !y32 && n_strips > 512 && K >= 512 && !(pe && pe[0] == '0')) {
+        const int per = (n_strips + 511) / 512;                 // strips per workgroup, balanced: 896 -> 448 x 2, 4008 -> 501 x 8
+        const dim3 pgrid((n_strips + per - 1) / per);
+        if (dtype == PIE_BF16)
+            hipLaunchKernelGGL(k_w4m_gemm_p<BF16>, pgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+        else
+            hipLaunchKernelGGL(k_w4m_gemm_p<F16>, pgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
     if (M >= stage_min) {
         if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
         else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
