@@ -68,5 +68,39 @@ def main():
             c[0].page_manager.release()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--engine" not in sys.argv:
     main()
+
+
+def engine_mode():
+    """End-to-end continuous batching: R requests (prompt P, G new tokens each) through BatchedEngine with at most S in flight."""
+    import argparse as _a
+    ap = _a.ArgumentParser()
+    ap.add_argument("--engine", action="store_true")
+    ap.add_argument("--requests", type=int, default=64)
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--new", type=int, default=64)
+    ap.add_argument("--slots", type=int, default=32)
+    args = ap.parse_args()
+    from proxy_inference_engine_amd.engine import BatchedEngine
+    cfg = dict(LLAMA3_8B)
+    model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16))
+    torch.cuda.empty_cache()
+    pages = args.slots * ((args.prompt + args.new + 63) // 64 + 1) + 4
+    eng = BatchedEngine(model, num_pages=pages, max_batch=args.slots)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, cfg["vocab_size"], (args.prompt + (i % 5),), generator=g).tolist() for i in range(args.requests)]
+    eng.generate(prompts[:args.slots], 4)                       # warm-up: scratch, tile copies, hipBLASLt plans
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = eng.generate(prompts, args.new)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_new = sum(len(o) for o in out)
+    print(json.dumps({"mode": "BatchedEngine", "requests": args.requests, "slots": args.slots, "prompt": args.prompt, "new_tokens": n_new,
+                      "seconds": round(dt, 3), "generated_tokens_per_s": round(n_new / dt, 1),
+                      "prompt_plus_generated_tokens_per_s": round((n_new + sum(len(p) for p in prompts)) / dt, 1), "batched_steps": eng.steps}))
+
+
+if __name__ == "__main__" and "--engine" in sys.argv:
+    engine_mode()
