@@ -127,13 +127,22 @@ int pie_page_alloc(pie_page_pool *p, uint32_t *page_id) {
 
 int pie_page_free(pie_page_pool *p, uint32_t id) {
     if (int rc = check_id(p, id, "pie_page_free")) return rc;
-    if (p->pages[id].ref_count.fetch_sub(1, std::memory_order_acq_rel) - 1 == 0) push_free(p, id);
+    // decrement unless already zero: the reference only asserts ("dec_ref on free page", page.hpp:88-91); a release build of it
+    // would push the page on the free list twice -- here a double free is an error and the pool stays intact
+    uint32_t c = p->pages[id].ref_count.load(std::memory_order_acquire);
+    do {
+        POOL_REQUIRE(c != 0, PIE_E_STATE, "pie_page_free: page " + std::to_string(id) + " is not allocated (double free)");
+    } while (!p->pages[id].ref_count.compare_exchange_weak(c, c - 1, std::memory_order_acq_rel, std::memory_order_acquire));
+    if (c == 1) push_free(p, id);
     return PIE_OK;
 }
 
 int pie_page_add_ref(pie_page_pool *p, uint32_t id) {
     if (int rc = check_id(p, id, "pie_page_add_ref")) return rc;
-    p->pages[id].ref_count.fetch_add(1, std::memory_order_acq_rel);
+    uint32_t c = p->pages[id].ref_count.load(std::memory_order_acquire);
+    do {  // "add_ref on free page" (page.hpp:79-82): refused, a free page may be handed to someone else at any moment
+        POOL_REQUIRE(c != 0, PIE_E_STATE, "pie_page_add_ref: page " + std::to_string(id) + " is not allocated");
+    } while (!p->pages[id].ref_count.compare_exchange_weak(c, c + 1, std::memory_order_acq_rel, std::memory_order_acquire));
     return PIE_OK;
 }
 

@@ -155,6 +155,19 @@ def test_invalid_id_throws():                                                # :
         alloc.add_ref(5)
 
 
+def test_double_free_and_add_ref_on_free_page_are_errors():
+    """The reference asserts on both (page.hpp:79-91); here they are reported and leave the pool consistent."""
+    alloc = make_allocator(TINY_POOL_SIZE)
+    pid = alloc.allocate_page()
+    alloc.free_page(pid)
+    with pytest.raises(RuntimeError, match="double free"):
+        alloc.free_page(pid)
+    with pytest.raises(RuntimeError, match="not allocated"):
+        alloc.add_ref(pid)
+    assert alloc.get_num_free_pages() == TINY_POOL_SIZE
+    assert sorted(allocate_pages(alloc, TINY_POOL_SIZE)) == list(range(TINY_POOL_SIZE))     # every page exactly once
+
+
 def test_key_cache_needs_device_storage():
     alloc = make_allocator(2)
     with pytest.raises(RuntimeError, match="without device storage"):
