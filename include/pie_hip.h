@@ -211,6 +211,14 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
 int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
                            const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
                            int flags, void *stream);
+/* Several FRESH prompts in one pass (the prefill-state half of BatchDetails, batch_details.hpp:10-88): their N rows are
+ * concatenated -- ids [N]; per row: row_context_lens (position + 1), row_seq (which prompt, = its block-table row), seg_lo
+ * (index of its prompt's first row), seg_hi (row index + 1: causal); per prompt: last_rows [S] (index of its last row).  K / V
+ * go to each prompt's pages; attention reads this pass's own rows.  Outputs per prompt as in pie_decoder_step_batch.
+ * All index arrays are device int32. */
+int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
+                              const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, size_t n_pages,
+                              const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);

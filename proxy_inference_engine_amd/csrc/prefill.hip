@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
                                                          int n_pages, const float *rope_cs, const int *ctx_len = nullptr, int bt_stride = 0,
-                                                         u16 *slab = nullptr) {
+                                                         u16 *slab = nullptr, const int *row_seq = nullptr, u16 *kc = nullptr, u16 *vc = nullptr) {
+    // row_seq / kc / vc (several prompts in one pass): row m belongs to sequence row_seq[m] (its block-table row), and the
+    // rotated K and the V rows are also written to contiguous [n_kv_heads, rows, HD] buffers the attention of this pass reads
     // ctx_len != nullptr (multi-sequence decode step): row m is its own sequence at position ctx_len[m] - 1 with its own block
     // table row and the layer's slab given directly; otherwise row m continues the decoder's one sequence at state->pos + m
     const int m = blockIdx.x, pos = ctx_len ? ctx_len[m] - 1 : state->pos + m, half = HD >> 1;
@@ -97,7 +99,8 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
     const int q_cols = n_heads * HD, k_cols = n_kv_heads * HD;
     u16 *kdst = slab ? slab : reinterpret_cast<u16 *>(kv_table[layer]);
     u16 *vdst = slab ? slab + (size_t)n_kv_heads * 64 * HD : reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
-    block_table = block_table ? block_table + (size_t)m * bt_stride : nullptr;
+    block_table = block_table ? block_table + (size_t)(row_seq ? row_seq[m] : m) * bt_stride : nullptr;
+    const int n_rows = gridDim.x;
     if (block_table) {  // paged KV: the row goes to slot pos % 64 of page block_table[pos / 64]
         const size_t pg_off = (size_t)min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u) * 2 * 64 * n_kv_heads * HD;
         kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
@@ -114,11 +117,16 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             const float cs = csn.x, sn = csn.y;
             u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
             const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
-            dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn)));
-            dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
+            const u16 o0 = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn))), o1 = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
+            dst[i0] = o0, dst[i1] = o1;
+            if (kc && R >= q_cols) {
+                u16 *c = kc + ((size_t)head * n_rows + m) * HD;
+                c[i0] = o0, c[i1] = o1;
+            }
         } else {
             const int rr = R - q_cols - k_cols;
             *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pr;
+            if (vc) *reinterpret_cast<u32 *>(vc + ((size_t)(rr / HD) * n_rows + m) * HD + rr % HD) = pr;
         }
     }
 }
@@ -360,6 +368,7 @@ struct PrefillScratch {
     size_t w_elems = 0;     // capacity of the dequantised-weight buffer (elements)
     u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
+    u16 *kc = nullptr, *vc = nullptr;  // [n_kv_heads, rows, head_dim]: this pass's K / V rows, contiguous (several prompts in one pass)
     float *y32 = nullptr;  // [rows, hidden] fp32, zero between uses: K-split few-row GEMM sums (o_proj, down), consumed by k_add_rms_norm_rows
     int part_splits = 0;
     // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
@@ -381,7 +390,7 @@ struct PrefillScratch {
 };
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
-    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->y32};
+    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->y32, s->kc, s->vc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
@@ -442,6 +451,8 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         PF_ALLOC(s->part_ml, 4 * R * c.n_heads * splits * 2);
         PF_ALLOC(s->rope_cs, 4 * R * c.head_dim);
         PF_ALLOC(s->y32, 4 * R * c.hidden);
+        PF_ALLOC(s->kc, 2 * R * c.n_kv_heads * c.head_dim);
+        PF_ALLOC(s->vc, 2 * R * c.n_kv_heads * c.head_dim);
         PIE_HIP_TRY(hipMemset(s->y32, 0, 4 * R * c.hidden));
         PIE_HIP_TRY(hipDeviceSynchronize());  // (re)allocation only: the zeros must be in place whatever stream the GEMMs run on
         PF_ALLOC(s->wT, 2 * we);
@@ -766,6 +777,94 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     }
     if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, B, logits, st, false, nullptr, true))) return rc;
     return logits_tail_rows_launch(c.dtype, logits, c.vocab, B, s->tail_stats, logprobs, next_tokens, st);
+}
+
+
+// ---------------------------------------------------------------- several fresh prompts in one pass
+__global__ void k_gather_rows(const uint4 *x, const int *rows, int H8, uint4 *y) {  // y[s] = x[rows[s]], H8 = hidden / 8
+    const uint4 *src = x + (size_t)rows[blockIdx.x] * H8;
+    for (int i = threadIdx.x; i < H8; i += blockDim.x) y[(size_t)blockIdx.x * H8 + i] = src[i];
+}
+
+// The rows of S prompts concatenated ([N] ids): one pass of GEMMs over all N rows, RoPE at each row's own position, K / V into
+// each prompt's own pages AND a contiguous copy the attention of this pass reads (causal inside each prompt = the segment
+// kernel with seg_hi[r] = r + 1), lm_head + tail on every prompt's last row.  Fresh prompts only (nothing cached before them).
+template <class T>
+static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *row_ctx, const int32_t *row_seq, const int32_t *seg_lo,
+                            const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, int n_pages,
+                            const int32_t *block_tables, int max_blocks, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
+    const pie_decoder_config &c = d->cfg;
+    const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
+    size_t w_elems = (size_t)2 * I * H;
+    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
+    if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    int rc = scratch_reserve(d, N > S ? N : S, w_elems, d->splits);
+    if (rc) return rc;
+    PrefillScratch *s = d->prefill;
+    if (s->tail_rows < S) {
+        if (s->tail_stats) (void)hipFree(s->tail_stats);
+        s->tail_stats = nullptr, s->tail_rows = 0;
+        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)S));
+        s->tail_rows = S, ++s->alloc_gen;
+    }
+    rc = c.weight_format == PIE_W_DENSE
+             ? pie_embedding_dense(ids, N, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
+             : embedding_launch(ids, N, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
+                                nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rope_cs_rows, dim3(N), dim3(64), 0, st, d->glob.rope_freqs, nullptr, row_ctx, D / 2, s->rope_cs);
+    PIE_LAUNCH_CHECK();
+    for (int li = 0; li < c.n_layers; ++li) {
+        const pie_layer_weights &w = d->layers[li];
+        if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, N, H, c.dtype, s->xn, st))) return rc;
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv))) return rc;
+        hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(N), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+                           c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, row_ctx, max_blocks, (u16 *)slabs[li],
+                           row_seq, s->kc, s->vc);
+        PIE_LAUNCH_CHECK();
+        PrefillAttnArgs pa = {};
+        pa.q = s->q, pa.k = s->kc, pa.v = s->vc, pa.offset = 0, pa.cap = N, pa.seg_lo = seg_lo, pa.seg_hi = seg_hi;
+        pa.M = N, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
+        if ((rc = segment_attn_gqa_launch_t<T>(pa, D, st))) return rc;
+        bool r32 = false;
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
+        bool fused_act = false;
+        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, N, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+        if (!fused_act) {
+            const size_t n_act = (size_t)N * I;
+            hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
+            PIE_LAUNCH_CHECK();
+        }
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, N, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+        const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr))) return rc;
+    }
+    // the normalised last row of every prompt -> lm_head -> tail
+    hipLaunchKernelGGL(k_gather_rows, dim3(S), dim3(256), 0, st, (const uint4 *)s->xn, last_rows, H / 8, (uint4 *)s->r);
+    PIE_LAUNCH_CHECK();
+    if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->r, S, logits, st, false, nullptr, true))) return rc;
+    return logits_tail_rows_launch(c.dtype, logits, c.vocab, S, s->tail_stats, logprobs, next_tokens, st);
+}
+
+extern "C" int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
+                                         const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *last_rows, int N, int S,
+                                         const void *const *slabs, size_t n_pages, const int32_t *block_tables, int max_blocks, void *logits,
+                                         float *logprobs, int32_t *next_tokens, void *stream) {
+    PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
+                PIE_E_ARG, "pie_decoder_prefill_batch: null pointer");
+    PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch: set_globals must be called first");
+    for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_prefill_batch: a layer has no weights (pie_decoder_set_layer)");
+    PIE_REQUIRE(S >= 1 && N >= S && N <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_prefill_batch: bad batch shape");
+    PIE_REQUIRE(d->cfg.hidden % 8 == 0 && d->cfg.hidden <= 8192, PIE_E_SHAPE, "pie_decoder_prefill_batch: hidden must be a multiple of 8, at most 8192");
+    const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
+    PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_prefill_batch: n_heads / n_kv_heads must be between 1 and 8");
+    for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_prefill_batch: null or misaligned slab");
+    hipStream_t st = (hipStream_t)stream;
+    return d->cfg.dtype == PIE_BF16 ? prefill_varlen_t<BF16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, slabs, (int)n_pages, block_tables,
+                                                             max_blocks, (u16 *)logits, logprobs, next_tokens, st)
+                                    : prefill_varlen_t<F16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, slabs, (int)n_pages, block_tables,
+                                                            max_blocks, (u16 *)logits, logprobs, next_tokens, st);
 }
 
 static int decode_batch(pie_decoder *d, const int32_t *tokens, const int32_t *ctx_len, const void *const *slabs, int n_pages, const int32_t *block_tables,

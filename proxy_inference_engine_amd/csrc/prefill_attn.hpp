@@ -279,6 +279,32 @@ static int segment_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
+// the same with grouped-query heads (several prompts prefilled in one pass: causal inside each prompt = seg_hi[r] = r + 1)
+template <class T, int D>
+static int segment_attn_gqa_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
+    const int rep = a.Hq / a.Hkv;
+    const dim3 grid(((a.M + 31) / 32) * a.Hkv);
+#define PA_SEG(R) hipLaunchKernelGGL((k_prefill_attn<T, D, R, 1, true>), grid, dim3(R * 64), 0, st, a); break
+    switch (rep) {
+        case 1: PA_SEG(1);
+        case 2: PA_SEG(2);
+        case 3: PA_SEG(3);
+        case 4: PA_SEG(4);
+        case 5: PA_SEG(5);
+        case 6: PA_SEG(6);
+        case 7: PA_SEG(7);
+        case 8: PA_SEG(8);
+        default: return pie::fail(PIE_E_SHAPE, "segment attention: n_heads / n_kv_heads must be between 1 and 8");
+    }
+#undef PA_SEG
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+template <class T>
+static int segment_attn_gqa_launch_t(const PrefillAttnArgs &a, int D, hipStream_t st) {
+    return D == 128 ? segment_attn_gqa_launch_d<T, 128>(a, st) : segment_attn_gqa_launch_d<T, 64>(a, st);
+}
+
 template <class T>
 static int segment_attn_launch_t(const PrefillAttnArgs &a, int D, hipStream_t st) {
     return D == 128 ? segment_attn_launch_d<T, 128>(a, st) : segment_attn_launch_d<T, 64>(a, st);

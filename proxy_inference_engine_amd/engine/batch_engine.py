@@ -27,12 +27,14 @@ class _Active:
 
 class BatchedEngine:
     def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
-                 sampler: Callable[[torch.Tensor], torch.Tensor] | None = None):
+                 sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096):
         self.model = model
         self.pool = model.enable_paged_kv(num_pages=num_pages)
         self.max_batch = max_batch
         self.stop_tokens = set(int(t) for t in stop_tokens)
         self.sampler = sampler
+        self.batch_prefill = batch_prefill          # admit several waiting prompts with one pass over the weights
+        self.max_prefill_rows = max_prefill_rows    # prompt tokens per such pass
         self.steps = 0                # batched decode steps taken (for throughput accounting)
 
     def _pages_for(self, n_tokens: int) -> int:
@@ -51,22 +53,32 @@ class BatchedEngine:
         reserved = 0                  # pages promised to the active sequences for their full length
         need = {}
         while pending or active:
-            # admit while there is a slot and the pool can hold the request to its end
-            while pending and len(active) < self.max_batch:
+            # admit while there is a slot and the pool can hold the request to its end; the admitted prompts run as ONE pass
+            batch = []
+            rows = 0
+            while pending and len(active) + len(batch) < self.max_batch:
                 idx, prompt = pending[0]
                 n_pages = self._pages_for(len(prompt) + max_new_tokens)
-                if reserved + n_pages > self.pool.size():
+                if reserved + n_pages > self.pool.size() or (rows > 0 and rows + len(prompt) > self.max_prefill_rows):
                     break
                 pending.popleft()
-                cache = self.model.make_cache()
-                ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
-                tok, logprobs, _ = self.model.step(ids.to(self.model.device), cache)
-                if self.sampler is not None:
-                    tok = self.sampler(logprobs[None]).reshape(1).to(torch.int32)
-                a = _Active(idx, cache, tok.reshape(1).clone())
                 need[idx] = n_pages
                 reserved += n_pages
-                active.append(a)
+                rows += len(prompt)
+                batch.append((idx, prompt, self.model.make_cache()))
+            if len(batch) == 1 or (batch and not self.batch_prefill):
+                for idx, prompt, cache in batch:
+                    ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
+                    tok, logprobs, _ = self.model.step(ids.to(self.model.device), cache)
+                    if self.sampler is not None:
+                        tok = self.sampler(logprobs[None]).reshape(1).to(torch.int32)
+                    active.append(_Active(idx, cache, tok.reshape(1).clone()))
+            elif batch:
+                toks, logprobs, _ = self.model.prefill_batch([p for _, p, _ in batch], [c for _, _, c in batch])
+                if self.sampler is not None:
+                    toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                for i, (idx, _, cache) in enumerate(batch):
+                    active.append(_Active(idx, cache, toks[i:i + 1].clone()))
             if not active:
                 raise RuntimeError("no request fits the page pool")      # unreachable after the check above
             # every active sequence holds one token not yet recorded (from its prompt or from the last step): record, retire, step

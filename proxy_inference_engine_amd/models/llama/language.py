@@ -409,6 +409,54 @@ class Model:
             s.advance(1)
         return nxt, logprobs, logits
 
+    def prefill_batch(self, prompts: list, caches: list[list[BaseCache]]):
+        """Several fresh prompts in ONE pass (pie_decoder_prefill_batch): their rows are concatenated for the GEMMs, every row keeps
+        its own position, every prompt its own pages and a causal attention over its own rows only.  caches: empty paged caches
+        (make_cache() after enable_paged_kv(), one per prompt).  Returns (next_tokens [S], logprobs [S, V], logits [S, V]) for the
+        prompts' last positions; every cache then holds its prompt."""
+        import numpy as np
+        seqs = []
+        for c in caches:
+            if len(c) != len(self.layers) or not isinstance(c[0], PagedKVCache):
+                raise TypeError("prefill_batch runs on paged caches (enable_paged_kv(), then make_cache())")
+            if c[0].offset != 0:
+                raise ValueError("prefill_batch takes fresh caches (nothing cached before the prompt)")
+            seqs.append(c[0].page_manager)
+        a = seqs[0].allocator
+        if len(prompts) != len(seqs) or any(s.allocator is not a for s in seqs) or len({id(s) for s in seqs}) != len(seqs):
+            raise ValueError("prefill_batch: one distinct fresh sequence of one page pool per prompt")
+        lens = [len(p) for p in prompts]
+        if min(lens) < 1 or sum(lens) > 65535:
+            raise ValueError("prefill_batch: prompts must be non-empty and hold at most 65535 tokens together")
+        for s, n in zip(seqs, lens):
+            s.reserve(n)
+        S, N = len(seqs), sum(lens)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        ids = np.concatenate([np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])
+        row_seq = np.repeat(np.arange(S, dtype=np.int32), lens)
+        row_ctx = (np.arange(N, dtype=np.int32) - np.repeat(starts, lens) + 1).astype(np.int32)
+        seg_lo = np.repeat(starts, lens).astype(np.int32)
+        seg_hi = np.arange(1, N + 1, dtype=np.int32)
+        last = (starts + np.asarray(lens, dtype=np.int32) - 1).astype(np.int32)
+        mb = max(len(s.pages) for s in seqs)
+        table = np.zeros((S, mb), np.int32)
+        for i, s in enumerate(seqs):
+            table[i, :len(s.pages)] = s.pages
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        t_ids, t_seq, t_ctx, t_lo, t_hi, t_last, t_table = (dev(x) for x in (ids, row_seq, row_ctx, seg_lo, seg_hi, last, table))
+        V = self.args.vocab_size
+        logits = torch.empty((S, V), dtype=self.dtype, device=self.device)
+        logprobs = torch.empty((S, V), dtype=torch.float32, device=self.device)
+        nxt = torch.empty(S, dtype=torch.int32, device=self.device)
+        n = len(self.layers)
+        slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
+        _ffi.check(_ffi.load().pie_decoder_prefill_batch(self._dec, _ffi.p(t_ids), _ffi.p(t_ctx), _ffi.p(t_seq), _ffi.p(t_lo), _ffi.p(t_hi), _ffi.p(t_last),
+                                                         N, S, slabs, a.size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt),
+                                                         _ffi.stream()))
+        for s, k in zip(seqs, lens):
+            s.advance(k)
+        return nxt, logprobs, logits
+
     def step_bytes(self, T: int, with_logits: bool = True) -> int:
         """Algorithmic HBM bytes of one decode step at context length T."""
         return int(_ffi.load().pie_decoder_step_bytes(self._dec, int(T), int(with_logits)))
