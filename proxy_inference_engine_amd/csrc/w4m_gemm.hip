@@ -1,10 +1,13 @@
 // w4m_gemm.hip -- int4 g=64 x T GEMM for a FEW rows (2..32 prompt tokens) on the MFMA units, weights read once in 4-bit form.
 //
-// Measured (8B model, whole prompt incl. lm_head and tail): 6..8 tokens 5.1 -> 3.3 ms, 16 tokens 5.2 -> 3.8, 32 tokens 5.1 -> 4.5.
-// tools/w4m_bench ablations at 8 rows (us: qkv / o_proj / gate|up / down): full 8.4 / 8.2 / 26.8 / 20.5; without x loads
-// 7.9 / 7.9 / 22.1 / 17.5; without dequantisation 8.1 / 8.1 / 26.3 / 19.7; stream + reduction only 5.3 / 5.1 / 16.7 / 9.6 -- the
-// arithmetic is nearly free; what is left is the grid shape (N / 32 workgroups of ~74 KB each: 128 workgroups for the two
-// N = 4096 matrices leave half the chip idle) and the x fragments.  Next: a persistent grid with K split across workgroups.
+// Measured (8B model, whole prompt incl. lm_head and tail): 6..8 tokens 5.1 -> 2.8 ms, 16 tokens 5.2 -> 3.2, 32 tokens 5.1 -> 3.8; the
+// 32-sequence decode step built on it: 3.7 ms.  Three kernel forms, one arithmetic: k_w4m_gemm (fragments of x
+// straight from L2; optionally K split over two workgroups with a commutative fp32 atomic pair), k_w4m_gemm_p (persistent: several
+// strips per workgroup behind one load ring, for gate|up and lm_head), k_w4m_gemm_lds (x staged through LDS, from 24 rows); three
+// epilogues: store, SwiGLU on the interleaved gate|up rows, RoPE + cache append on the packed q|k|v rows.
+// tools/w4m_bench ablations of the first form at 8 rows (us: qkv / o_proj / gate|up / down): full 8.4 / 8.2 / 26.8 / 20.5; without x
+// loads 7.9 / 7.9 / 22.1 / 17.5; without dequantisation 8.1 / 8.1 / 26.3 / 19.7; stream + reduction only 5.3 / 5.1 / 16.7 / 9.6 -- the
+// arithmetic is nearly free; what costs is the grid shape (N / 32 workgroups of ~74 KB each) and the x fragments.
 //
 // Why: a short prompt (a chat turn appended to a cached prefix) sits between the two existing paths -- the GEMV reads the
 // 0.5625 B/weight stream once PER TOKEN, the hipBLASLt path reads a 2 B/weight T copy (and its skinny-GEMM kernels reach
