@@ -118,6 +118,28 @@ VARIANTS = [
     ("tiny_w8_bf16_trad", {"quantization": {"group_size": 64, "bits": 8}, "rope_traditional": True, "tie_word_embeddings": False}, "bfloat16", 202),
 ]
 
+def vision_fixture():
+    """A small Qwen2.5-VL-shaped vision tower (head_dim 80 like the 7B tower, windowed + full-attention blocks, two images, one
+    with two frames) from oracle/vision_oracle.py, and a few-row int4 product in the many-row regime (the W4M kernel's contract)."""
+    from oracle import vision_oracle as vo
+    cfg = dict(depth=3, hidden_size=160, intermediate_size=212, out_hidden_size=96, num_heads=2, patch_size=14, in_channels=3,
+               spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])
+    grid = [(1, 6, 10), (2, 4, 4)]
+    w = vo.synth_vision_checkpoint(cfg, seed=4, dtype=DT)
+    n = sum(t * h * ww for t, h, ww in grid)
+    pix = po.round_T(np.random.default_rng(7).standard_normal((n, 3 * 2 * 14 * 14)), DT)
+    import json
+    d = {"source": "oracle", "dtype": DT, "config_json": json.dumps(cfg), "grid": np.array(grid, np.int32), "pixels": po.to_bits(pix, DT),
+         "features": po.to_bits(vo.vision_forward(cfg, w, pix, grid, DT), DT)}
+    d.update({"w:" + k: v for k, v in w.items()})
+    rng = np.random.default_rng(99)
+    wq, sc, bi = po.quantize(po.round_T(rng.standard_normal((96, 1408)) * 0.05, DT), 64, 4, DT)
+    x = po.round_T(rng.standard_normal((17, 1408)), DT)
+    d["qmm_wq"], d["qmm_scales"], d["qmm_biases"], d["qmm_x"] = wq, sc, bi, po.to_bits(x, DT)
+    d["qmm_y"] = po.to_bits(po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=DT, regime="qmm"), DT)
+    np.savez_compressed(OUT / "tiny_vision_bf16.npz", **d)
+
+
 if __name__ == "__main__":
     ops_fixture()
     tiny_llama_fixture()
@@ -125,3 +147,4 @@ if __name__ == "__main__":
         variant_fixture(*v)
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size // 1024, "KiB")
+    vision_fixture()

@@ -59,3 +59,18 @@ def test_variant_fixtures_reproduced(golden_dir, name):
         tok, lp = next(gen)
         assert tok == int(want), f"{name} step {i}"
         assert np.allclose(lp, g["logprobs"][i], atol=1e-6)
+
+
+def test_vision_and_few_row_fixture_reproduced(golden_dir):
+    """The vision-tower oracle (oracle/vision_oracle.py) and the many-row regime of quantized_matmul reproduce their committed
+    outputs bit for bit (pins both against drift; the GPU tests read the same file)."""
+    from oracle import vision_oracle as vo
+    g = np.load(golden_dir / "tiny_vision_bf16.npz")
+    dt = str(g["dtype"])
+    cfg = json.loads(str(g["config_json"]))
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    grid = [tuple(int(v) for v in row) for row in g["grid"]]
+    feats = vo.vision_forward(cfg, w, po.from_bits(g["pixels"], dt), grid, dt)
+    assert np.array_equal(po.to_bits(feats, dt), g["features"])
+    y = po.quantized_matmul(po.from_bits(g["qmm_x"], dt), g["qmm_wq"], g["qmm_scales"], g["qmm_biases"], group_size=64, bits=4, dtype=dt, regime="qmm")
+    assert np.array_equal(po.to_bits(y, dt), g["qmm_y"])

@@ -181,3 +181,19 @@ def test_image_to_text_logits_end_to_end():
     want = orc.forward(None, [po.OracleKVCache() for _ in orc.layers], inputs_embeds=table)
     # the image rows carry the tower's own rounding noise into the text tower: one more factor on the end-to-end bound
     assert_vec_close(logits[0, -1].float().cpu().numpy(), want[-1], DT, c_max=8.0, c_rms=6.0, what="image -> text logits")
+
+
+def test_vision_tower_and_few_row_gemm_against_golden_fixture(ops, golden_dir):
+    """The committed oracle-captured vectors (tests/golden/tiny_vision_bf16.npz): the tower's features and a 17-row int4 product."""
+    import json
+    from proxy_inference_engine_amd.models.intern.vision import VisionConfig, VisionModel
+    from tests._util import codes_dev
+    g = np.load(golden_dir / "tiny_vision_bf16.npz")
+    cfg = json.loads(str(g["config_json"]))
+    tw = {k[2:]: to_dev(g[k], DT) for k in g.files if k.startswith("w:")}
+    model = VisionModel(VisionConfig(**cfg), tw)
+    got = model(to_dev(g["pixels"], DT), torch.from_numpy(g["grid"]))
+    assert_vec_close(got.float().cpu().numpy(), po.from_bits(g["features"], DT), DT, c_max=6.0, c_rms=5.0, what="golden tower features")
+    packed = ops.repack_w4s(codes_dev(g["qmm_wq"]), to_dev(g["qmm_scales"], DT), to_dev(g["qmm_biases"], DT))
+    y = ops.quantized_matmul_rows(to_dev(g["qmm_x"], DT), packed)
+    assert_dot_close(y.float().cpu().numpy(), po.from_bits(g["qmm_y"], DT), DT, max_frac=0.03, what="golden few-row product")
