@@ -1,7 +1,9 @@
 """CPU restatement of the reference's Qwen2.5-VL vision tower (models/intern/vision.py).  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: MLX is not available here and the reference holds no fixtures for this tower, so nothing pins the
-rounding points below to MLX's actual kernels; they follow the same contracts as oracle/pie_oracle.c (every op's result
+PARITY UNPINNED with respect to MLX: MLX is not available here and the reference holds no fixtures for this tower, so nothing
+pins the rounding points below to MLX's actual kernels.  The ALGORITHM is pinned: in fp32 this restatement agrees to 2e-7 with HF
+transformers' independent Qwen2_5_VisionTransformerPretrainedModel on identical weights (tests/test_oracle.py), the model the
+reference's vision.py is a port of.  The rounding points they follow the same contracts as oracle/pie_oracle.c (every op's result
 is rounded to the activation dtype T once; matmuls, softmax, RMSNorm statistics and elementwise formulas run in fp32 inside
 an op; a Linear's bias is added to the T-rounded product).  Only tests/ may import this module.
 
@@ -18,7 +20,7 @@ from . import pie_oracle as po
 
 
 def finfo_min(dtype: str) -> float:
-    return {"bfloat16": -3.3895313892515355e38, "float16": -65504.0}[dtype]
+    return {"bfloat16": -3.3895313892515355e38, "float16": -65504.0, "float32": -3.4028234663852886e38}[dtype]
 
 
 def rot_pos_emb(grid_thw, head_dim: int, merge: int) -> np.ndarray:

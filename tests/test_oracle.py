@@ -197,3 +197,29 @@ def test_qmm_regime_is_dequantize_then_matmul_and_close_to_qmv():
     assert err.max() <= 4 * 2.0 ** -8 * np.abs(a).max()                # ... inside the end-to-end parity bound
     d = np.abs(exact - dense)
     assert d.max() <= 2.0 ** -7 * np.abs(exact).max() and (d > 0).mean() < 0.6
+
+
+def test_vision_oracle_matches_hf_qwen2_5_vl_tower_fp32():
+    """oracle/vision_oracle.py against an independent implementation of the same tower -- HF transformers'
+    Qwen2_5_VisionTransformerPretrainedModel on torch-CPU with identical weights, fp32: patch embedding, 2-D rotary, window
+    order and cu_seqlens, windowed and full-attention blocks, SwiGLU MLP, patch merger and the inverse permutation."""
+    torch = pytest.importorskip("torch")
+    modeling = pytest.importorskip("transformers.models.qwen2_5_vl.modeling_qwen2_5_vl")
+    configuration = pytest.importorskip("transformers.models.qwen2_5_vl.configuration_qwen2_5_vl")
+    from oracle import vision_oracle as vo
+    cfg = dict(depth=3, hidden_size=64, intermediate_size=48, out_hidden_size=40, num_heads=2, patch_size=14, in_channels=3,
+               spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])
+    hc = configuration.Qwen2_5_VLVisionConfig(**cfg, hidden_act="silu")
+    hc._attn_implementation = "eager"
+    torch.manual_seed(0)
+    hf = modeling.Qwen2_5_VisionTransformerPretrainedModel(hc).float().eval()
+    w = {"vision_tower." + k: v.detach().numpy().astype(np.float32) for k, v in hf.state_dict().items()}
+    for grid in ([(1, 6, 10), (2, 4, 4)], [(1, 2, 2)], [(1, 8, 8)]):
+        n = sum(t * h * ww for t, h, ww in grid)
+        pix = np.random.default_rng(n).standard_normal((n, 3 * 2 * 14 * 14)).astype(np.float32)
+        with torch.no_grad():
+            out = hf(torch.from_numpy(pix), grid_thw=torch.tensor(grid))
+        ref = out if isinstance(out, torch.Tensor) else (out.pooler_output if getattr(out, "pooler_output", None) is not None else out[0])
+        got = vo.vision_forward(cfg, w, pix, grid, "float32")
+        assert got.shape == tuple(ref.shape)
+        assert np.max(np.abs(got - ref.numpy())) <= 2e-5 * max(1.0, float(ref.abs().max())), grid
