@@ -3,7 +3,7 @@
 PARITY UNPINNED with respect to MLX: MLX is not available here and the reference holds no fixtures for this tower, so nothing
 pins the rounding points below to MLX's actual kernels.  The ALGORITHM is pinned: in fp32 this restatement agrees to 2e-7 with HF
 transformers' independent Qwen2_5_VisionTransformerPretrainedModel on identical weights (tests/test_oracle.py), the model the
-reference's vision.py is a port of.  The rounding points they follow the same contracts as oracle/pie_oracle.c (every op's result
+reference's vision.py is a port of.  The rounding points follow the same contracts as oracle/pie_oracle.c (every op's result
 is rounded to the activation dtype T once; matmuls, softmax, RMSNorm statistics and elementwise formulas run in fp32 inside
 an op; a Linear's bias is added to the T-rounded product).  Only tests/ may import this module.
 
