@@ -223,3 +223,45 @@ def test_vision_oracle_matches_hf_qwen2_5_vl_tower_fp32():
         got = vo.vision_forward(cfg, w, pix, grid, "float32")
         assert got.shape == tuple(ref.shape)
         assert np.max(np.abs(got - ref.numpy())) <= 2e-5 * max(1.0, float(ref.abs().max())), grid
+
+
+def test_oracle_variants_vs_hf_transformers_fp32():
+    """The configuration switches of the reference's Llama (language.py:19-53) against independent implementations, fp32:
+    attention / MLP biases and llama3 rope scaling against HF LlamaForCausalLM, the Qwen2-VL text tower's form (biases on q, k, v
+    only, theta 1e6) against HF Qwen2ForCausalLM."""
+    from transformers import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM
+    base = dict(po.TINY_CONFIG)
+    base.pop("quantization")
+    ids = RNG.integers(0, base["vocab_size"], 14)
+
+    def check(cfg, hf, w):
+        missing, unexpected = hf.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=False)
+        assert not unexpected and all("rotary" in k for k in missing), (missing, unexpected)
+        with torch.no_grad():
+            ref = hf(torch.from_numpy(ids[None, :]).long()).logits[0].numpy()
+        orc = po.OracleLlama(cfg, w, "float32")
+        cache = [po.OracleKVCache() for _ in orc.layers]
+        got = np.concatenate([orc.forward(ids[:11], cache)] + [orc.forward(ids[t:t + 1], cache) for t in range(11, 14)])
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.abs(ref).max() + 1e-5
+
+    # Llama with every Linear biased and llama3 rope scaling
+    cfg = dict(base, attention_bias=True, mlp_bias=True, max_position_embeddings=8192,
+               rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192})   # the reference takes
+    # max_position_embeddings for both lengths of Llama3RoPE (language.py:57-66), i.e. HF's original_max_position_embeddings
+    hc = LlamaConfig(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                     num_attention_heads=cfg["num_attention_heads"], num_key_value_heads=cfg["num_key_value_heads"], vocab_size=cfg["vocab_size"],
+                     rms_norm_eps=cfg["rms_norm_eps"], rope_theta=cfg["rope_theta"], max_position_embeddings=8192, tie_word_embeddings=False,
+                     attention_bias=True, mlp_bias=True, rope_scaling=dict(cfg["rope_scaling"]))
+    hc._attn_implementation = "eager"
+    check(cfg, LlamaForCausalLM(hc).eval(), po.synth_checkpoint(cfg, seed=8, dtype="float32"))
+    # Qwen2: q / k / v biases only
+    cfg = dict(base, attention_bias=True, rope_theta=1000000.0)
+    w = po.synth_checkpoint(cfg, seed=9, dtype="float32")
+    for k in [k for k in w if k.endswith("o_proj.bias")]:
+        del w[k]
+    qc = Qwen2Config(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                     num_attention_heads=cfg["num_attention_heads"], num_key_value_heads=cfg["num_key_value_heads"], vocab_size=cfg["vocab_size"],
+                     rms_norm_eps=cfg["rms_norm_eps"], rope_theta=1000000.0, max_position_embeddings=cfg["max_position_embeddings"],
+                     tie_word_embeddings=False, use_sliding_window=False)
+    qc._attn_implementation = "eager"
+    check(cfg, Qwen2ForCausalLM(qc).eval(), w)
