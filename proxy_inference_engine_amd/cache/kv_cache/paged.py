@@ -70,7 +70,7 @@ class PageAllocator:
         """num_layers > 1: one slab plane per decoder layer ([num_layers, slab bytes]); a page id names the same slice
         of every plane, so one block table serves all layers."""
         self._h = C.c_void_p()
-        lib = _f.load()
+        lib = self._lib = _f.load()
         code = _f.dtype_code(dtype)
         if num_pages < 0 or num_heads < 0 or head_dim < 0:
             raise ValueError("PageAllocator: negative argument")
@@ -85,8 +85,12 @@ class PageAllocator:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            _f.load().pie_page_pool_destroy(h)
+        lib = getattr(self, "_lib", None)   # kept on the object: module globals may already be gone at interpreter shutdown
+        if h and lib is not None:
+            try:
+                lib.pie_page_pool_destroy(h)
+            except Exception:  # noqa: BLE001
+                pass
 
     def allocate_page(self) -> int | None:
         """A free page id with ref count 1 and no tokens, or None when the pool is exhausted (page_allocator.cpp:68-79)."""
