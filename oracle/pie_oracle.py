@@ -380,7 +380,7 @@ class OracleKVCache:
             self.values = np.zeros((1, n_kv, cap, D), np.float32)
             self.offset = 0
         elif self.offset + needed > self.keys.shape[2]:
-            if self.offset % self.step != 0:  # "safety" trim, reusable.py:125-129 (no effect on the result)
+            if self.offset % self.step != 0:  # "safety" trim, reusable.py:125-129: growth is then computed from the offset, not the old capacity
                 self.keys = np.ascontiguousarray(self.keys[..., : self.offset, :])
                 self.values = np.ascontiguousarray(self.values[..., : self.offset, :])
             current = self.keys.shape[2]

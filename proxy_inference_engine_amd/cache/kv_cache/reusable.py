@@ -61,7 +61,10 @@ class ReusableKVCache(BaseCache):
             self.values = torch.zeros((batch, n_kv_heads, cap, head_dim), dtype=dtype, device=device)
             self.offset = 0
         elif self.offset + needed > self.keys.shape[2]:
-            current = self.keys.shape[2]
+            # reusable.py:125-129: at an offset that is not a multiple of `step` the reference first slices the buffers to
+            # the offset, so the growth is computed from the OFFSET, not from the old capacity (520 then 300 tokens:
+            # 1024, not 1280).  Only the number matters here: the rows beyond the offset are zeros either way.
+            current = self.offset if self.offset % self.step != 0 else self.keys.shape[2]
             self._reallocate(self._aligned(max(int(current * self.growth_factor), self.offset + needed)))
         if self.offset + needed > self.keys.shape[2]:
             raise RuntimeError(f"KV cache max_capacity={self.max_capacity} exceeded")

@@ -82,7 +82,10 @@ class PromptCache:
         for layer_cache in self.cache:
             assert isinstance(layer_cache, (ReusableKVCache, PagedKVCache))
             layer_cache.reuse(len(ids), common)
-        # Like the reference, computed_ids is NOT truncated here; update() appends the processed suffix.
+        # DEVIATION from prompt_cache.py:52-76, which leaves computed_ids untouched here: after a diverging request B the
+        # reference's history reads A + B[k:] while the KV rows beyond k belong to B, so a later request that matches A beyond k
+        # (chat pattern A -> B -> A) attends over B's rows as if they were A's.  The history is cut to what the caches now hold.
+        del history[common:]
         return prompt_ids[common:]
 
     def cache_prompt(self) -> None:

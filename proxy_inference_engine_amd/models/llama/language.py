@@ -390,7 +390,7 @@ class Model:
                    "logprobs": torch.empty((B, V), dtype=torch.float32, device=self.device),
                    "next": torch.empty(B, dtype=torch.int32, device=self.device), "key": None}
             self._batch_bufs[B] = buf
-        key = tuple((id(s), len(s.pages)) for s in seqs)
+        key = tuple(tuple(s.pages) for s in seqs)  # the page ids themselves: truncate + regrow reorders them at equal length, and id() of a retired sequence can be reused
         if buf["key"] != key:
             table = torch.zeros(buf["table"].shape, dtype=torch.int32)
             for i, s in enumerate(seqs):

@@ -38,6 +38,41 @@ def test_reusable_cache_capacity_sequence_matches_oracle():
         capped.reserve(100, 1, 8, torch.float32, "cpu")
 
 
+@pytest.mark.parametrize("chunks", [(520, 300), (700, 400), (255, 2, 300), (256, 300), (100, 1, 1, 700, 5, 900)])
+def test_reusable_cache_growth_at_unaligned_offsets_matches_oracle(chunks):
+    """reusable.py:125-129: growing at an offset that is not a multiple of `step` first slices the buffers to the offset, so the
+    new capacity is computed from the offset (520 then 300 tokens -> 1024, not 1280).  Both halves of the product's API."""
+    ref, mine, split = po.OracleKVCache(), ReusableKVCache(), ReusableKVCache()
+    for n in chunks:
+        ref.update_and_fetch(np.ones((1, 2, n, 8), np.float32), np.ones((1, 2, n, 8), np.float32))
+        mine.update_and_fetch(torch.ones(1, 2, n, 8), torch.ones(1, 2, n, 8))
+        split.reserve(n, 2, 8, torch.float32, "cpu")
+        split.advance(n)
+        assert (mine.offset, mine.capacity) == (ref.offset, ref.keys.shape[2])
+        assert (split.offset, split.capacity) == (ref.offset, ref.keys.shape[2])
+    if chunks == (520, 300):
+        assert mine.capacity == 1024
+
+
+def test_prompt_cache_history_is_cut_on_reuse():
+    """A -> B -> A: after B diverged at k the caches hold B beyond k; the history must say so (deviation from
+    prompt_cache.py:52-76, which keeps A + B[k:] and would let the third request reuse B's rows as A's)."""
+    pc = PromptCache()
+    pc.cache = [ReusableKVCache()]
+    A, B = list(range(100, 140)), list(range(100, 120)) + list(range(500, 530))
+    one = lambda n: torch.ones(1, 1, n, 8)
+
+    def request(ids):
+        todo = pc(torch.tensor(ids))
+        pc.cache[0].update_and_fetch(one(len(todo)), one(len(todo)))
+        pc.update(todo)
+        return len(todo)
+
+    assert request(A) == 40 and pc.computed_ids == A
+    assert request(B) == 30 and pc.computed_ids == B and pc.cache[0].offset == 50
+    assert request(A) == 20 and pc.computed_ids == A and pc.cache[0].offset == 40      # the reference would process 1 token here
+
+
 def test_prompt_cache_lcp_matches_oracle():
     ref, mine = po.OraclePromptCache(), PromptCache()
     ref.cache, mine.cache = [po.OracleKVCache()], [ReusableKVCache()]

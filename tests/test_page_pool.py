@@ -198,7 +198,8 @@ def test_concurrent_alloc_free_producers_consumer():                         # :
         import time
         for i in range(total):
             pid = None
-            for _ in range(5000):
+            deadline = time.monotonic() + 120.0           # bounded by time, not by spins: producers may be descheduled
+            while time.monotonic() < deadline:
                 pid = alloc.allocate_page()
                 if pid is not None:
                     break
