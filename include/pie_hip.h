@@ -261,6 +261,14 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
 /* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
 size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
+/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_MEGA: 1 runs the
+ * whole step as ONE persistent launch where the configuration allows (int4 weights, contiguous caches up to 1024 positions,
+ * no Linear biases), 0 (default; env PIE_STEP_MEGA=1 flips it) keeps the per-kernel launch sequence; both produce identical bits.  Changing an option drops the
+ * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of the persistent launch's bounded
+ * grid barriers in *error (0 = none; the outputs of that step are then undefined). */
+enum { PIE_OPT_MEGA = 1 };
+int pie_decoder_configure(pie_decoder *d, int option, int value);
+int pie_decoder_status(pie_decoder *d, unsigned *error);
 
 /* ---------------------------------------------------------------- KV page pool
  * Replaces pie_core's PageAllocator / KVPage: src/pie_core/include/engine/page_allocator.hpp:17-72,

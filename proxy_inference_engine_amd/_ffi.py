@@ -25,7 +25,7 @@ EXPORTS = [
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
     "pie_decoder_set_kv", "pie_decoder_set_paged_kv", "pie_decoder_step_batch", "pie_decoder_prefill_batch", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill", "pie_decoder_prefill_embeds",
     "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
-    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes",
+    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status",
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",

@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libpie_hip.so"
-SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "prefill.hip", "vision.hip", "w4m_gemm.hip", "page_pool.cpp"]
+SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "step_mega.hip", "prefill.hip", "vision.hip", "w4m_gemm.hip", "page_pool.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 
@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)

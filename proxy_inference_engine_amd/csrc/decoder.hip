@@ -141,6 +141,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
 
 // The launch sequence of one step.  token_ptr: device int32 holding the input token id.
 static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
+    if (mega_supported(d, with_logits)) return mega_step_enqueue(d, token_ptr, with_logits, logits_dst, st);  // one persistent launch
     int rc = enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
     if (rc) return rc;
     for (int li = 0; li < d->cfg.n_layers; ++li)
@@ -225,6 +226,7 @@ int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
     prefill_free(d);
+    mega_free(d);
     void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -242,6 +244,7 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
     prefill_free(d);  // resident T copies of the previous weights are stale
+    mega_invalidate(d);  // so is the persistent step's layer table
     drop_graphs(d);
     return PIE_OK;
 }
@@ -329,6 +332,7 @@ static int ready(pie_decoder *d) {
 int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
     int rc = ready(d);
     if (rc) return rc;
+    if ((rc = mega_prepare(d))) return rc;  // allocates once: must happen before stream capture
     hipStream_t st = (hipStream_t)stream;
     const bool with_logits = (flags & PIE_STEP_LOGITS) != 0;
     if (!(flags & PIE_STEP_GRAPH)) return enqueue_step(d, &d->state->token, with_logits, d->logits, st);
@@ -369,6 +373,7 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     if (rc) return rc;
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = mega_prepare(d))) return rc;
     if (L >= prefill_min_rows()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime: dequantise-to-T GEMMs
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
@@ -415,6 +420,26 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
     PIE_REQUIRE(layer >= 0 && layer < d->cfg.n_layers, PIE_E_ARG, "pie_decoder_launch_kernel: layer out of range");
     PIE_REQUIRE(which != PIE_K_TAIL, PIE_E_ARG, "pie_decoder_launch_kernel: the tail advances the decode state; not launchable alone");
     return enqueue_kernel(d, which, layer, &d->state->token, d->logits, (hipStream_t)stream);
+}
+
+// Developer hook (not in the public header): the decoder's internal scratch vectors, for tools/step_bench's bisection.
+void *pie_debug_buffer(pie_decoder *d, int which) {
+    void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, mega_prof_ptr(d)};
+    return which >= 0 && which < 6 ? p[which] : nullptr;
+}
+
+int pie_decoder_configure(pie_decoder *d, int option, int value) {
+    PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_configure: null decoder");
+    PIE_REQUIRE(option == PIE_OPT_MEGA, PIE_E_ARG, "pie_decoder_configure: unknown option");
+    mega_enable(d, value != 0);
+    drop_graphs(d);
+    return PIE_OK;
+}
+
+int pie_decoder_status(pie_decoder *d, unsigned *error) {
+    PIE_REQUIRE(d && error, PIE_E_ARG, "pie_decoder_status: null pointer");
+    PIE_HIP_TRY(hipDeviceSynchronize());
+    return mega_status(d, error);
 }
 
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T) {

@@ -40,6 +40,7 @@ struct pie_decoder {
     int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
+    struct MegaState *mega = nullptr;               // the persistent one-launch step (step_mega.hip), allocated on first use
 };
 
 // prefill.hip: batched prompt processing (L >= prefill_min_rows() tokens): per layer the W4S weights are dequantised to T
@@ -48,3 +49,13 @@ int prefill_min_rows();
 int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st);
 void prefill_free(pie_decoder *d);
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st);
+
+// step_mega.hip: the whole decode step as one persistent launch (int4 checkpoints, contiguous caches up to the merged-split plan).
+bool mega_supported(pie_decoder *d, bool with_logits);
+int mega_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st);
+int mega_status(pie_decoder *d, unsigned *err);
+void *mega_prof_ptr(pie_decoder *d);
+int mega_prepare(pie_decoder *d);
+void mega_free(pie_decoder *d);
+void mega_invalidate(pie_decoder *d);
+void mega_enable(pie_decoder *d, bool on);

@@ -270,6 +270,17 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE(a.fmt == FMT_W4S || a.fmt == FMT_W16S || a.fmt == FMT_W8S, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
+    // Every pointer the chosen prologue / epilogue dereferences, checked HERE so that a null can never reach a kernel (a dense
+    // checkpoint legitimately leaves embed scales / biases and rope_cs null; see DESIGN.md "the 00:40 fault").
+    PIE_REQUIRE(a.w, PIE_E_ARG, "w4s_gemv: null weight stream");
+    PIE_REQUIRE(pro == PRO_ATTN ? (a.part_acc && a.part_ml && a.state) : a.x != nullptr, PIE_E_ARG, "w4s_gemv: null activation input");
+    PIE_REQUIRE(pro != PRO_RMSNORM || a.norm_w, PIE_E_ARG, "w4s_gemv: RMSNorm prologue without a norm weight");
+    PIE_REQUIRE((epi != EPI_STORE && epi != EPI_LOGITS && epi != EPI_SWIGLU) || a.y, PIE_E_ARG, "w4s_gemv: null output");
+    PIE_REQUIRE(epi != EPI_LOGITS || a.stats, PIE_E_ARG, "w4s_gemv: EPI_LOGITS without a partials buffer");
+    PIE_REQUIRE(epi != EPI_PARTIAL_F32 || a.y32, PIE_E_ARG, "w4s_gemv: EPI_PARTIAL_F32 without an fp32 output");
+    PIE_REQUIRE(epi != EPI_RESIDUAL || a.resid, PIE_E_ARG, "w4s_gemv: EPI_RESIDUAL without a residual stream");
+    PIE_REQUIRE(epi != EPI_ROPE_KV || (a.state && a.q_out && a.kv_table && (a.rope_cs || a.freqs)), PIE_E_ARG,
+                "w4s_gemv: EPI_ROPE_KV needs state, q_out, kv_table and rope_cs or freqs");
     a.n_slices = a.fmt == FMT_W16S ? w16s_slices(a.K) : w4s_slices(a.K);
     a.n_pairs = a.N / 2;
     a.n_waves = w4s_gemv_waves(a.N, a.K);

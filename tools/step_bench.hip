@@ -1,0 +1,329 @@
+// tools/step_bench.hip -- C++ driver of the decode step through the C ABI (developer / profiling tool, not part of the product).
+//
+// Builds a synthetic Llama-shaped int4 g=64 model (random weights, quantised and repacked on the device through
+// pie_quantize_w4g64 / pie_repack_w4g64), then replays pie_decoder_step.  Because it is a plain binary it can sit directly
+// after `rocprofv3 ... --` (kernel trace or --pmc passes on the PRODUCT step; a Python host crashed the profiler in round 1).
+//   step_bench [--model 8b|70b|tiny] [--layers N] [--steps K] [--warmup W] [--ctx P] [--cap C] [--mode mega|launch|both]
+//              [--graph 0|1] [--check N]
+// --check N: runs N steps with the launch sequence and N with the persistent launch from the same state and compares
+//            logits / logprobs / tokens / hidden state bit for bit.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/step_bench.hip -Iinclude -Lproxy_inference_engine_amd/lib -lpie_hip \
+//        -Wl,-rpath,'$ORIGIN/../proxy_inference_engine_amd/lib' -o tools/step_bench
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pie_hip.h"
+extern "C" void *pie_debug_buffer(pie_decoder *d, int which);
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);      \
+            exit(1);                                                                           \
+        }                                                                                      \
+    } while (0)
+#define PK(x)                                                                        \
+    do {                                                                             \
+        int rc_ = (x);                                                               \
+        if (rc_ != 0) {                                                              \
+            printf("pie error %d (%s) at %s:%d\n", rc_, pie_last_error(), __FILE__, __LINE__); \
+            exit(1);                                                                 \
+        }                                                                            \
+    } while (0)
+
+typedef unsigned short u16;
+
+// bf16 values in (-amp, amp) + offset from a counter hash (deterministic, no host traffic)
+__global__ void k_fill_bf16(u16 *out, size_t n, unsigned seed, float amp, float offset) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) * 40503u ^ seed * 0x9E3779B9u;
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    const float f = ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f) * amp + offset;
+    const unsigned u = __float_as_uint(f);
+    out[i] = (u16)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+static void fill(u16 *p, size_t n, unsigned seed, float amp, float offset = 0.0f) {
+    hipLaunchKernelGGL(k_fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n, seed, amp, offset);
+    CK(hipGetLastError());
+}
+
+struct Geo {
+    int H, I, heads, kv, D, V, L;
+};
+
+static void *dmalloc(size_t b) {
+    void *p;
+    CK(hipMalloc(&p, b));
+    return p;
+}
+
+// one [N, K] Linear -> W4S (optionally row-mapped); scratch buffers are reused
+struct Quant {
+    u16 *w = nullptr;
+    uint32_t *codes = nullptr;
+    u16 *scales = nullptr, *biases = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n_elems) {
+        if (n_elems <= cap) return;
+        if (w) { CK(hipFree(w)); CK(hipFree(codes)); CK(hipFree(scales)); CK(hipFree(biases)); }
+        cap = n_elems;
+        w = (u16 *)dmalloc(cap * 2), codes = (uint32_t *)dmalloc(cap / 2), scales = (u16 *)dmalloc(cap / 32), biases = (u16 *)dmalloc(cap / 32);
+    }
+    void *pack(int N, int K, unsigned seed, float amp, const int32_t *row_map_dev) {
+        reserve((size_t)N * K);
+        fill(w, (size_t)N * K, seed, amp);
+        PK(pie_quantize_w4g64(w, N, K, PIE_BF16, codes, scales, biases, nullptr));
+        void *packed = dmalloc(pie_w4s_bytes(N, K));
+        PK(pie_repack_w4g64(codes, scales, biases, N, K, row_map_dev, N, packed, nullptr));
+        return packed;
+    }
+};
+
+int main(int argc, char **argv) {
+    Geo g = {4096, 14336, 32, 8, 128, 128256, 32};
+    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1;
+    std::string mode = "both";
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() { return i + 1 < argc ? argv[++i] : (char *)"0"; };
+        if (a == "--model") {
+            std::string m = next();
+            if (m == "70b") g = {8192, 28672, 64, 8, 128, 128256, 80};
+            else if (m == "tiny") g = {512, 1536, 8, 2, 64, 4096, 4};
+            else if (m == "3b") g = {3072, 8192, 24, 8, 128, 128256, 28};
+        } else if (a == "--layers") g.L = atoi(next());
+        else if (a == "--steps") steps = atoi(next());
+        else if (a == "--warmup") warmup = atoi(next());
+        else if (a == "--ctx") ctx = atoi(next());
+        else if (a == "--cap") cap = atoi(next());
+        else if (a == "--mode") mode = next();
+        else if (a == "--graph") graph = atoi(next());
+        else if (a == "--check") check = atoi(next());
+    }
+    char name[64];
+    int n_cus = 0;
+    size_t hbm = 0;
+    PK(pie_device_info(name, sizeof name, &n_cus, &hbm));
+    printf("device %s, %d CUs, %.0f GB; model H=%d I=%d heads=%d/%d D=%d V=%d L=%d; ctx %d cap %d\n", name, n_cus, hbm / 1e9, g.H, g.I, g.heads, g.kv,
+           g.D, g.V, g.L, ctx, cap);
+
+    const int QD = g.heads * g.D, KVD = g.kv * g.D, NQ = QD + 2 * KVD;
+    std::vector<int32_t> qmap(NQ), gmap(2 * g.I);
+    PK(pie_qkv_row_map(g.heads, g.kv, g.D, qmap.data()));
+    PK(pie_gateup_row_map(g.I, gmap.data()));
+    int32_t *qmap_d = (int32_t *)dmalloc(NQ * 4), *gmap_d = (int32_t *)dmalloc(2 * g.I * 4);
+    CK(hipMemcpy(qmap_d, qmap.data(), NQ * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(gmap_d, gmap.data(), 2 * g.I * 4, hipMemcpyHostToDevice));
+
+    pie_decoder_config cfg = {};
+    cfg.dtype = PIE_BF16, cfg.hidden = g.H, cfg.n_layers = g.L, cfg.n_heads = g.heads, cfg.n_kv_heads = g.kv, cfg.head_dim = g.D, cfg.inter = g.I,
+    cfg.vocab = g.V, cfg.rms_eps = 1e-5f, cfg.weight_format = PIE_W_INT4_G64;
+    pie_decoder *dec = nullptr;
+    PK(pie_decoder_create(&cfg, &dec));
+
+    Quant q;
+    const float amp = 1.7f / sqrtf((float)g.H);  // uniform(-a, a): std a / sqrt(3) ~ 1 / sqrt(H)
+    for (int l = 0; l < g.L; ++l) {
+        pie_layer_weights lw = {};
+        u16 *n1 = (u16 *)dmalloc(g.H * 2), *n2 = (u16 *)dmalloc(g.H * 2);
+        fill(n1, g.H, 1000 + l, 0.1f, 1.0f), fill(n2, g.H, 2000 + l, 0.1f, 1.0f);
+        lw.attn_norm = n1, lw.mlp_norm = n2;
+        lw.wqkv = q.pack(NQ, g.H, 10 * l + 1, amp, qmap_d);
+        lw.wo = q.pack(g.H, QD, 10 * l + 2, amp, nullptr);
+        lw.wgateup = q.pack(2 * g.I, g.H, 10 * l + 3, amp, gmap_d);
+        lw.wdown = q.pack(g.H, g.I, 10 * l + 4, 1.7f / sqrtf((float)g.I), nullptr);
+        PK(pie_decoder_set_layer(dec, l, &lw));
+    }
+    pie_global_weights gw = {};
+    {
+        q.reserve((size_t)g.V * g.H);
+        fill(q.w, (size_t)g.V * g.H, 777, 0.05f);
+        uint32_t *ec = (uint32_t *)dmalloc((size_t)g.V * g.H / 2);
+        u16 *es = (u16 *)dmalloc((size_t)g.V * g.H / 32), *eb = (u16 *)dmalloc((size_t)g.V * g.H / 32);
+        PK(pie_quantize_w4g64(q.w, g.V, g.H, PIE_BF16, ec, es, eb, nullptr));
+        gw.embed_codes = ec, gw.embed_scales = es, gw.embed_biases = eb;
+        gw.lm_head = q.pack(g.V, g.H, 888, amp, nullptr);
+        u16 *fn = (u16 *)dmalloc(g.H * 2);
+        fill(fn, g.H, 999, 0.1f, 1.0f);
+        gw.final_norm = fn;
+        std::vector<float> fr(g.D / 2);
+        for (int i = 0; i < g.D / 2; ++i) fr[i] = powf(500000.0f, (float)(2 * i) / (float)g.D);
+        float *fd = (float *)dmalloc(g.D * 2);
+        CK(hipMemcpy(fd, fr.data(), g.D * 2, hipMemcpyHostToDevice));
+        gw.rope_freqs = fd;
+    }
+    PK(pie_decoder_set_globals(dec, &gw));
+
+    const size_t kv_bytes = (size_t)g.kv * cap * g.D * 2;
+    std::vector<const void *> kp(g.L), vp(g.L);
+    for (int l = 0; l < g.L; ++l) {
+        u16 *k = (u16 *)dmalloc(kv_bytes), *v = (u16 *)dmalloc(kv_bytes);
+        fill(k, kv_bytes / 2, 5000 + l, 1.0f), fill(v, kv_bytes / 2, 6000 + l, 1.0f);  // a "prompt" already in the caches
+        kp[l] = k, vp[l] = v;
+    }
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    PK(pie_decoder_set_kv(dec, kp.data(), vp.data(), cap, st));
+    u16 *logits = (u16 *)dmalloc((size_t)g.V * 2), *hidden = (u16 *)dmalloc(g.H * 2);
+    float *logprobs = (float *)dmalloc((size_t)g.V * 4);
+    int32_t *token = (int32_t *)dmalloc(4), *hist = (int32_t *)dmalloc(4 * 65536);
+    PK(pie_decoder_bind_outputs(dec, logits, logprobs, token, hidden, hist, 65536));
+    CK(hipDeviceSynchronize());
+    const int flags = PIE_STEP_LOGITS | (graph ? PIE_STEP_GRAPH : 0);
+
+    struct Snap {
+        std::vector<u16> logits, hidden;
+        std::vector<float> logprobs;
+        int token;
+    };
+    auto run = [&](int use_mega, int n, std::vector<Snap> *snaps) -> double {
+        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, use_mega));
+        PK(pie_decoder_set_state(dec, ctx, 1, st));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        if (snaps) {
+            for (int i = 0; i < n; ++i) {
+                PK(pie_decoder_step(dec, flags, st));
+                Snap s;
+                s.logits.resize(g.V), s.hidden.resize(g.H), s.logprobs.resize(g.V);
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(s.logits.data(), logits, (size_t)g.V * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(s.hidden.data(), hidden, g.H * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(s.logprobs.data(), logprobs, (size_t)g.V * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(&s.token, token, 4, hipMemcpyDeviceToHost));
+                snaps->push_back(std::move(s));
+            }
+            return 0.0;
+        }
+        for (int i = 0; i < warmup; ++i) PK(pie_decoder_step(dec, flags, st));
+        CK(hipStreamSynchronize(st));
+        PK(pie_decoder_set_state(dec, ctx, 1, st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) PK(pie_decoder_step(dec, flags, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned err = 0;
+        PK(pie_decoder_status(dec, &err));
+        if (err) printf("  !! persistent launch gave up at grid barrier %u\n", err);
+        return ms / n;
+    };
+
+    int rc = 0;
+    if (const char *dbg = getenv("PIE_MEGA_STOP")) {  // developer aid: compare the residual stream after the first n GEMV phases
+        const int n = atoi(dbg);
+        static const int seq[5] = {PIE_K_QKV, PIE_K_ATTN, PIE_K_OPROJ, PIE_K_GATEUP, PIE_K_DOWN};
+        std::vector<u16> ha(g.H), hb(g.H);
+        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 0));
+        PK(pie_decoder_set_state(dec, ctx, 1, st));
+        PK(pie_decoder_launch_kernel(dec, PIE_K_EMBED, 0, st));
+        int done = 0;  // GEMV phases (attention is not one)
+        const int n_ref = getenv("PIE_MEGA_HYBRID") ? 2 : n;
+        for (int l = 0; l < g.L && done < n_ref; ++l)
+            for (int k = 0; k < 5 && done < n_ref; ++k) {
+                PK(pie_decoder_launch_kernel(dec, seq[k], l, st));
+                if (seq[k] != PIE_K_ATTN) ++done;
+            }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), hidden, g.H * 2, hipMemcpyDeviceToHost));
+        if (getenv("PIE_MEGA_HYBRID")) {  // poison the attention partials so that stale values cannot pass for fresh ones
+            PK(pie_decoder_set_state(dec, ctx - 37, 1, st));
+            PK(pie_decoder_launch_kernel(dec, PIE_K_ATTN, 0, st));
+        }
+        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 1));
+        PK(pie_decoder_set_state(dec, ctx, 1, st));
+        PK(pie_decoder_step(dec, PIE_STEP_LOGITS, st));
+        if (getenv("PIE_MEGA_HYBRID")) {  // persistent launch up to phase n, then the launch sequence's kernels up to o_proj of layer 0
+            PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 0));
+            if (n <= 1) PK(pie_decoder_launch_kernel(dec, PIE_K_ATTN, 0, st));
+            if (n <= 1 || n == 100) PK(pie_decoder_launch_kernel(dec, PIE_K_OPROJ, 0, st));
+        }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(hb.data(), hidden, g.H * 2, hipMemcpyDeviceToHost));
+        if (n == 2) {  // x of o_proj as the persistent launch built it (dumped into `act`) vs the launch path's split merge
+            std::vector<u16> xm(QD);
+            CK(hipMemcpy(xm.data(), pie_debug_buffer(dec, 2), QD * 2, hipMemcpyDeviceToHost));
+            std::vector<float> pacc((size_t)g.heads * 4 * g.D), pml((size_t)g.heads * 4 * 2);
+            CK(hipMemcpy(pacc.data(), pie_debug_buffer(dec, 3), pacc.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(pml.data(), pie_debug_buffer(dec, 4), pml.size() * 4, hipMemcpyDeviceToHost));
+            printf("x[0..7] (mega): ");
+            for (int j = 0; j < 8; ++j) printf("%04x ", xm[j]);
+            printf("\npartials head 0: m,l = ");
+            for (int sp = 0; sp < 4; ++sp) printf("(%g, %g) ", pml[sp * 2], pml[sp * 2 + 1]);
+            printf("acc[0][0..3] = %g %g %g %g\n", pacc[0], pacc[1], pacc[2], pacc[3]);
+            // merged value of dim 0, head 0, in double
+            double M = -1e300, L = 0, A = 0;
+            for (int sp = 0; sp < 4; ++sp) M = pml[sp * 2] > M ? pml[sp * 2] : M;
+            for (int sp = 0; sp < 4; ++sp) { double w = exp2((double)pml[sp * 2] - M); L += w * pml[sp * 2 + 1]; A += w * pacc[(size_t)sp * g.D]; }
+            printf("expected x[0] ~ %g\n", A / L);
+        }
+        size_t diff = 0;
+        for (int j = 0; j < g.H; ++j) diff += ha[j] != hb[j];
+        printf("after %d GEMV phases: hidden differs in %zu / %d elements; first values %04x %04x %04x %04x vs %04x %04x %04x %04x\n", n, diff, g.H, ha[0], ha[1], ha[2],
+               ha[3], hb[0], hb[1], hb[2], hb[3]);
+        return diff != 0;
+    }
+    if (check > 0) {
+        std::vector<Snap> a, b;
+        run(0, check, &a);
+        run(1, check, &b);
+        unsigned err = 0;
+        PK(pie_decoder_status(dec, &err));
+        if (err) printf("  !! persistent launch gave up at grid barrier %u\n", err), rc = 2;
+        for (int i = 0; i < check; ++i) {
+            size_t dl = 0, dh = 0, dp = 0;
+            for (int j = 0; j < g.V; ++j) dl += a[i].logits[j] != b[i].logits[j], dp += memcmp(&a[i].logprobs[j], &b[i].logprobs[j], 4) != 0;
+            for (int j = 0; j < g.H; ++j) dh += a[i].hidden[j] != b[i].hidden[j];
+            printf("check step %d: token %d vs %d, differing logits %zu / %d, logprobs %zu, hidden %zu / %d\n", i, a[i].token, b[i].token, dl, g.V, dp, dh, g.H);
+            if (dl || dh || dp || a[i].token != b[i].token) rc = 1;
+        }
+        printf(rc ? "CHECK FAILED\n" : "check ok: persistent launch == launch sequence, bit for bit\n");
+    }
+    const double bytes = (double)pie_decoder_step_bytes(dec, ctx + steps / 2, 1);
+    if (mode == "launch" || mode == "both") {
+        const double ms = run(0, steps, nullptr);
+        printf("launch sequence : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
+    }
+    if (mode == "mega" || mode == "both") {
+        const double ms = run(1, steps, nullptr);
+        printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
+    }
+    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of one workgroup during the LAST step
+        std::vector<unsigned long long> t(512 * 16);
+        CK(hipMemcpy(t.data(), pp, t.size() * 8, hipMemcpyDeviceToHost));
+        const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
+        double sum[5][8] = {}, cnt[5] = {};
+        const int n_ph = 4 * g.L + 1;
+        for (int ph = 0; ph < n_ph && ph < 512; ++ph) {
+            const unsigned long long *c = &t[ph * 16], *sy = c + 8;
+            if (!c[0]) continue;
+            const int kd = ph == n_ph - 1 ? 4 : ph % 4;
+            // consumer wave 0: 0 start, 1 x published, 2 stream done, 3 epilogue+prefetch done, 4 after B1, 6 after B2; sync wave: 13 poll done
+            const double v[8] = {(double)(c[1] - c[0]), (double)(c[2] - c[1]), (double)(c[3] - c[2]), (double)(c[4] - c[3]), (double)(sy[5] - c[4]),
+                                 (double)(c[6] - sy[5]), ph + 1 < n_ph && t[(ph + 1) * 16] ? (double)(t[(ph + 1) * 16] - c[0]) : 0.0, c[7] ? (double)(c[7] - c[6]) : 0.0};
+            for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
+            cnt[kd] += 1;
+        }
+        printf("per-phase timeline of workgroup %s (us): prologue | stream | epilogue+prefetch+drain | wg-barrier | grid poll | release | TOTAL | attention\n",
+               getenv("PIE_MEGA_PROF_BLOCK") ? getenv("PIE_MEGA_PROF_BLOCK") : "0");
+        for (int kd = 0; kd < 5; ++kd)
+            if (cnt[kd] > 0) {
+                printf("  %-7s", names[kd]);
+                for (int i = 0; i < 8; ++i) printf(" %7.2f", sum[kd][i] / cnt[kd]);
+                printf("\n");
+            }
+    }
+    PK(pie_decoder_destroy(dec));
+    return rc;
+}
