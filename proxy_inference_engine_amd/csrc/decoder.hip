@@ -424,6 +424,7 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 
 // Developer hook (not in the public header): the decoder's internal scratch vectors, for tools/step_bench's bisection.
 void *pie_debug_buffer(pie_decoder *d, int which) {
+    if (which == 6) return (mega_prepare(d) == PIE_OK && mega_supported(d, true)) ? (void *)d : nullptr;  // would a step run as the persistent launch?
     void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, mega_prof_ptr(d)};
     return which >= 0 && which < 6 ? p[which] : nullptr;
 }

@@ -90,7 +90,7 @@ struct Quant {
 
 int main(int argc, char **argv) {
     Geo g = {4096, 14336, 32, 8, 128, 128256, 32};
-    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1;
+    int steps = 50, warmup = 10, ctx = 128, cap = 256, check = 0, graph = 1, kv_splits = 1;
     std::string mode = "both";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -108,7 +108,9 @@ int main(int argc, char **argv) {
         else if (a == "--mode") mode = next();
         else if (a == "--graph") graph = atoi(next());
         else if (a == "--check") check = atoi(next());
+        else if (a == "--kv-splits") kv_splits = atoi(next());
     }
+    if (ctx + steps + warmup + 2 > cap) steps = cap - ctx - warmup - 2 > 1 ? cap - ctx - warmup - 2 : 1;
     char name[64];
     int n_cus = 0;
     size_t hbm = 0;
@@ -126,7 +128,7 @@ int main(int argc, char **argv) {
 
     pie_decoder_config cfg = {};
     cfg.dtype = PIE_BF16, cfg.hidden = g.H, cfg.n_layers = g.L, cfg.n_heads = g.heads, cfg.n_kv_heads = g.kv, cfg.head_dim = g.D, cfg.inter = g.I,
-    cfg.vocab = g.V, cfg.rms_eps = 1e-5f, cfg.weight_format = PIE_W_INT4_G64;
+    cfg.vocab = g.V, cfg.rms_eps = 1e-5f, cfg.weight_format = PIE_W_INT4_G64, cfg.kv_splits = kv_splits;
     pie_decoder *dec = nullptr;
     PK(pie_decoder_create(&cfg, &dec));
 
@@ -179,6 +181,8 @@ int main(int argc, char **argv) {
     PK(pie_decoder_bind_outputs(dec, logits, logprobs, token, hidden, hist, 65536));
     CK(hipDeviceSynchronize());
     const int flags = PIE_STEP_LOGITS | (graph ? PIE_STEP_GRAPH : 0);
+    PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 1));
+    printf("persistent launch %s for this configuration (kv_splits %d, capacity %d)\n", pie_debug_buffer(dec, 6) ? "AVAILABLE" : "NOT available: both modes run the launch sequence", kv_splits, cap);
 
     struct Snap {
         std::vector<u16> logits, hidden;
@@ -221,59 +225,6 @@ int main(int argc, char **argv) {
     };
 
     int rc = 0;
-    if (const char *dbg = getenv("PIE_MEGA_STOP")) {  // developer aid: compare the residual stream after the first n GEMV phases
-        const int n = atoi(dbg);
-        static const int seq[5] = {PIE_K_QKV, PIE_K_ATTN, PIE_K_OPROJ, PIE_K_GATEUP, PIE_K_DOWN};
-        std::vector<u16> ha(g.H), hb(g.H);
-        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 0));
-        PK(pie_decoder_set_state(dec, ctx, 1, st));
-        PK(pie_decoder_launch_kernel(dec, PIE_K_EMBED, 0, st));
-        int done = 0;  // GEMV phases (attention is not one)
-        const int n_ref = getenv("PIE_MEGA_HYBRID") ? 2 : n;
-        for (int l = 0; l < g.L && done < n_ref; ++l)
-            for (int k = 0; k < 5 && done < n_ref; ++k) {
-                PK(pie_decoder_launch_kernel(dec, seq[k], l, st));
-                if (seq[k] != PIE_K_ATTN) ++done;
-            }
-        CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(ha.data(), hidden, g.H * 2, hipMemcpyDeviceToHost));
-        if (getenv("PIE_MEGA_HYBRID")) {  // poison the attention partials so that stale values cannot pass for fresh ones
-            PK(pie_decoder_set_state(dec, ctx - 37, 1, st));
-            PK(pie_decoder_launch_kernel(dec, PIE_K_ATTN, 0, st));
-        }
-        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 1));
-        PK(pie_decoder_set_state(dec, ctx, 1, st));
-        PK(pie_decoder_step(dec, PIE_STEP_LOGITS, st));
-        if (getenv("PIE_MEGA_HYBRID")) {  // persistent launch up to phase n, then the launch sequence's kernels up to o_proj of layer 0
-            PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 0));
-            if (n <= 1) PK(pie_decoder_launch_kernel(dec, PIE_K_ATTN, 0, st));
-            if (n <= 1 || n == 100) PK(pie_decoder_launch_kernel(dec, PIE_K_OPROJ, 0, st));
-        }
-        CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(hb.data(), hidden, g.H * 2, hipMemcpyDeviceToHost));
-        if (n == 2) {  // x of o_proj as the persistent launch built it (dumped into `act`) vs the launch path's split merge
-            std::vector<u16> xm(QD);
-            CK(hipMemcpy(xm.data(), pie_debug_buffer(dec, 2), QD * 2, hipMemcpyDeviceToHost));
-            std::vector<float> pacc((size_t)g.heads * 4 * g.D), pml((size_t)g.heads * 4 * 2);
-            CK(hipMemcpy(pacc.data(), pie_debug_buffer(dec, 3), pacc.size() * 4, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(pml.data(), pie_debug_buffer(dec, 4), pml.size() * 4, hipMemcpyDeviceToHost));
-            printf("x[0..7] (mega): ");
-            for (int j = 0; j < 8; ++j) printf("%04x ", xm[j]);
-            printf("\npartials head 0: m,l = ");
-            for (int sp = 0; sp < 4; ++sp) printf("(%g, %g) ", pml[sp * 2], pml[sp * 2 + 1]);
-            printf("acc[0][0..3] = %g %g %g %g\n", pacc[0], pacc[1], pacc[2], pacc[3]);
-            // merged value of dim 0, head 0, in double
-            double M = -1e300, L = 0, A = 0;
-            for (int sp = 0; sp < 4; ++sp) M = pml[sp * 2] > M ? pml[sp * 2] : M;
-            for (int sp = 0; sp < 4; ++sp) { double w = exp2((double)pml[sp * 2] - M); L += w * pml[sp * 2 + 1]; A += w * pacc[(size_t)sp * g.D]; }
-            printf("expected x[0] ~ %g\n", A / L);
-        }
-        size_t diff = 0;
-        for (int j = 0; j < g.H; ++j) diff += ha[j] != hb[j];
-        printf("after %d GEMV phases: hidden differs in %zu / %d elements; first values %04x %04x %04x %04x vs %04x %04x %04x %04x\n", n, diff, g.H, ha[0], ha[1], ha[2],
-               ha[3], hb[0], hb[1], hb[2], hb[3]);
-        return diff != 0;
-    }
     if (check > 0) {
         std::vector<Snap> a, b;
         run(0, check, &a);
@@ -299,28 +250,41 @@ int main(int argc, char **argv) {
         const double ms = run(1, steps, nullptr);
         printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
     }
-    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of one workgroup during the LAST step
-        std::vector<unsigned long long> t(512 * 16);
+    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of every workgroup during the LAST step
+        const size_t per_wg = 512 * 16;
+        std::vector<unsigned long long> t(per_wg * 256);
         CK(hipMemcpy(t.data(), pp, t.size() * 8, hipMemcpyDeviceToHost));
         const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
-        double sum[5][8] = {}, cnt[5] = {};
+        // streaming wave 0: 0 = phase start (image published), 2 = stream done, 3 = epilogue (+ attention) done
+        // IO wave 0 (+8): 0 = phase start, 3 = probe hit, 1 = next input swept, 2 = next image published
+        const int slots[7] = {0, 2, 3, 8 + 0, 8 + 3, 8 + 1, 8 + 2};
+        const char *sn[7] = {"start", "stream-end", "epi-end", "io-start", "probe-hit", "swept", "published"};
         const int n_ph = 4 * g.L + 1;
-        for (int ph = 0; ph < n_ph && ph < 512; ++ph) {
-            const unsigned long long *c = &t[ph * 16], *sy = c + 8;
-            if (!c[0]) continue;
+        double mn[5][7] = {}, mx[5][7] = {}, cnt[5] = {};
+        for (int ph = 4; ph < n_ph && ph < 512; ++ph) {  // skip the first layer
+            unsigned long long base = ~0ull;
+            for (int b = 0; b < n_cus; ++b) {
+                const unsigned long long v = t[b * per_wg + ph * 16];
+                if (v && v < base) base = v;
+            }
+            if (base == ~0ull) continue;
             const int kd = ph == n_ph - 1 ? 4 : ph % 4;
-            // consumer wave 0: 0 start, 1 x published, 2 stream done, 3 epilogue+prefetch done, 4 after B1, 6 after B2; sync wave: 13 poll done
-            const double v[8] = {(double)(c[1] - c[0]), (double)(c[2] - c[1]), (double)(c[3] - c[2]), (double)(c[4] - c[3]), (double)(sy[5] - c[4]),
-                                 (double)(c[6] - sy[5]), ph + 1 < n_ph && t[(ph + 1) * 16] ? (double)(t[(ph + 1) * 16] - c[0]) : 0.0, c[7] ? (double)(c[7] - c[6]) : 0.0};
-            for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
+            for (int i = 0; i < 7; ++i) {
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int b = 0; b < n_cus; ++b) {
+                    const unsigned long long v = t[b * per_wg + ph * 16 + slots[i]];
+                    if (!v) continue;
+                    lo = v < lo ? v : lo, hi = v > hi ? v : hi;
+                }
+                if (hi) mn[kd][i] += (double)(lo - base) * 0.01, mx[kd][i] += (double)(hi - base) * 0.01;
+            }
             cnt[kd] += 1;
         }
-        printf("per-phase timeline of workgroup %s (us): prologue | stream | epilogue+prefetch+drain | wg-barrier | grid poll | release | TOTAL | attention\n",
-               getenv("PIE_MEGA_PROF_BLOCK") ? getenv("PIE_MEGA_PROF_BLOCK") : "0");
+        printf("per-phase timeline over ALL workgroups, us after the first workgroup entered the phase: earliest .. latest\n");
         for (int kd = 0; kd < 5; ++kd)
             if (cnt[kd] > 0) {
                 printf("  %-7s", names[kd]);
-                for (int i = 0; i < 8; ++i) printf(" %7.2f", sum[kd][i] / cnt[kd]);
+                for (int i = 0; i < 7; ++i) printf(" %s %.2f..%.2f |", sn[i], mn[kd][i] / cnt[kd], mx[kd][i] / cnt[kd]);
                 printf("\n");
             }
     }
