@@ -14,6 +14,7 @@ import torch
 _PKG = Path(__file__).resolve().parent
 PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
+PIE_OPT_MEGA = 1
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
 
 EXPORTS = [
@@ -84,6 +85,8 @@ def load() -> C.CDLL:
     lib.pie_add.argtypes = lib.pie_silu_mul.argtypes
     lib.pie_decoder_step_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pie_decoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pie_decoder_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
     for name in ("pie_page_pool_slab_bytes", "pie_page_pool_size", "pie_page_pool_num_free"):
         getattr(lib, name).restype = C.c_size_t
     lib.pie_page_pool_slab_bytes.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int]

@@ -90,7 +90,7 @@ struct Quant {
 
 int main(int argc, char **argv) {
     Geo g = {4096, 14336, 32, 8, 128, 128256, 32};
-    int steps = 50, warmup = 10, ctx = 128, cap = 256, check = 0, graph = 1, kv_splits = 1;
+    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1, kv_splits = 0;
     std::string mode = "both";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -250,41 +250,28 @@ int main(int argc, char **argv) {
         const double ms = run(1, steps, nullptr);
         printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
     }
-    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of every workgroup during the LAST step
-        const size_t per_wg = 512 * 16;
-        std::vector<unsigned long long> t(per_wg * 256);
+    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of one workgroup during the LAST step
+        std::vector<unsigned long long> t(512 * 16);
         CK(hipMemcpy(t.data(), pp, t.size() * 8, hipMemcpyDeviceToHost));
         const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
-        // streaming wave 0: 0 = phase start (image published), 2 = stream done, 3 = epilogue (+ attention) done
-        // IO wave 0 (+8): 0 = phase start, 3 = probe hit, 1 = next input swept, 2 = next image published
-        const int slots[7] = {0, 2, 3, 8 + 0, 8 + 3, 8 + 1, 8 + 2};
-        const char *sn[7] = {"start", "stream-end", "epi-end", "io-start", "probe-hit", "swept", "published"};
+        double sum[5][8] = {}, cnt[5] = {};
         const int n_ph = 4 * g.L + 1;
-        double mn[5][7] = {}, mx[5][7] = {}, cnt[5] = {};
-        for (int ph = 4; ph < n_ph && ph < 512; ++ph) {  // skip the first layer
-            unsigned long long base = ~0ull;
-            for (int b = 0; b < n_cus; ++b) {
-                const unsigned long long v = t[b * per_wg + ph * 16];
-                if (v && v < base) base = v;
-            }
-            if (base == ~0ull) continue;
+        for (int ph = 0; ph < n_ph && ph < 512; ++ph) {
+            const unsigned long long *c = &t[ph * 16], *sy = c + 8;
+            if (!c[0]) continue;
             const int kd = ph == n_ph - 1 ? 4 : ph % 4;
-            for (int i = 0; i < 7; ++i) {
-                unsigned long long lo = ~0ull, hi = 0;
-                for (int b = 0; b < n_cus; ++b) {
-                    const unsigned long long v = t[b * per_wg + ph * 16 + slots[i]];
-                    if (!v) continue;
-                    lo = v < lo ? v : lo, hi = v > hi ? v : hi;
-                }
-                if (hi) mn[kd][i] += (double)(lo - base) * 0.01, mx[kd][i] += (double)(hi - base) * 0.01;
-            }
+            // consumer wave 0: 0 start, 1 x published, 2 stream done, 3 epilogue+prefetch done, 4 after B1, 6 after B2; sync wave: 13 poll done
+            const double v[8] = {(double)(c[1] - c[0]), (double)(c[2] - c[1]), (double)(c[3] - c[2]), (double)(c[4] - c[3]), (double)(sy[5] - c[4]),
+                                 (double)(c[6] - sy[5]), ph + 1 < n_ph && t[(ph + 1) * 16] ? (double)(t[(ph + 1) * 16] - c[0]) : 0.0, c[7] ? (double)(c[7] - c[6]) : 0.0};
+            for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
             cnt[kd] += 1;
         }
-        printf("per-phase timeline over ALL workgroups, us after the first workgroup entered the phase: earliest .. latest\n");
+        printf("per-phase timeline of workgroup %s (us): prologue | stream | epilogue+prefetch+drain | wg-barrier | grid poll | release | TOTAL | attention\n",
+               getenv("PIE_MEGA_PROF_BLOCK") ? getenv("PIE_MEGA_PROF_BLOCK") : "0");
         for (int kd = 0; kd < 5; ++kd)
             if (cnt[kd] > 0) {
                 printf("  %-7s", names[kd]);
-                for (int i = 0; i < 7; ++i) printf(" %s %.2f..%.2f |", sn[i], mn[kd][i] / cnt[kd], mx[kd][i] / cnt[kd]);
+                for (int i = 0; i < 8; ++i) printf(" %7.2f", sum[kd][i] / cnt[kd]);
                 printf("\n");
             }
     }
