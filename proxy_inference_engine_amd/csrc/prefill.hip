@@ -385,6 +385,8 @@ struct PrefillScratch {
     hipGraphExec_t batch_graph = nullptr;
     std::vector<uintptr_t> batch_key, warm_key;
     unsigned batch_gen = 0, warm_gen = 0;
+    void *w4l_ws = nullptr;   // fp32 partial tiles of the K-split prompt GEMM (w4m_gemm.hip)
+    size_t w4l_ws_bytes = 0;
     int resident_mode = -1;   // -1: budget not fixed yet
     size_t resident_left = 0; // bytes still available for resident copies
 };
@@ -401,7 +403,10 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
     if (s->batch_graph) (void)hipGraphExecDestroy(s->batch_graph);
     const int mode = s->resident_mode;
     const size_t left = s->resident_left;
+    void *keep_ws = s->w4l_ws;
+    const size_t keep_wsb = s->w4l_ws_bytes;
     *s = PrefillScratch();
+    s->w4l_ws = keep_ws, s->w4l_ws_bytes = keep_wsb;
     s->resident = std::move(keep), s->resident_w4m = std::move(keep_m), s->resident_mode = mode, s->resident_left = left;
     s->tail_stats = keep_ts, s->tail_rows = keep_tr, s->alloc_gen = gen;
 }
@@ -412,6 +417,7 @@ void prefill_free(pie_decoder *d) {
     for (auto &kv : d->prefill->resident) (void)hipFree(kv.second);
     for (auto &kv : d->prefill->resident_w4m) (void)hipFree(kv.second);
     if (d->prefill->tail_stats) (void)hipFree(d->prefill->tail_stats);
+    if (d->prefill->w4l_ws) (void)hipFree(d->prefill->w4l_ws);
     if (d->prefill->batch_graph) (void)hipGraphExecDestroy(d->prefill->batch_graph);
     delete d->prefill;
     d->prefill = nullptr;
@@ -519,6 +525,15 @@ struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.h
 };
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
                     const void *bias, const W4mRope *rope);
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st);  // many rows (MFMA-bound)
+size_t w4l_workspace_bytes(int M, int N, int K);
+
+// int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
+// copy of the weights, no hipBLASLt.  PIE_W4L=0 restores round 1's dequantise-to-T + hipBLASLt path (kept for A/B timing).
+static bool w4l_enabled() {
+    const char *e = getenv("PIE_W4L");
+    return !(e && e[0] == '0');
+}
 
 // Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
 static int small_rows() {
@@ -582,6 +597,31 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr, 0, nullptr, nullptr);
             if (split) *used32 = rc == PIE_OK;
             if (rc || !bias || split) return rc;
+            return bias_rows<T>(y, bias, M, N, st);
+        }
+    }
+    if (d->cfg.weight_format == PIE_W_INT4_G64 && N % 32 == 0 && K % 64 == 0 && w4l_enabled()) {
+        void *wm = nullptr;
+        auto it = s->resident_w4m.find(packed);
+        if (it != s->resident_w4m.end()) wm = it->second;
+        else if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
+            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K), ++s->alloc_gen;
+            const int rc = w4m_repack_launch(packed, N, K, wm, st);
+            if (rc) return rc;
+        } else {
+            (void)hipGetLastError();
+            wm = nullptr;
+        }
+        if (wm) {
+            const size_t wb = w4l_workspace_bytes(M, N, K);  // fp32 partial tiles of a K-split shape (medium prompts)
+            if (wb > s->w4l_ws_bytes) {
+                if (s->w4l_ws) (void)hipFree(s->w4l_ws);
+                s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
+                PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
+                s->w4l_ws_bytes = wb, ++s->alloc_gen;
+            }
+            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st);
+            if (rc || !bias) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }
     }

@@ -408,6 +408,206 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
     else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
+// ---------------------------------------------------------------- MANY rows (33 .. thousands): the prompt GEMM
+// y[M, N] = x[M, K] . dequant(W)[N, K]^T on the same W4M tiles, MFMA-bound (round 1 expanded the weights to a 16-bit copy --
+// 15 GB on the 8B model -- and called hipBLASLt).  One workgroup = 256 rows of x by 256 output columns:
+//   * wave w owns the 32-column strip nb * 8 + w: its W4M tiles arrive straight from HBM / L2 in registers (1 KiB coalesced per
+//     tile, ring of W4L_WDEPTH) and are dequantised IN REGISTERS into the A fragments of v_mfma_f32_32x32x16 (w4m_dequant: the
+//     T(fp32(s q) + b) of mx.dequantize) -- the weights never see LDS and move at 0.5625 B each;
+//   * the x tile [256 rows, 64 columns] of a K step is staged ONCE per workgroup in LDS (double-buffered, 144-byte rows:
+//     16-byte fragment reads of 32 consecutive rows hit distinct bank quads) and read by all 8 waves: per K step and wave
+//     32 MFMAs (8 row blocks x 4 k-steps) against 32 ds_read_b128 and ~110 VALU instructions of dequantisation per lane, i.e. the
+//     matrix pipe is the busiest unit and the conversion rides in its shadow on the partner wave of the SIMD;
+//   * 128 accumulator registers per lane (8 row blocks x 16), one 8-wave workgroup per CU.
+// Prompts of up to 64 / 128 rows use 64- / 128-row tiles (MB = 2 / 4) and split K over blockIdx.z so that the grid still fills the chip.
+#ifndef W4L_ABL
+#define W4L_ABL 0  // developer ablation mask (scripts/bench_w4l.py): 1 no dequantisation, 2 no LDS fragment reads, 4 no x staging; 0 in the product
+#endif
+constexpr int W4L_XROW = 128 + 16;  // LDS bytes per staged x row: 64 columns + pad
+constexpr int W4L_WDEPTH = 4;       // weight tiles in flight per wave
+
+// MB: 32-row blocks of x per workgroup (tile = 32 MB rows x 256 columns).  gridDim.z > 1: the K groups are split over blockIdx.z
+// and the fp32 partial tiles go to `part` [z][M][N] (summed in z order by k_w4l_reduce: deterministic) -- prompts of a few dozen to
+// a few hundred rows leave too few 256-column workgroups to fill 256 CUs otherwise.
+template <class T, int MB>
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4l_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *part) {
+    constexpr int MT = 32 * MB;
+    constexpr int PPT = MT * 8 / (W4M_WAVES * 64);  // 16-byte x pieces per thread and K step (MB = 2: 1, 4: 2, 8: 4)
+    __shared__ __attribute__((aligned(16))) char s_x[2][MT * W4L_XROW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
+    const int per_z = (all_groups + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int g_lo = blockIdx.z * per_z, g_hi = min(all_groups, g_lo + per_z);
+    const int groups = g_hi - g_lo;  // >= 1 (launcher)
+    const int m0 = blockIdx.y * MT;
+    const int rows = M - m0 < MT ? M - m0 : MT;  // live rows of this tile
+    const int nt = blockIdx.x * W4M_WAVES + wave;
+    const bool has_strip = nt * 32 < N;  // wave-uniform; an idle wave still stages x and joins the barriers
+    const char *strip = w4m + ((size_t)(has_strip ? nt : 0) * all_groups + g_lo) * W4M_TILE_BYTES;
+    x += (size_t)g_lo * 64;
+
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    uint4 cw[W4L_WDEPTH];
+    u32 sb[W4L_WDEPTH];
+#define W4L_WISSUE(d, g)                                                                                   \
+    {                                                                                                      \
+        const char *tile_ = strip + (size_t)((g) < groups ? (g) : groups - 1) * W4M_TILE_BYTES;             \
+        const nt_u32x4 c_ = *(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);                            \
+        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                        \
+        sb[d] = *(reinterpret_cast<const u32 *>(tile_ + 1024) + n);                                         \
+    }
+    // x staging: MT rows x 8 pieces of 16 bytes per K step; piece p = tid + 512 j -> row p >> 3, piece p & 7
+    uint4 xs[PPT];
+    auto x_fetch = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = threadIdx.x + 512 * j, r = p >> 3, c = p & 7;
+            xs[j] = r < rows ? *reinterpret_cast<const uint4 *>(x + (size_t)(m0 + r) * K + g * 64 + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = threadIdx.x + 512 * j;
+            *reinterpret_cast<uint4 *>(s_x[buf] + (p >> 3) * W4L_XROW + (p & 7) * 16) = xs[j];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < W4L_WDEPTH; ++d) W4L_WISSUE(d, d)
+    x_fetch(0);
+    x_store(0);
+    if (groups > 1) x_fetch(1);
+
+    f32x16_t acc[MB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mi][i] = 0.0f;
+    // A fragments of the CURRENT K step; the next step's are dequantised between this step's MFMAs (the barrier puts the two waves
+    // of a SIMD in phase, so conversion ahead of the MFMAs would idle the matrix pipe on both)
+    uint4 af[4];
+    {
+        const float s0 = lo_f32<T>(sb[0]), b0 = hi_f32<T>(sb[0]);
+        const u32 w0[4] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[k] = w4m_dequant<T>(w0[k], s0, b0);
+    }
+    for (int base = 0; base < groups; base += W4L_WDEPTH) {
+#pragma unroll
+        for (int d = 0; d < W4L_WDEPTH; ++d) {
+            const int g = base + d;
+            if (g < groups) {  // uniform for the workgroup
+                __syncthreads();  // image g is complete; nobody reads image g + 1's buffer (= g - 1's) any more
+                if (!(W4L_ABL & 4)) {
+                    if (g + 1 < groups) x_store((g + 1) & 1);
+                    if (g + 2 < groups) x_fetch(g + 2);
+                }
+                const int dn = (d + 1) % W4L_WDEPTH;  // ring slot of tile g + 1 (a constant after unrolling)
+                const float sn = lo_f32<T>(sb[dn]), bn = hi_f32<T>(sb[dn]);
+                const u32 wn[4] = {cw[dn].x, cw[dn].y, cw[dn].z, cw[dn].w};
+                uint4 afn[4];
+                const char *xr = s_x[g & 1] + n * W4L_XROW + kh * 16;
+                // 4 MB steps t = (k, mi); B fragments ride a 4-deep register ring so an LDS read has 4 MFMAs to land
+                constexpr int NS = 4 * MB;
+                uint4 bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const uint4 *>(xr + (t % MB) * 32 * W4L_XROW + 32 * (t / MB));
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const int k = t / MB, mi = t % MB;
+                    acc[mi] = MfmaT<T>::run(af[k], bq[t & 3], acc[mi]);
+                    if (t + 4 < NS && !(W4L_ABL & 2)) bq[t & 3] = *reinterpret_cast<const uint4 *>(xr + ((t + 4) % MB) * 32 * W4L_XROW + 32 * ((t + 4) / MB));
+                    if (mi == 0) afn[k] = (W4L_ABL & 1) ? make_uint4(wn[k], wn[k] ^ sb[dn], wn[k] + 1, sb[dn]) : w4m_dequant<T>(wn[k], sn, bn);  // one word of the next tile per k-step, in the MFMAs' shadow
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) af[k] = afn[k];
+                W4L_WISSUE(d, g + W4L_WDEPTH)
+            }
+        }
+    }
+#undef W4L_WISSUE
+    if (!has_strip) return;
+    // accumulator register i of lane l <-> output column 32 nt + (i & 3) + 8 (i >> 2) + 4 kh, row m0 + 32 mi + (l & 31): four
+    // consecutive columns per register quad -> one 8-byte (T) or 16-byte (fp32 partial) store
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+        const int m = 32 * mi + n;
+        if (m < rows) {
+            const size_t o = (size_t)(m0 + m) * N + 32 * nt + 4 * kh;
+            if (part) {
+                float *pr = part + (size_t)blockIdx.z * M * N + o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(pr + 8 * q) = make_float4(acc[mi][4 * q], acc[mi][4 * q + 1], acc[mi][4 * q + 2], acc[mi][4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint2 *>(y + o + 8 * q) = make_uint2(w4m_pack<T>(acc[mi][4 * q], acc[mi][4 * q + 1]), w4m_pack<T>(acc[mi][4 * q + 2], acc[mi][4 * q + 3]));
+            }
+        }
+    }
+}
+
+// y = T(sum over z, in z order, of the fp32 partial tiles)
+template <class T>
+__global__ void __launch_bounds__(256) k_w4l_reduce(const float *part, int S, size_t MN, u16 *y) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    float4 a = *reinterpret_cast<const float4 *>(part + i);
+    for (int z = 1; z < S; ++z) {
+        const float4 b = *reinterpret_cast<const float4 *>(part + (size_t)z * MN + i);
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+    *reinterpret_cast<uint2 *>(y + i) = make_uint2(w4m_pack<T>(a.x, a.y), w4m_pack<T>(a.z, a.w));
+}
+
+// K-split factor the launcher will use for [M, N, K]: enough workgroups for the chip, at least 8 groups (512 columns) per split.
+int w4l_splits(int M, int N, int K) {
+    const int mt = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+    const int wgs = ((N / 32 + W4M_WAVES - 1) / W4M_WAVES) * ((M + mt - 1) / mt);
+    int s = wgs >= 192 ? 1 : (256 + wgs - 1) / wgs;
+    const int max_s = (K >> 6) / 8 > 0 ? (K >> 6) / 8 : 1;
+    s = s > max_s ? max_s : s;
+    return s > 16 ? 16 : s;
+}
+size_t w4l_workspace_bytes(int M, int N, int K) {
+    const int s = w4l_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+// workspace: w4l_workspace_bytes() of device scratch (may be null when that is 0)
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st) {
+    PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4 GEMM: N must be a multiple of 32 and K of 64");
+    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "W4 GEMM: 16-byte alignment required");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4 GEMM: dtype must be PIE_BF16 or PIE_F16");
+    const int S = w4l_splits(M, N, K);
+    PIE_REQUIRE(S == 1 || workspace, PIE_E_ARG, "W4 GEMM: this shape splits K and needs its workspace");
+    const int mt = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+    // blockIdx.x = column block (fastest): the workgroups that share an x tile are dispatched together and read it through every XCD's L2
+    const dim3 grid((unsigned)((N / 32 + W4M_WAVES - 1) / W4M_WAVES), (unsigned)((M + mt - 1) / mt), (unsigned)S), block(W4M_WAVES * 64);
+    float *part = S > 1 ? (float *)workspace : nullptr;
+#define W4L_GO(TT, MB_) hipLaunchKernelGGL((k_w4l_gemm<TT, MB_>), grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part)
+    if (dtype == PIE_BF16) {
+        if (mt == 64) W4L_GO(BF16, 2);
+        else if (mt == 128) W4L_GO(BF16, 4);
+        else W4L_GO(BF16, 8);
+    } else {
+        if (mt == 64) W4L_GO(F16, 2);
+        else if (mt == 128) W4L_GO(F16, 4);
+        else W4L_GO(F16, 8);
+    }
+#undef W4L_GO
+    PIE_LAUNCH_CHECK();
+    if (S > 1) {
+        const size_t MN = (size_t)M * N;
+        const dim3 rg((unsigned)((MN / 4 + 255) / 256));
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l_reduce<BF16>, rg, dim3(256), 0, st, part, S, MN, (u16 *)y);
+        else hipLaunchKernelGGL(k_w4l_reduce<F16>, rg, dim3(256), 0, st, part, S, MN, (u16 *)y);
+        PIE_LAUNCH_CHECK();
+    }
+    return PIE_OK;
+}
+
 size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
 
 int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) {
@@ -467,6 +667,15 @@ int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
+    if (M > 32) {  // the prompt GEMM; a K-split shape takes stream-ordered scratch for its fp32 partial tiles
+        hipStream_t st = (hipStream_t)stream;
+        void *ws = nullptr;
+        const size_t wb = w4l_workspace_bytes(M, N, K);
+        if (wb && hipMallocAsync(&ws, wb, st) != hipSuccess) return pie::fail(PIE_E_HIP, "pie_qgemm_w4m: hipMallocAsync failed");
+        const int rc = w4l_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st);
+        if (ws) (void)hipFreeAsync(ws, st);
+        return rc;
+    }
     return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr, 0, nullptr, nullptr);
 }
 

@@ -484,15 +484,15 @@ def add_bias_rms_norm(x: torch.Tensor, r: torch.Tensor, bias: torch.Tensor, norm
 
 
 def quantized_matmul_rows(x: torch.Tensor, w: "W4SWeight", w4m: torch.Tensor | None = None) -> torch.Tensor:
-    """mx.quantized_matmul for a few rows (2..32) in its many-row regime -- weights dequantised to T, T x T products on the
-    MFMA units, fp32 accumulation -- reading the int4 weights once (pie_qgemm_w4m).  x [M, K]; w: the W4S matrix (N % 32 == 0);
-    w4m: its W4M tile copy from `repack_w4m` (built here when absent)."""
+    """mx.quantized_matmul in its many-row regime -- weights dequantised to T, T x T products on the MFMA units, fp32
+    accumulation -- reading the int4 weights in 4-bit form (pie_qgemm_w4m: the few-row kernels up to 32 rows, the 256 x 256-tile
+    prompt GEMM beyond).  x [M, K]; w: the W4S matrix (N % 32 == 0); w4m: its W4M tile copy from `repack_w4m` (built here when absent)."""
     _dev(x)
     if not isinstance(w, W4SWeight):
         raise TypeError("quantized_matmul_rows takes a W4SWeight (int4 g=64)")
     M, K = x.shape
-    if K != w.K or not 1 <= M <= 32 or w.N % 32:
-        raise ValueError("quantized_matmul_rows: x [M <= 32, K], N % 32 == 0")
+    if K != w.K or M < 1 or w.N % 32:
+        raise ValueError("quantized_matmul_rows: x [M, K], N % 32 == 0")
     if w4m is None:
         w4m = repack_w4m(w)
     y = torch.empty((M, w.N), dtype=x.dtype, device=x.device)

@@ -59,12 +59,19 @@ class TransformerBlock:
 
 
 def _triplet(weights: dict, prefix: str):
-    try:
-        return weights[f"{prefix}.weight"], weights[f"{prefix}.scales"], weights[f"{prefix}.biases"]
-    except KeyError as e:
+    """The MLX-quantised triplet of one module.  The reference decides PER MODULE (models/utils.py:99-111: quantised iff the module
+    has to_quantized, weight.shape[-1] % 64 == 0 and "{path}.scales" is in the checkpoint); this build streams every Linear of a
+    checkpoint in ONE format, so a module the reference would leave dense among quantised ones is refused by name."""
+    w, s, b = weights.get(f"{prefix}.weight"), weights.get(f"{prefix}.scales"), weights.get(f"{prefix}.biases")
+    if w is None:
+        raise ValueError(f"{prefix}.weight is missing from the checkpoint")
+    if s is None or b is None:
+        why = ("its input width is not a multiple of 64" if w.dtype not in (torch.int32, torch.uint32) and w.shape[-1] % 64 else
+               f'the checkpoint has no "{prefix}.scales"')
         raise ValueError(
-            f"{prefix}: expected an MLX-quantised triplet (.weight/.scales/.biases); dense 16-bit Linear layers are "
-            "not on the MI355X decode path yet") from e
+            f"{prefix}: the reference would keep this module dense ({why}: models/utils.py:99-109) while config['quantization'] "
+            "quantises the others; mixed quantised / dense checkpoints are not supported on the MI355X path (one weight format per model)")
+    return w, s, b
 
 
 def _dense(weights: dict, prefix: str, dtype: torch.dtype) -> torch.Tensor:
@@ -84,8 +91,11 @@ class Model:
         q = args.quantization or {}
         self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
         if q and (q.get("group_size") != 64 or q.get("bits") not in (4, 8)):
-            raise ValueError("quantised checkpoints must be group_size=64 with 4 or 8 bits (config['quantization']); other MLX "
-                             "quantisations are not on the MI355X path")
+            # nn.quantize(model, **config["quantization"]) takes any group_size in {32, 64, 128} and bits in {2, 3, 4, 6, 8}
+            # (models/utils.py:96-111); the W4S / W8S streaming units are built around one 64-wide group per lane
+            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size=64 with bits 4 or 8 only "
+                             f"(got group_size={q.get('group_size')}, bits={q.get('bits')}); re-quantise the checkpoint with "
+                             "mlx_lm.convert -q --q-group-size 64 --q-bits 4")
         self.bits = int(q["bits"]) if q else 16
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads or self.n_heads

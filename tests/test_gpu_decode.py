@@ -742,7 +742,14 @@ def test_tied_embeddings_and_errors(tiny):
     assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
     with pytest.raises(ValueError):
         build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match="group_size=32"):
         build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other group sizes / bit widths are not on this path
+    with pytest.raises(ValueError, match="bits=6"):
+        build(dict(cfg, quantization={"group_size": 64, "bits": 6}), w)
+    # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109): one dense Linear among int4 ones
+    mixed = {k: v for k, v in w.items() if not k.startswith("model.layers.1.mlp.down_proj.")}
+    mixed["model.layers.1.mlp.down_proj.weight"] = np.zeros((cfg["hidden_size"], cfg["intermediate_size"]), np.uint16)
+    with pytest.raises(ValueError, match=r"model\.layers\.1\.mlp\.down_proj.*keep this module dense"):
+        build(cfg, mixed)
     with pytest.raises(ValueError):
         model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])

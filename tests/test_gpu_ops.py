@@ -336,3 +336,27 @@ def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
         cols = ops.quantized_matmul_rows(to_dev(po.to_bits(eye, dt), dt), packed)          # [32, N]: row j = column j of W
         deq = po.dequantize(wq, sc, bi, dtype=dt)
         assert np.array_equal(to_bits(cols), po.to_bits(deq[:, :min(32, K)].T.copy(), dt))
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K", [(33, 64, 64), (64, 256, 512), (100, 96, 4096), (256, 4096, 1408), (300, 6144, 4096), (513, 1024, 14336), (1000, 288, 192)])
+def test_many_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
+    """pie_qgemm_w4m beyond 32 rows: the 256-row x 256-column MFMA tile kernel (k_w4l_gemm) that processes prompts -- partial row
+    tiles (33, 100, 300, 513, 1000), column counts that leave waves of the last workgroup idle (64, 96, 288), a ragged W4S slice
+    (K = 1408, 192) -- against the oracle's many-row regime of mx.quantized_matmul (weights dequantised to T first)."""
+    rng = np.random.default_rng(M * 11 + N)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    wq, sc, bi = po.quantize(w, 64, 4, dt)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+    got = ops.quantized_matmul_rows(to_dev(po.to_bits(x, dt), dt), packed)
+    want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w4l {M}x{N}x{K} {dt}")
+    if K <= 192:  # the identity product recovers the dequantised matrix bit for bit (rows beyond K are zero rows of x)
+        r = min(M, K)
+        eye = np.zeros((M, K), np.float32)
+        eye[np.arange(r), np.arange(r)] = 1.0
+        cols = ops.quantized_matmul_rows(to_dev(po.to_bits(eye, dt), dt), packed)
+        deq = po.dequantize(wq, sc, bi, dtype=dt)
+        assert np.array_equal(to_bits(cols)[:r], po.to_bits(deq.T[:r].copy(), dt))
+        assert not to_bits(cols)[r:].any()
