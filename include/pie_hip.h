@@ -159,6 +159,11 @@ typedef struct {
                            weights, W16S units; embed_codes is then the T [vocab, hidden] table, scales/biases NULL) */
     int rope_traditional; /* ModelArgs.rope_traditional (language.py:27,69): rotate the interleaved pairs (2i, 2i+1); wqkv is
                              then the plain q|k|v concatenation (row_map NULL), not pie_qkv_row_map's order */
+    int tp_rank, tp_world; /* tensor parallelism (0, 0 or 0, 1 = none).  With tp_world > 1 this decoder is ONE RANK's shard:
+                             n_heads, n_kv_heads, inter and vocab are the LOCAL sizes (heads / world, intermediate / world, vocabulary
+                             rows / world: proxy_inference_engine_amd/tp.py shard_config), hidden is the full width, the embedding
+                             table holds all vocab * tp_world rows.  o_proj / down_proj produce fp32 partial sums that
+                             pie_decoder_set_comm's communicator adds over the ranks before the one rounding + residual add. */
 } pie_decoder_config;
 enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1, PIE_W_INT8_G64 = 2 /* W8S units, embed_codes uint32 [vocab, hidden/4] */ };
 
@@ -269,6 +274,31 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
 enum { PIE_OPT_MEGA = 1 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);
+
+/* ---------------------------------------------------------------- tensor-parallel communicator (SURVEY.md 8 row e)
+ * The reference has no multi-GPU path; BASELINE.json configs[4] (Llama-3-70B over the 8 GPUs of one node) needs
+ * one.  A decode step has two all-reduces of ONE hidden vector per layer and a 3-number exchange in the tail: latency-bound, so
+ * this is a one-shot push over IPC-mapped peer memory, not a ring: every rank stores its fp32 vector as 8-byte {value, epoch}
+ * granules into its slot of every peer's receive area (one xGMI hop, the data is its own flag), then adds the slots of its own
+ * area in rank order -- bit-identical sums on all ranks.  One process per GPU:
+ *   pie_comm_create(rank, world, max_elems, &c)   allocates this rank's receive area (fine-grained device memory)
+ *   pie_comm_export(c, handle64)                  64-byte hipIpcMemHandle_t of that area; the host gathers all ranks' handles
+ *                                                 (torch.distributed all_gather, MPI, a file: any side channel)
+ *   pie_comm_connect(c, handles)                  handles: world * 64 bytes in rank order (own entry ignored); maps the peers
+ *   pie_allreduce_f32(c, data, n, stream)         in-place sum over the ranks, stream-ordered, no host synchronisation
+ *   pie_decoder_set_comm(d, c)                    the decoder's steps (eager or captured in a hipGraph) use c; every rank must
+ *                                                 enqueue the same sequence of steps.  c must outlive d.
+ *   pie_comm_status(c, &err)                      synchronises; err != 0: a bounded wait (2 s) for a peer's data gave up
+ *   pie_comm_destroy(c)
+ * world == 1 is a valid (self-connected) communicator.  A peer may run at most one collective ahead of the slowest rank. */
+typedef struct pie_comm pie_comm;
+int pie_comm_create(int rank, int world, size_t max_elems, pie_comm **out);
+int pie_comm_export(const pie_comm *c, void *handle64);
+int pie_comm_connect(pie_comm *c, const void *handles);
+int pie_allreduce_f32(pie_comm *c, float *data, size_t n, void *stream);
+int pie_comm_status(pie_comm *c, unsigned *error);
+int pie_comm_destroy(pie_comm *c);
+int pie_decoder_set_comm(pie_decoder *d, pie_comm *c);
 
 /* ---------------------------------------------------------------- KV page pool
  * Replaces pie_core's PageAllocator / KVPage: src/pie_core/include/engine/page_allocator.hpp:17-72,

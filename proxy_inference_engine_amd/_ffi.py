@@ -32,13 +32,15 @@ EXPORTS = [
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
     "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
+    "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm",
 ]
 
 
 class pie_decoder_config(C.Structure):
     _fields_ = [("dtype", C.c_int), ("hidden", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int),
                 ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("inter", C.c_int), ("vocab", C.c_int),
-                ("rms_eps", C.c_float), ("tie_word_embeddings", C.c_int), ("kv_splits", C.c_int), ("weight_format", C.c_int), ("rope_traditional", C.c_int)]
+                ("rms_eps", C.c_float), ("tie_word_embeddings", C.c_int), ("kv_splits", C.c_int), ("weight_format", C.c_int), ("rope_traditional", C.c_int),
+                ("tp_rank", C.c_int), ("tp_world", C.c_int)]
 
 
 class pie_layer_weights(C.Structure):
@@ -87,6 +89,13 @@ def load() -> C.CDLL:
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    lib.pie_comm_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.pie_comm_export.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pie_comm_connect.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pie_allreduce_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.pie_comm_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    lib.pie_comm_destroy.argtypes = [C.c_void_p]
+    lib.pie_decoder_set_comm.argtypes = [C.c_void_p, C.c_void_p]
     for name in ("pie_page_pool_slab_bytes", "pie_page_pool_size", "pie_page_pool_num_free"):
         getattr(lib, name).restype = C.c_size_t
     lib.pie_page_pool_slab_bytes.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_int]

@@ -80,8 +80,8 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     const int fmt = dense ? FMT_W16S : (int8 ? FMT_W8S : FMT_W4S);
     switch (which) {
         case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
-            if (dense) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, c.vocab, H, c.dtype, d->h, st);
-            return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, d->h,
+            if (dense) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, d->embed_vocab(), H, c.dtype, d->h, st);
+            return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, d->embed_vocab(), H, c.dtype, d->h,
                                     d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st, int8 ? 8 : 4);
         case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
             GemvArgs a = {};
@@ -109,12 +109,14 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
             a.fmt = fmt, a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h, a.lin_bias = (const u16 *)w.bo;
-            if (d->combine) {
-                a.x = d->attn;
-                return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
-            }
-            a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
-            return w4s_gemv_launch(c.dtype, PRO_ATTN, EPI_RESIDUAL, a, 1, st);
+            // tensor-parallel shard (row-parallel Linear over the local heads): un-rounded fp32 partial, summed over the ranks,
+            // THEN the Linear's one rounding and the residual add
+            const int epi = d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL;
+            a.y32 = d->tp_part;
+            if (d->combine) a.x = d->attn;
+            else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
+            const int rc = w4s_gemv_launch(c.dtype, d->combine ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
+            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
@@ -125,7 +127,9 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
             a.fmt = fmt, a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
-            return w4s_gemv_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, a, 1, st);
+            a.y32 = d->tp_part;
+            const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL, a, 1, st);
+            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
         case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials
             GemvArgs a = {};
@@ -134,6 +138,9 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_LOGITS, a, 1, st);
         }
         case PIE_K_TAIL:  // log-softmax + greedy argmax, advances the device-side state (inference_engine.py:268-271)
+            if (d->tp())  // vocabulary-parallel: (max, sum exp, argmax) of every shard -> global log-sum-exp and token
+                return tp_tail_launch(d->comm, c.dtype, logits_dst, c.vocab, c.tp_rank * c.vocab, d->stats, d->n_stats, d->tp_part + H, d->logprobs, d->token_out,
+                                      d->state, d->history, d->hist_cap, st);
             return logits_tail_launch(c.dtype, logits_dst, c.vocab, d->stats, d->n_stats, d->logprobs, d->token_out, d->state, d->history, d->hist_cap, st);
         default: return pie::fail(PIE_E_ARG, "pie_decoder: unknown kernel id");
     }
@@ -188,6 +195,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_REQUIRE(c.hidden <= 32768 && c.inter <= 32768 && c.n_heads * c.head_dim <= 32768, PIE_E_SHAPE, "pie_decoder_create: K > 32768 not supported");
     PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE || c.weight_format == PIE_W_INT8_G64, PIE_E_ARG,
                 "pie_decoder_create: unknown weight_format");
+    PIE_REQUIRE(c.tp_world >= 0 && c.tp_world <= 8 && c.tp_rank >= 0 && c.tp_rank < (c.tp_world > 0 ? c.tp_world : 1), PIE_E_ARG,
+                "pie_decoder_create: 0 <= tp_rank < tp_world <= 8");
     pie_decoder *d = new (std::nothrow) pie_decoder();
     PIE_REQUIRE(d, PIE_E_HIP, "pie_decoder_create: out of host memory");
     d->cfg = c;
@@ -208,6 +217,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
     PIE_ALLOC(d->pf_sink, 16);
+    if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)
         const long mb = e ? atol(e) : 0;
@@ -227,7 +237,7 @@ int pie_decoder_destroy(pie_decoder *d) {
     drop_graphs(d);
     prefill_free(d);
     mega_free(d);
-    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink};
+    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete d;
@@ -241,6 +251,8 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
     PIE_REQUIRE(pie_aligned(w->wqkv, 256) && pie_aligned(w->wo, 256) && pie_aligned(w->wgateup, 256) && pie_aligned(w->wdown, 256) &&
                     pie_aligned(w->attn_norm, 16) && pie_aligned(w->mlp_norm, 16),
                 PIE_E_ALIGN, "pie_decoder_set_layer: W4S buffers need 256-byte, norm weights 16-byte alignment");
+    PIE_REQUIRE(!d->tp() || (!w->bo && !w->bdown), PIE_E_ARG,
+                "pie_decoder_set_layer: o_proj / down_proj biases are not supported on a tensor-parallel shard (they would be added once per rank)");
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
     prefill_free(d);  // resident T copies of the previous weights are stale
@@ -316,7 +328,7 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream) {
     PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_set_state: null decoder");
     PIE_REQUIRE(offset >= 0, PIE_E_ARG, "pie_decoder_set_state: negative offset");
-    PIE_REQUIRE(token < d->cfg.vocab, PIE_E_ARG, "pie_decoder_set_state: token id out of range");
+    PIE_REQUIRE(token < d->embed_vocab(), PIE_E_ARG, "pie_decoder_set_state: token id out of range");
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, (hipStream_t)stream, d->state, offset, token, -1);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
@@ -326,6 +338,7 @@ static int ready(pie_decoder *d) {
     PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder: null decoder");
     PIE_REQUIRE(d->glob_set && d->kv_set && d->out_set, PIE_E_STATE, "pie_decoder: set_globals, set_kv and bind_outputs must be called before stepping");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder: a layer has no weights (pie_decoder_set_layer)");
+    PIE_REQUIRE(!d->tp() || d->comm, PIE_E_STATE, "pie_decoder: a tensor-parallel shard needs a communicator (pie_decoder_set_comm)");
     return PIE_OK;
 }
 
@@ -374,7 +387,9 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
     if ((rc = mega_prepare(d))) return rc;
-    if (L >= prefill_min_rows()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime: dequantise-to-T GEMMs
+    // a tensor-parallel shard feeds its prompt through the step kernels (2 all-reduces per layer and token); the many-row GEMM
+    // path has no collective yet
+    if (L >= prefill_min_rows() && !d->tp()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
         u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;
@@ -391,6 +406,7 @@ int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *
     if (rc) return rc;
     PIE_REQUIRE(embeds && L > 0, PIE_E_ARG, "pie_decoder_prefill_embeds: need at least one row");
     PIE_REQUIRE(pie_aligned(embeds, 16), PIE_E_ALIGN, "pie_decoder_prefill_embeds: 16-byte alignment required");
+    PIE_REQUIRE(!d->tp(), PIE_E_STATE, "pie_decoder_prefill_embeds: not available on a tensor-parallel shard");
     return prefill_batched(d, nullptr, embeds, L, logits_all, (hipStream_t)stream);
 }
 
@@ -437,9 +453,26 @@ int pie_decoder_configure(pie_decoder *d, int option, int value) {
     return PIE_OK;
 }
 
+int pie_decoder_set_comm(pie_decoder *d, pie_comm *c) {
+    PIE_REQUIRE(d && c, PIE_E_ARG, "pie_decoder_set_comm: null pointer");
+    int rank = 0, world = 0;
+    size_t max_elems = 0;
+    PIE_REQUIRE(tp_comm_geometry(c, &rank, &world, &max_elems) == PIE_OK, PIE_E_STATE, "pie_decoder_set_comm: the communicator is not connected");
+    PIE_REQUIRE(d->tp() && rank == d->cfg.tp_rank && world == d->cfg.tp_world, PIE_E_ARG,
+                "pie_decoder_set_comm: rank / world differ from the decoder's tp_rank / tp_world");
+    PIE_REQUIRE(max_elems >= (size_t)d->cfg.hidden, PIE_E_SHAPE, "pie_decoder_set_comm: the communicator's slots are shorter than the hidden size");
+    d->comm = c;
+    drop_graphs(d);
+    return PIE_OK;
+}
+
 int pie_decoder_status(pie_decoder *d, unsigned *error) {
     PIE_REQUIRE(d && error, PIE_E_ARG, "pie_decoder_status: null pointer");
     PIE_HIP_TRY(hipDeviceSynchronize());
+    if (d->comm) {
+        int rc = pie_comm_status(d->comm, error);
+        if (rc || *error) return rc;
+    }
     return mega_status(d, error);
 }
 

@@ -41,7 +41,18 @@ struct pie_decoder {
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
     struct MegaState *mega = nullptr;               // the persistent one-launch step (step_mega.hip), allocated on first use
+    // tensor parallelism (cfg.tp_world > 1): this decoder is one rank's shard; comm is caller-owned (pie_decoder_set_comm)
+    pie_comm *comm = nullptr;
+    float *tp_part = nullptr;  // [hidden] fp32 partial of the row-parallel Linears, [hidden] = log-sum-exp of the step
+    bool tp() const { return cfg.tp_world > 1; }
+    int embed_vocab() const { return tp() ? cfg.vocab * cfg.tp_world : cfg.vocab; }
 };
+
+// tp_comm.hip: sum over the ranks of data[n] (rank order), then h = T(h + T(sum)) when resid != nullptr
+int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st);
+int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int vocab_offset, const LogitStat *stats, int n_stats, float *lse, float *logprobs,
+                   int *token, DecState *state, int *history, int hist_cap, hipStream_t st);
+int tp_comm_geometry(const pie_comm *c, int *rank, int *world, size_t *max_elems);
 
 // prefill.hip: batched prompt processing (L >= prefill_min_rows() tokens): per layer the W4S weights are dequantised to T
 // and multiplied by hipBLASLt, with hand-written HIP kernels for RoPE + cache append, causal attention and SwiGLU.

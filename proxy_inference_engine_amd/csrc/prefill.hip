@@ -919,6 +919,7 @@ extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, con
                                       int flags, void *stream) {
     PIE_REQUIRE(d && tokens && context_lens && slabs && block_tables && logits && logprobs && next_tokens, PIE_E_ARG, "pie_decoder_step_batch: null pointer");
     PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_step_batch: set_globals must be called first");
+    PIE_REQUIRE(!d->tp(), PIE_E_STATE, "pie_decoder_step_batch: not available on a tensor-parallel shard");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_step_batch: a layer has no weights (pie_decoder_set_layer)");
     PIE_REQUIRE(B >= 1 && B <= 4096 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_step_batch: bad batch shape");
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;

@@ -226,6 +226,7 @@ static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     else if (pro == PRO_NONE && epi == EPI_STORE) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_STORE, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_ATTN && epi == EPI_PARTIAL_F32) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_PARTIAL_F32, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_SWIGLU, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_LOGITS) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_LOGITS, NPT, 0, FMT>), grid, block, lds, st, a);

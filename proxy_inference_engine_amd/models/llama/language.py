@@ -82,10 +82,15 @@ def _dense(weights: dict, prefix: str, dtype: torch.dtype) -> torch.Tensor:
 
 
 class Model:
-    def __init__(self, args: ModelArgs, weights: dict[str, torch.Tensor], kv_splits: int = 0):
+    def __init__(self, args: ModelArgs, weights: dict[str, torch.Tensor], kv_splits: int = 0, tp=None):
         """weights: the checkpoint in the layout models/utils.py:51-125 of the reference consumes (HF names,
-        `.weight` uint32 codes carried as int32, `.scales`/`.biases` in the activation dtype), on the GPU."""
+        `.weight` uint32 codes carried as int32, `.scales`/`.biases` in the activation dtype), on the GPU.
+        tp: a connected proxy_inference_engine_amd.tp.HipComm -- this model is then ONE RANK of a tensor-parallel group: `args`
+        and `weights` are the rank's shard (tp.shard_checkpoint: local heads / intermediate rows, its own `lm_head` rows, the
+        full embedding table), every rank must make the same calls in the same order, and logits / logprobs cover the rank's
+        vocabulary rows [rank * V / world, (rank + 1) * V / world) while the sampled token is global."""
         self.args = args
+        self.tp = tp
         self.model_type = args.model_type
         device = _ffi.require_gpu()
         q = args.quantization or {}
@@ -103,6 +108,11 @@ class Model:
         self.dtype = weights["model.norm.weight"].dtype
         self.device = device
         H, I, V = args.hidden_size, args.intermediate_size, args.vocab_size
+        if tp is not None and tp.world > 1:
+            if args.tie_word_embeddings or V % (2 * tp.world):
+                raise ValueError("a tensor-parallel shard carries its own lm_head rows (tie_word_embeddings=False) and needs vocab_size % (2 * world) == 0")
+            V //= tp.world  # the rank's slice of the vocabulary: lm_head rows, logits, logprobs
+        self.vocab_out = V
         weights = base.sanitize(weights, args.tie_word_embeddings)  # language.py:212-219
 
         rs = args.rope_scaling or {}
@@ -166,9 +176,12 @@ class Model:
         lib = _ffi.load()
         cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
                                       self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits),
-                                      1 if self.dense else (2 if self.bits == 8 else 0), int(bool(args.rope_traditional)))
+                                      1 if self.dense else (2 if self.bits == 8 else 0), int(bool(args.rope_traditional)),
+                                      tp.rank if tp is not None else 0, tp.world if tp is not None else 0)
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
+        if tp is not None and tp.world > 1:
+            _ffi.check(lib.pie_decoder_set_comm(self._dec, tp.handle))
         for i, blk in enumerate(self.layers):
             lw = _ffi.pie_layer_weights(blk.input_layernorm.data_ptr(), blk.post_attention_layernorm.data_ptr(),
                                         blk.wqkv.packed.data_ptr(), blk.wo.packed.data_ptr(), blk.wgateup.packed.data_ptr(),
@@ -296,7 +309,7 @@ class Model:
             emb = self._check_embeds(inputs_embeds)
             L = emb.shape[0]
             self._sync_cache(cache, L)
-            out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
+            out = torch.empty((L, self.vocab_out), dtype=self.dtype, device=self.device)
             _ffi.check(lib.pie_decoder_prefill_embeds(self._dec, _ffi.p(emb), L, _ffi.p(out), _ffi.stream()))
         else:
             if inputs.dim() != 2 or inputs.shape[0] != 1:
@@ -304,7 +317,7 @@ class Model:
             ids = inputs.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
             L = ids.numel()
             self._sync_cache(cache, L)
-            out = torch.empty((L, self.args.vocab_size), dtype=self.dtype, device=self.device)
+            out = torch.empty((L, self.vocab_out), dtype=self.dtype, device=self.device)
             _ffi.check(lib.pie_decoder_prefill(self._dec, _ffi.p(ids), L, _ffi.p(out), _ffi.stream()))
         self._advance(cache, L)
         return out.unsqueeze(0)

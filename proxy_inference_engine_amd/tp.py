@@ -105,6 +105,67 @@ class TPGroup:
         return float(lse), int(cand[:, 2].min().item())  # ties: the lowest vocabulary index wins (mx.argmax)
 
 
+class HipComm:
+    """The native communicator of the fused tensor-parallel step (include/pie_hip.h, pie_comm_*): a one-shot all-reduce over
+    IPC-mapped peer buffers, enqueued on HIP streams and capturable in the decoder's hipGraph.  torch.distributed is only the
+    side channel that carries the 64-byte IPC handles at start-up (any backend; gloo in the one-card test)."""
+
+    def __init__(self, max_elems: int, group=None):
+        import ctypes as C
+        from . import _ffi
+        _ffi.require_gpu()
+        self._lib = _ffi.load()
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.handle = C.c_void_p()
+        _ffi.check(self._lib.pie_comm_create(self.rank, self.world, int(max_elems), C.byref(self.handle)))
+        if self.world > 1:
+            mine = C.create_string_buffer(64)
+            _ffi.check(self._lib.pie_comm_export(self.handle, mine))
+            handles: list = [None] * self.world
+            dist.all_gather_object(handles, mine.raw, group=group)
+            _ffi.check(self._lib.pie_comm_connect(self.handle, b"".join(handles)))
+            dist.barrier(group=group)  # every rank has mapped every peer before anyone pushes
+
+    def all_reduce(self, partial_f32: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks (rank order: bit-identical on every rank), stream-ordered, no host synchronisation."""
+        from . import _ffi
+        if partial_f32.dtype != torch.float32 or not partial_f32.is_contiguous() or not partial_f32.is_cuda:
+            raise ValueError("HipComm.all_reduce: contiguous float32 device tensor expected")
+        _ffi.check(self._lib.pie_allreduce_f32(self.handle, _ffi.p(partial_f32), partial_f32.numel(), _ffi.stream()))
+        return partial_f32
+
+    def status(self) -> int:
+        """Synchronises; non-zero = a bounded wait for a peer's data gave up (the number is the collective's epoch)."""
+        import ctypes as C
+        from . import _ffi
+        err = C.c_uint(0)
+        _ffi.check(self._lib.pie_comm_status(self.handle, C.byref(err)))
+        return int(err.value)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            torch.cuda.synchronize()
+            if self.world > 1 and dist.is_initialized():
+                dist.barrier(group=self.group)  # no peer may still be pushing into this rank's area when it is freed
+            self._lib.pie_comm_destroy(self.handle)
+            self.handle = None
+
+
+def fused_shard(config: dict, weights: dict, comm: HipComm, kv_splits: int = 0):
+    """This rank's shard of an int4 checkpoint as a models.llama.Model whose decode step is the FUSED launch sequence with
+    tensor parallelism inside (o_proj / down_proj as fp32 partials + one-shot all-reduce + residual, vocabulary-parallel tail):
+    the product path of SURVEY.md 8 row e.  `weights` is the FULL checkpoint (on the host or the device); only the shard is kept."""
+    from .models.llama import Model, ModelArgs
+    w, c = shard_checkpoint(weights, config, comm.rank, comm.world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    w = {k: v.to(dev) for k, v in w.items()}
+    c = {k: v for k, v in c.items() if k not in ("tp_world", "tp_vocab_shard")}
+    c["tie_word_embeddings"] = False  # shard_checkpoint always emits this rank's `lm_head.*` rows
+    return Model(ModelArgs(**c), w, kv_splits=kv_splits, tp=comm)
+
+
 class TPLlama:
     """One rank of a tensor-parallel Llama decode step ON THE DEVICE: this rank's shard of an int4 g=64 checkpoint through the
     op-level HIP kernels (hip_ops), the two row-parallel Linears as un-rounded fp32 partials (pie_qgemv_w4g64_f32) summed with

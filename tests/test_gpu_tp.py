@@ -82,3 +82,73 @@ def test_tp2_decode_matches_unsharded_oracle():
         assert checked >= 3
     finally:
         po.set_qmm_min_rows(6)
+
+
+# ---------------------------------------------------------------- the FUSED tensor-parallel step (product path): tp.fused_shard + HipComm
+def _fused_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = None
+    try:
+        from proxy_inference_engine_amd.tp import HipComm, TPGroup, TPLlama, fused_shard
+        torch.cuda.set_device(0)
+        w = po.synth_checkpoint(CFG, seed=71, dtype=DT, lm_head_gain=4.0)
+        dev_w = {k: (codes_dev(v) if v.dtype == np.uint32 else to_dev(v, DT)) for k, v in w.items()}
+        comm = HipComm(CFG["hidden_size"])
+        # the collective alone: rank-order fp32 sum, in place, stream-ordered
+        g = torch.Generator(device="cpu").manual_seed(100 + rank)
+        mine = torch.randn(CFG["hidden_size"], generator=g, dtype=torch.float32)
+        both = [torch.randn(CFG["hidden_size"], generator=torch.Generator().manual_seed(100 + r), dtype=torch.float32) for r in range(world)]
+        for rep in range(5):  # epochs alternate the two receive areas
+            buf = (mine * (rep + 1)).cuda()
+            comm.all_reduce(buf)
+            want = both[0] * (rep + 1)
+            for r in range(1, world):
+                want = want + both[r] * (rep + 1)
+            assert torch.equal(buf.cpu(), want), f"all-reduce rep {rep}"
+        functional = TPLlama(CFG, dev_w, TPGroup())
+        fused = fused_shard(CFG, dev_w, comm)
+        cache = fused.make_cache()
+        prompt = np.random.default_rng(PROMPT_SEED).integers(0, CFG["vocab_size"], 6)
+        tok = None
+        for t in prompt:
+            tok, lse, hid = functional.step(int(t))
+        ftok, flp, flog = fused.step(torch.tensor(prompt, dtype=torch.int32, device="cuda"), cache)  # prompt through the step kernels
+        f_tokens, t_tokens, hid_err, lse_err = [], [], [], []
+        V_loc = CFG["vocab_size"] // world
+        for i in range(STEPS):
+            f_tokens.append(int(ftok.item()))
+            t_tokens.append(int(tok))
+            hid_err.append(float((fused.hidden.float() - hid[0].float()).abs().max().item() / max(float(hid.float().abs().max().item()), 1e-6)))
+            # logprobs = logits - lse on this rank's vocabulary rows
+            f_lse = (flog.float() - flp)[:V_loc]
+            lse_err.append(float((f_lse - lse).abs().max().item()))
+            assert flp.numel() == V_loc and flog.numel() == V_loc
+            tok, lse, hid = functional.step(tok)
+            # eager for the first steps, then the captured hipGraph (the collectives replay inside it)
+            ftok, flp, flog = fused.step(None, cache, graph=i >= 2)
+        ret[f"fused{rank}"] = f_tokens
+        ret[f"func{rank}"] = t_tokens
+        ret[f"hid_err{rank}"] = max(hid_err)
+        ret[f"lse_err{rank}"] = max(lse_err)
+        ret[f"status{rank}"] = comm.status()
+        del fused
+    finally:
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+def test_tp2_fused_step_equals_functional_tp():
+    """Two ranks on one card: the fused step (decoder launches + pie_comm all-reduce, eager and as a hipGraph) produces the same
+    greedy tokens as the functional TPLlama reference on both ranks, hidden state and log-sum-exp within the 16-bit tolerance."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_fused_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["status0"] == 0 and ret["status1"] == 0
+    assert ret["fused0"] == ret["fused1"] == ret["func0"] == ret["func1"], (ret["fused0"], ret["func0"])
+    assert ret["hid_err0"] <= 4 * EPS[DT] and ret["hid_err1"] <= 4 * EPS[DT]
+    assert ret["lse_err0"] <= 0.05 and ret["lse_err1"] <= 0.05
