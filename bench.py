@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--paged", action="store_true", help="KV cache in 64-token pages of one slab (PagedKVCache) instead of contiguous per-layer buffers")
     ap.add_argument("--model", choices=["8b", "70b", "qv", "3b"], default="8b",
                     help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; 3b: Llama-3.2-3B; not the metric's workload")
+    ap.add_argument("--tp", type=int, default=0, help="tensor parallelism over ALL ranks (== --gpus): ONE sequence decoded by the sharded model "
+                    "(BASELINE.json configs[4] with --model 70b); strong scaling, value = that sequence's tokens/s")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
@@ -155,20 +157,45 @@ def main():
         cfg["quantization"] = None
     elif args.bits != 4:
         cfg["quantization"] = {"group_size": 64, "bits": args.bits}
-    weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
+    tp = args.tp if args.tp > 1 else 0
+    if tp and (tp != world or args.dense or args.bits != 4 or args.paged):
+        raise SystemExit("--tp N needs N ranks (--gpus N under torch.distributed.run), int4 weights and contiguous caches")
+    comm = None
+    if tp:
+        # every rank generates ITS shard directly in the local shapes (the full 70B checkpoint never exists anywhere); the replicated
+        # tensors (embedding table, norm weights) are rank 0's, broadcast once
+        from proxy_inference_engine_amd.tp import HipComm, shard_config
+        full_cfg = cfg
+        cfg = {k: v for k, v in shard_config(full_cfg, tp).items() if k not in ("tp_world", "tp_vocab_shard")}
+        cfg["tie_word_embeddings"] = False
+        weights = synthetic_checkpoint(cfg, seed=100 + rank, dtype=torch.bfloat16)
+        v_loc = full_cfg["vocab_size"] // tp
+        for k in ("weight", "scales", "biases"):
+            weights[f"lm_head.{k}"] = weights[f"lm_head.{k}"][:v_loc].contiguous()
+        for k, t in weights.items():
+            if k.startswith("model.embed_tokens.") or k.endswith("layernorm.weight") or k == "model.norm.weight":
+                if dist.get_backend() == "nccl":
+                    dist.broadcast(t, src=0)
+                else:
+                    h = t.cpu()
+                    dist.broadcast(h, src=0)
+                    t.copy_(h)
+        comm = HipComm(cfg["hidden_size"])
+    else:
+        weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b" and args.bits == 4
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
         weights_host = {k: (v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.view(torch.int16).cpu().numpy().view(np.uint16))
                         for k, v in weights.items()}
-    model = Model(ModelArgs(**cfg), weights, kv_splits=args.kv_splits)
+    model = Model(ModelArgs(**cfg), weights, kv_splits=args.kv_splits, tp=comm)
     del weights
     torch.cuda.empty_cache()
 
     if args.paged:
         model.enable_paged_kv(num_pages=(args.prompt + args.warmup + args.steps + 2) // 64 + 2)
     eng = InferenceEngine(model=model)
-    prompt = torch.randint(0, cfg["vocab_size"], (args.prompt,), generator=torch.Generator().manual_seed(1 + rank))
+    prompt = torch.randint(0, cfg["vocab_size"], (args.prompt,), generator=torch.Generator().manual_seed(1 if tp else 1 + rank))
     eng.prepare_engine(prompt, temp=0)
     gen = eng.generate_step(prompt)
     next(gen)  # prefill + first token
@@ -192,7 +219,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
-    tokens_per_s = world * args.steps / elapsed
+    tokens_per_s = (1 if tp else world) * args.steps / elapsed  # TP: all ranks decode ONE sequence together
     T_mid = args.prompt + 1 + args.warmup + args.steps // 2  # context length in the middle of the timed region
     step_bytes = model.step_bytes(T_mid, True)
     step_gbps = step_bytes * (args.steps / elapsed) / 1e9  # per GPU
@@ -222,14 +249,17 @@ def main():
     if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
         traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
 
+    shape_cfg = full_cfg if tp else cfg
     out = {
-        "metric": "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s",
+        "metric": (f"decode tokens/sec, Llama-3-{args.model.upper()} int4 g=64 batch=1, TP={tp}; achieved HBM GB/s per GPU" if tp else
+                   "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s"),
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": "bf16", "dtype_detail": ("bf16 weights" if args.dense else f"uint{args.bits} g=64 weights") + " x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
-        "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{cfg['hidden_size']} L{n_l} {cfg['num_attention_heads']}/{cfg['num_key_value_heads']} heads I{cfg['intermediate_size']} V{cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
+        "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{shape_cfg['hidden_size']} L{n_l} {shape_cfg['num_attention_heads']}/{shape_cfg['num_key_value_heads']} heads I{shape_cfg['intermediate_size']} V{shape_cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
-                   "parallelism": "replicas" if world > 1 else "single GPU", "launches_per_step": 3 + 5 * n_l,
+                   "parallelism": f"TP={tp}" if tp else ("replicas" if world > 1 else "single GPU"),
+                   "launches_per_step": (4 + 7 * n_l) if tp else 3 + 5 * n_l,
                    "hipgraph": True, "kv": "paged (64-token pages)" if args.paged else "contiguous"},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,
@@ -248,6 +278,12 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                    "sample": "skipped (timed on rank 0 at N=1 only)"}
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        err = comm.status()
+        del eng, gen, model
+        comm.close()
+        if err:
+            raise SystemExit(f"tensor-parallel communicator gave up waiting for a peer (epoch {err})")
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and out.get("parity") is not None and not out["parity"].get("ok", False):
