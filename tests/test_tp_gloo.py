@@ -115,3 +115,71 @@ def test_shard_plan_rejects_misaligned_splits():
         tp.shard_config(CFG, 4)                                   # 2 kv heads cannot be split 4 ways
     c = tp.shard_config(CFG, 2)
     assert (c["num_attention_heads"], c["num_key_value_heads"], c["intermediate_size"], c["tp_vocab_shard"]) == (2, 1, 256, 256)
+
+
+def _fused_tail_f32(stats):
+    """Restatement of k_tp_tail_stats' merge (csrc/tp_comm.hip): fp32 arithmetic, ranks visited in order."""
+    gm = np.array([s[0] for s in stats], dtype=np.float32)
+    GM = gm.max()
+    S = np.float32(0.0)
+    tok = 2 ** 31 - 1
+    for m, se, arg in stats:
+        S = np.float32(S + np.float32(se) * np.exp(np.float32(m) - GM, dtype=np.float32))
+        if np.float32(m) == GM:
+            tok = min(tok, int(arg))
+    return float(GM + np.log(S, dtype=np.float32)), tok
+
+
+def _tail_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from proxy_inference_engine_amd import tp
+        grp = tp.TPGroup()
+        rng = np.random.default_rng(11)
+        logits = po.round_T(rng.standard_normal(CFG["vocab_size"]) * 3.0, DT).astype(np.float32)
+        logits[[17, 300]] = logits.max() + 1.0          # the maximum appears on BOTH shards: the lowest vocabulary index must win
+        vs = CFG["vocab_size"] // world
+        mine = logits[rank * vs:(rank + 1) * vs]
+        m = float(mine.max())
+        triple = (m, float(np.exp(mine - np.float32(m), dtype=np.float32).sum(dtype=np.float32)), int(mine.argmax()) + rank * vs)
+        lse64, tok64 = grp.merge_logit_stats(triple[0], triple[1], triple[2] - rank * vs, rank * vs)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, triple)       # what the device kernel's push / pull delivers: every rank's triple, rank order
+        lse32, tok32 = _fused_tail_f32(gathered)
+        assert tok32 == tok64 == 17, (tok32, tok64)
+        assert abs(lse32 - lse64) <= 4e-6 * max(1.0, abs(lse64))
+        ret[rank] = "ok"
+    except Exception as e:
+        ret[rank] = f"{type(e).__name__}: {e}"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_fused_tail_merge_matches_functional_merge():
+    """The fused step's vocabulary-parallel tail merges (max, sum exp, argmax) triples in fp32 on the device; same token (ties:
+    lowest index across shards) and log-sum-exp as TPGroup.merge_logit_stats' float64 host merge."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_tail_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_70b_shards_fit_the_fused_decoder(world):
+    """BASELINE.json configs[4]: every TP degree of Llama-3-70B yields a shard the fused decoder accepts (pie_decoder_create's shape
+    rules, the o_proj attention-merge prologue's K limit, the per-wave run limit of the GEMV, the communicator's slot size)."""
+    from proxy_inference_engine_amd import tp
+    from proxy_inference_engine_amd.models.utils import LLAMA3_70B
+    c = tp.shard_config(LLAMA3_70B, world)
+    nh, nkv, D, I, H = c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"], c["intermediate_size"], c["hidden_size"]
+    v_loc = c["tp_vocab_shard"]
+    assert (nh, nkv, I, v_loc) == (64 // world, 8 // world, 28672 // world, 128256 // world)
+    assert H % 64 == 0 and I % 64 == 0 and D in (64, 128) and nh % nkv == 0 and v_loc % 2 == 0
+    assert nh * D <= 2 * 8 * 8 * 64          # PRO_ATTN stages the merged attention vector with <= 2 pieces per thread
+    assert H <= 1 << 20                       # pie_comm_create's max_elems bound
+    for n_rows in (nh * D + 2 * nkv * D, H, 2 * I, v_loc):
+        assert (n_rows // 2 + 2047) // 2048 <= 64, n_rows   # GEMV_MAX_RUN row pairs per wave on 2048 waves
