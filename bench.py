@@ -245,7 +245,7 @@ def main():
     k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
 
     traffic = None
-    tf = ROOT / "profiles" / "r01_traffic.json"  # PMC passes (separate rocprofv3 runs), see profiles/README.md
+    tf = ROOT / "profiles" / "r02_traffic.json"  # PMC passes over the product step (tools/step_bench under rocprofv3 --pmc), see profiles/README.md
     if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
         traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
 

@@ -4,7 +4,7 @@
 // pie_quantize_w4g64 / pie_repack_w4g64), then replays pie_decoder_step.  Because it is a plain binary it can sit directly
 // after `rocprofv3 ... --` (kernel trace or --pmc passes on the PRODUCT step; a Python host crashed the profiler in round 1).
 //   step_bench [--model 8b|70b|tiny] [--layers N] [--steps K] [--warmup W] [--ctx P] [--cap C] [--mode mega|launch|both]
-//              [--graph 0|1] [--check N]
+//              [--graph 0|1] [--check N] [--prefill N [--prefill-reps R]]
 // --check N: runs N steps with the launch sequence and N with the persistent launch from the same state and compares
 //            logits / logprobs / tokens / hidden state bit for bit.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/step_bench.hip -Iinclude -Lproxy_inference_engine_amd/lib -lpie_hip \
@@ -90,7 +90,7 @@ struct Quant {
 
 int main(int argc, char **argv) {
     Geo g = {4096, 14336, 32, 8, 128, 128256, 32};
-    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1, kv_splits = 0;
+    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1, kv_splits = 0, prefill = 0, prefill_reps = 3, no_mega = 0, sync_every = 0;
     std::string mode = "both";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -109,7 +109,13 @@ int main(int argc, char **argv) {
         else if (a == "--graph") graph = atoi(next());
         else if (a == "--check") check = atoi(next());
         else if (a == "--kv-splits") kv_splits = atoi(next());
+        else if (a == "--sync-every") sync_every = atoi(next());       // under rocprofv3: bound the dispatches in flight (thousands of queued
+                                                                       // graph nodes overran the profiler: SIGSEGV in its interception)
+        else if (a == "--no-mega") no_mega = 1;                        // never touch the persistent-launch machinery (no allocation, no attribute call)
+        else if (a == "--prefill") prefill = atoi(next());            // time pie_decoder_prefill of N tokens instead of decode steps
+        else if (a == "--prefill-reps") prefill_reps = atoi(next());
     }
+    if (prefill > 0 && cap < prefill) cap = (prefill + 255) / 256 * 256;
     if (ctx + steps + warmup + 2 > cap) steps = cap - ctx - warmup - 2 > 1 ? cap - ctx - warmup - 2 : 1;
     char name[64];
     int n_cus = 0;
@@ -181,8 +187,8 @@ int main(int argc, char **argv) {
     PK(pie_decoder_bind_outputs(dec, logits, logprobs, token, hidden, hist, 65536));
     CK(hipDeviceSynchronize());
     const int flags = PIE_STEP_LOGITS | (graph ? PIE_STEP_GRAPH : 0);
-    PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 1));
-    printf("persistent launch %s for this configuration (kv_splits %d, capacity %d)\n", pie_debug_buffer(dec, 6) ? "AVAILABLE" : "NOT available: both modes run the launch sequence", kv_splits, cap);
+    if (!no_mega) PK(pie_decoder_configure(dec, PIE_OPT_MEGA, 1));
+    if (!no_mega) printf("persistent launch %s for this configuration (kv_splits %d, capacity %d)\n", pie_debug_buffer(dec, 6) ? "AVAILABLE" : "NOT available: both modes run the launch sequence", kv_splits, cap);
 
     struct Snap {
         std::vector<u16> logits, hidden;
@@ -190,7 +196,7 @@ int main(int argc, char **argv) {
         int token;
     };
     auto run = [&](int use_mega, int n, std::vector<Snap> *snaps) -> double {
-        PK(pie_decoder_configure(dec, PIE_OPT_MEGA, use_mega));
+        if (!no_mega) PK(pie_decoder_configure(dec, PIE_OPT_MEGA, use_mega));
         PK(pie_decoder_set_state(dec, ctx, 1, st));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
@@ -213,7 +219,10 @@ int main(int argc, char **argv) {
         CK(hipStreamSynchronize(st));
         PK(pie_decoder_set_state(dec, ctx, 1, st));
         CK(hipEventRecord(e0, st));
-        for (int i = 0; i < n; ++i) PK(pie_decoder_step(dec, flags, st));
+        for (int i = 0; i < n; ++i) {
+            PK(pie_decoder_step(dec, flags, st));
+            if (sync_every > 0 && (i + 1) % sync_every == 0) CK(hipStreamSynchronize(st));
+        }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -225,6 +234,27 @@ int main(int argc, char **argv) {
     };
 
     int rc = 0;
+    if (prefill > 0) {  // the batched prompt path (many-row int4 MFMA GEMM, causal attention): for rocprofv3 --kernel-trace / --pmc passes
+        std::vector<int32_t> ids(prefill);
+        for (int i = 0; i < prefill; ++i) ids[i] = (int32_t)((1315423911u * (unsigned)(i + 1)) % (unsigned)g.V);
+        int32_t *ids_d = (int32_t *)dmalloc((size_t)prefill * 4);
+        CK(hipMemcpy(ids_d, ids.data(), (size_t)prefill * 4, hipMemcpyHostToDevice));
+        for (int r = 0; r < prefill_reps + 1; ++r) {  // first pass: one-off tile repack of the weights
+            PK(pie_decoder_set_state(dec, 0, -1, st));
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0, st));
+            PK(pie_decoder_prefill(dec, ids_d, prefill, nullptr, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("prefill of %d tokens, pass %d%s: %8.3f ms  (%.0f tokens/s)\n", prefill, r, r ? "" : " (includes the one-off W4M repack)", ms, prefill / ms * 1e3);
+        }
+        PK(pie_decoder_destroy(dec));
+        return 0;
+    }
     if (check > 0) {
         std::vector<Snap> a, b;
         run(0, check, &a);
