@@ -88,6 +88,24 @@ __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
     return make_uint4(w4m_pack<T>(dq(c0), dq(c1)), w4m_pack<T>(dq(c2), dq(c3)), w4m_pack<T>(dq(c4), dq(c5)), w4m_pack<T>(dq(c6), dq(c7)));
 }
 
+// The same conversion with the scale and the bias held as explicit register PAIRS {s, s}, {b, b} (opaque to the optimiser): with
+// scalars the compiler forms v_pk_fma_f32 with an op_sel broadcast from whatever pair the scalar happens to sit in, and when the
+// neighbouring register is the destination of a load still in flight the instruction waits for that load (seen in k_w4l2_gemm).
+typedef float w4m_f32x2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ uint4 w4m_dequant_pk(u32 word, w4m_f32x2 s2, w4m_f32x2 b2) {
+    // pin the word to THIS point of the step sequence: the masks below are plain VALU ops that the scheduler otherwise hoists to
+    // right behind the load of the word, three steps earlier, where they wait for it (volatile statements keep their order)
+    asm volatile("" : "+v"(word));
+    u32 e = word & 0x0F0F0F0Fu, o = (word >> 4) & 0x0F0F0F0Fu;  // bytes: codes (0, 4, 1, 5) and (2, 6, 3, 7)
+    asm volatile("" : "+v"(e), "+v"(o));
+    const w4m_f32x2 q01 = {(float)(e & 0xFFu), (float)((e >> 16) & 0xFFu)}, q45 = {(float)((e >> 8) & 0xFFu), (float)(e >> 24)};
+    const w4m_f32x2 q23 = {(float)(o & 0xFFu), (float)((o >> 16) & 0xFFu)}, q67 = {(float)((o >> 8) & 0xFFu), (float)(o >> 24)};
+    const w4m_f32x2 r01 = __builtin_elementwise_fma(s2, q01, b2), r23 = __builtin_elementwise_fma(s2, q23, b2);
+    const w4m_f32x2 r45 = __builtin_elementwise_fma(s2, q45, b2), r67 = __builtin_elementwise_fma(s2, q67, b2);
+    return make_uint4(w4m_pack<T>(r01.x, r01.y), w4m_pack<T>(r23.x, r23.y), w4m_pack<T>(r45.x, r45.y), w4m_pack<T>(r67.x, r67.y));
+}
+
 // Sum of the 8 waves' partial tiles (fixed order), then either the T result or -- K split over two workgroups (gridDim.y = 2:
 // the N = 4096 matrices have only 128 strips, half the chip) -- an fp32 atomic add into a zeroed [M, N] buffer that the consumer
 // kernel rounds and re-zeroes.  Two addends commute exactly, so the sum does not depend on which workgroup arrives first.
@@ -548,6 +566,185 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4l_gemm(const char *w4m, co
     }
 }
 
+// ---------------------------------------------------------------- the 256-row form: ONE wave per SIMD with the whole register file
+// k_w4l_gemm above keeps 8 waves of 256 registers; each reads a B fragment (x) from LDS per MFMA and stages x through registers.
+// Measured ablations (scripts/bench_w4l.py, M = 4096): that x path costs 18 % of the kernel.  This form halves it and takes it off
+// the VALU / VGPR path:  4 waves x 512 registers (256 accumulators in AGPRs), wave tile = 256 rows x 64 columns (TWO W strips), so
+// one B fragment feeds two MFMAs; the x tile [256 rows x 64 k] goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
+// ds_write), its 128-byte rows XOR-swizzled on the SOURCE side (chunk c of row r lands in slot c ^ ((r >> 1) & 7): the reads of a
+// ds_read_b128 lane group then cover all 64 banks; the DMA's destination is lane-linear, so the permutation has to be applied to the
+// per-lane global address).  Everything a step issues (the next x tile, the weight tiles two steps ahead) has the whole step --
+// 64 MFMAs = 2048 matrix-pipe cycles -- to land before the step's closing barrier.
+#ifndef W4L2_SPREAD
+#define W4L2_SPREAD 4  // first MFMA iteration of a step after which its memory issue starts (0 = all of it in front of the MFMAs: 2-3 % slower)
+#endif
+#ifndef W4L2_ABL
+#define W4L2_ABL 0  // developer ablation mask (0 in the product): 1 no conversion, 2 no barrier, 4 no x DMA, 8 no LDS fragment reads, 16 no weight loads
+#endif
+typedef __attribute__((address_space(3))) void w4l_lds_void;
+typedef __attribute__((address_space(1))) const void w4l_glb_void;
+
+template <class T>
+__global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *part) {
+    __shared__ __attribute__((aligned(1024))) char s_x[2][256 * 128];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
+    const int per_z = (all_groups + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int g_lo = blockIdx.z * per_z, g_hi = min(all_groups, g_lo + per_z);
+    const int groups = g_hi - g_lo;  // >= 1 (launcher)
+    const int m0 = blockIdx.y * 256;
+    const int rows = M - m0 < 256 ? M - m0 : 256;
+    const int nt0 = (blockIdx.x * 4 + wave) * 2;  // this wave's two strips: nt0, nt0 + 1
+    const int n_strips = N >> 5;
+    const bool has0 = nt0 < n_strips, has1 = nt0 + 1 < n_strips;  // wave-uniform; idle waves still stage x and join the barriers
+    const char *strip0 = w4m + ((size_t)(has0 ? nt0 : 0) * all_groups + g_lo) * W4M_TILE_BYTES;
+    const char *strip1 = w4m + ((size_t)(has1 ? nt0 + 1 : 0) * all_groups + g_lo) * W4M_TILE_BYTES;
+
+    // x staging: wave w moves rows [64 w, 64 w + 64) of the tile with 8 DMA instructions of 8 rows each
+    const u16 *xsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 64 * wave + 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = r < rows ? r : rows - 1;  // ragged tile: rows past the end repeat the last one (never stored)
+        xsrc[j] = x + (size_t)(m0 + rr) * K + (size_t)g_lo * 64 + c * 8;
+    }
+    // The DMA is issued through an asm statement on purpose: issued through __builtin_amdgcn_global_load_lds the compiler knows it
+    // writes LDS, cannot tell the two tile buffers apart, and puts s_waitcnt vmcnt(0) in front of the step's first ds_read -- the
+    // transfer it was meant to overlap.  (M0 = LDS destination base of the wave; the compiler reserves M0, so it is saved and
+    // restored inside the statement.)  The step's closing barrier is preceded by an explicit vmcnt(0).
+    auto x_issue1 = [&](int g, int buf, int j) {
+        const u16 *src = xsrc[j] + (size_t)g * 64;
+        const unsigned dst = (unsigned)(size_t)(w4l_lds_void *)(s_x[0]) + (unsigned)(buf * (256 * 128) + (64 * wave + 8 * j) * 128);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+    };
+    auto x_issue = [&](int g, int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x_issue1(g, buf, j);
+    };
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    // raw weight tiles: tile j lives in ring slot j % 4 from its issue (step j - 4) to its conversion (during step j - 1)
+    uint4 cw[4][2];  // [slot][strip]
+    u32 sb[4][2];
+    auto w_issue = [&](int slot, int g) {
+        const size_t o = (size_t)(g < groups ? g : groups - 1) * W4M_TILE_BYTES;
+        const nt_u32x4 c0 = *(reinterpret_cast<const nt_u32x4 *>(strip0 + o) + lane);
+        const nt_u32x4 c1 = *(reinterpret_cast<const nt_u32x4 *>(strip1 + o) + lane);
+        cw[slot][0] = make_uint4(c0.x, c0.y, c0.z, c0.w), cw[slot][1] = make_uint4(c1.x, c1.y, c1.z, c1.w);
+        sb[slot][0] = *(reinterpret_cast<const u32 *>(strip0 + o + 1024) + n);
+        sb[slot][1] = *(reinterpret_cast<const u32 *>(strip1 + o + 1024) + n);
+    };
+    x_issue(0, 0);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w_issue(d, d);
+    // an (empty) statement with an AGPR operand: without any, hipcc marks the kernel "no AGPRs needed" and may select the VGPR form of
+    // the MFMAs, using the AGPR half of the file as a spill area
+    asm volatile("" : : "a"(0.0f));
+
+    f32x16_t acc[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s2][mi][i] = 0.0f;
+    uint4 af[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const float s0 = lo_f32<T>(sb[0][s2]), b0 = hi_f32<T>(sb[0][s2]);
+        const u32 w0[4] = {cw[0][s2].x, cw[0][s2].y, cw[0][s2].z, cw[0][s2].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[s2][k] = w4m_dequant<T>(w0[k], s0, b0);
+    }
+    // B fragment of (row block mi, k-step k): row 32 mi + n, 16-byte chunk 2 k + kh, swizzled by the row
+    int xoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xoff[k] = n * 128 + (((2 * k + kh) ^ ((n >> 1) & 7)) << 4);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of tile 0 has landed
+    __syncthreads();
+
+    // groups % 4 == 0 (launcher): four copies of the step with static ring slots and tile buffers and NO control flow around the
+    // accumulators (with a per-step `if (g < groups)` the 256 accumulators went through phi copies and 180 registers spilled).
+    // Queue order per step: [x DMA of tile g + 1][raw weight tile g + 4]; the closing wait leaves only that weight tile in flight.
+    for (int base = 0; base < groups; base += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int g = base + d;
+#if !W4L2_SPREAD
+            if (!(W4L2_ABL & 4)) x_issue(g + 1 < groups ? g + 1 : g, (d + 1) & 1);  // that buffer was last read in step g - 1, closed by its barrier (last step: a harmless re-read)
+            if (!(W4L2_ABL & 16)) w_issue(d, g + 4);            // slot d held tile g, converted during step g - 1
+#endif
+            const int dn = (d + 1) & 3;                         // slot of tile g + 1: converted during this step
+            w4m_f32x2 sc[2], bi[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float sv = lo_f32<T>(sb[dn][s2]), bv = hi_f32<T>(sb[dn][s2]);
+                sc[s2] = (w4m_f32x2){sv, sv}, bi[s2] = (w4m_f32x2){bv, bv};
+                asm volatile("" : "+v"(sc[s2]), "+v"(bi[s2]));
+            }
+            const char *xb = s_x[d & 1];
+            uint4 afn[2][4];
+            uint4 bq[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const uint4 *>(xb + (t % 8) * 4096 + xoff[t / 8]);
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const int k = t / 8, mi = t % 8;
+                acc[0][mi] = MfmaT<T>::run(af[0][k], bq[t & 3], acc[0][mi]);
+                acc[1][mi] = MfmaT<T>::run(af[1][k], bq[t & 3], acc[1][mi]);
+#if W4L2_SPREAD
+                // the step's memory issue rides between the MFMAs instead of in front of them (each DMA is 5 scalar instructions + the
+                // load: at the top of the step the matrix pipe idles while they issue): x tile g + 1 one piece per iteration, then
+                // the raw weight tile g + 4 -- the queue order [DMA x 8][weights x 4] the closing vmcnt(4) relies on is unchanged
+                if (t >= W4L2_SPREAD && t < W4L2_SPREAD + 8 && !(W4L2_ABL & 4)) x_issue1(g + 1 < groups ? g + 1 : g, (d + 1) & 1, t - W4L2_SPREAD);
+                if (t == W4L2_SPREAD + 8 && !(W4L2_ABL & 16)) w_issue(d, g + 4);
+#endif
+                if (t + 4 < 32 && !(W4L2_ABL & 8)) bq[t & 3] = *reinterpret_cast<const uint4 *>(xb + ((t + 4) % 8) * 4096 + xoff[(t + 4) / 8]);
+                if ((t & 3) == 0) {  // one word of the next tiles per 4 B fragments: 8 conversions in the shadow of 64 MFMAs
+                    const int q = t >> 2, s2 = q & 1, kk = q >> 1;
+                    const u32 wn[4] = {cw[dn][s2].x, cw[dn][s2].y, cw[dn][s2].z, cw[dn][s2].w};
+                    afn[s2][kk] = (W4L2_ABL & 1) ? af[s2][kk] : w4m_dequant_pk<T>(wn[kk], sc[s2], bi[s2]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) af[s2][k] = afn[s2][k];
+            __builtin_amdgcn_s_waitcnt(0x0F70 | 4);  // vmcnt(4): everything but the weight tile just issued -- i.e. the DMA of tile g + 1 -- has landed
+            if (!(W4L2_ABL & 2)) __syncthreads();     // ... everyone's has, and everyone is done reading buffer d & 1
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the clamped look-ahead loads of the last steps
+    // accumulator register i of lane l <-> output column 32 nt + (i & 3) + 8 (i >> 2) + 4 kh, row m0 + 32 mi + (l & 31)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (!(s2 ? has1 : has0)) continue;
+        const int nt = nt0 + s2;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = 32 * mi + n;
+            if (m < rows) {
+                const size_t o = (size_t)(m0 + m) * N + 32 * nt + 4 * kh;
+                if (part) {
+                    float *pr = part + (size_t)blockIdx.z * M * N + o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4 *>(pr + 8 * q) = make_float4(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1], acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<uint2 *>(y + o + 8 * q) =
+                            make_uint2(w4m_pack<T>(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1]), w4m_pack<T>(acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]));
+                }
+            }
+        }
+    }
+}
+
 // y = T(sum over z, in z order, of the fp32 partial tiles)
 template <class T>
 __global__ void __launch_bounds__(256) k_w4l_reduce(const float *part, int S, size_t MN, u16 *y) {
@@ -568,7 +765,11 @@ int w4l_splits(int M, int N, int K) {
     int s = wgs >= 192 ? 1 : (256 + wgs - 1) / wgs;
     const int max_s = (K >> 6) / 8 > 0 ? (K >> 6) / 8 : 1;
     s = s > max_s ? max_s : s;
-    return s > 16 ? 16 : s;
+    s = s > 16 ? 16 : s;
+    if (M > 128)  // 256-row tiles: k_w4l2_gemm's unrolled step ring wants a multiple of 4 K groups per split -- take the nearest split that gives one
+        for (int t = s; t >= 1; --t)
+            if ((K >> 6) % (4 * t) == 0) return t;
+    return s;
 }
 size_t w4l_workspace_bytes(int M, int N, int K) {
     const int s = w4l_splits(M, N, K);
@@ -583,6 +784,25 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     const int S = w4l_splits(M, N, K);
     PIE_REQUIRE(S == 1 || workspace, PIE_E_ARG, "W4 GEMM: this shape splits K and needs its workspace");
     const int mt = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+    static const bool v2 = [] {
+        const char *e = getenv("PIE_W4L2");  // A/B switch: 0 = the 8-wave register-staged form for 256-row tiles too
+        return !(e && e[0] == '0');
+    }();
+    if (mt == 256 && v2 && ((K >> 6) % (4 * S)) == 0) {  // the unrolled step ring needs a multiple of 4 K groups per split
+        float *part2 = S > 1 ? (float *)workspace : nullptr;
+        const dim3 g2((unsigned)((N / 32 + 7) / 8), (unsigned)((M + 255) / 256), (unsigned)S);
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l2_gemm<BF16>, g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
+        else hipLaunchKernelGGL(k_w4l2_gemm<F16>, g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
+        PIE_LAUNCH_CHECK();
+        if (S > 1) {
+            const size_t MN = (size_t)M * N;
+            const dim3 rg((unsigned)((MN / 4 + 255) / 256));
+            if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l_reduce<BF16>, rg, dim3(256), 0, st, part2, S, MN, (u16 *)y);
+            else hipLaunchKernelGGL(k_w4l_reduce<F16>, rg, dim3(256), 0, st, part2, S, MN, (u16 *)y);
+            PIE_LAUNCH_CHECK();
+        }
+        return PIE_OK;
+    }
     // blockIdx.x = column block (fastest): the workgroups that share an x tile are dispatched together and read it through every XCD's L2
     const dim3 grid((unsigned)((N / 32 + W4M_WAVES - 1) / W4M_WAVES), (unsigned)((M + mt - 1) / mt), (unsigned)S), block(W4M_WAVES * 64);
     float *part = S > 1 ? (float *)workspace : nullptr;

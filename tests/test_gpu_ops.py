@@ -339,11 +339,13 @@ def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
-@pytest.mark.parametrize("M,N,K", [(33, 64, 64), (64, 256, 512), (100, 96, 4096), (256, 4096, 1408), (300, 6144, 4096), (513, 1024, 14336), (1000, 288, 192)])
+@pytest.mark.parametrize("M,N,K", [(33, 64, 64), (64, 256, 512), (100, 96, 4096), (256, 4096, 1408), (300, 6144, 4096), (513, 1024, 14336), (1000, 288, 192),
+                                   (512, 2048, 4096), (1300, 8192, 1024), (257, 96, 256)])
 def test_many_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
     """pie_qgemm_w4m beyond 32 rows: the 256-row x 256-column MFMA tile kernel (k_w4l_gemm) that processes prompts -- partial row
     tiles (33, 100, 300, 513, 1000), column counts that leave waves of the last workgroup idle (64, 96, 288), a ragged W4S slice
-    (K = 1408, 192) -- against the oracle's many-row regime of mx.quantized_matmul (weights dequantised to T first)."""
+    (K = 1408, 192), and from 129 rows with K / 64 a multiple of 4 the one-wave-per-SIMD form k_w4l2_gemm (LDS-DMA staged x, AGPR
+    accumulators; with and without a K split, ragged last row tile, idle strips) -- against the oracle's many-row regime of mx.quantized_matmul (weights dequantised to T first)."""
     rng = np.random.default_rng(M * 11 + N)
     w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
     wq, sc, bi = po.quantize(w, 64, 4, dt)
