@@ -176,6 +176,10 @@ typedef struct {
     /* optional Linear biases (attention_bias / mlp_bias, models/llama/language.py:42-53,117-126), T, NULL = none;
        bqkv in the packed q|k|v row order (pie_qkv_row_map), bgateup interleaved (pie_gateup_row_map) */
     const void *bqkv, *bo, *bgateup, *bdown;
+    /* Per-matrix weight format: 0 = the decoder's weight_format, else PIE_W_* + 1.  The reference decides quantisation PER MODULE
+       (models/utils.py:99-109: quantised iff the checkpoint holds "{path}.scales" and the input width is a multiple of 64), so a
+       checkpoint may mix int4 and 16-bit Linears; the fused groups (q|k|v, gate|up) must be uniform inside. */
+    int fmt_qkv, fmt_o, fmt_gateup, fmt_down;
 } pie_layer_weights;
 
 typedef struct {
@@ -184,6 +188,8 @@ typedef struct {
     const void *final_norm;              /* T [hidden] */
     const void *lm_head;                 /* W4S [vocab, hidden] (of embed_tokens when tied) */
     const float *rope_freqs;             /* fp32 [head_dim/2], Llama3RoPE._freqs (models/llama/utils.py:39) */
+    int fmt_embed, fmt_lm_head;          /* 0 = the decoder's weight_format, else PIE_W_* + 1 (see pie_layer_weights); a dense embedding:
+                                            embed_codes is the T [vocab, hidden] table, scales / biases NULL */
 } pie_global_weights;
 
 /* Host helpers producing the row maps the decoder's fused epilogues assume (host int32 arrays). */

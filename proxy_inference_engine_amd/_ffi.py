@@ -46,12 +46,14 @@ class pie_decoder_config(C.Structure):
 class pie_layer_weights(C.Structure):
     _fields_ = [("attn_norm", C.c_void_p), ("mlp_norm", C.c_void_p), ("wqkv", C.c_void_p), ("wo", C.c_void_p),
                 ("wgateup", C.c_void_p), ("wdown", C.c_void_p),
-                ("bqkv", C.c_void_p), ("bo", C.c_void_p), ("bgateup", C.c_void_p), ("bdown", C.c_void_p)]
+                ("bqkv", C.c_void_p), ("bo", C.c_void_p), ("bgateup", C.c_void_p), ("bdown", C.c_void_p),
+                ("fmt_qkv", C.c_int), ("fmt_o", C.c_int), ("fmt_gateup", C.c_int), ("fmt_down", C.c_int)]
 
 
 class pie_global_weights(C.Structure):
     _fields_ = [("embed_codes", C.c_void_p), ("embed_scales", C.c_void_p), ("embed_biases", C.c_void_p),
-                ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_freqs", C.c_void_p)]
+                ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_freqs", C.c_void_p),
+                ("fmt_embed", C.c_int), ("fmt_lm_head", C.c_int)]
 
 
 def lib_path() -> Path:

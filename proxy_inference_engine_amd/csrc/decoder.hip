@@ -75,19 +75,26 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
     const pie_layer_weights &w = d->layers[li];
-    const bool dense = c.weight_format == PIE_W_DENSE;
-    const bool int8 = c.weight_format == PIE_W_INT8_G64;
-    const int fmt = dense ? FMT_W16S : (int8 ? FMT_W8S : FMT_W4S);
+    auto gfmt = [d](const void *m) {  // streaming format of one matrix (per-module quantisation: models/utils.py:99-109)
+        const int f = d->mat_fmt(m);
+        return f == PIE_W_DENSE ? FMT_W16S : (f == PIE_W_INT8_G64 ? FMT_W8S : FMT_W4S);
+    };
+    auto mat_bytes = [d](const void *m, int n, int k) {
+        const int f = d->mat_fmt(m);
+        return f == PIE_W_DENSE ? pie_w16s_bytes(n, k) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(n, k) : pie_w4s_bytes(n, k));
+    };
+    const int efmt = d->mat_fmt(d->glob.embed_codes);
+    const bool dense_embed = efmt == PIE_W_DENSE;
     switch (which) {
         case PIE_K_EMBED:  // h = embed_tokens(inputs)  (language.py:176)
-            if (dense) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, d->embed_vocab(), H, c.dtype, d->h, st);
+            if (dense_embed) return pie_embedding_dense(token_ptr, 1, d->glob.embed_codes, d->embed_vocab(), H, c.dtype, d->h, st);
             return embedding_launch(token_ptr, 1, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, d->embed_vocab(), H, c.dtype, d->h,
-                                    d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st, int8 ? 8 : 4);
+                                    d->glob.rope_freqs, d->state, d->rope_cs, D / 2, st, efmt == PIE_W_INT8_G64 ? 8 : 4);
         case PIE_K_QKV: {  // q,k,v = proj(input_layernorm(x)); rope(offset=cache.offset); cache.update_and_fetch  (language.py:83-95)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
+            a.fmt = gfmt(w.wqkv), a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
-            a.freqs = d->glob.rope_freqs, a.rope_cs = dense ? nullptr : d->rope_cs /* filled by the int4 embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
+            a.freqs = d->glob.rope_freqs, a.rope_cs = dense_embed ? nullptr : d->rope_cs /* filled by the quantised embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             a.block_table = d->block_table, a.n_pages = d->n_pages;
@@ -102,13 +109,13 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
             // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
             a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
-            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = dense ? pie_w16s_bytes(H, QD) : (int8 ? pie_w8s_bytes(H, QD) : pie_w4s_bytes(H, QD));
+            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = mat_bytes(w.wo, H, QD);
             a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h, a.lin_bias = (const u16 *)w.bo;
+            a.fmt = gfmt(w.wo), a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h, a.lin_bias = (const u16 *)w.bo;
             // tensor-parallel shard (row-parallel Linear over the local heads): un-rounded fp32 partial, summed over the ranks,
             // THEN the Linear's one rounding and the residual add
             const int epi = d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL;
@@ -120,20 +127,20 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
+            a.fmt = gfmt(w.wgateup), a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
             a.y = d->act, a.lin_bias = (const u16 *)w.bgateup;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
         }
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
+            a.fmt = gfmt(w.wdown), a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
             a.y32 = d->tp_part;
             const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
         case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials
             GemvArgs a = {};
-            a.fmt = fmt, a.w = (const char *)d->glob.lm_head, a.K = H, a.N = c.vocab, a.x = d->h, a.norm_w = (const u16 *)d->glob.final_norm, a.eps = c.rms_eps;
+            a.fmt = gfmt(d->glob.lm_head), a.w = (const char *)d->glob.lm_head, a.K = H, a.N = c.vocab, a.x = d->h, a.norm_w = (const u16 *)d->glob.final_norm, a.eps = c.rms_eps;
             a.y = logits_dst, a.stats = d->stats;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_LOGITS, a, 1, st);
         }
@@ -253,6 +260,15 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
                 PIE_E_ALIGN, "pie_decoder_set_layer: W4S buffers need 256-byte, norm weights 16-byte alignment");
     PIE_REQUIRE(!d->tp() || (!w->bo && !w->bdown), PIE_E_ARG,
                 "pie_decoder_set_layer: o_proj / down_proj biases are not supported on a tensor-parallel shard (they would be added once per rank)");
+    {
+        const int f[4] = {w->fmt_qkv, w->fmt_o, w->fmt_gateup, w->fmt_down};
+        const void *m[4] = {w->wqkv, w->wo, w->wgateup, w->wdown};
+        for (int i = 0; i < 4; ++i) {
+            PIE_REQUIRE(f[i] >= 0 && f[i] <= PIE_W_INT8_G64 + 1, PIE_E_ARG, "pie_decoder_set_layer: unknown per-matrix weight format");
+            if (f[i]) d->fmt_map[m[i]] = f[i] - 1;
+            else d->fmt_map.erase(m[i]);
+        }
+    }
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
     prefill_free(d);  // resident T copies of the previous weights are stale
@@ -264,8 +280,14 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
 int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w) {
     PIE_REQUIRE(d && w, PIE_E_ARG, "pie_decoder_set_globals: null pointer");
     PIE_REQUIRE(w->embed_codes && w->final_norm && w->lm_head && w->rope_freqs, PIE_E_ARG, "pie_decoder_set_globals: null weight");
-    PIE_REQUIRE(d->cfg.weight_format == PIE_W_DENSE || (w->embed_scales && w->embed_biases), PIE_E_ARG,
-                "pie_decoder_set_globals: an int4 embedding needs scales and biases");
+    PIE_REQUIRE(w->fmt_embed >= 0 && w->fmt_embed <= PIE_W_INT8_G64 + 1 && w->fmt_lm_head >= 0 && w->fmt_lm_head <= PIE_W_INT8_G64 + 1, PIE_E_ARG,
+                "pie_decoder_set_globals: unknown per-matrix weight format");
+    PIE_REQUIRE((w->fmt_embed ? w->fmt_embed - 1 : d->cfg.weight_format) == PIE_W_DENSE || (w->embed_scales && w->embed_biases), PIE_E_ARG,
+                "pie_decoder_set_globals: a quantised embedding needs scales and biases");
+    if (w->fmt_embed) d->fmt_map[w->embed_codes] = w->fmt_embed - 1;
+    else d->fmt_map.erase(w->embed_codes);
+    if (w->fmt_lm_head) d->fmt_map[w->lm_head] = w->fmt_lm_head - 1;
+    else if (w->lm_head != w->embed_codes) d->fmt_map.erase(w->lm_head);
     PIE_REQUIRE(pie_aligned(w->lm_head, 256) && pie_aligned(w->final_norm, 16) && pie_aligned(w->embed_codes, 16), PIE_E_ALIGN,
                 "pie_decoder_set_globals: misaligned weight");
     d->glob = *w;
@@ -476,20 +498,24 @@ int pie_decoder_status(pie_decoder *d, unsigned *error) {
     return mega_status(d, error);
 }
 
+static size_t lin_bytes(const pie_decoder *d, const void *m, size_t n, size_t k) {  // algorithmic bytes of one Linear's weights
+    const int f = d->mat_fmt(m);
+    if (f == PIE_W_DENSE) return n * k * 2;
+    return n * k / (f == PIE_W_INT8_G64 ? 1 : 2) + 2 * (n * k / 64) * 2;  // codes + 16-bit scale and bias per group of 64
+}
+
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T) {
     if (!d) return 0;
     const pie_decoder_config &c = d->cfg;
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
-    const bool dense = c.weight_format == PIE_W_DENSE;
-    const size_t code_div = c.weight_format == PIE_W_INT8_G64 ? 1 : 2;  // codes: 1 B / parameter (int8) or 0.5 (int4)
-    auto lin = [dense, code_div](size_t n, size_t k) { return dense ? n * k * 2 : n * k / code_div + 2 * (n * k / 64) * 2; };
+    const pie_layer_weights &w = d->layers[0];  // per-kernel figure of layer 0 (layers of one checkpoint normally share their formats)
     switch (which) {
-        case PIE_K_QKV: return lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2;
+        case PIE_K_QKV: return lin_bytes(d, w.wqkv, QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2;
         case PIE_K_ATTN: return 2 * KVD * 2 * (size_t)T;
-        case PIE_K_OPROJ: return lin(H, QD);
-        case PIE_K_GATEUP: return lin(2 * I, H) + H * 2;
-        case PIE_K_DOWN: return lin(H, I);
-        case PIE_K_LMHEAD: return lin(c.vocab, H) + H * 2;
+        case PIE_K_OPROJ: return lin_bytes(d, w.wo, H, QD);
+        case PIE_K_GATEUP: return lin_bytes(d, w.wgateup, 2 * I, H) + H * 2;
+        case PIE_K_DOWN: return lin_bytes(d, w.wdown, H, I);
+        case PIE_K_LMHEAD: return lin_bytes(d, d->glob.lm_head, c.vocab, H) + H * 2;
         case PIE_K_TAIL: return (size_t)c.vocab * 4;
         default: return 0;
     }
@@ -500,12 +526,11 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits) {
     const pie_decoder_config &c = d->cfg;
     const size_t H = c.hidden, I = c.inter, QD = (size_t)c.n_heads * c.head_dim, KVD = (size_t)c.n_kv_heads * c.head_dim;
     // int4 codes + 16-bit scale and bias per group of 64 = 0.5625 B / parameter  (SURVEY.md 8d); dense: 2 B / parameter
-    const bool dense = c.weight_format == PIE_W_DENSE;
-    const size_t code_div = c.weight_format == PIE_W_INT8_G64 ? 1 : 2;
-    auto lin = [dense, code_div](size_t n, size_t k) { return dense ? n * k * 2 : n * k / code_div + 2 * (n * k / 64) * 2; };
-    size_t per_layer = lin(QD + 2 * KVD, H) + lin(H, QD) + lin(2 * I, H) + lin(H, I);
-    size_t bytes = (size_t)c.n_layers * (per_layer + 2 * H * 2 /* norm weights */ + 2 * KVD * 2 * (size_t)T /* KV read */ + 2 * KVD * 2 /* KV write */);
-    if (with_logits) bytes += lin(c.vocab, H) + H * 2 + (size_t)c.vocab * 4 /* fp32 logprobs */;
+    size_t bytes = 0;
+    for (const pie_layer_weights &w : d->layers)
+        bytes += lin_bytes(d, w.wqkv, QD + 2 * KVD, H) + lin_bytes(d, w.wo, H, QD) + lin_bytes(d, w.wgateup, 2 * I, H) + lin_bytes(d, w.wdown, H, I) +
+                 2 * H * 2 /* norm weights */ + 2 * KVD * 2 * (size_t)T /* KV read */ + 2 * KVD * 2 /* KV write */;
+    if (with_logits) bytes += lin_bytes(d, d->glob.lm_head, c.vocab, H) + H * 2 + (size_t)c.vocab * 4 /* fp32 logprobs */;
     return bytes;
 }
 

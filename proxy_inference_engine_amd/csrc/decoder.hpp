@@ -1,5 +1,6 @@
 // decoder.hpp -- the decoder object shared by decoder.hip (single-token step) and prefill.hip (batched prompt).
 #pragma once
+#include <unordered_map>
 #include <vector>
 
 #include "attention.hpp"
@@ -45,6 +46,18 @@ struct pie_decoder {
     pie_comm *comm = nullptr;
     float *tp_part = nullptr;  // [hidden] fp32 partial of the row-parallel Linears, [hidden] = log-sum-exp of the step
     bool tp() const { return cfg.tp_world > 1; }
+    // per-matrix weight format (PIE_W_*), keyed by the packed matrix pointer; matrices not listed use cfg.weight_format
+    std::unordered_map<const void *, int> fmt_map;
+    int mat_fmt(const void *packed) const {
+        auto it = fmt_map.find(packed);
+        return it == fmt_map.end() ? cfg.weight_format : it->second;
+    }
+    bool uniform_int4() const {
+        if (cfg.weight_format != PIE_W_INT4_G64) return false;
+        for (const auto &kv : fmt_map)
+            if (kv.second != PIE_W_INT4_G64) return false;
+        return true;
+    }
     int embed_vocab() const { return tp() ? cfg.vocab * cfg.tp_world : cfg.vocab; }
 };
 

@@ -494,8 +494,9 @@ static size_t resident_budget(pie_decoder *d) {
 
 template <class T>
 static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 *dst, hipStream_t st) {
-    if (d->cfg.weight_format == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
-    if (d->cfg.weight_format == PIE_W_INT8_G64) {
+    const int wf = d->mat_fmt(packed);  // per-module quantisation: a checkpoint may mix formats (models/utils.py:99-109)
+    if (wf == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
+    if (wf == PIE_W_INT8_G64) {
         const size_t w8 = (size_t)N * (K >> 2);
         hipLaunchKernelGGL(k_dequant_w8s<T>, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
         PIE_LAUNCH_CHECK();
@@ -565,7 +566,8 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     PrefillScratch *s = d->prefill;
     if (used32) *used32 = false;
     if (used_act) *used_act = false;
-    if ((keep || keep_w4m) && d->cfg.weight_format == PIE_W_INT4_G64 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
+    const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
+    if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
         if (it != s->resident_w4m.end()) wm = it->second;
@@ -600,7 +602,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
-    if (d->cfg.weight_format == PIE_W_INT4_G64 && N % 32 == 0 && K % 64 == 0 && w4l_enabled()) {
+    if (is_int4 && N % 32 == 0 && K % 64 == 0 && w4l_enabled()) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
         if (it != s->resident_w4m.end()) wm = it->second;
@@ -665,10 +667,10 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             PIE_HIP_TRY(hipMemcpyAsync(s->x, (const u16 *)embeds + (size_t)c0 * H, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
             rc = PIE_OK;
         } else
-            rc = c.weight_format == PIE_W_DENSE
+            rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
                  ? pie_embedding_dense(ids + c0, M, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
                  : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
-                                    nullptr, nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
+                                    nullptr, nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
         if (rc) return rc;
         hipLaunchKernelGGL(k_rope_cs_rows, dim3(M), dim3(64), 0, st, d->glob.rope_freqs, d->state, nullptr, D / 2, s->rope_cs);
         PIE_LAUNCH_CHECK();
@@ -776,10 +778,10 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)B));
         s->tail_rows = B, ++s->alloc_gen;
     }
-    rc = c.weight_format == PIE_W_DENSE
+    rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(tokens, B, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
              : embedding_launch(tokens, B, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
-                                nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
+                                nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
     if (rc) return rc;
     hipLaunchKernelGGL(k_rope_cs_rows, dim3(B), dim3(64), 0, st, d->glob.rope_freqs, nullptr, ctx_len, D / 2, s->rope_cs);
     PIE_LAUNCH_CHECK();
@@ -847,10 +849,10 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)S));
         s->tail_rows = S, ++s->alloc_gen;
     }
-    rc = c.weight_format == PIE_W_DENSE
+    rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(ids, N, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
              : embedding_launch(ids, N, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
-                                nullptr, 0, st, c.weight_format == PIE_W_INT8_G64 ? 8 : 4);
+                                nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
     if (rc) return rc;
     hipLaunchKernelGGL(k_rope_cs_rows, dim3(N), dim3(64), 0, st, d->glob.rope_freqs, nullptr, row_ctx, D / 2, s->rope_cs);
     PIE_LAUNCH_CHECK();

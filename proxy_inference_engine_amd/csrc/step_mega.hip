@@ -869,7 +869,7 @@ bool mega_supported(pie_decoder *d, bool with_logits) {
     const pie_decoder_config &c = d->cfg;
     MegaState *ms = mega_state(d);
     if (!ms || !ms->enabled || !ms->layers_dev) return false;
-    if (c.weight_format != PIE_W_INT4_G64 || d->block_table || d->combine || d->splits > GEMV_ATTN_SPLITS || d->tp()) return false;
+    if (!d->uniform_int4() || d->block_table || d->combine || d->splits > GEMV_ATTN_SPLITS || d->tp()) return false;
     for (const pie_layer_weights &w : d->layers)
         if (w.bqkv || w.bo || w.bgateup || w.bdown) return false;
     const int rep = c.n_heads / c.n_kv_heads, QD = c.n_heads * c.head_dim;

@@ -58,26 +58,39 @@ class TransformerBlock:
         return sum(w.nbytes for w in (self.wqkv, self.wo, self.wgateup, self.wdown))
 
 
+def _is_quantized(weights: dict, prefix: str) -> bool:
+    """The reference's per-module predicate (models/utils.py:99-109): a Linear / Embedding is quantised iff the checkpoint holds
+    "{path}.scales" (and its input width is a multiple of 64, which mlx_lm guarantees when it wrote the scales)."""
+    return f"{prefix}.scales" in weights
+
+
+def _group_format(weights: dict, names: list[str]) -> bool:
+    """Quantised (True) or dense (False) for a group of Linears that this build streams as ONE matrix (q|k|v, gate|up).  The reference
+    decides per module; a group whose members disagree cannot be one matrix and is refused by name."""
+    flags = [_is_quantized(weights, n) for n in names]
+    if any(flags) != all(flags):
+        qs = [n for n, f in zip(names, flags) if f]
+        ds = [n for n, f in zip(names, flags) if not f]
+        raise ValueError(
+            f"{', '.join(qs)} quantised but {', '.join(ds)} dense (models/utils.py:99-109 decides per module): the MI355X path streams "
+            f"{' | '.join(n.rsplit('.', 1)[-1] for n in names)} as one packed matrix, so these Linears must share a format")
+    return flags[0]
+
+
 def _triplet(weights: dict, prefix: str):
-    """The MLX-quantised triplet of one module.  The reference decides PER MODULE (models/utils.py:99-111: quantised iff the module
-    has to_quantized, weight.shape[-1] % 64 == 0 and "{path}.scales" is in the checkpoint); this build streams every Linear of a
-    checkpoint in ONE format, so a module the reference would leave dense among quantised ones is refused by name."""
+    """The MLX-quantised triplet of one module."""
     w, s, b = weights.get(f"{prefix}.weight"), weights.get(f"{prefix}.scales"), weights.get(f"{prefix}.biases")
     if w is None:
         raise ValueError(f"{prefix}.weight is missing from the checkpoint")
     if s is None or b is None:
-        why = ("its input width is not a multiple of 64" if w.dtype not in (torch.int32, torch.uint32) and w.shape[-1] % 64 else
-               f'the checkpoint has no "{prefix}.scales"')
-        raise ValueError(
-            f"{prefix}: the reference would keep this module dense ({why}: models/utils.py:99-109) while config['quantization'] "
-            "quantises the others; mixed quantised / dense checkpoints are not supported on the MI355X path (one weight format per model)")
+        raise ValueError(f'{prefix}: the checkpoint has "{prefix}.{"scales" if s is not None else "biases"}" but not both halves of the affine pair')
     return w, s, b
 
 
 def _dense(weights: dict, prefix: str, dtype: torch.dtype) -> torch.Tensor:
     w = weights.get(f"{prefix}.weight")
     if w is None or w.dtype != dtype or f"{prefix}.scales" in weights:
-        raise ValueError(f"{prefix}: expected a dense {dtype} weight (the config has no 'quantization' entry)")
+        raise ValueError(f"{prefix}: expected a dense {dtype} weight (no '{prefix}.scales' in the checkpoint)")
     return w
 
 
@@ -125,13 +138,23 @@ class Model:
         qkv_map = None if args.rope_traditional else hip_ops.qkv_row_map(self.n_heads, self.n_kv_heads, self.head_dim).to(device)
         gu_map = hip_ops.gateup_row_map(I).to(device)
 
-        def pack(names: list[str], row_map=None):
-            """One streaming-layout matrix from the (concatenated) Linear weights `names`."""
+        fmt_code = {False: 2, True: (3 if self.bits == 8 else 1)}  # pie_layer_weights.fmt_*: PIE_W_* + 1 (dense 1 -> 2, int4 0 -> 1, int8 2 -> 3)
+        self.mixed = False  # some module is dense although config["quantization"] is set (per-module predicate, models/utils.py:99-109)
+
+        def quantized(names: list[str]) -> bool:
             if self.dense:
+                return False
+            qf = _group_format(weights, names)
+            self.mixed |= not qf
+            return qf
+
+        def pack(names: list[str], row_map=None):
+            """One streaming-layout matrix from the (concatenated) Linear weights `names`; returns (matrix, format code)."""
+            if not quantized(names):
                 ws = [_dense(weights, n, self.dtype) for n in names]
-                return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map)
+                return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map), fmt_code[False]
             trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
-            return (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s)(*trip, row_map=row_map)
+            return (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s)(*trip, row_map=row_map), fmt_code[True]
 
         def bias(names: list[str], row_map=None):
             """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix; a Linear without a
@@ -147,25 +170,28 @@ class Model:
         self.layers: list[TransformerBlock] = []
         for i in range(args.num_hidden_layers):
             pfx = f"model.layers.{i}"
-            self.layers.append(TransformerBlock(
+            (wqkv, f_qkv), (wo, f_o) = pack([f"{pfx}.self_attn.{n}_proj" for n in "qkv"], qkv_map), pack([f"{pfx}.self_attn.o_proj"])
+            (wgu, f_gu), (wdown, f_down) = pack([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map), pack([f"{pfx}.mlp.down_proj"])
+            blk = TransformerBlock(
                 weights[f"{pfx}.input_layernorm.weight"].contiguous(),
                 weights[f"{pfx}.post_attention_layernorm.weight"].contiguous(),
-                pack([f"{pfx}.self_attn.{n}_proj" for n in "qkv"], qkv_map),
-                pack([f"{pfx}.self_attn.o_proj"]),
-                pack([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map),
-                pack([f"{pfx}.mlp.down_proj"]),
+                wqkv, wo, wgu, wdown,
                 biases=(bias([f"{pfx}.self_attn.{n}_proj" for n in "qkv"], qkv_map) if args.attention_bias else None,
                         bias([f"{pfx}.self_attn.o_proj"]) if args.attention_bias else None,
                         bias([f"{pfx}.mlp.gate_proj", f"{pfx}.mlp.up_proj"], gu_map) if args.mlp_bias else None,
                         bias([f"{pfx}.mlp.down_proj"]) if args.mlp_bias else None),
-            ))
-        if self.dense:
+            )
+            blk.formats = (f_qkv, f_o, f_gu, f_down)
+            self.layers.append(blk)
+        self.embed_quantized = quantized(["model.embed_tokens"])
+        if not self.embed_quantized:
             self.embed_tokens = (_dense(weights, "model.embed_tokens", self.dtype).contiguous(), None, None)
         else:
             self.embed_tokens = tuple(t.contiguous() for t in _triplet(weights, "model.embed_tokens"))
         self.norm = weights["model.norm.weight"].contiguous()
         head = "model.embed_tokens" if args.tie_word_embeddings else "lm_head"  # language.py:206-209
-        self.lm_head = pack([head])
+        self.lm_head, f_head = pack([head])
+        f_embed = fmt_code[self.embed_quantized]
 
         # decoder-owned outputs live in torch tensors so callers can read them without copies
         self.logits = torch.zeros(V, dtype=self.dtype, device=device)
@@ -186,10 +212,11 @@ class Model:
             lw = _ffi.pie_layer_weights(blk.input_layernorm.data_ptr(), blk.post_attention_layernorm.data_ptr(),
                                         blk.wqkv.packed.data_ptr(), blk.wo.packed.data_ptr(), blk.wgateup.packed.data_ptr(),
                                         blk.wdown.packed.data_ptr(),
-                                        *(b.data_ptr() if b is not None else None for b in (blk.bqkv, blk.bo, blk.bgateup, blk.bdown)))
+                                        *(b.data_ptr() if b is not None else None for b in (blk.bqkv, blk.bo, blk.bgateup, blk.bdown)),
+                                        *blk.formats)
             _ffi.check(lib.pie_decoder_set_layer(self._dec, i, C.byref(lw)))
         gw = _ffi.pie_global_weights(self.embed_tokens[0].data_ptr(), *(t.data_ptr() if t is not None else None for t in self.embed_tokens[1:]),
-                                     self.norm.data_ptr(), self.lm_head.packed.data_ptr(), self.rope.freqs.data_ptr())
+                                     self.norm.data_ptr(), self.lm_head.packed.data_ptr(), self.rope.freqs.data_ptr(), f_embed, f_head)
         _ffi.check(lib.pie_decoder_set_globals(self._dec, C.byref(gw)))
         # device-side token history: history[p] = greedy token chosen for position p (written by the tail kernel)
         self.history = torch.zeros(1 << 20, dtype=torch.int32, device=device)

@@ -746,10 +746,51 @@ def test_tied_embeddings_and_errors(tiny):
         build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other group sizes / bit widths are not on this path
     with pytest.raises(ValueError, match="bits=6"):
         build(dict(cfg, quantization={"group_size": 64, "bits": 6}), w)
-    # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109): one dense Linear among int4 ones
-    mixed = {k: v for k, v in w.items() if not k.startswith("model.layers.1.mlp.down_proj.")}
-    mixed["model.layers.1.mlp.down_proj.weight"] = np.zeros((cfg["hidden_size"], cfg["intermediate_size"]), np.uint16)
-    with pytest.raises(ValueError, match=r"model\.layers\.1\.mlp\.down_proj.*keep this module dense"):
-        build(cfg, mixed)
+    # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109); Linears this build streams as ONE packed
+    # matrix (q|k|v, gate|up) must agree -- a dense k_proj next to quantised q / v is refused by name
+    bad = {k: v for k, v in w.items() if not k.startswith("model.layers.1.self_attn.k_proj.")}
+    kv_rows = cfg["num_key_value_heads"] * (cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"])
+    bad["model.layers.1.self_attn.k_proj.weight"] = np.zeros((kv_rows, cfg["hidden_size"]), np.uint16)
+    with pytest.raises(ValueError, match=r"q_proj.*quantised but .*k_proj dense"):
+        build(cfg, bad)
     with pytest.raises(ValueError):
         model.step(torch.tensor([1], dtype=torch.int32, device="cuda"), model.make_cache()[:1])
+
+
+def test_mixed_quantised_and_dense_modules_vs_oracle(tiny):
+    """The reference's per-module quantisation predicate (models/utils.py:99-109: a module is quantised iff the checkpoint holds
+    "{path}.scales"): an int4 checkpoint in which layer 1's o_proj and down_proj, layer 0's gate|up pair and the lm_head are plain 16-bit
+    Linears.  Decode steps (GEMV per matrix format), a batched prompt (int4 MFMA GEMM next to the 16-bit GEMM) and greedy feedback,
+    against the oracle, which applies the same predicate."""
+    g, cfg, w, _ = tiny
+    mixed = dict(w)
+
+    def make_dense(name):
+        deq = po.dequantize(mixed[f"{name}.weight"], mixed[f"{name}.scales"], mixed[f"{name}.biases"], dtype=DT)
+        for k in ("scales", "biases"):
+            del mixed[f"{name}.{k}"]
+        mixed[f"{name}.weight"] = po.to_bits(deq, DT)
+
+    for name in ("model.layers.1.self_attn.o_proj", "model.layers.1.mlp.down_proj", "model.layers.0.mlp.gate_proj", "model.layers.0.mlp.up_proj", "lm_head"):
+        make_dense(name)
+    model = build(cfg, mixed)
+    assert model.mixed and not model.dense
+    orc = po.OracleLlama(cfg, mixed, DT)
+    rng = np.random.default_rng(12)
+    for L in (5, 40):  # iterated steps; the batched path
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in range(L):
+            assert_vec_close(got_all[l], want_all[l], DT, what=f"mixed checkpoint L={L} position {l}")
+        tok = model.token
+        for _ in range(3):
+            t = int(tok.item())
+            want = orc.forward(np.array([t]), ocache)[0]
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, DT, what=f"mixed checkpoint decode after L={L}")
+    # byte accounting follows the per-matrix formats: more than the all-int4 model, less than the all-dense one
+    full = build(cfg, w)
+    assert full.step_bytes(50) < model.step_bytes(50)
