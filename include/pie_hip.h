@@ -140,6 +140,23 @@ int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *st
  * token = first argmax.  logits [V] T, logprobs fp32 [V], token device int32 [1]. */
 int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, int32_t *token, void *stream);
 
+/* The stochastic branches of make_sampler (samplers/__init__.py:39-46) over fp32 log-probabilities [rows, V], one kernel, no sort:
+ * every branch scales by 1 / temp, filters, and draws argmax(x + Gumbel) like mx.random.categorical.
+ *   mode PIE_SAMPLE_CATEGORICAL  categorical_sampling (categorical.py:6-8)
+ *        PIE_SAMPLE_TOP_K        top_k_sampling(k)                        (top_k.py:14-29; k in (0, V), else PIE_E_ARG like its ValueError)
+ *        PIE_SAMPLE_TOP_P        top_p_sampling(p)                        (top_p.py:18-33; kept: ascending cumulative probability > 1 - p)
+ *        PIE_SAMPLE_MIN_P        min_p_sampling(p, min_tokens_to_keep=k)  (min_p.py:30-60)
+ * seed + counter: the random stream (Philox-4x32-10; the library's own, not MLX's).  counter = DEVICE uint64[2], zeroed by the caller when
+ * it (re)seeds; the last workgroup advances it, so a captured graph keeps drawing fresh numbers.  workspace: pie_sample_workspace_bytes(rows, V)
+ * bytes of device memory, ZEROED once by the caller and then reused from call to call (the kernels leave it ready for the next one).
+ * tokens int32 [rows]; kept_count (nullable) int32 [rows] = number of drawable ids; kept_mask (nullable) uint8 [rows, V] = which ids the
+ * filter keeps (tests compare it with the reference's sort-based definition).  2 launches (categorical, min-p) or 5 (top-k, top-p), a row
+ * spread over V / 512 workgroups; V <= 524288. */
+enum { PIE_SAMPLE_CATEGORICAL = 0, PIE_SAMPLE_TOP_K = 1, PIE_SAMPLE_TOP_P = 2, PIE_SAMPLE_MIN_P = 3 };
+size_t pie_sample_workspace_bytes(int rows, int V);
+int pie_sample(const float *logprobs, int rows, int V, int mode, double temp, double p, int k, unsigned long long seed, unsigned long long *counter,
+               void *workspace, int32_t *tokens, int32_t *kept_count, unsigned char *kept_mask, void *stream);
+
 /* ---------------------------------------------------------------- fused decode step
  * One forward of Model.__call__ (models/llama/language.py:199-210) for inputs[1,1] over per-layer
  * ReusableKVCache buffers (cache/kv_cache/reusable.py:96-142) followed by the tail of _inference

@@ -32,7 +32,7 @@ EXPORTS = [
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
     "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
-    "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm",
+    "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
 ]
 
 
@@ -91,6 +91,10 @@ def load() -> C.CDLL:
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    lib.pie_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pie_sample_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.pie_sample_workspace_bytes.restype = C.c_size_t
     lib.pie_comm_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.pie_comm_export.argtypes = [C.c_void_p, C.c_void_p]
     lib.pie_comm_connect.argtypes = [C.c_void_p, C.c_void_p]

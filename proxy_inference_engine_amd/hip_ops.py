@@ -511,3 +511,39 @@ def repack_w4m(w: "W4SWeight") -> torch.Tensor:
     out = torch.empty(n, dtype=torch.uint8, device=w.packed.device)
     _ffi.check(lib.pie_repack_w4s_to_w4m(_ffi.p(w.packed), w.N, w.K, _ffi.p(out), _ffi.stream()))
     return out
+
+
+SAMPLE_MODES = {"categorical": 0, "top_k": 1, "top_p": 2, "min_p": 3}
+
+
+def sample(logprobs: torch.Tensor, mode: str, temp: float, p: float = 0.0, k: int = 0, want_mask: bool = False):
+    """The stochastic branches of make_sampler (samplers/__init__.py:39-46) as ONE HIP kernel (pie_sample): logprobs fp32 [rows, V] or [V]
+    on the GPU -> token ids int32 [rows] on the same device, no host sync.  want_mask: also return (kept_count int32 [rows], kept uint8
+    [rows, V]) -- the filter's kept set, for tests."""
+    from .samplers import _rng
+    x = logprobs
+    if not x.is_cuda:
+        raise ValueError("hip_ops.sample needs the log-probabilities on the GPU")
+    if x.dim() == 1:
+        x = x[None]
+    if x.dtype != torch.float32:
+        x = x.float()
+    x = x.contiguous()
+    rows, V = x.shape
+    seed, counter = _rng.hip_state(x.device)
+    lib = _ffi.load()
+    key = (str(x.device), rows, V)
+    ws = _sample_ws.get(key)
+    if ws is None:  # zeroed once; the kernels leave it ready for the next call
+        if len(_sample_ws) > 8:
+            _sample_ws.clear()
+        ws = _sample_ws[key] = torch.zeros(int(lib.pie_sample_workspace_bytes(rows, V)) // 8, dtype=torch.int64, device=x.device)
+    tokens = torch.empty(rows, dtype=torch.int32, device=x.device)
+    kept = torch.empty(rows, dtype=torch.int32, device=x.device) if want_mask else None
+    mask = torch.empty((rows, V), dtype=torch.uint8, device=x.device) if want_mask else None
+    _ffi.check(lib.pie_sample(_ffi.p(x), rows, V, SAMPLE_MODES[mode], float(temp), float(p), int(k), seed, _ffi.p(counter), _ffi.p(ws), _ffi.p(tokens),
+                              _ffi.p(kept) if want_mask else None, _ffi.p(mask) if want_mask else None, _ffi.stream()))
+    return (tokens, kept, mask) if want_mask else tokens
+
+
+_sample_ws: dict = {}

@@ -16,4 +16,7 @@ def sample_from_logits(logits: torch.Tensor) -> torch.Tensor:
 
 
 def categorical_sampling(logits: torch.Tensor, temp: float) -> torch.Tensor:
+    if logits.is_cuda:  # the product path: one HIP kernel (csrc/sampler.hip); the torch ops below serve host tensors (CPU tests) only
+        from .. import hip_ops
+        return hip_ops.sample(logits, "categorical", temp)
     return sample_from_logits(logits * (1 / temp))

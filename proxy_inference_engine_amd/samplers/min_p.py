@@ -15,6 +15,9 @@ def min_p_sampling(logprobs: torch.Tensor, min_p: float, min_tokens_to_keep: int
         raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
     if not isinstance(min_tokens_to_keep, int) or (min_tokens_to_keep < 1):
         raise ValueError(f"`min_tokens_to_keep` has to be a positive integer, but is {min_tokens_to_keep}")
+    if logprobs.is_cuda and min_p > 0:  # the product path: one HIP kernel (csrc/sampler.hip), no sort
+        from .. import hip_ops
+        return hip_ops.sample(logprobs, "min_p", temperature, p=min_p, k=min_tokens_to_keep)
     logprobs = logprobs.float() * (1 / temperature)
     sorted_logprobs, sorted_indices = torch.sort(logprobs, dim=-1, descending=True)
     scaled_min_p = sorted_logprobs[..., 0:1] + (math.log(min_p) if min_p > 0 else float("-inf"))

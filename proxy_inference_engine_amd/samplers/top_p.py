@@ -9,6 +9,9 @@ from .categorical import sample_from_logits
 def top_p_sampling(logits: torch.Tensor, top_p: float, temperature: float) -> torch.Tensor:
     """Nucleus sampling exactly as the reference writes it: ascending sort, cumulative sum, keep the tokens whose
     cumulative probability exceeds 1 - top_p (top_p.py:18-31), sample among them, map back to vocabulary ids."""
+    if logits.is_cuda:  # the product path: one HIP kernel (csrc/sampler.hip), no sort
+        from .. import hip_ops
+        return hip_ops.sample(logits, "top_p", temperature, p=top_p)
     probs = torch.softmax(logits.float() * (1 / temperature), dim=-1)
     sorted_probs, sorted_indices = torch.sort(probs, dim=-1)              # ascending, like mx.argsort
     cumulative = torch.cumsum(sorted_probs, dim=-1)
