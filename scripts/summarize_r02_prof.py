@@ -74,6 +74,29 @@ for name in sorted(set(m.Kernel_Name)):
     out[short(name)] = {"launches": int(mm["count"].iloc[0]), "SQ_INSTS_VALU_MFMA_MOPS_BF16": mops, "mfma_flops_per_launch": mops * 512,
                         "SQ_BUSY_CU_CYCLES": float(cu), "GRBM_GUI_ACTIVE": float(bb.get("GRBM_GUI_ACTIVE", 0)),
                         "SQ_BUSY_CYCLES": float(bb.get("SQ_BUSY_CYCLES", 0)), "SQ_WAVES": float(bb.get("SQ_WAVES", 0))}
+# the few-row kernel (16-token prompt)
+try:
+    m16 = counters("prefill16_mfma")
+    st16 = pd.read_csv(glob.glob(str(P / "prefill16_stats" / "runc" / "*_kernel_stats.csv"))[0])
+    shutil.copy(glob.glob(str(P / "prefill16_stats" / "runc" / "*_kernel_stats.csv"))[0], OUT / "r02_prefill16_kernel_stats.csv")
+    for name in sorted(set(m16.Kernel_Name)):
+        mm = m16[(m16.Kernel_Name == name) & (m16.Counter_Name == "SQ_INSTS_VALU_MFMA_MOPS_BF16")]
+        if mm.empty or mm["mean"].iloc[0] == 0 or "w4m" not in name:
+            continue
+        dur = st16[st16.Name == name]["AverageNs"]
+        out[short(name) + " @16 rows"] = {"launches": int(mm["count"].iloc[0]), "SQ_INSTS_VALU_MFMA_MOPS_BF16": float(mm["mean"].iloc[0]),
+                                          "mfma_flops_per_launch": float(mm["mean"].iloc[0]) * 512,
+                                          "mean_duration_us": float(dur.iloc[0]) / 1e3 if len(dur) else None}
+except (IndexError, FileNotFoundError) as e:
+    print("no 16-row passes:", e)
+# durations of the 4096-row kernels from the kernel-trace pass
+st = pd.read_csv(glob.glob(str(P / "prefill_stats" / "runc" / "*_kernel_stats.csv"))[0])
+for k in list(out):
+    hit = st[st.Name.map(short) == k]
+    if len(hit):
+        out[k]["mean_duration_us"] = float(hit["AverageNs"].iloc[0]) / 1e3
+        out[k]["mfma_TFLOPs"] = out[k]["mfma_flops_per_launch"] / (out[k]["mean_duration_us"] * 1e-6) / 1e12
+        out[k]["frac_of_dense_bf16_peak_2500"] = out[k]["mfma_TFLOPs"] / 2500.0
 json.dump({"workload": "tools/step_bench --model 8b --no-mega --prefill 4096 (one 4096-token prompt through pie_decoder_prefill, after the one-off tile repack)",
            "note": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES and --pmc SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes), means per "
                    "launch over all launches of a kernel (its shapes differ per Linear).  mfma_flops_per_launch = MOPS x 512 (rocprofv3's MfmaFlopsBF16).",
