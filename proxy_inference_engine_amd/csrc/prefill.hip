@@ -526,7 +526,7 @@ struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.h
 };
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
                     const void *bias, const W4mRope *rope);
-int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st);  // many rows (MFMA-bound)
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused);  // many rows (MFMA-bound)
 size_t w4l_workspace_bytes(int M, int N, int K);
 
 // int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
@@ -622,7 +622,9 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
                 PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
                 s->w4l_ws_bytes = wb, ++s->alloc_gen;
             }
-            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st);
+            bool fused = false;  // gate|up without a Linear bias: the SwiGLU rides in the GEMM's epilogue where the shape allows
+            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused);
+            if (fused) *used_act = true;
             if (rc || !bias) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }

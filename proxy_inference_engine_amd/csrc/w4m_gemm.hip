@@ -584,7 +584,9 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4l_gemm(const char *w4m, co
 typedef __attribute__((address_space(3))) void w4l_lds_void;
 typedef __attribute__((address_space(1))) const void w4l_glb_void;
 
-template <class T>
+// SWIGLU: the packed gate|up matrix (columns (2 i, 2 i + 1) = (gate_i, up_i)): y is the MLP activation [M, N / 2] = T(silu(T(gate)) * T(up))
+// (language.py:127), which saves the [M, N] round trip and the row kernel's launch (60 us per layer at 4096 rows); needs the whole K here.
+template <class T, bool SWIGLU = false>
 __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *part) {
     __shared__ __attribute__((aligned(1024))) char s_x[2][256 * 128];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -729,7 +731,19 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
             const int m = 32 * mi + n;
             if (m < rows) {
                 const size_t o = (size_t)(m0 + m) * N + 32 * nt + 4 * kh;
-                if (part) {
+                if (SWIGLU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u16 out2[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const u32 gu = w4m_pack<T>(acc[s2][mi][4 * q + 2 * e], acc[s2][mi][4 * q + 2 * e + 1]);  // the Linear's rounding to T
+                            const float g = lo_f32<T>(gu), u = hi_f32<T>(gu);
+                            out2[e] = T::from_f32(round_T<T>(g / (1.0f + expf(-g))) * u);
+                        }
+                        *reinterpret_cast<u32 *>(y + (size_t)(m0 + m) * (N >> 1) + ((32 * nt + 4 * kh + 8 * q) >> 1)) = (u32)out2[0] | ((u32)out2[1] << 16);
+                    }
+                } else if (part) {
                     float *pr = part + (size_t)blockIdx.z * M * N + o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -777,7 +791,9 @@ size_t w4l_workspace_bytes(int M, int N, int K) {
 }
 
 // workspace: w4l_workspace_bytes() of device scratch (may be null when that is 0)
-int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st) {
+// swiglu_act (nullable): gate|up matrix and the caller wants the MLP activation [M, N / 2] there instead of y; *fused says whether it got it
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused) {
+    if (fused) *fused = false;
     PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4 GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "W4 GEMM: 16-byte alignment required");
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4 GEMM: dtype must be PIE_BF16 or PIE_F16");
@@ -791,8 +807,15 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     if (mt == 256 && v2 && ((K >> 6) % (4 * S)) == 0) {  // the unrolled step ring needs a multiple of 4 K groups per split
         float *part2 = S > 1 ? (float *)workspace : nullptr;
         const dim3 g2((unsigned)((N / 32 + 7) / 8), (unsigned)((M + 255) / 256), (unsigned)S);
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l2_gemm<BF16>, g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
-        else hipLaunchKernelGGL(k_w4l2_gemm<F16>, g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
+        if (S == 1 && swiglu_act && fused) {
+            if (dtype == PIE_BF16) hipLaunchKernelGGL((k_w4l2_gemm<BF16, true>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)swiglu_act, nullptr);
+            else hipLaunchKernelGGL((k_w4l2_gemm<F16, true>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)swiglu_act, nullptr);
+            PIE_LAUNCH_CHECK();
+            *fused = true;
+            return PIE_OK;
+        }
+        if (dtype == PIE_BF16) hipLaunchKernelGGL((k_w4l2_gemm<BF16, false>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
+        else hipLaunchKernelGGL((k_w4l2_gemm<F16, false>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
         PIE_LAUNCH_CHECK();
         if (S > 1) {
             const size_t MN = (size_t)M * N;
@@ -892,7 +915,7 @@ int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype
         void *ws = nullptr;
         const size_t wb = w4l_workspace_bytes(M, N, K);
         if (wb && hipMallocAsync(&ws, wb, st) != hipSuccess) return pie::fail(PIE_E_HIP, "pie_qgemm_w4m: hipMallocAsync failed");
-        const int rc = w4l_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st);
+        const int rc = w4l_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st, nullptr, nullptr);
         if (ws) (void)hipFreeAsync(ws, st);
         return rc;
     }

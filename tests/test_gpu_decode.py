@@ -794,3 +794,23 @@ def test_mixed_quantised_and_dense_modules_vs_oracle(tiny):
     # byte accounting follows the per-matrix formats: more than the all-int4 model, less than the all-dense one
     full = build(cfg, w)
     assert full.step_bytes(50) < model.step_bytes(50)
+
+
+def test_long_prompt_gate_up_with_fused_swiglu_epilogue():
+    """A 1536-token prompt on a wide-MLP layer (I = 4096: the packed gate|up matrix has 8192 columns, 32 x 6 = 192 tiles of the
+    256-row prompt GEMM, so K is not split and the SwiGLU rides in k_w4l2_gemm's epilogue; q|k|v / o_proj / down take the K-split form
+    with the fp32 reduce) against the oracle's many-row regime, every position."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 1, "intermediate_size": 4096,
+           "num_attention_heads": 4, "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 512,
+           "rope_theta": 10000.0, "max_position_embeddings": 4096, "tie_word_embeddings": True,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=33, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    L = 1536
+    prompt = np.random.default_rng(8).integers(0, cfg["vocab_size"], L)
+    want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
+    got = model(torch.from_numpy(prompt)[None].cuda(), cache=model.make_cache())[0].float().cpu().numpy()
+    for l in list(range(0, L, 97)) + [L - 1]:
+        assert_vec_close(got[l], want[l], dtype, what=f"long prompt position {l}")
