@@ -57,46 +57,48 @@ __device__ __forceinline__ bool tp_pull(const unsigned long long *p, unsigned e,
     }
 }
 
-// One workgroup.  data[n] (this rank's fp32 partial) -> the sum over the ranks, in rank order:
+// data[n] (this rank's fp32 partial) -> the sum over the ranks, in rank order:
 //   resid == nullptr: written back to data (pie_allreduce_f32);
 //   resid != nullptr: the row-parallel Linear's tail, h = T(h + T(sum)) -- the Linear's one rounding, then the residual add
 //   (language.py:151,153; proxy_inference_engine_amd/tp.py: TPLlama._row_parallel).
+// One thread per PAIR of elements, n / 2048 workgroups (4 for H = 8192): every thread pushes its two values to all peers, then pulls
+// the same two positions of all ranks' slots.  The last workgroup to finish advances the epoch (arrival counter in epoch[2]).
 template <class T>
 __global__ void __launch_bounds__(1024) k_tp_allreduce(unsigned long long *const *peers, unsigned *epoch, int rank, int world, size_t stride, float *data,
                                                        int n, u16 *resid) {
     const unsigned e = epoch[0] + 1;
     const size_t slot = ((size_t)(e & 1) * world + rank) * stride;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float v = data[i];
-        for (int r = 0; r < world; ++r) tp_push(peers[r] + slot + i, v, e);
-    }
-    const unsigned long long *mine = peers[rank] + (size_t)(e & 1) * world * stride;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (resid) {
-        for (int i = 2 * threadIdx.x; i < n; i += 2048) {
-            float s0 = 0.0f, s1 = 0.0f;
-            for (int r = 0; r < world; ++r) {
-                float a, b;
-                tp_pull(mine + (size_t)r * stride + i, e, a, t0, epoch + 1);
-                tp_pull(mine + (size_t)r * stride + i + 1, e, b, t0, epoch + 1);
-                s0 = r ? s0 + a : a, s1 = r ? s1 + b : b;
-            }
+    const int i = 2 * (blockIdx.x * 1024 + threadIdx.x);
+    if (i < n) {
+        const float v0 = data[i], v1 = i + 1 < n ? data[i + 1] : 0.0f;
+        for (int r = 0; r < world; ++r) {
+            tp_push(peers[r] + slot + i, v0, e);
+            if (i + 1 < n) tp_push(peers[r] + slot + i + 1, v1, e);
+        }
+        const unsigned long long *mine = peers[rank] + (size_t)(e & 1) * world * stride;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int r = 0; r < world; ++r) {
+            float a, b = 0.0f;
+            tp_pull(mine + (size_t)r * stride + i, e, a, t0, epoch + 1);
+            if (i + 1 < n) tp_pull(mine + (size_t)r * stride + i + 1, e, b, t0, epoch + 1);
+            s0 = r ? s0 + a : a, s1 = r ? s1 + b : b;
+        }
+        if (resid) {  // n is even here (launcher)
             const u32 h2 = *reinterpret_cast<const u32 *>(resid + i);
             *reinterpret_cast<u32 *>(resid + i) = pack2<T>(lo_f32<T>(h2) + round_T<T>(s0), hi_f32<T>(h2) + round_T<T>(s1));
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            float s = 0.0f;
-            for (int r = 0; r < world; ++r) {
-                float a;
-                tp_pull(mine + (size_t)r * stride + i, e, a, t0, epoch + 1);
-                s = r ? s + a : a;
-            }
-            data[i] = s;
+        } else {
+            data[i] = s0;
+            if (i + 1 < n) data[i + 1] = s1;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) epoch[0] = e;
+    if (threadIdx.x == 0) {
+        if (atomicAdd(epoch + 2, 1u) == gridDim.x - 1) {  // every workgroup read epoch[0] before its own arrival
+            epoch[2] = 0;
+            __hip_atomic_store(epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Vocabulary-parallel tail, part 1 (one workgroup of 256): merge this rank's per-wave partials of the lm_head GEMV, exchange
@@ -194,8 +196,9 @@ int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, 
     PIE_REQUIRE(c && c->connected, PIE_E_STATE, "tensor-parallel communicator is not connected (pie_comm_connect)");
     PIE_REQUIRE(data && n > 0 && (size_t)n <= c->max_elems && (!resid || n % 2 == 0), PIE_E_SHAPE, "tp all-reduce: vector longer than the communicator's slots");
     const size_t stride = c->max_elems + 8;
-    if (dtype == PIE_F16) hipLaunchKernelGGL(k_tp_allreduce<F16>, dim3(1), dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
-    else hipLaunchKernelGGL(k_tp_allreduce<BF16>, dim3(1), dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
+    const dim3 grid((unsigned)((n + 2047) / 2048));
+    if (dtype == PIE_F16) hipLaunchKernelGGL(k_tp_allreduce<F16>, grid, dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
+    else hipLaunchKernelGGL(k_tp_allreduce<BF16>, grid, dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
