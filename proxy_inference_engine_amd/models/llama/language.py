@@ -431,6 +431,8 @@ class Model:
         # the block table (batch_details.hpp:52-66) is rewritten in place when a sequence takes a page or the batch changes.
         mb = max(len(s.pages) for s in seqs)
         buf = self._batch_bufs.get(B)
+        if buf is not None:
+            self._batch_bufs[B] = self._batch_bufs.pop(B)  # most recently used last
         if buf is None or buf["table"].shape[1] < mb:
             V = self.args.vocab_size
             width = max(mb, 2 * buf["table"].shape[1]) if buf is not None else max(mb, 4)
@@ -439,6 +441,9 @@ class Model:
                    "logits": torch.empty((B, V), dtype=self.dtype, device=self.device),
                    "logprobs": torch.empty((B, V), dtype=torch.float32, device=self.device),
                    "next": torch.empty(B, dtype=torch.int32, device=self.device), "key": None}
+            self._batch_bufs.pop(B, None)
+            while len(self._batch_bufs) >= 4:  # a serving loop revisits few batch sizes: keep the 4 most recent sets (each [B, V] fp32 + T)
+                self._batch_bufs.pop(next(iter(self._batch_bufs)))
             self._batch_bufs[B] = buf
         key = tuple(tuple(s.pages) for s in seqs)  # the page ids themselves: truncate + regrow reorders them at equal length, and id() of a retired sequence can be reused
         if buf["key"] != key:
