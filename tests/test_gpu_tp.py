@@ -94,18 +94,17 @@ def _fused_worker(rank, world, port, ret):
         torch.cuda.set_device(0)
         w = po.synth_checkpoint(CFG, seed=71, dtype=DT, lm_head_gain=4.0)
         dev_w = {k: (codes_dev(v) if v.dtype == np.uint32 else to_dev(v, DT)) for k, v in w.items()}
-        comm = HipComm(CFG["hidden_size"])
-        # the collective alone: rank-order fp32 sum, in place, stream-ordered
-        g = torch.Generator(device="cpu").manual_seed(100 + rank)
-        mine = torch.randn(CFG["hidden_size"], generator=g, dtype=torch.float32)
-        both = [torch.randn(CFG["hidden_size"], generator=torch.Generator().manual_seed(100 + r), dtype=torch.float32) for r in range(world)]
-        for rep in range(5):  # epochs alternate the two receive areas
-            buf = (mine * (rep + 1)).cuda()
-            comm.all_reduce(buf)
-            want = both[0] * (rep + 1)
-            for r in range(1, world):
-                want = want + both[r] * (rep + 1)
-            assert torch.equal(buf.cpu(), want), f"all-reduce rep {rep}"
+        comm = HipComm(8192)
+        # the collective alone: rank-order fp32 sum, in place, stream-ordered; one workgroup (n = 512), several (8192), an odd length
+        for n in (CFG["hidden_size"], 8192, 4097):
+            both = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r), dtype=torch.float32) for r in range(world)]
+            for rep in range(5):  # epochs alternate the two receive areas
+                buf = (both[rank] * (rep + 1)).cuda()
+                comm.all_reduce(buf)
+                want = both[0] * (rep + 1)
+                for r in range(1, world):
+                    want = want + both[r] * (rep + 1)
+                assert torch.equal(buf.cpu(), want), f"all-reduce n={n} rep {rep}"
         functional = TPLlama(CFG, dev_w, TPGroup())
         fused = fused_shard(CFG, dev_w, comm)
         cache = fused.make_cache()
