@@ -409,6 +409,16 @@ size_t pie_w4m_bytes(int N, int K);
 int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream);
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream);
 
+/* nn.Linear on many rows with 16-bit weights, hand-written (no library GEMM): y [M, N] = x [M, K] . W^T (+ bias [N]: T(T(x W^T) + b)),
+ * T x T products on the MFMA units, fp32 accumulation (models/intern/vision.py:97-121,129-133,150-151,192-194; the dense-checkpoint
+ * Linears of models/llama/language.py at L > 1 take the same kernel inside pie_decoder_prefill).  The weights live in "W16M" tiles
+ * (32 output rows x 64 columns in MFMA operand order, zero-padded to N % 32 == 0 and K % 256 == 0), built once from the row-major
+ * [N, K] matrix by pie_repack_w16m -- the row-major copy is not needed afterwards.  K % 8 == 0, N % 4 == 0, x rows 16-byte aligned. */
+size_t pie_w16m_bytes(int N, int K);
+int pie_repack_w16m(const void *weight_rows, int N, int K, void *w16m, void *stream);
+size_t pie_linear_w16m_workspace_bytes(int M, int N, int K);   /* 0 for most shapes; fp32 partial tiles where K is split over workgroups */
+int pie_linear_w16m(const void *x, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

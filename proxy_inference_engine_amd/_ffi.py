@@ -31,7 +31,7 @@ EXPORTS = [
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
-    "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
+    "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m", "pie_w16m_bytes", "pie_repack_w16m", "pie_linear_w16m", "pie_linear_w16m_workspace_bytes",
     "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
 ]
 
@@ -125,6 +125,12 @@ def load() -> C.CDLL:
     lib.pie_add_bias.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2
     lib.pie_sdpa_segments.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_w4m_bytes.restype = C.c_size_t
+    lib.pie_w16m_bytes.restype = C.c_size_t
+    lib.pie_w16m_bytes.argtypes = [C.c_int, C.c_int]
+    lib.pie_repack_w16m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_linear_w16m.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pie_linear_w16m_workspace_bytes.restype = C.c_size_t
+    lib.pie_linear_w16m_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.pie_repack_w4s_to_w4m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_qgemm_w4m.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_decoder_step_batch.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]

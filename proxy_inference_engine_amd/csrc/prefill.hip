@@ -528,12 +528,25 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
                     const void *bias, const W4mRope *rope);
 int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused);  // many rows (MFMA-bound)
 size_t w4l_workspace_bytes(int M, int N, int K);
+int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
+                     const void *bias, bool *bias_done);  // 16-bit weights in W16M tiles
+size_t w16l_workspace_bytes(int M, int N, int K);
+size_t w16m_bytes(int N, int K);
+int w16m_repack_launch(const void *w16s, const void *rows, int N, int K, void *w16m, hipStream_t st);
 
 // int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
 // copy of the weights, no hipBLASLt.  PIE_W4L=0 restores round 1's dequantise-to-T + hipBLASLt path (kept for A/B timing).
 static bool w4l_enabled() {
     const char *e = getenv("PIE_W4L");
     return !(e && e[0] == '0');
+}
+// dense (16-bit) modules: PIE_W16L=1 takes the hand-written prompt GEMM on W16M tiles (k_w16l_gemm, w4m_gemm.hip) instead of the
+// unpack-to-T + hipBLASLt path.  Off by default on measurement: for 16-bit weights the library GEMM is a plain GEMM done well -- the own
+// kernel ties it up to 128 rows and is 13-20 % slower from 256 rows (8B dense prefill: 8.8 vs 7.8 ms at 256 tokens, 64.9 vs 53.8 at
+// 4096) -- and the tile copy saves no memory over the row-major copy (unlike int4, where the own kernel replaced 15 GB of copies).
+static bool w16l_enabled() {
+    const char *e = getenv("PIE_W16L");
+    return e && e[0] == '1';
 }
 
 // Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
@@ -626,6 +639,34 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused);
             if (fused) *used_act = true;
             if (rc || !bias) return rc;
+            return bias_rows<T>(y, bias, M, N, st);
+        }
+    }
+    if (keep && d->mat_fmt(packed) == PIE_W_DENSE && N % 32 == 0 && K % 64 == 0 && w16l_enabled()) {
+        // the layer's matrix as MFMA-ordered 16-bit tiles (same bytes as the row-major copy the library path keeps), built at first use
+        void *wm = nullptr;
+        auto it = s->resident_w4m.find(packed);
+        if (it != s->resident_w4m.end()) wm = it->second;
+        else if (resident_budget(d) >= w16m_bytes(N, K) && hipMalloc(&wm, w16m_bytes(N, K)) == hipSuccess) {
+            s->resident_w4m[packed] = wm, s->resident_left -= w16m_bytes(N, K), ++s->alloc_gen;
+            const int rc = w16m_repack_launch(packed, nullptr, N, K, wm, st);
+            if (rc) return rc;
+        } else {
+            (void)hipGetLastError();
+            wm = nullptr;  // no room for the tile copy: the scratch + library path below
+        }
+        if (wm) {
+            const size_t wb = w16l_workspace_bytes(M, N, K);
+            if (wb > s->w4l_ws_bytes) {
+                if (s->w4l_ws) (void)hipFree(s->w4l_ws);
+                s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
+                PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
+                s->w4l_ws_bytes = wb, ++s->alloc_gen;
+            }
+            bool fused = false, bias_done = false;
+            const int rc = w16l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused, bias, &bias_done);
+            if (fused) *used_act = true;
+            if (rc || !bias || bias_done) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }
     }

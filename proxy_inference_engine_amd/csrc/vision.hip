@@ -228,6 +228,15 @@ static int by_dt(int dtype, F16F &&f16, BF16F &&bf16, const char *who) {
     return PIE_OK;
 }
 
+// y[m, :] = T(y[m, :] + bias) for any N (w4m_gemm.hip's dense GEMM uses it behind a K split)
+int bias_any_launch(int dtype, void *y, const void *bias, int M, int N, hipStream_t st) {
+    const size_t n = (size_t)M * ((N + 1) >> 1);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return by_dt(
+        dtype, [&] { hipLaunchKernelGGL(k_bias_any<F16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); },
+        [&] { hipLaunchKernelGGL(k_bias_any<BF16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); }, "bias");
+}
+
 extern "C" {
 
 int pie_linear(const void *x, const void *w, const void *bias, int M, int N, int K, int dtype, void *y, void *stream) {

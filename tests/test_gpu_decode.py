@@ -814,3 +814,22 @@ def test_long_prompt_gate_up_with_fused_swiglu_epilogue():
     got = model(torch.from_numpy(prompt)[None].cuda(), cache=model.make_cache())[0].float().cpu().numpy()
     for l in list(range(0, L, 97)) + [L - 1]:
         assert_vec_close(got[l], want[l], dtype, what=f"long prompt position {l}")
+
+
+def test_dense_checkpoint_on_the_own_prompt_gemm(monkeypatch):
+    """PIE_W16L=1: a dense checkpoint's prompt GEMMs on the hand-written 16-bit MFMA kernel (k_w16l_gemm on W16M tiles, incl. the fused
+    SwiGLU epilogue and K-split shapes) instead of hipBLASLt: every position of a 300-token prompt against the oracle's dense path."""
+    monkeypatch.setenv("PIE_W16L", "1")
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 512, "num_hidden_layers": 2, "intermediate_size": 1408,
+           "num_attention_heads": 8, "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 1024,
+           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": True}
+    w = po.synth_checkpoint(cfg, seed=23, dtype=dtype, lm_head_gain=4.0)
+    model = build(cfg, w, dtype)
+    orc = po.OracleLlama(cfg, w, dtype)
+    for L in (40, 300):
+        prompt = np.random.default_rng(L).integers(0, cfg["vocab_size"], L)
+        want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
+        got = model(torch.from_numpy(prompt)[None].cuda(), cache=model.make_cache())[0].float().cpu().numpy()
+        for l in list(range(0, L, 17)) + [L - 1]:
+            assert_vec_close(got[l], want[l], dtype, what=f"own dense GEMM L={L} position {l}")
