@@ -586,27 +586,30 @@ typedef __attribute__((address_space(1))) const void w4l_glb_void;
 
 // SWIGLU: the packed gate|up matrix (columns (2 i, 2 i + 1) = (gate_i, up_i)): y is the MLP activation [M, N / 2] = T(silu(T(gate)) * T(up))
 // (language.py:127), which saves the [M, N] round trip and the row kernel's launch (60 us per layer at 4096 rows); needs the whole K here.
-template <class T, bool SWIGLU = false>
+// MB: 32-row blocks of x per workgroup (row tile 64 / 128 / 256): medium prompts reach ~192 workgroups with smaller row tiles instead of
+// deep K splits, whose fp32 partial tiles cost a reduce pass
+template <class T, int MB, bool SWIGLU = false>
 __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *part) {
-    __shared__ __attribute__((aligned(1024))) char s_x[2][256 * 128];
+    constexpr int MT = 32 * MB, XJ = MB;  // rows per tile; DMA instructions per wave and tile (MT / 8 row groups over 4 waves)
+    __shared__ __attribute__((aligned(1024))) char s_x[2][MT * 128];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
     const int per_z = (all_groups + (int)gridDim.z - 1) / (int)gridDim.z;
     const int g_lo = blockIdx.z * per_z, g_hi = min(all_groups, g_lo + per_z);
     const int groups = g_hi - g_lo;  // >= 1 (launcher)
-    const int m0 = blockIdx.y * 256;
-    const int rows = M - m0 < 256 ? M - m0 : 256;
+    const int m0 = blockIdx.y * MT;
+    const int rows = M - m0 < MT ? M - m0 : MT;
     const int nt0 = (blockIdx.x * 4 + wave) * 2;  // this wave's two strips: nt0, nt0 + 1
     const int n_strips = N >> 5;
     const bool has0 = nt0 < n_strips, has1 = nt0 + 1 < n_strips;  // wave-uniform; idle waves still stage x and join the barriers
     const char *strip0 = w4m + ((size_t)(has0 ? nt0 : 0) * all_groups + g_lo) * W4M_TILE_BYTES;
     const char *strip1 = w4m + ((size_t)(has1 ? nt0 + 1 : 0) * all_groups + g_lo) * W4M_TILE_BYTES;
 
-    // x staging: wave w moves rows [64 w, 64 w + 64) of the tile with 8 DMA instructions of 8 rows each
-    const u16 *xsrc[8];
+    // x staging: wave w moves rows [8 MB w, 8 MB (w + 1)) of the tile with MB DMA instructions of 8 rows each
+    const u16 *xsrc[XJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = 64 * wave + 8 * j + (lane >> 3);
+    for (int j = 0; j < XJ; ++j) {
+        const int r = 8 * MB * wave + 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int rr = r < rows ? r : rows - 1;  // ragged tile: rows past the end repeat the last one (never stored)
         xsrc[j] = x + (size_t)(m0 + rr) * K + (size_t)g_lo * 64 + c * 8;
@@ -617,7 +620,7 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
     // restored inside the statement.)  The step's closing barrier is preceded by an explicit vmcnt(0).
     auto x_issue1 = [&](int g, int buf, int j) {
         const u16 *src = xsrc[j] + (size_t)g * 64;
-        const unsigned dst = (unsigned)(size_t)(w4l_lds_void *)(s_x[0]) + (unsigned)(buf * (256 * 128) + (64 * wave + 8 * j) * 128);
+        const unsigned dst = (unsigned)(size_t)(w4l_lds_void *)(s_x[0]) + (unsigned)(buf * (MT * 128) + (8 * MB * wave + 8 * j) * 128);
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -626,7 +629,7 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
     };
     auto x_issue = [&](int g, int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x_issue1(g, buf, j);
+        for (int j = 0; j < XJ; ++j) x_issue1(g, buf, j);
     };
     typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
     // raw weight tiles: tile j lives in ring slot j % 4 from its issue (step j - 4) to its conversion (during step j - 1)
@@ -647,11 +650,11 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
     // the MFMAs, using the AGPR half of the file as a spill area
     asm volatile("" : : "a"(0.0f));
 
-    f32x16_t acc[2][8];
+    f32x16_t acc[2][MB];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[s2][mi][i] = 0.0f;
     uint4 af[2][4];
@@ -691,23 +694,25 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
             const char *xb = s_x[d & 1];
             uint4 afn[2][4];
             uint4 bq[4];
+            constexpr int NS = 4 * MB, CV = MB / 2;  // (k-step, row block) pairs of a step; pairs per word conversion (8 words per step)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const uint4 *>(xb + (t % 8) * 4096 + xoff[t / 8]);
+            for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const uint4 *>(xb + (t % MB) * 4096 + xoff[t / MB]);
 #pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                const int k = t / 8, mi = t % 8;
+            for (int t = 0; t < NS; ++t) {
+                const int k = t / MB, mi = t % MB;
                 acc[0][mi] = MfmaT<T>::run(af[0][k], bq[t & 3], acc[0][mi]);
                 acc[1][mi] = MfmaT<T>::run(af[1][k], bq[t & 3], acc[1][mi]);
 #if W4L2_SPREAD
                 // the step's memory issue rides between the MFMAs instead of in front of them (each DMA is 5 scalar instructions + the
                 // load: at the top of the step the matrix pipe idles while they issue): x tile g + 1 one piece per iteration, then
-                // the raw weight tile g + 4 -- the queue order [DMA x 8][weights x 4] the closing vmcnt(4) relies on is unchanged
-                if (t >= W4L2_SPREAD && t < W4L2_SPREAD + 8 && !(W4L2_ABL & 4)) x_issue1(g + 1 < groups ? g + 1 : g, (d + 1) & 1, t - W4L2_SPREAD);
-                if (t == W4L2_SPREAD + 8 && !(W4L2_ABL & 16)) w_issue(d, g + 4);
+                // the raw weight tile g + 4 -- the queue order [DMA x MB][weights x 4] the closing vmcnt(4) relies on is unchanged
+                constexpr int SP = W4L2_SPREAD + XJ < NS ? W4L2_SPREAD : 1;
+                if (t >= SP && t < SP + XJ && !(W4L2_ABL & 4)) x_issue1(g + 1 < groups ? g + 1 : g, (d + 1) & 1, t - SP);
+                if (t == SP + XJ && !(W4L2_ABL & 16)) w_issue(d, g + 4);
 #endif
-                if (t + 4 < 32 && !(W4L2_ABL & 8)) bq[t & 3] = *reinterpret_cast<const uint4 *>(xb + ((t + 4) % 8) * 4096 + xoff[(t + 4) / 8]);
-                if ((t & 3) == 0) {  // one word of the next tiles per 4 B fragments: 8 conversions in the shadow of 64 MFMAs
-                    const int q = t >> 2, s2 = q & 1, kk = q >> 1;
+                if (t + 4 < NS && !(W4L2_ABL & 8)) bq[t & 3] = *reinterpret_cast<const uint4 *>(xb + ((t + 4) % MB) * 4096 + xoff[(t + 4) / MB]);
+                if (t % CV == 0) {  // one word of the next tiles per CV pairs: 8 conversions in the shadow of the step's MFMAs
+                    const int q = t / CV, s2 = q & 1, kk = q >> 1;
                     const u32 wn[4] = {cw[dn][s2].x, cw[dn][s2].y, cw[dn][s2].z, cw[dn][s2].w};
                     afn[s2][kk] = (W4L2_ABL & 1) ? af[s2][kk] : w4m_dequant_pk<T>(wn[kk], sc[s2], bi[s2]);
                 }
@@ -727,7 +732,7 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
         if (!(s2 ? has1 : has0)) continue;
         const int nt = nt0 + s2;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MB; ++mi) {
             const int m = 32 * mi + n;
             if (m < rows) {
                 const size_t o = (size_t)(m0 + m) * N + 32 * nt + 4 * kh;
@@ -1033,18 +1038,54 @@ int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, i
 }
 
 // K-split factor the launcher will use for [M, N, K]: enough workgroups for the chip, at least 8 groups (512 columns) per split.
-int w4l_splits(int M, int N, int K) {
-    const int mt = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-    const int wgs = ((N / 32 + W4M_WAVES - 1) / W4M_WAVES) * ((M + mt - 1) / mt);
+// Decomposition: row tile (64 / 128 / 256 rows) x K split, and which kernel.  The one-wave-per-SIMD form (k_w4l2_gemm) needs a multiple
+// of 4 K groups per split; where it applies, the plan takes the shallowest split that yields ~192 workgroups, and for that split the
+// largest row tile -- a smaller row tile costs a few per cent of MFMA efficiency, a deeper split costs a whole fp32 reduce pass
+// (at 1024 rows the K-split q|k|v / o_proj / down products spent 15 % of the prefill in it).  Other shapes keep the 8-wave form.
+struct W4lPlan {
+    int mt, S;
+    bool v2;
+};
+static W4lPlan w4l_plan(int M, int N, int K) {
+    static const bool v2_on = [] {
+        const char *e = getenv("PIE_W4L2");  // A/B switch: 0 = the 8-wave register-staged form only
+        return !(e && e[0] == '0');
+    }();
+    const int groups = K >> 6, col_t = (N / 32 + 7) / 8;
+    const int mt_max = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
+    if (v2_on && groups % 4 == 0 && M > 32) {
+        {  // developer override for sweeps: PIE_W4L_MT (64 / 128 / 256) and PIE_W4L_S (a valid split)
+            const char *em = getenv("PIE_W4L_MT"), *es = getenv("PIE_W4L_S");
+            if (em && es) {
+                const int mt = atoi(em), sp = atoi(es);
+                if ((mt == 64 || mt == 128 || mt == 256) && mt <= mt_max && sp >= 1 && sp <= 16 && groups % (4 * sp) == 0) return {mt, sp, true};
+            }
+        }
+        // a small cost model, calibrated on the 8B shapes at 512 / 1024 / 2048 rows (scripts/bench_w4l.py with PIE_W4L_MT / PIE_W4L_S):
+        // a K step costs ~1.30 / 0.85 / 0.75 us for 256 / 128 / 64-row tiles (below 256 rows the conversion of the weights, which does
+        // not shrink with the tile, bounds the step), workgroups run in rounds of 256, a K split pays an fp32 write + read of S + 1
+        // [M, N] slabs at ~1.3 TB/s.  The plan is the cheapest (row tile, split) under it.
+        W4lPlan best = {mt_max, 1, true};
+        double best_us = 1e30;
+        for (int s = 1; s <= 16 && (s == 1 || 8 * s <= groups); ++s) {  // a split keeps at least 8 groups (512 columns)
+            if (groups % (4 * s)) continue;
+            for (int mt = mt_max; mt >= 64; mt >>= 1) {
+                const double step_us = mt == 256 ? 1.30 : (mt == 128 ? 0.85 : 0.75);
+                const int wgs = col_t * ((M + mt - 1) / mt) * s;
+                double us = (double)((wgs + 255) / 256) * (groups / s) * step_us + 4.0;
+                if (s > 1) us += (double)M * N * 4.0 * (s + 1) / 1.3e6 + 4.0;
+                if (us < best_us) best_us = us, best = {mt, s, true};
+            }
+        }
+        return best;
+    }
+    const int wgs = col_t * ((M + mt_max - 1) / mt_max);
     int s = wgs >= 192 ? 1 : (256 + wgs - 1) / wgs;
-    const int max_s = (K >> 6) / 8 > 0 ? (K >> 6) / 8 : 1;
+    const int max_s = groups / 8 > 0 ? groups / 8 : 1;
     s = s > max_s ? max_s : s;
-    s = s > 16 ? 16 : s;
-    if (M > 128)  // 256-row tiles: k_w4l2_gemm's unrolled step ring wants a multiple of 4 K groups per split -- take the nearest split that gives one
-        for (int t = s; t >= 1; --t)
-            if ((K >> 6) % (4 * t) == 0) return t;
-    return s;
+    return {mt_max, s > 16 ? 16 : s, false};
 }
+int w4l_splits(int M, int N, int K) { return w4l_plan(M, N, K).S; }
 size_t w4l_workspace_bytes(int M, int N, int K) {
     const int s = w4l_splits(M, N, K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
@@ -1057,25 +1098,28 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4 GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "W4 GEMM: 16-byte alignment required");
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4 GEMM: dtype must be PIE_BF16 or PIE_F16");
-    const int S = w4l_splits(M, N, K);
+    const W4lPlan plan = w4l_plan(M, N, K);
+    const int S = plan.S, mt = plan.mt;
     PIE_REQUIRE(S == 1 || workspace, PIE_E_ARG, "W4 GEMM: this shape splits K and needs its workspace");
-    const int mt = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-    static const bool v2 = [] {
-        const char *e = getenv("PIE_W4L2");  // A/B switch: 0 = the 8-wave register-staged form for 256-row tiles too
-        return !(e && e[0] == '0');
-    }();
-    if (mt == 256 && v2 && ((K >> 6) % (4 * S)) == 0) {  // the unrolled step ring needs a multiple of 4 K groups per split
+    if (plan.v2) {
         float *part2 = S > 1 ? (float *)workspace : nullptr;
-        const dim3 g2((unsigned)((N / 32 + 7) / 8), (unsigned)((M + 255) / 256), (unsigned)S);
+        const dim3 grid((unsigned)((N / 32 + 7) / 8), (unsigned)((M + mt - 1) / mt), (unsigned)S);
+#define W4L2_GO(TT, MB_, SW_, Y_, P_) hipLaunchKernelGGL((k_w4l2_gemm<TT, MB_, SW_>), grid, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)(Y_), P_)
+#define W4L2_MB(TT, SW_, Y_, P_) \
+    if (mt == 64) W4L2_GO(TT, 2, SW_, Y_, P_); \
+    else if (mt == 128) W4L2_GO(TT, 4, SW_, Y_, P_); \
+    else W4L2_GO(TT, 8, SW_, Y_, P_)
         if (S == 1 && swiglu_act && fused) {
-            if (dtype == PIE_BF16) hipLaunchKernelGGL((k_w4l2_gemm<BF16, true>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)swiglu_act, nullptr);
-            else hipLaunchKernelGGL((k_w4l2_gemm<F16, true>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)swiglu_act, nullptr);
+            if (dtype == PIE_BF16) { W4L2_MB(BF16, true, swiglu_act, nullptr); }
+            else { W4L2_MB(F16, true, swiglu_act, nullptr); }
             PIE_LAUNCH_CHECK();
             *fused = true;
             return PIE_OK;
         }
-        if (dtype == PIE_BF16) hipLaunchKernelGGL((k_w4l2_gemm<BF16, false>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
-        else hipLaunchKernelGGL((k_w4l2_gemm<F16, false>), g2, dim3(256), 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, part2);
+        if (dtype == PIE_BF16) { W4L2_MB(BF16, false, y, part2); }
+        else { W4L2_MB(F16, false, y, part2); }
+#undef W4L2_MB
+#undef W4L2_GO
         PIE_LAUNCH_CHECK();
         if (S > 1) {
             const size_t MN = (size_t)M * N;
