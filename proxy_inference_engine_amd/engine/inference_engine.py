@@ -78,8 +78,10 @@ class InferenceEngine:
         """Yields (next_token_id[1] int32, logprobs[V] fp32) per step, forever (inference_engine.py:228-297).
         Prefill of the non-cached prompt suffix, then one forward per token; all device work is queued
         asynchronously, the consumer synchronises when it reads a token (generate() does, like `.tolist()` :202)."""
-        if mask is not None:
-            raise NotImplementedError("explicit masks are not supported: the causal mask of models/base.py:37-53 is implicit")
+        if mask is not None and not (isinstance(mask, str) and mask == "causal"):
+            # the reference forwards ONE mask array to the prefill and to every later single-token call (inference_engine.py:246-249),
+            # which only type-checks for a mask that broadcasts against both; the causal structure is implicit in the kernels here
+            raise NotImplementedError("generate_step(mask=array) is not supported: pass mask=None (or \"causal\"); Model.__call__ accepts an explicit causal mask")
         if pixel_values is not None and not hasattr(self.model, "get_input_embeddings"):
             raise TypeError("pixel_values need a VLM ensemble (models/intern/ensemble.py: Model) as the engine's model")
         if "root" not in self.samplers:

@@ -325,12 +325,12 @@ class Model:
         lm_head on every position like the reference (the engine's fast path is `step`).
         inputs_embeds [1, L, hidden] replaces embed_tokens(inputs): the VLM text tower's entry
         (models/intern/language.py:148-158, LanguageModel(None, cache=cache, inputs_embeds=...), intern/ensemble.py:108)."""
-        if mask is not None:
-            raise NotImplementedError("explicit masks are not supported: the causal mask of models/base.py:37-53 is implicit")
         if inputs is None and inputs_embeds is None:
             raise ValueError("Either inputs or inputs_embeds must be provided")  # intern/language.py:188-189
         if cache is None:
             cache = self.make_cache()  # reference: cache=None means no caching; a throw-away cache is equivalent
+        if mask is not None:
+            self._check_mask(mask, (inputs_embeds.shape[-2] if inputs_embeds is not None else inputs.shape[-1]), cache)
         lib = _ffi.load()
         if inputs_embeds is not None:
             emb = self._check_embeds(inputs_embeds)
@@ -348,6 +348,25 @@ class Model:
             _ffi.check(lib.pie_decoder_prefill(self._dec, _ffi.p(ids), L, _ffi.p(out), _ffi.stream()))
         self._advance(cache, L)
         return out.unsqueeze(0)
+
+    def _check_mask(self, mask, L: int, cache) -> None:
+        """Model.__call__(mask=...) (language.py:199-204): the reference builds the causal mask itself when none is given
+        (models/base.py:37-53) and otherwise hands the caller's to sdpa.  The kernels here apply the causal mask implicitly, so a
+        caller's mask is accepted when it IS that mask -- "causal", or an array blocking exactly the future positions (additive: < 0
+        where blocked; boolean: False where blocked) -- and refused otherwise instead of being silently ignored."""
+        if isinstance(mask, str):
+            if mask != "causal":
+                raise NotImplementedError(f"mask={mask!r}: only the causal mask is supported")
+            return
+        c0 = cache[0]
+        offset = int(c0.page_manager.offset if isinstance(c0, PagedKVCache) else c0.offset)
+        m = torch.as_tensor(mask)
+        blocked = (~m) if m.dtype == torch.bool else (m < 0)
+        blocked = blocked.reshape(-1, blocked.shape[-1]) if blocked.dim() > 2 else blocked
+        want = base.create_causal_mask(L, offset, device=blocked.device) < 0
+        if blocked.shape != want.shape or not torch.equal(blocked, want):
+            raise NotImplementedError(f"an explicit mask of shape {tuple(m.shape)} that is not the causal mask for {L} new positions at offset {offset} "
+                                      "is not supported: the attention kernels apply the causal mask of models/base.py:37-53 implicitly")
 
     def _check_embeds(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         emb = inputs_embeds

@@ -282,3 +282,24 @@ def test_persistent_step_equals_launch_sequence():
             assert a[0] == b[0], (key, i)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)) and np.array_equal(a[3], b[3]), (key, i)
     _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_MEGA, 0))
+
+
+def test_model_call_accepts_the_causal_mask_it_would_build_itself(tiny):
+    """Model.__call__(inputs, mask=...) (language.py:199-204): the reference builds create_attention_mask(h, cache) when mask is None
+    and passes a caller's mask through to sdpa; here the causal mask is implicit in the kernels, so that very mask (additive array,
+    boolean array or "causal") is accepted and gives the same logits, at offset 0 and behind a cached prefix; any other mask is refused."""
+    from proxy_inference_engine_amd.models.base import create_causal_mask
+    g, cfg, w, model = tiny
+    ids = torch.from_numpy(g["prompt"][:12])[None].cuda()
+    ref = model(ids, cache=model.make_cache())
+    for mk in ("causal", create_causal_mask(12, 0, device="cuda"), ~(create_causal_mask(12, 0, device="cuda") < 0)):
+        assert torch.equal(model(ids, mask=mk, cache=model.make_cache()), ref)
+    cache, cache2 = model.make_cache(), model.make_cache()
+    model(ids[:, :7], cache=cache)
+    model(ids[:, :7], cache=cache2)
+    tail = model(ids[:, 7:], mask=create_causal_mask(5, 7, device="cuda"), cache=cache).clone()
+    assert torch.equal(tail, model(ids[:, 7:], cache=cache2))
+    with pytest.raises(NotImplementedError):
+        model(ids, mask=torch.zeros(12, 12, device="cuda"), cache=model.make_cache())      # blocks nothing: bidirectional attention
+    with pytest.raises(NotImplementedError):
+        model(ids, mask=create_causal_mask(12, 3, device="cuda"), cache=model.make_cache())  # wrong offset
