@@ -88,6 +88,13 @@ __device__ __forceinline__ uint4 attn_load_row(const u16 *p) {
     }
 }
 
+#ifdef PIE_ATTN_PROF  // developer build: s_memrealtime stamps (100 MHz) of workgroup (0, 0, 0), read by tools/step_bench
+// stamps go to the decoder's 128-byte pf_sink scratch, words 2..9 (pie_debug_buffer(d, 7) hands it out)
+#define ATTN_STAMP(i) if (a.pf_sink && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(a.pf_sink)[2 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define ATTN_STAMP(i)
+#endif
+
 template <class T, int D, int REP, bool PAGED = false, bool NTKV = false>
 __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs a) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
@@ -95,9 +102,18 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     constexpr int NSUB = ATTN_WAVES;  // one merged online-softmax stream per wave reaches LDS
     constexpr int NT = ATTN_WAVES * 64;
     constexpr int DA = ATTN_DEPTH;
-    __shared__ float s_m[REP][NSUB], s_l[REP][NSUB];
-    __shared__ float s_acc[REP][NSUB][D];
+    // WIDE: every 16-lane token group of every wave publishes its own online-softmax stream and the final pass merges all of them -- the
+    // permlane merge of a wave's groups (4 heads x 8 accumulators x 2 swap steps, ~1 us measured in a 4.8 us workgroup at T = 190) goes
+    // away for the price of a longer final pass.  Where the streams fit 64 KB of LDS (REP 4, D 128: the 8B / 70B geometry).
+#ifndef PIE_ATTN_WIDE
+#define PIE_ATTN_WIDE 1
+#endif
+    constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * ATTN_WAVES * TPW * D * 4 <= 65536;
+    constexpr int NSTR = WIDE ? ATTN_WAVES * TPW : NSUB;  // streams in LDS
+    __shared__ float s_m[REP][NSTR], s_l[REP][NSTR];
+    __shared__ float s_acc[REP][NSTR][D];
 
+    ATTN_STAMP(0);
     const int g = blockIdx.x, split = blockIdx.y;
     if (split >= a.splits) {  // prefetch role (uniform per workgroup)
         const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
@@ -121,6 +137,7 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
     const int Ttot = PAGED && a.ctx_len ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
     const int cap = PAGED ? 64 : a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
+    ATTN_STAMP(1);  // the position has arrived
     if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
     const int t_begin = split * sp.chunk;
     const int t_end = min(Ttot, t_begin + sp.chunk);
@@ -177,6 +194,10 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
         for (int j = 0; j < 8; ++j) acc[h][j] = 0.0f;
     }
 
+#ifdef PIE_ATTN_PROF
+    if (kq[0].x == 0x12345678u && vq[0].x == 0x9abcdef0u && a.pf_sink) a.pf_sink[1] = 1;  // forces a wait for the first K / V rows: stamp 2 = they have landed
+    ATTN_STAMP(2);
+#endif
     // Reductions: DPP inside a 16-lane row; v_permlane{16,32}_swap across rows only in the post-loop merge -- no LDS traffic.
     for (int base = 0; base < n_blk; base += DA) {
 #pragma unroll
@@ -238,6 +259,17 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
         }
     }
 
+    ATTN_STAMP(3);  // scoring loop done
+    if constexpr (WIDE) {
+        // lane (ts, dc): stream wave * TPW + ts, dims dc * 8 .. + 7 of every head
+        const int str = wave * TPW + ts;
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            if (dc == 0) s_m[h][str] = m[h], s_l[h][str] = l[h];
+            *reinterpret_cast<float4 *>(&s_acc[h][str][dc * 8]) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+            *reinterpret_cast<float4 *>(&s_acc[h][str][dc * 8 + 4]) = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
+        }
+    } else {
     // merge the token groups of the wave (lanes with equal dc): common max, rescale, plain sums; then one stream per
     // wave goes to LDS
 #pragma unroll
@@ -265,15 +297,19 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
             for (int j = 0; j < 8; ++j) s_acc[h][wave][dc * 8 + j] = acc[h][j];
         }
     }
+    }
+    ATTN_STAMP(4);
     __syncthreads();
+    ATTN_STAMP(5);
+    {
     for (int o = threadIdx.x; o < REP * D; o += NT) {
         const int h = o / D, d = o % D;
         float M = ATTN_NEG;
 #pragma unroll
-        for (int i = 0; i < NSUB; ++i) M = fmaxf(M, s_m[h][i]);
+        for (int i = 0; i < NSTR; ++i) M = fmaxf(M, s_m[h][i]);
         float Lsum = 0.0f, A = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NSUB; ++i) {
+        for (int i = 0; i < NSTR; ++i) {
             const float w = attn_exp2(s_m[h][i] - M);
             Lsum = fmaf(w, s_l[h][i], Lsum);
             A = fmaf(w, s_acc[h][i][d], A);
@@ -285,6 +321,8 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
             a.part_ml[(hq * a.splits + split) * 2 + 1] = Lsum;
         }
     }
+    }
+    ATTN_STAMP(6);
 }
 
 // Merge of the active splits for 8 consecutive dims [d0, d0+8) of q-head h (fp32):

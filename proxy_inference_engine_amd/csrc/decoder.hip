@@ -223,7 +223,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
-    PIE_ALLOC(d->pf_sink, 16);
+    PIE_ALLOC(d->pf_sink, 128);  // 16 bytes of sink + room for the developer build's attention stamps
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)
@@ -463,6 +463,7 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 // Developer hook (not in the public header): the decoder's internal scratch vectors, for tools/step_bench's bisection.
 void *pie_debug_buffer(pie_decoder *d, int which) {
     if (which == 6) return (mega_prepare(d) == PIE_OK && mega_supported(d, true)) ? (void *)d : nullptr;  // would a step run as the persistent launch?
+    if (which == 7) return d->pf_sink;
     void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, mega_prof_ptr(d)};
     return which >= 0 && which < 6 ? p[which] : nullptr;
 }

@@ -566,9 +566,12 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
         MEGA_SYNC(attn_wg);  // workgroups without an attention role only announce their q|k|v rows
         if (attn_wg && !is_sync) {
             constexpr int LPT = HD / 8, TPW = 64 / LPT, NSUB = MEGA_CONSUMERS, DA = 2;  // short caches only: two row blocks in flight are enough
-            float *s_m = reinterpret_cast<float *>(smem);              // [REP][NSUB]
-            float *s_l = s_m + REP * NSUB;                             // [REP][NSUB]
-            float *s_acc = s_l + REP * NSUB;                           // [REP][NSUB][HD]
+            // the same stream layout as k_attn_decode (attention.hpp: WIDE), so the two paths stay bit-identical
+            constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * MEGA_CONSUMERS * TPW * HD * 4 <= 65536;
+            constexpr int NSTR = WIDE ? NSUB * TPW : NSUB;
+            float *s_m = reinterpret_cast<float *>(smem);              // [REP][NSTR]
+            float *s_l = s_m + REP * NSTR;                             // [REP][NSTR]
+            float *s_acc = s_l + REP * NSTR;                           // [REP][NSTR][HD]
             const int g = blockIdx.x % a.n_kv, split = blockIdx.x / a.n_kv;
             const int ts = lane / LPT, dc = lane % LPT;
             const int Ttot = pos + 1;
@@ -659,6 +662,15 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
                         aissue(d, b + DA);
                     }
                 }
+                if constexpr (WIDE) {
+                    const int str = wave * TPW + ts;
+#pragma unroll
+                    for (int h = 0; h < REP; ++h) {
+                        if (dc == 0) s_m[h * NSTR + str] = m[h], s_l[h * NSTR + str] = l[h];
+                        *reinterpret_cast<float4 *>(&s_acc[(h * NSTR + str) * HD + dc * 8]) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+                        *reinterpret_cast<float4 *>(&s_acc[(h * NSTR + str) * HD + dc * 8 + 4]) = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
+                    }
+                } else {
 #pragma unroll
                 for (int h = 0; h < REP; ++h) {
                     float mw = m[h];
@@ -679,17 +691,20 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
                 if (ts == 0) {
 #pragma unroll
                     for (int h = 0; h < REP; ++h) {
-                        if (dc == 0) s_m[h * NSUB + wave] = m[h], s_l[h * NSUB + wave] = l[h];
+                        if (dc == 0) s_m[h * NSTR + wave] = m[h], s_l[h * NSTR + wave] = l[h];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) s_acc[(h * NSUB + wave) * HD + dc * 8 + j] = acc[h][j];
+                        for (int j = 0; j < 8; ++j) s_acc[(h * NSTR + wave) * HD + dc * 8 + j] = acc[h][j];
                     }
+                }
                 }
             }
         }
         if (attn_wg) {
             MEGA_BAR();
             if (!is_sync) {
-                constexpr int NSUB = MEGA_CONSUMERS;
+                constexpr int TPW2 = 64 / (HD / 8);
+                constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * MEGA_CONSUMERS * TPW2 * HD * 4 <= 65536;
+                constexpr int NSUB = WIDE ? MEGA_CONSUMERS * TPW2 : MEGA_CONSUMERS;  // streams in LDS
                 const float *s_m = reinterpret_cast<const float *>(smem), *s_l = s_m + REP * NSUB, *s_acc = s_l + REP * NSUB;
                 const int g = blockIdx.x % a.n_kv, split = blockIdx.x / a.n_kv;
                 if (split < attn_split(pos + 1, a.splits).active) {
@@ -931,7 +946,7 @@ int mega_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u1
     int kmax = c.hidden > c.inter ? c.hidden : c.inter;
     kmax = kmax > QD ? kmax : QD;
     unsigned lds = (unsigned)gemv_lds(kmax).total;
-    const unsigned attn_lds = (unsigned)((c.n_heads / c.n_kv_heads) * MEGA_CONSUMERS * (c.head_dim + 2) * 4);
+    const unsigned attn_lds = (unsigned)((c.n_heads / c.n_kv_heads) * MEGA_CONSUMERS * (64 / (c.head_dim / 8)) * (c.head_dim + 2) * 4);  // every token group's stream (attention.hpp: WIDE)
     lds = lds > attn_lds ? lds : attn_lds;
     lds = (lds + 15u) & ~15u;
     a.lds_rope = lds, lds += (unsigned)c.head_dim * 4;

@@ -9,6 +9,7 @@
 //            logits / logprobs / tokens / hidden state bit for bit.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/step_bench.hip -Iinclude -Lproxy_inference_engine_amd/lib -lpie_hip \
 //        -Wl,-rpath,'$ORIGIN/../proxy_inference_engine_amd/lib' -o tools/step_bench
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -279,6 +280,15 @@ int main(int argc, char **argv) {
     if (mode == "mega" || mode == "both") {
         const double ms = run(1, steps, nullptr);
         printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
+    }
+    if (void *ps = pie_debug_buffer(dec, 7)) {  // -DPIE_ATTN_PROF build of the library: stamps of the last attention launch
+        unsigned long long t[10] = {};
+        CK(hipMemcpy(t, ps, sizeof t, hipMemcpyDeviceToHost));
+        const unsigned long long *q = t + 2;
+        if (q[0] && q[6] > q[0])
+            printf("attention launch, workgroup (0,0,0), us after its start: position arrived %.2f | first K/V rows %.2f | scoring done %.2f | wave merge %.2f | "
+                   "barrier %.2f | partials stored %.2f\n", (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01,
+                   (q[6] - q[0]) * 0.01);
     }
     if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_MEGA_PROF build of the library: stamps of one workgroup during the LAST step
         std::vector<unsigned long long> t(512 * 16);
