@@ -98,6 +98,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             a.block_table = d->block_table, a.n_pages = d->n_pages;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 16;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
@@ -122,6 +123,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.y32 = d->tp_part;
             if (d->combine) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
             const int rc = w4s_gemv_launch(c.dtype, d->combine ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
@@ -129,12 +131,14 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             GemvArgs a = {};
             a.fmt = gfmt(w.wgateup), a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
             a.y = d->act, a.lin_bias = (const u16 *)w.bgateup;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 24;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
         }
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
             a.fmt = gfmt(w.wdown), a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
             a.y32 = d->tp_part;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 28;
             const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
@@ -223,7 +227,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
-    PIE_ALLOC(d->pf_sink, 128);  // 16 bytes of sink + room for the developer build's attention stamps
+    PIE_ALLOC(d->pf_sink, 512);  // 16 bytes of sink + room for the developer builds' stamps (attention: words 2..9; GEMVs: 16 + 4 kind ..)
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)

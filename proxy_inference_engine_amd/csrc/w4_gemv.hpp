@@ -55,6 +55,7 @@ struct GemvArgs {
     float eps;
     u16 *y;               // EPI_STORE / EPI_LOGITS [M,N]; EPI_SWIGLU act [N/2]
     float *y32;           // EPI_PARTIAL_F32 [M,N] fp32
+    unsigned long long *prof;  // developer build (-DPIE_GEMV_PROF): 4 s_memrealtime stamps of workgroup 0 (nullptr otherwise)
     const u16 *lin_bias;  // optional nn.Linear / nn.QuantizedLinear bias [N] in PACKED row order (attention_bias / mlp_bias,
                           // language.py:42-53,117-126): added to the T-rounded product, rounded again; not with EPI_LOGITS
     u16 *resid;           // EPI_RESIDUAL: residual stream, updated in place
@@ -135,8 +136,15 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 // FMT: weight format of the stream.  FMT_W16S serves dense checkpoints (nn.Linear, language.py:83,108,127,209 when the
 //      config has no "quantization" entry): same persistent-wave stream, prologues and epilogues; a unit is 2 x 1 KB of
 //      16-bit weights, a lane multiplies its 16 weights with 16 activations (8 v_dot2), no scale/bias.
+#ifdef PIE_GEMV_PROF
+#define GEMV_STAMP(i) if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define GEMV_STAMP(i)
+#endif
+
 template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs a) {
+    GEMV_STAMP(0);
     constexpr int D = GEMV_DEPTH;
     constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : W4S_UNIT_BYTES);
     constexpr int NT = GEMV_WAVES * 64;
@@ -317,6 +325,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         __syncthreads();
     }
 
+    GEMV_STAMP(1);  // x staged
     // 3. the stream: unit i = (pair p_begin + i / ns, slice i % ns); lanes 0-31 / 32-63 = the pair's two rows.
     //    No global store and no data-dependent branch in here: stores share vmcnt with the loads and would make the
     //    compiler drain the ring.  Row sums are parked in LDS; the epilogue runs after the loop, one lane per pair.
@@ -369,6 +378,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
 
+    GEMV_STAMP(2);  // stream done
     // 4. epilogue: lane l owns local pair l (rows R, R+1 of the packed order); consecutive lanes -> consecutive addresses.
     float va = 0.0f, vb = 0.0f;
     if (live) {
@@ -434,6 +444,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             }
         }
     }
+    GEMV_STAMP(3);
 }
 
 // Host-side launch: sizes the persistent grid for (N, K) and dispatches the template.

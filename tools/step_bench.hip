@@ -282,8 +282,15 @@ int main(int argc, char **argv) {
         printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
     }
     if (void *ps = pie_debug_buffer(dec, 7)) {  // -DPIE_ATTN_PROF build of the library: stamps of the last attention launch
-        unsigned long long t[10] = {};
+        unsigned long long t[32] = {};
         CK(hipMemcpy(t, ps, sizeof t, hipMemcpyDeviceToHost));
+        const char *kn[4] = {"qkv", "o_proj", "gate_up", "down"};
+        for (int k = 0; k < 4; ++k) {  // -DPIE_GEMV_PROF build: workgroup 0 of the last launch of each GEMV
+            const unsigned long long *g4 = t + 16 + 4 * k;
+            if (g4[0] && g4[3] > g4[0])
+                printf("%-8s launch, workgroup 0, us after its start: x staged %.2f | stream done %.2f | epilogue done %.2f\n", kn[k], (g4[1] - g4[0]) * 0.01,
+                       (g4[2] - g4[0]) * 0.01, (g4[3] - g4[0]) * 0.01);
+        }
         const unsigned long long *q = t + 2;
         if (q[0] && q[6] > q[0])
             printf("attention launch, workgroup (0,0,0), us after its start: position arrived %.2f | first K/V rows %.2f | scoring done %.2f | wave merge %.2f | "
