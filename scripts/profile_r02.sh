@@ -19,6 +19,7 @@ timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prefill_busy -- $B --model 8b --no-mega --prefill 4096 --prefill-reps 1 > $O/prefill_busy.log 2>&1 || echo "busy pass failed" >> $O/prefill_busy.log
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES --output-format csv -d $O/prefill16_mfma -- $B --model 8b --no-mega --prefill 16 --prefill-reps 8 > $O/prefill16_mfma.log 2>&1 || echo "mfma16 pass failed" >> $O/prefill16_mfma.log
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prefill16_stats -- $B --model 8b --no-mega --prefill 16 --prefill-reps 8 > $O/prefill16_stats.log 2>&1 || echo "stats16 pass failed" >> $O/prefill16_stats.log
+(cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 > $O/bench_stats.log 2>&1) || echo "bench stats pass failed" >> $O/bench_stats.log
 (rocprofv3 -L 2>/dev/null | grep -i "mfma\|SQ_BUSY\|FETCH_SIZE\|WRITE_SIZE" | head -60) > $O/counters.txt || true
 # keep only the csv summaries small enough to merge back
 find $O -name "*.csv" -size +30M -delete

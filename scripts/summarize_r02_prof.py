@@ -22,6 +22,9 @@ def short(name):
 
 shutil.copy(glob.glob(str(P / "step_stats" / "runc" / "*_kernel_stats.csv"))[0], OUT / "r02_step_kernel_stats.csv")
 shutil.copy(glob.glob(str(P / "prefill_stats" / "runc" / "*_kernel_stats.csv"))[0], OUT / "r02_prefill4096_kernel_stats.csv")
+bs = glob.glob(str(P / "bench_stats" / "*" / "*_kernel_stats.csv"))
+if bs:
+    shutil.copy(bs[0], OUT / "r02_bench_kernel_stats.csv")
 
 # ---- HBM traffic of the product decode step (8B int4, context 128..138, capacity 512, eager launches of the same kernels)
 H, I, QD, KVD, V, L = 4096, 14336, 4096, 1024, 128256, 32
