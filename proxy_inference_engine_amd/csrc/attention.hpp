@@ -73,6 +73,10 @@ struct AttnArgs {
 };
 
 constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VALU scoring overlaps the other's loads)
+// Short caches (the merged-split plan, capacity <= 1024) run 4 waves: a split then holds a few dozen positions, the scoring loop is two or
+// three row blocks per wave either way, and half the waves mean half the streams in the closing merge and less barrier skew: 1.250 vs
+// 1.263 ms per step at T ~ 200 (16 waves: 1.334).  Long caches keep 8 (the scoring loop is VALU work there).
+constexpr int ATTN_SHORT_WAVES = 4;
 
 // 16-byte K/V row piece.  NT = non-temporal (the cache is read once per step): measured on the 8B decode step with nt weight
 // streams, nt K/V is -0.6 % at 200 cached positions (the rows then survive in the Infinity Cache from step to step), +2.1 % at
@@ -95,12 +99,12 @@ __device__ __forceinline__ uint4 attn_load_row(const u16 *p) {
 #define ATTN_STAMP(i)
 #endif
 
-template <class T, int D, int REP, bool PAGED = false, bool NTKV = false>
-__global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs a) {
+template <class T, int D, int REP, bool PAGED = false, bool NTKV = false, int WAVES = ATTN_WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
     constexpr int TPW = 64 / LPT;  // token rows per wave-load
-    constexpr int NSUB = ATTN_WAVES;  // one merged online-softmax stream per wave reaches LDS
-    constexpr int NT = ATTN_WAVES * 64;
+    constexpr int NSUB = WAVES;  // one merged online-softmax stream per wave reaches LDS
+    constexpr int NT = WAVES * 64;
     constexpr int DA = ATTN_DEPTH;
     // WIDE: every 16-lane token group of every wave publishes its own online-softmax stream and the final pass merges all of them -- the
     // permlane merge of a wave's groups (4 heads x 8 accumulators x 2 swap steps, ~1 us measured in a 4.8 us workgroup at T = 190) goes
@@ -108,8 +112,8 @@ __global__ void __launch_bounds__(ATTN_WAVES * 64) k_attn_decode(const AttnArgs 
 #ifndef PIE_ATTN_WIDE
 #define PIE_ATTN_WIDE 1
 #endif
-    constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * ATTN_WAVES * TPW * D * 4 <= 65536;
-    constexpr int NSTR = WIDE ? ATTN_WAVES * TPW : NSUB;  // streams in LDS
+    constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * WAVES * TPW * D * 4 <= 65536;
+    constexpr int NSTR = WIDE ? WAVES * TPW : NSUB;  // streams in LDS
     __shared__ float s_m[REP][NSTR], s_l[REP][NSTR];
     __shared__ float s_acc[REP][NSTR][D];
 

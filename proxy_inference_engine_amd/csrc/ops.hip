@@ -5,19 +5,19 @@
 #include "tail.hpp"
 
 // ---------------------------------------------------------------- attention launch
-template <class T, int D, bool PAGED, bool NT>
+template <class T, int D, bool PAGED, bool NT, int WAVES = ATTN_WAVES>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
-    dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(ATTN_WAVES * 64);
+    dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(WAVES * 64);
     switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
-        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED, NT>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED, NT>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED, NT>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED, NT>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED, NT>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED, NT>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED, NT>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED, NT>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
         default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be between 1 and 8");
     }
     PIE_LAUNCH_CHECK();
@@ -31,6 +31,9 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
 template <class T, int D>
 static int attn_launch_d(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     if (a.nt_kv) return a.block_table ? attn_launch_rep<T, D, true, true>(rep, a, combine, st) : attn_launch_rep<T, D, false, true>(rep, a, combine, st);
+    if (!combine)  // the merged-split plan of short caches (capacity <= 1024): 4-wave workgroups
+        return a.block_table ? attn_launch_rep<T, D, true, false, ATTN_SHORT_WAVES>(rep, a, combine, st)
+                             : attn_launch_rep<T, D, false, false, ATTN_SHORT_WAVES>(rep, a, combine, st);
     return a.block_table ? attn_launch_rep<T, D, true, false>(rep, a, combine, st) : attn_launch_rep<T, D, false, false>(rep, a, combine, st);
 }
 

@@ -565,9 +565,10 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
         }
         MEGA_SYNC(attn_wg);  // workgroups without an attention role only announce their q|k|v rows
         if (attn_wg && !is_sync) {
-            constexpr int LPT = HD / 8, TPW = 64 / LPT, NSUB = MEGA_CONSUMERS, DA = 2;  // short caches only: two row blocks in flight are enough
-            // the same stream layout as k_attn_decode (attention.hpp: WIDE), so the two paths stay bit-identical
-            constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * MEGA_CONSUMERS * TPW * HD * 4 <= 65536;
+            constexpr int LPT = HD / 8, TPW = 64 / LPT, NSUB = ATTN_SHORT_WAVES, DA = 2;  // short caches only: two row blocks in flight are enough
+            // the same wave count and stream layout as k_attn_decode's short-cache form (attention.hpp: ATTN_SHORT_WAVES, WIDE), so the two paths
+            // stay bit-identical: waves NSUB.. of the workgroup sit the scoring out
+            constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * NSUB * TPW * HD * 4 <= 65536;
             constexpr int NSTR = WIDE ? NSUB * TPW : NSUB;
             float *s_m = reinterpret_cast<float *>(smem);              // [REP][NSTR]
             float *s_l = s_m + REP * NSTR;                             // [REP][NSTR]
@@ -576,7 +577,7 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
             const int ts = lane / LPT, dc = lane % LPT;
             const int Ttot = pos + 1;
             const AttnSplit sp = attn_split(Ttot, a.splits);
-            if (split < sp.active) {  // uniform for the workgroup
+            if (split < sp.active && wave < NSUB) {  // uniform per wave
                 const int t_begin = split * sp.chunk, t_end = min(Ttot, t_begin + sp.chunk);
                 const unsigned kv_bytes = (unsigned)((size_t)a.n_kv * cap * HD * 2);
                 const __amdgpu_buffer_rsrc_t kr = coh_rsrc(reinterpret_cast<const void *>(const_load(a.kv_table + li)), kv_bytes);
@@ -703,8 +704,8 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
             MEGA_BAR();
             if (!is_sync) {
                 constexpr int TPW2 = 64 / (HD / 8);
-                constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * MEGA_CONSUMERS * TPW2 * HD * 4 <= 65536;
-                constexpr int NSUB = WIDE ? MEGA_CONSUMERS * TPW2 : MEGA_CONSUMERS;  // streams in LDS
+                constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * ATTN_SHORT_WAVES * TPW2 * HD * 4 <= 65536;
+                constexpr int NSUB = WIDE ? ATTN_SHORT_WAVES * TPW2 : ATTN_SHORT_WAVES;  // streams in LDS
                 const float *s_m = reinterpret_cast<const float *>(smem), *s_l = s_m + REP * NSUB, *s_acc = s_l + REP * NSUB;
                 const int g = blockIdx.x % a.n_kv, split = blockIdx.x / a.n_kv;
                 if (split < attn_split(pos + 1, a.splits).active) {
