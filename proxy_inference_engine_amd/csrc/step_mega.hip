@@ -709,20 +709,22 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
                 const float *s_m = reinterpret_cast<const float *>(smem), *s_l = s_m + REP * NSUB, *s_acc = s_l + REP * NSUB;
                 const int g = blockIdx.x % a.n_kv, split = blockIdx.x / a.n_kv;
                 if (split < attn_split(pos + 1, a.splits).active) {
-                    for (int o = tid; o < REP * HD; o += NT) {
-                        const int h = o / HD, d = o % HD;
+                    for (int o = tid; o < REP * (HD / 2); o += NT) {  // (head, dim pair) per thread, as k_attn_decode's final pass
+                        const int h = o / (HD / 2), d = (o % (HD / 2)) * 2;
                         float M = ATTN_NEG;
 #pragma unroll
                         for (int i = 0; i < NSUB; ++i) M = fmaxf(M, s_m[h * NSUB + i]);
-                        float Lsum = 0.0f, A = 0.0f;
+                        float Lsum = 0.0f, A0 = 0.0f, A1 = 0.0f;
 #pragma unroll
                         for (int i = 0; i < NSUB; ++i) {
                             const float w = attn_exp2(s_m[h * NSUB + i] - M);
+                            const float2 av = *reinterpret_cast<const float2 *>(&s_acc[(h * NSUB + i) * HD + d]);
                             Lsum = fmaf(w, s_l[h * NSUB + i], Lsum);
-                            A = fmaf(w, s_acc[(h * NSUB + i) * HD + d], A);
+                            A0 = fmaf(w, av.x, A0), A1 = fmaf(w, av.y, A1);
                         }
                         const size_t hq = (size_t)g * REP + h;
-                        coh_stf(a.part_acc + (hq * a.splits + split) * HD + d, A);
+                        coh_stf(a.part_acc + (hq * a.splits + split) * HD + d, A0);
+                        coh_stf(a.part_acc + (hq * a.splits + split) * HD + d + 1, A1);
                         if (d == 0) {
                             coh_stf(a.part_ml + (hq * a.splits + split) * 2 + 0, M);
                             coh_stf(a.part_ml + (hq * a.splits + split) * 2 + 1, Lsum);
