@@ -76,7 +76,9 @@ constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VA
 // Short caches (the merged-split plan, capacity <= 1024) run 4 waves: a split then holds a few dozen positions, the scoring loop is two or
 // three row blocks per wave either way, and half the waves mean half the streams in the closing merge and less barrier skew: 1.250 vs
 // 1.263 ms per step at T ~ 200 (16 waves: 1.334).  Long caches keep 8 (the scoring loop is VALU work there).
-constexpr int ATTN_SHORT_WAVES = 4;
+// ... with up to 4 q-heads per kv-head; with 8 (the 70B geometry) a wave carries twice the heads and the 8-wave form stays ahead
+// (70B step: 7.95-8.13 vs 8.27-8.44 ms)
+constexpr int attn_short_waves(int rep) { return rep <= 4 ? 4 : ATTN_WAVES; }
 
 // 16-byte K/V row piece.  NT = non-temporal (the cache is read once per step): measured on the 8B decode step with nt weight
 // streams, nt K/V is -0.6 % at 200 cached positions (the rows then survive in the Infinity Cache from step to step), +2.1 % at

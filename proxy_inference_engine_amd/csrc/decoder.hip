@@ -227,7 +227,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
-    PIE_ALLOC(d->pf_sink, 512);  // 16 bytes of sink + room for the developer builds' stamps (attention: words 2..9; GEMVs: 16 + 4 kind ..)
+    PIE_ALLOC(d->pf_sink, 8192);  // 16 bytes of sink + room for the developer builds' stamps (attention: words 2..9; GEMVs: 16 + 4 kind ..)
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
     {
         const char *e = getenv("PIE_PREFETCH_MB");  // tuning knob: MB of gate/up weights warmed during attention (default 0 = o_proj only: +1 % measured; warming gate/up made the step slower; -1 = no warm-up at all)

@@ -5,21 +5,28 @@
 #include "tail.hpp"
 
 // ---------------------------------------------------------------- attention launch
-template <class T, int D, bool PAGED, bool NT, int WAVES = ATTN_WAVES>
+template <class T, int D, bool PAGED, bool NT, bool SHORT = false>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
-    dim3 grid(a.Hkv, a.splits + a.pf_rows, rows), block(WAVES * 64);
+    const dim3 grid(a.Hkv, a.splits + a.pf_rows, rows);
+#define ATTN_GO(R)                                                                                                                      \
+    {                                                                                                                                   \
+        constexpr int W_ = SHORT ? attn_short_waves(R) : ATTN_WAVES;                                                                    \
+        hipLaunchKernelGGL((k_attn_decode<T, D, R, PAGED, NT, W_>), grid, dim3(W_ * 64), 0, st, a);                                      \
+    }                                                                                                                                   \
+    break
     switch (rep) {  // q-heads per kv-head: Llama-3-8B/70B 4/8, Llama-3.2-3B 3, Qwen2.5-7B 7, MHA 1
-        case 1: hipLaunchKernelGGL((k_attn_decode<T, D, 1, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<T, D, 2, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<T, D, 3, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<T, D, 4, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_decode<T, D, 5, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_decode<T, D, 6, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_decode<T, D, 7, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<T, D, 8, PAGED, NT, WAVES>), grid, block, 0, st, a); break;
+        case 1: ATTN_GO(1);
+        case 2: ATTN_GO(2);
+        case 3: ATTN_GO(3);
+        case 4: ATTN_GO(4);
+        case 5: ATTN_GO(5);
+        case 6: ATTN_GO(6);
+        case 7: ATTN_GO(7);
+        case 8: ATTN_GO(8);
         default: return pie::fail(PIE_E_SHAPE, "sdpa_decode: n_heads / n_kv_heads must be between 1 and 8");
     }
+#undef ATTN_GO
     PIE_LAUNCH_CHECK();
     if (combine) {
         hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, rows), dim3(256), 0, st, a, D);
@@ -32,8 +39,8 @@ template <class T, int D>
 static int attn_launch_d(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     if (a.nt_kv) return a.block_table ? attn_launch_rep<T, D, true, true>(rep, a, combine, st) : attn_launch_rep<T, D, false, true>(rep, a, combine, st);
     if (!combine)  // the merged-split plan of short caches (capacity <= 1024): 4-wave workgroups
-        return a.block_table ? attn_launch_rep<T, D, true, false, ATTN_SHORT_WAVES>(rep, a, combine, st)
-                             : attn_launch_rep<T, D, false, false, ATTN_SHORT_WAVES>(rep, a, combine, st);
+        return a.block_table ? attn_launch_rep<T, D, true, false, true>(rep, a, combine, st)
+                             : attn_launch_rep<T, D, false, false, true>(rep, a, combine, st);
     return a.block_table ? attn_launch_rep<T, D, true, false>(rep, a, combine, st) : attn_launch_rep<T, D, false, false>(rep, a, combine, st);
 }
 

@@ -565,8 +565,8 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
         }
         MEGA_SYNC(attn_wg);  // workgroups without an attention role only announce their q|k|v rows
         if (attn_wg && !is_sync) {
-            constexpr int LPT = HD / 8, TPW = 64 / LPT, NSUB = ATTN_SHORT_WAVES, DA = 2;  // short caches only: two row blocks in flight are enough
-            // the same wave count and stream layout as k_attn_decode's short-cache form (attention.hpp: ATTN_SHORT_WAVES, WIDE), so the two paths
+            constexpr int LPT = HD / 8, TPW = 64 / LPT, NSUB = attn_short_waves(REP), DA = 2;  // short caches only: two row blocks in flight are enough
+            // the same wave count and stream layout as k_attn_decode's short-cache form (attention.hpp: attn_short_waves, WIDE), so the two paths
             // stay bit-identical: waves NSUB.. of the workgroup sit the scoring out
             constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * NSUB * TPW * HD * 4 <= 65536;
             constexpr int NSTR = WIDE ? NSUB * TPW : NSUB;
@@ -704,8 +704,8 @@ __global__ void __launch_bounds__(MEGA_THREADS) k_step_mega(const MegaArgs a) {
             MEGA_BAR();
             if (!is_sync) {
                 constexpr int TPW2 = 64 / (HD / 8);
-                constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * ATTN_SHORT_WAVES * TPW2 * HD * 4 <= 65536;
-                constexpr int NSUB = WIDE ? ATTN_SHORT_WAVES * TPW2 : ATTN_SHORT_WAVES;  // streams in LDS
+                constexpr bool WIDE = PIE_ATTN_WIDE && (size_t)REP * attn_short_waves(REP) * TPW2 * HD * 4 <= 65536;
+                constexpr int NSUB = WIDE ? attn_short_waves(REP) * TPW2 : attn_short_waves(REP);  // streams in LDS
                 const float *s_m = reinterpret_cast<const float *>(smem), *s_l = s_m + REP * NSUB, *s_acc = s_l + REP * NSUB;
                 const int g = blockIdx.x % a.n_kv, split = blockIdx.x / a.n_kv;
                 if (split < attn_split(pos + 1, a.splits).active) {
@@ -949,7 +949,9 @@ int mega_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u1
     int kmax = c.hidden > c.inter ? c.hidden : c.inter;
     kmax = kmax > QD ? kmax : QD;
     unsigned lds = (unsigned)gemv_lds(kmax).total;
-    const unsigned attn_lds = (unsigned)((c.n_heads / c.n_kv_heads) * MEGA_CONSUMERS * (64 / (c.head_dim / 8)) * (c.head_dim + 2) * 4);  // every token group's stream (attention.hpp: WIDE)
+    const int a_rep = c.n_heads / c.n_kv_heads, a_waves = attn_short_waves(a_rep), a_tpw = 64 / (c.head_dim / 8);
+    const bool a_wide = PIE_ATTN_WIDE && (size_t)a_rep * a_waves * a_tpw * c.head_dim * 4 <= 65536;  // attention.hpp: WIDE
+    const unsigned attn_lds = (unsigned)(a_rep * (a_wide ? a_waves * a_tpw : a_waves) * (c.head_dim + 2) * 4);  // the online-softmax streams
     lds = lds > attn_lds ? lds : attn_lds;
     lds = (lds + 15u) & ~15u;
     a.lds_rope = lds, lds += (unsigned)c.head_dim * 4;

@@ -137,7 +137,14 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 //      config has no "quantization" entry): same persistent-wave stream, prologues and epilogues; a unit is 2 x 1 KB of
 //      16-bit weights, a lane multiplies its 16 weights with 16 activations (8 v_dot2), no scale/bias.
 #ifdef PIE_GEMV_PROF
-#define GEMV_STAMP(i) if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime()
+// stamps 0..3: workgroup 0; with PIE_GEMV_PROF=2 also every workgroup's start / end at prof[64 + 2 b], prof[65 + 2 b] (gate/up only: its prof slot is the last)
+#define GEMV_STAMP(i)                                                                                                   \
+    do {                                                                                                                \
+        if (a.prof && blockIdx.y == 0 && threadIdx.x == 0) {                                                            \
+            if (blockIdx.x == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime();                                          \
+            if (PIE_GEMV_PROF == 2 && EPI == EPI_SWIGLU && ((i) == 0 || (i) == 3)) a.prof[64 + 2 * blockIdx.x + ((i) == 3)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                               \
+    } while (0)
 #else
 #define GEMV_STAMP(i)
 #endif
@@ -337,6 +344,15 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         for (int d = 0; d < D; ++d) {
             const int i = base + d;
             if (i < n_units) {  // wave-uniform
+              // The two waves of a SIMD take turns at the higher issue priority, two units each.  With equal priorities the older wave of
+              // every SIMD wins the arbitration: stamps showed waves 0-3 of a gate/up workgroup finishing their (equal) share of the
+              // stream 0.8-1.0 us before waves 4-7, and the workgroup -- and the launch -- waiting for the late half.  Turns of one
+              // unit, a wider priority gap or the younger wave first measured within noise of this; the younger wave ALWAYS ahead was
+              // slower than no priorities (1.262 vs 1.243 ms per step); this form: 1.227-1.232.
+#ifndef PIE_GEMV_NO_PRIO
+              if (((i >> 1) + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+              else __builtin_amdgcn_s_setprio(0);
+#endif
               if (FMT == FMT_W16S) {  // lane (row, chunk): 16 weights x 16 activations
                 const int chunk = sl * 32 + (lane & 31);
                 const bool cvalid = chunk * 16 < a.K;
@@ -378,6 +394,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
 
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 2
+    if (a.prof && EPI == EPI_SWIGLU && blockIdx.y == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 201))
+        a.prof[32 + (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 8 : 16)) + wave] = __builtin_amdgcn_s_memrealtime();  // every wave's stream end
+#endif
     GEMV_STAMP(2);  // stream done
     // 4. epilogue: lane l owns local pair l (rows R, R+1 of the packed order); consecutive lanes -> consecutive addresses.
     float va = 0.0f, vb = 0.0f;

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -290,6 +291,50 @@ int main(int argc, char **argv) {
             if (g4[0] && g4[3] > g4[0])
                 printf("%-8s launch, workgroup 0, us after its start: x staged %.2f | stream done %.2f | epilogue done %.2f\n", kn[k], (g4[1] - g4[0]) * 0.01,
                        (g4[2] - g4[0]) * 0.01, (g4[3] - g4[0]) * 0.01);
+        }
+        {  // -DPIE_GEMV_PROF=2: start / end of every workgroup of the last gate/up launch
+            std::vector<unsigned long long> w(64 + 512);
+            CK(hipMemcpy(w.data(), (const unsigned long long *)ps + 24, w.size() * 8, hipMemcpyDeviceToHost));  // gate/up's stamp block starts at word 24
+            for (int wg = 0; wg < 3; ++wg)
+                if (w[32 + 8 * wg]) {
+                    printf("  gate_up workgroup %d, stream end of its 8 waves, us after the launch's first start:", wg == 0 ? 0 : (wg == 1 ? 100 : 201));
+                    for (int k = 0; k < 8; ++k) printf(" %.2f", (double)(long long)(w[32 + 8 * wg + k] - w[64]) * 0.01);
+                    printf("\n");
+                }
+            unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+            int n = 0;
+            for (int b = 0; b < 256; ++b)
+                if (w[64 + 2 * b] && w[65 + 2 * b]) {
+                    ++n;
+                    s0 = std::min(s0, w[64 + 2 * b]), s1 = std::max(s1, w[64 + 2 * b]), e0 = std::min(e0, w[65 + 2 * b]), e1 = std::max(e1, w[65 + 2 * b]);
+                }
+            if (n) {
+                printf("gate_up: %d workgroups; starts spread over %.2f us; first end %.2f us, last end %.2f us after the first start\n", n, (s1 - s0) * 0.01, (e0 - s0) * 0.01,
+                       (e1 - s0) * 0.01);
+                int hist[12] = {};
+                for (int b = 0; b < 256; ++b)
+                    if (w[65 + 2 * b]) {
+                        int k = (int)((w[65 + 2 * b] - e0) * 0.01 / 0.25);
+                        hist[k < 11 ? k : 11]++;
+                    }
+                {  // which workgroups end last, and the mean end per XCD (blockIdx % 8 under round-robin placement)
+                    std::vector<std::pair<unsigned long long, int>> o;
+                    double xs[8] = {}, xn[8] = {};
+                    for (int b = 0; b < 256; ++b)
+                        if (w[65 + 2 * b]) o.push_back({w[65 + 2 * b], b}), xs[b % 8] += (w[65 + 2 * b] - s0) * 0.01, xn[b % 8] += 1;
+                    std::sort(o.begin(), o.end());
+                    printf("  last 12 to end:");
+                    for (size_t k = o.size() >= 12 ? o.size() - 12 : 0; k < o.size(); ++k) printf(" %d", o[k].second);
+                    printf("\n  first 12 to end:");
+                    for (size_t k = 0; k < 12 && k < o.size(); ++k) printf(" %d", o[k].second);
+                    printf("\n  mean end per blockIdx %% 8:");
+                    for (int k = 0; k < 8; ++k) printf(" %.2f", xn[k] ? xs[k] / xn[k] : 0.0);
+                    printf("\n");
+                }
+                printf("  ends, 0.25 us bins after the first end:");
+                for (int k = 0; k < 12; ++k) printf(" %d", hist[k]);
+                printf("\n");
+            }
         }
         const unsigned long long *q = t + 2;
         if (q[0] && q[6] > q[0])
