@@ -44,10 +44,19 @@ alg = {"k_w4s_gemv<BF16, 1, 2, 1, 0, 0>": ("qkv: rmsnorm + GEMV + RoPE + cache a
        "k_logits_finish<BF16>": ("tail: log-softmax + argmax", V * 4, 1),
        "k_embedding_w4g64<BF16, 4>": ("embedding row + RoPE table", H // 2 + 2 * (H // 64) * 2, 1)}
 f, w = counters("step_fetch"), counters("step_write")
+
+
+def pick(df, key):
+    """Rows of one kernel; a key matches its exact short name or, for templates that grew parameters, its prefix."""
+    names = df.Kernel_Name.map(short)
+    hit = df[names == key]
+    return hit if len(hit) else df[names.str.startswith(key[:-1] + ",")]
+
+
 rows, step_meas, step_alg = {}, 0.0, 0.0
 for key, (what, a, per_step) in alg.items():
-    fk = f[f.Kernel_Name.map(short) == key]["mean"].iloc[0] * 1024 * 2  # KB; gfx950: wide streaming reads are tallied at half their size
-    wk = w[w.Kernel_Name.map(short) == key]["mean"].iloc[0] * 1024
+    fk = pick(f, key)["mean"].iloc[0] * 1024 * 2  # KB; gfx950: wide streaming reads are tallied at half their size
+    wk = pick(w, key)["mean"].iloc[0] * 1024
     rows[key] = {"what": what, "launches_per_step": per_step, "algorithmic_bytes": a, "hbm_bytes_per_launch": int(fk + wk),
                  "FETCH_SIZE_KB": round(fk / 2048, 2), "WRITE_SIZE_KB": round(wk / 1024, 2), "ratio": round((fk + wk) / a, 4)}
     step_meas += (fk + wk) * per_step
@@ -60,8 +69,8 @@ json.dump({"kernel": "k_w4s_gemv<BF16, rmsnorm, swiglu> (gate/up, N=28672 K=4096
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the PRODUCT decode step driven through the C ABI by "
                    "tools/step_bench (--mode launch --graph 0: the launch sequence of pie_decoder_step, the kernels and arguments the hipGraph replays; "
                    "8 steps after 2 warm-up, means over all dispatches).  FETCH_SIZE doubled (gfx950 tallies the 128-B requests of wide coalesced "
-                   "streams at 64 B: MI355X_MICROARCH.md, HBM section; calibrated in round 1 against a pure stream kernel).  Attention and the tail "
-                   "fetch less than their algorithmic bytes on the memory side because the KV working set of one layer and the logits are L2 hits."},
+                   "streams at 64 B: MI355X_MICROARCH.md, HBM section; calibrated in round 1 against a pure stream kernel).  The doubling over-states "
+                   "the small kernels whose reads are not wide streams (attention, tail, embedding: a few hundred KB per step in all)."},
           open(OUT / "r02_traffic.json", "w"), indent=1)
 
 # ---- MFMA activity of the prompt path (4096-token prefill, 8B int4): the many-row W4 GEMM and the causal attention
