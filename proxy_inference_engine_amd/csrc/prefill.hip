@@ -80,6 +80,41 @@ __global__ void k_rope_cs_rows(const float *freqs, const DecState *state, const 
     }
 }
 
+// A K-split many-row GEMM (w4m_gemm.hip) leaves S fp32 partial slabs [S][M][N]; its consumer can form the Linear's output itself --
+// the slabs summed in slab order, then the one rounding to T: exactly k_w4l_reduce's arithmetic -- which saves that launch and the
+// round trip of y through memory (prompts of 33..~700 rows split K; a launch is ~5 us of a 150-300 us layer there).
+struct W4lSlabs {
+    const float *part = nullptr;
+    int S = 0;
+    size_t MN = 0;
+};
+// V = float2 / float4: one thread's NV vectors at element offsets off[]; the slabs are fetched four at a time (all 4 NV loads in flight
+// before the first add -- a plain loop over the slabs waits out one memory latency per slab: 15 us instead of 5 for a 64-row o_proj
+// consumer) and added strictly in slab order.
+template <class V, int NV>
+__device__ __forceinline__ void slab_sum(const float *part, int S, size_t MN, const size_t (&off)[NV], V (&acc)[NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = *reinterpret_cast<const V *>(part + off[v]);
+    for (int z = 1; z < S; z += 4) {
+        V b[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t zz = (size_t)(z + u < S ? z + u : S - 1) * MN;  // clamp, never branch around a load
+#pragma unroll
+            for (int v = 0; v < NV; ++v) b[u][v] = *reinterpret_cast<const V *>(part + zz + off[v]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (z + u < S) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    acc[v].x += b[u][v].x, acc[v].y += b[u][v].y;
+                    if constexpr (sizeof(V) == 16) acc[v].z += b[u][v].z, acc[v].w += b[u][v].w;
+                }
+            }
+    }
+}
+
 // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:134-137) for M rows of the packed
 // q|k|v projection: packed columns (2i, 2i+1) of a q/k head are its dims (i, i + D/2); v columns are natural.
 // grid M, one thread per packed column pair.
@@ -88,7 +123,9 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
                                                          int n_pages, const float *rope_cs, const int *ctx_len = nullptr, int bt_stride = 0,
-                                                         u16 *slab = nullptr, const int *row_seq = nullptr, u16 *kc = nullptr, u16 *vc = nullptr) {
+                                                         u16 *slab = nullptr, const int *row_seq = nullptr, u16 *kc = nullptr, u16 *vc = nullptr,
+                                                         const float *part = nullptr, int S = 0, size_t MN = 0) {
+    // part != nullptr: the projection arrives as the fp32 slabs of a K-split GEMM (W4lSlabs) instead of qkv
     // row_seq / kc / vc (several prompts in one pass): row m belongs to sequence row_seq[m] (its block-table row), and the
     // rotated K and the V rows are also written to contiguous [n_kv_heads, rows, HD] buffers the attention of this pass reads
     // ctx_len != nullptr (multi-sequence decode step): row m is its own sequence at position ctx_len[m] - 1 with its own block
@@ -108,7 +145,13 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
     const u16 *row = qkv + (size_t)m * n_cols;
     for (int p = threadIdx.x; p < (n_cols >> 1); p += blockDim.x) {
         const int R = 2 * p;
-        const u32 pr = *reinterpret_cast<const u32 *>(row + R);
+        u32 pr;
+        if (part) {
+            const size_t i[1] = {(size_t)m * n_cols + R};
+            float2 a[1];
+            slab_sum<float2, 1>(part, S, MN, i, a);
+            pr = pack2<T>(a[0].x, a[0].y);
+        } else pr = *reinterpret_cast<const u32 *>(row + R);
         const float ra = lo_f32<T>(pr), rb = hi_f32<T>(pr);
         if (R < q_cols + k_cols) {
             const int rr = R < q_cols ? R : R - q_cols;
@@ -166,7 +209,8 @@ __global__ void k_bias_rows(u16 *y, const u16 *b, size_t n8, int N8) {
 // here (the Linear's own roundings) and the buffer is handed back zeroed for the next GEMM.
 template <class T>
 __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn, float *r32 = nullptr,
-                                                          const u16 *bias = nullptr) {
+                                                          const u16 *bias = nullptr, const float *part = nullptr, int S = 0, size_t MN = 0) {
+    // part != nullptr: the Linear's output arrives as the fp32 slabs of a K-split many-row GEMM (W4lSlabs): r = T(T(sum of the slabs) + bias)
     __shared__ float red[4];
     u16 *xr = x + (size_t)blockIdx.x * H;
     const u16 *rr = r + (size_t)blockIdx.x * H;
@@ -181,9 +225,17 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
         if (i < H) {
             const uint4 a = *reinterpret_cast<const uint4 *>(xr + i);
             uint4 b;
-            if (r32r) {
-                const float4 f0 = *reinterpret_cast<const float4 *>(r32r + i), f1 = *reinterpret_cast<const float4 *>(r32r + i + 4);
-                *reinterpret_cast<float4 *>(r32r + i) = make_float4(0, 0, 0, 0), *reinterpret_cast<float4 *>(r32r + i + 4) = make_float4(0, 0, 0, 0);
+            if (r32r || part) {
+                float4 f0, f1;
+                if (part) {
+                    const size_t o[2] = {(size_t)blockIdx.x * H + i, (size_t)blockIdx.x * H + i + 4};
+                    float4 f[2];
+                    slab_sum<float4, 2>(part, S, MN, o, f);
+                    f0 = f[0], f1 = f[1];
+                } else {
+                    f0 = *reinterpret_cast<const float4 *>(r32r + i), f1 = *reinterpret_cast<const float4 *>(r32r + i + 4);
+                    *reinterpret_cast<float4 *>(r32r + i) = make_float4(0, 0, 0, 0), *reinterpret_cast<float4 *>(r32r + i + 4) = make_float4(0, 0, 0, 0);
+                }
                 float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
                 if (bias) {
                     const uint4 bb = *reinterpret_cast<const uint4 *>(bias + i);
@@ -229,7 +281,13 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
 
 template <class T>
 static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int M, int H, int dtype, u16 *xn, hipStream_t st,
-                             float *r32 = nullptr, const void *bias = nullptr) {
+                             float *r32 = nullptr, const void *bias = nullptr, const W4lSlabs *sl = nullptr) {
+    if (sl && sl->S > 1) {  // (linear_rows only hands out slabs for H <= 8192)
+        hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, (float *)nullptr, (const u16 *)bias, sl->part, sl->S,
+                           sl->MN);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
     if (H > 8192) {  // wider than the register-resident row: the two separate kernels
         const int rc = pie_add(x, r, (size_t)M * H, dtype, x, st);
         return rc ? rc : pie_rms_norm(x, w, eps, M, H, dtype, xn, st);
@@ -526,7 +584,8 @@ struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.h
 };
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
                     const void *bias, const W4mRope *rope);
-int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused);  // many rows (MFMA-bound)
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
+                    int *slabs);  // many rows (MFMA-bound)
 size_t w4l_workspace_bytes(int M, int N, int K);
 int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
                      const void *bias, bool *bias_done);  // 16-bit weights in W16M tiles
@@ -572,13 +631,22 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
                        const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr, u16 *act = nullptr,
-                       bool *used_act = nullptr, W4mRope *rope = nullptr) {
+                       bool *used_act = nullptr, W4mRope *rope = nullptr, W4lSlabs *slabs = nullptr) {
+    // slabs: the caller's consumer takes the fp32 slabs of a K-split many-row GEMM (and the bias) instead of y; slabs->S > 1 tells whether it must
     // rope / used_act: for the packed q|k|v matrix the few-row kernel can rotate q / k and append k / v itself
     // act / used_act: for the packed gate|up matrix the few-row kernel can apply the SwiGLU itself and write act [M, N / 2]
     // y32 / used32: the caller's consumer can take fp32 K-split sums (+ the bias) instead of y; *used32 tells whether it must
     PrefillScratch *s = d->prefill;
     if (used32) *used32 = false;
     if (used_act) *used_act = false;
+    if (slabs) *slabs = W4lSlabs();
+    if (const char *e = getenv("PIE_W4L_SLABS"))  // 0: always reduce in the GEMM's own launch (A/B and the bit-equality test)
+        if (e[0] == '0') slabs = nullptr;
+    // Below ~200 rows the consumers (one workgroup per row) have too few workgroups to fetch 8-16 slabs as fast as the reduce launch's
+    // M N / 1024 do: 8B prompt of 64 / 128 / 256 / 512 / 700 tokens, slabs vs reduce launch: 4.21 / 4.85 / 6.13 / 9.56 / 14.26 ms vs
+    // 3.92 / 4.78 / 6.20 / 9.75 / 14.38.
+    static const int slabs_min_rows = getenv("PIE_W4L_SLABS_MIN_ROWS") ? atoi(getenv("PIE_W4L_SLABS_MIN_ROWS")) : 192;
+    if (M < slabs_min_rows) slabs = nullptr;
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
     if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
@@ -636,8 +704,13 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
                 s->w4l_ws_bytes = wb, ++s->alloc_gen;
             }
             bool fused = false;  // gate|up without a Linear bias: the SwiGLU rides in the GEMM's epilogue where the shape allows
-            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused);
+            int n_slabs = 0;
+            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused, slabs ? &n_slabs : nullptr);
             if (fused) *used_act = true;
+            if (!rc && n_slabs > 1) {  // y was NOT written: the consumer sums the slabs, rounds and adds the bias
+                slabs->part = (const float *)s->w4l_ws, slabs->S = n_slabs, slabs->MN = (size_t)M * N;
+                return PIE_OK;
+            }
             if (rc || !bias) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }
@@ -725,10 +798,13 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             W4mRope re = {s->rope_cs, d->state, nullptr, d->kv_table, nullptr, d->block_table, 0, d->n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads, D,
                           c.rope_traditional, s->q, nullptr};
             bool roped = false;
-            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
+            W4lSlabs sq, so, sd;  // K-split products handed over as fp32 slabs (q|k|v only without a bias: RoPE takes T(x W^T + b))
+            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
+                return rc;
             if (!roped) {
                 hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
-                                   c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs);
+                                   c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs, (const int *)nullptr, 0,
+                                   (u16 *)nullptr, (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN);
                 PIE_LAUNCH_CHECK();
             }
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
@@ -746,9 +822,12 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
             }
             bool r32 = false;
-            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                     H <= 8192 ? &so : nullptr)))
+                return rc;
             // h = x + r (language.py:151) + post_attention_layernorm(h) for MLP.__call__ (language.py:126-127)
-            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
+            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+                return rc;
             bool fused_act = false;
             if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
             if (!fused_act) {
@@ -757,9 +836,13 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                 PIE_LAUNCH_CHECK();
             }
             const bool fused_next = li + 1 < c.n_layers;
-            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, fused_next && H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, fused_next && H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                     fused_next && H <= 8192 ? &sd : nullptr)))
+                return rc;
             // out = h + r (language.py:153), fused with the next block's input_layernorm when there is one
-            if (fused_next) rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr);
+            if (fused_next)
+                rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr,
+                                          r32 || sd.S > 1 ? w.bdown : nullptr, &sd);
             else rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st);
             if (rc) return rc;
         }

@@ -1093,8 +1093,12 @@ size_t w4l_workspace_bytes(int M, int N, int K) {
 
 // workspace: w4l_workspace_bytes() of device scratch (may be null when that is 0)
 // swiglu_act (nullable): gate|up matrix and the caller wants the MLP activation [M, N / 2] there instead of y; *fused says whether it got it
-int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused) {
+// slabs (nullable): the caller's consumer can sum the fp32 partial slabs of a K-split shape itself (in z order, then the Linear's one rounding:
+//   what k_w4l_reduce does) -- *slabs = S and NO reduce launch then, workspace holds [S][M][N]; *slabs = 0 when y was written
+int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
+                    int *slabs) {
     if (fused) *fused = false;
+    if (slabs) *slabs = 0;
     PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4 GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "W4 GEMM: 16-byte alignment required");
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4 GEMM: dtype must be PIE_BF16 or PIE_F16");
@@ -1121,6 +1125,10 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
 #undef W4L2_MB
 #undef W4L2_GO
         PIE_LAUNCH_CHECK();
+        if (S > 1 && slabs) {
+            *slabs = S;
+            return PIE_OK;
+        }
         if (S > 1) {
             const size_t MN = (size_t)M * N;
             const dim3 rg((unsigned)((MN / 4 + 255) / 256));
@@ -1145,6 +1153,10 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     }
 #undef W4L_GO
     PIE_LAUNCH_CHECK();
+    if (S > 1 && slabs) {
+        *slabs = S;
+        return PIE_OK;
+    }
     if (S > 1) {
         const size_t MN = (size_t)M * N;
         const dim3 rg((unsigned)((MN / 4 + 255) / 256));
@@ -1240,7 +1252,7 @@ int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype
         void *ws = nullptr;
         const size_t wb = w4l_workspace_bytes(M, N, K);
         if (wb && hipMallocAsync(&ws, wb, st) != hipSuccess) return pie::fail(PIE_E_HIP, "pie_qgemm_w4m: hipMallocAsync failed");
-        const int rc = w4l_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st, nullptr, nullptr);
+        const int rc = w4l_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st, nullptr, nullptr, nullptr);
         if (ws) (void)hipFreeAsync(ws, st);
         return rc;
     }

@@ -330,6 +330,43 @@ def test_batched_prefill_llama8b_shapes(monkeypatch):
         assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode after batched prefill")
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias):
+    """Prompts of a few dozen to a few hundred rows split K in the many-row int4 GEMM; the fp32 partial slabs are summed by the kernels that
+    consume the product (RoPE + append for q|k|v, residual add + RMSNorm for o_proj / down) instead of a reduce launch of their own.  Same
+    arithmetic in the same order: logits, hidden state and the decode steps that follow are bit-identical to the reduce-launch form
+    (PIE_W4L_SLABS=0), and both follow the oracle.  Two Llama-3-8B-shaped layers, 200-token prompt; with Linear biases the q|k|v product
+    keeps its reduce launch and o_proj / down add the bias after their own rounding."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "attention_bias": bias, "mlp_bias": bias, "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=5, dtype=dtype, lm_head_gain=4.0)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(21).integers(0, cfg["vocab_size"], 200)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PIE_W4L_SLABS", mode)
+        model = build(cfg, w, dtype)
+        cache = model.make_cache()
+        tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+        rec = [model.hidden.clone(), logits.clone(), int(tok.item())]
+        for _ in range(2):
+            tok, lp, logits = model.step(None, cache)
+            rec += [logits.clone(), int(tok.item())]
+        outs[mode] = rec
+    assert_vec_close(outs["1"][0].float().cpu().numpy(), hid[-1], dtype, what="prefill hidden")
+    assert_vec_close(outs["1"][1].float().cpu().numpy(), want, dtype, what="prefill logits")
+    for a, b in zip(outs["1"], outs["0"]):
+        if isinstance(a, int):
+            assert a == b
+        else:
+            assert torch.equal(a, b), "slab-consuming kernels differ from the reduce launch"
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
     """head_dim 128 prompts use the MFMA causal flash-attention kernel (prefill_attn.hpp).  One Llama-3-8B-shaped layer,
