@@ -32,7 +32,7 @@ extern "C" {
 
 enum { PIE_OK = 0, PIE_E_ARG = -1, PIE_E_SHAPE = -2, PIE_E_ALIGN = -3, PIE_E_HIP = -4, PIE_E_STATE = -5, PIE_E_ARCH = -6, PIE_E_RANGE = -7,
        PIE_EXHAUSTED = 1 /* pie_page_alloc: no free page (the reference's std::nullopt); not an error */ };
-enum { PIE_BF16 = 1, PIE_F16 = 2 };
+enum { PIE_BF16 = 1, PIE_F16 = 2, PIE_I8 = 3 /* KV page storage only: int8 rows + per-head fp16 scales (page pool, pie_paged_*_i8) */ };
 
 /* pie_core.hello()  (src/pie_core/src/bindings.cpp:8; asserted by tests/python/test_basic.py:16). */
 const char *pie_hello(void);
@@ -294,7 +294,8 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
  * no Linear biases), 0 (default; env PIE_STEP_MEGA=1 flips it) keeps the per-kernel launch sequence; both produce identical bits.  Changing an option drops the
  * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of the persistent launch's bounded
  * grid barriers in *error (0 = none; the outputs of that step are then undefined). */
-enum { PIE_OPT_MEGA = 1 };
+enum { PIE_OPT_MEGA = 1, PIE_OPT_KV_I8 = 2 /* 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
+                                              pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back */ };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);
 
@@ -336,8 +337,10 @@ int pie_decoder_set_comm(pie_decoder *d, pie_comm *c);
  *   alloc:  PIE_OK and *page_id with ref count 1 and num_tokens 0 (page_allocator.cpp:68-79), or PIE_EXHAUSTED
  *   free:   drops one reference; the page returns to the pool when the count reaches 0 (page_allocator.cpp:81-87)
  *   any id >= size: PIE_E_RANGE (std::out_of_range of check_page_id, page_allocator.cpp:110-117)
- * The reference's page stores int8 K/V with per-head scales (page.hpp:25-32) that nothing in the reference reads yet;
- * these pages hold T (bf16 / f16) rows, the layout the decode attention of this library consumes. */
+ * dtype PIE_BF16 / PIE_F16: the pages hold T rows, the layout the decoder's attention kernels consume.
+ * dtype PIE_I8: the reference's own storage (page.hpp:25-32,109-117): int8 K block, int8 V block (each [n_kv_heads, 64, head_dim]), then
+ * the fp16 per-head scales of K and of V ([n_kv_heads, 1] each: key_cache_scale_ / value_cache_scale_), padded to 256 bytes
+ * (pie_page_i8_bytes); pie_page_scale_ptrs hands out the two scale vectors of a page.  See pie_paged_kv_append_i8 below. */
 enum { PIE_PAGE_TOKENS = 64 };
 typedef struct pie_page_pool pie_page_pool;
 size_t pie_page_pool_slab_bytes(size_t num_pages, int n_kv_heads, int head_dim, int dtype);
@@ -352,6 +355,8 @@ int pie_page_ref_count(const pie_page_pool *pool, uint32_t page_id, uint32_t *co
 int pie_page_num_tokens(const pie_page_pool *pool, uint32_t page_id, size_t *n);
 int pie_page_set_num_tokens(pie_page_pool *pool, uint32_t page_id, size_t n);
 int pie_page_ptrs(const pie_page_pool *pool, uint32_t page_id, void **k, void **v);
+size_t pie_page_i8_bytes(int n_kv_heads, int head_dim);
+int pie_page_scale_ptrs(const pie_page_pool *pool, uint32_t page_id, void **k_scale, void **v_scale);
 
 /* Paged decode attention over a batch of sequences: what the reference's placeholder
  * Attention::invoke_paged_attention_kernel (src/pie_core/src/layers/attention.cpp:71-83) and its dummy Metal kernel
@@ -370,6 +375,23 @@ int pie_paged_attn_decode(const void *q, const void *slab, size_t n_pages, const
  * position positions[s] (< 0 = idle slot) -> page block_table[s][positions[s] / 64], row positions[s] % 64. */
 int pie_paged_kv_append(const void *k, const void *v, void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
                         const int32_t *positions, int B, int n_kv_heads, int head_dim, int dtype, void *stream);
+
+/* int8 pages (PIE_I8 pools).  The reference declares the storage (page.hpp:25-32; "head-wise quant for now", :114) and neither a
+ * quantiser nor a reader, so the arithmetic is this library's (restated in oracle/pie_oracle.py):
+ *   store  q = clamp(rint(x / s), -127, 127)   x = the T element as fp32, s = the page's fp16 scale of that kv-head
+ *   read   x' = fp32(q) * fp32(s), used in fp32 by the attention (softmax and P.V in fp32, one rounding of the output to T)
+ * pie_page_i8_set_scales: writes the K / V scale vectors (fp16 [n_kv_heads], DEVICE; null = ones, the reference constructor's
+ *   value) into the listed pages (page_ids: DEVICE int32 [n]; null = pages 0 .. n - 1).  A page's scales must not change under
+ *   rows already stored in it.
+ * pie_paged_kv_append_i8 / pie_paged_attn_decode_i8: as pie_paged_kv_append / pie_paged_attn_decode (k, v, q, out are T;
+ *   `dtype` is T), on a slab of int8 pages.  Workspace: pie_paged_attn_workspace_bytes. */
+int pie_page_i8_set_scales(void *slab, size_t n_pages, int n_kv_heads, int head_dim, const int32_t *page_ids, int n, const void *k_scales,
+                           const void *v_scales, void *stream);
+int pie_paged_kv_append_i8(const void *k, const void *v, void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                           const int32_t *positions, int B, int n_kv_heads, int head_dim, int dtype, void *stream);
+int pie_paged_attn_decode_i8(const void *q, const void *slab, size_t n_pages, const int32_t *block_table, int max_blocks,
+                             const int32_t *context_lens, int B, int n_heads, int n_kv_heads, int head_dim, float scale, int dtype,
+                             void *out, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------- vision tower ops
  * Call sites: models/intern/vision.py (Qwen2.5-VL vision tower: PatchEmbed :87-121, Attention :143-186, MLP :189-197,

@@ -210,6 +210,24 @@ def sdpa(q, k, v, scale, mask=None, dtype="bfloat16", fused=True, T=None):
     return out
 
 
+# ------------------------------------------------------------------ int8 KV pages (src/pie_core/include/engine/page.hpp:25-32,109-117)
+# The reference declares the storage -- int8 key / value blocks [64, heads, head_dim] and float16 per-head scales [heads, 1] that start
+# as ones ("head-wise quant for now") -- and neither a quantiser nor a reader; the arithmetic below is the product's definition
+# (csrc/paged_i8.hip), restated: parity for this piece is oracle == HIP, not oracle == reference.
+def kv_i8_quantize(x, scale):
+    """x [..., heads, D] (values already rounded to T), scale [..., heads] float16 -> int8: clamp(rint(x / s), -127, 127) in float32."""
+    s = np.asarray(scale, np.float16).astype(np.float32)[..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.rint(np.asarray(x, np.float32) / s)   # float32 division, round-half-even
+    q = np.where(np.isnan(q), np.float32(0), np.clip(q, -127, 127))
+    return q.astype(np.int8)
+
+
+def kv_i8_dequantize(q, scale):
+    """fp32(q) * fp32(s): what the attention multiplies with -- no rounding to T in between."""
+    return np.asarray(q, np.int8).astype(np.float32) * np.asarray(scale, np.float16).astype(np.float32)[..., None]
+
+
 def causal_mask(L, offset, dtype="bfloat16"):
     m = np.empty((L, offset + L), np.float32)
     lib().orc_causal_mask(L, offset, _dt(dtype), _p(m))

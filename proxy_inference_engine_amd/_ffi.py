@@ -15,6 +15,8 @@ _PKG = Path(__file__).resolve().parent
 PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
 PIE_OPT_MEGA = 1
+PIE_OPT_KV_I8 = 2
+PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
 
 EXPORTS = [
@@ -30,6 +32,7 @@ EXPORTS = [
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
+    "pie_page_i8_bytes", "pie_page_scale_ptrs", "pie_page_i8_set_scales", "pie_paged_kv_append_i8", "pie_paged_attn_decode_i8",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
     "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m", "pie_w16m_bytes", "pie_repack_w16m", "pie_linear_w16m", "pie_linear_w16m_workspace_bytes",
     "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
@@ -116,6 +119,12 @@ def load() -> C.CDLL:
     lib.pie_paged_attn_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [
         C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pie_paged_kv_append.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    lib.pie_page_i8_bytes.restype = C.c_size_t
+    lib.pie_page_i8_bytes.argtypes = [C.c_int, C.c_int]
+    lib.pie_page_scale_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.pie_page_i8_set_scales.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pie_paged_attn_decode_i8.argtypes = lib.pie_paged_attn_decode.argtypes
+    lib.pie_paged_kv_append_i8.argtypes = lib.pie_paged_kv_append.argtypes
     lib.pie_decoder_set_paged_kv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
     lib.pie_linear.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_gelu.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]

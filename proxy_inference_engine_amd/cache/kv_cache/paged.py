@@ -49,7 +49,7 @@ class KVPage:
         p = self._pool
         if p.slab is None:
             raise RuntimeError("this PageAllocator was created without device storage (device=None)")
-        half = p.page_bytes // 2
+        half = TOKEN_CAPACITY_PER_PAGE * p.num_heads * p.head_dim * p.dtype.itemsize  # (an int8 page carries its scales after the two blocks)
         raw = p.slab[layer, self._id * p.page_bytes + which * half: self._id * p.page_bytes + (which + 1) * half]
         # stored head-major [heads, 64, head_dim]; presented in the reference's logical order
         return raw.view(p.dtype).view(p.num_heads, TOKEN_CAPACITY_PER_PAGE, p.head_dim).permute(1, 0, 2)
@@ -61,6 +61,22 @@ class KVPage:
     def value_cache(self, layer: int = 0) -> torch.Tensor:
         return self._block(1, layer)
 
+    def _scale(self, which: int, layer: int) -> torch.Tensor:
+        p = self._pool
+        if p.dtype != torch.int8:
+            raise RuntimeError("only int8 pages carry scales (page.hpp:25-32)")
+        if p.slab is None:
+            raise RuntimeError("this PageAllocator was created without device storage (device=None)")
+        off = self._id * p.page_bytes + 2 * TOKEN_CAPACITY_PER_PAGE * p.num_heads * p.head_dim + which * 2 * p.num_heads
+        return p.slab[layer, off: off + 2 * p.num_heads].view(torch.float16).view(p.num_heads, 1)
+
+    def key_cache_scale(self, layer: int = 0) -> torch.Tensor:
+        """[num_heads, 1] float16 view into the slab (page.hpp:31,74); ones until set."""
+        return self._scale(0, layer)
+
+    def value_cache_scale(self, layer: int = 0) -> torch.Tensor:
+        return self._scale(1, layer)
+
 
 class PageAllocator:
     """Fixed pool of KV pages with a lock-free LIFO free list (page_allocator.hpp:17-72)."""
@@ -71,7 +87,7 @@ class PageAllocator:
         of every plane, so one block table serves all layers."""
         self._h = C.c_void_p()
         lib = self._lib = _f.load()
-        code = _f.dtype_code(dtype)
+        code = _f.PIE_I8 if dtype == torch.int8 else _f.dtype_code(dtype)  # int8: the reference page's own storage (page.hpp:25-32)
         if num_pages < 0 or num_heads < 0 or head_dim < 0:
             raise ValueError("PageAllocator: negative argument")
         self.slab = None
@@ -82,6 +98,10 @@ class PageAllocator:
                                           C.c_void_p(self.slab.data_ptr() if self.slab is not None else None), C.byref(self._h)))
         self.num_heads, self.head_dim, self.dtype, self.num_layers = num_heads, head_dim, dtype, num_layers
         self.page_bytes = nbytes // num_pages
+        if dtype == torch.int8 and self.slab is not None:  # key_cache_scale_ / value_cache_scale_ = mx::ones (page.hpp:31-32)
+            for layer in range(num_layers):
+                _f.check(lib.pie_page_i8_set_scales(C.c_void_p(self.slab[layer].data_ptr()), num_pages, num_heads, head_dim, None, num_pages, None, None,
+                                                    _f.stream()))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -255,7 +275,7 @@ class PagedKVCache(BaseCache):
 
     def _rows(self, which: int) -> torch.Tensor:
         seq, a = self.page_manager, self.page_manager.allocator
-        half = a.page_bytes // 2
+        half = TOKEN_CAPACITY_PER_PAGE * a.num_heads * a.head_dim * a.dtype.itemsize  # (int8 pages: the raw codes; their scales follow the blocks)
         if not seq.pages:
             return torch.zeros((1, a.num_heads, 0, a.head_dim), dtype=a.dtype, device=a.slab.device)
         blocks = [a.slab[self.layer, p * a.page_bytes + which * half: p * a.page_bytes + (which + 1) * half].view(a.dtype).view(
@@ -271,6 +291,8 @@ class PagedKVCache(BaseCache):
     def state(self, v):
         keys, values = v
         seq, a = self.page_manager, self.page_manager.allocator
+        if a.dtype == torch.int8:
+            raise NotImplementedError("restoring rows into int8 pages is not supported (their scales are the pool's)")
         n = keys.shape[2]
         if self.layer == 0 or seq.offset != n:
             seq.truncate(0)

@@ -330,6 +330,7 @@ int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *co
 int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_pages, const int32_t *block_table, int max_blocks,
                              void *stream) {
     PIE_REQUIRE(d && slabs && block_table, PIE_E_ARG, "pie_decoder_set_paged_kv: null pointer");
+    PIE_REQUIRE(!d->kv_i8, PIE_E_STATE, "pie_decoder_set_paged_kv: the single-sequence step reads T pages; int8 pages serve pie_decoder_step_batch / _prefill_batch");
     PIE_REQUIRE(n_pages > 0 && n_pages < 0x7FFFFFFFu && max_blocks > 0 && max_blocks <= (1 << 24), PIE_E_SHAPE,
                 "pie_decoder_set_paged_kv: n_pages and max_blocks must be positive");
     const int L = d->cfg.n_layers;
@@ -477,8 +478,9 @@ void *pie_debug_buffer(pie_decoder *d, int which) {
 
 int pie_decoder_configure(pie_decoder *d, int option, int value) {
     PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_configure: null decoder");
-    PIE_REQUIRE(option == PIE_OPT_MEGA, PIE_E_ARG, "pie_decoder_configure: unknown option");
-    mega_enable(d, value != 0);
+    PIE_REQUIRE(option == PIE_OPT_MEGA || option == PIE_OPT_KV_I8, PIE_E_ARG, "pie_decoder_configure: unknown option");
+    if (option == PIE_OPT_MEGA) mega_enable(d, value != 0);
+    else d->kv_i8 = value != 0;
     drop_graphs(d);
     return PIE_OK;
 }

@@ -39,6 +39,7 @@ struct pie_decoder {
     // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
     bool combine = false;
     int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
+    bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs of pie_decoder_step_batch / _prefill_batch hold int8 pages (paged_i8.hip)
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
     struct MegaState *mega = nullptr;               // the persistent one-launch step (step_mega.hip), allocated on first use
@@ -66,6 +67,9 @@ int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, 
 int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int vocab_offset, const LogitStat *stats, int n_stats, float *lse, float *logprobs,
                    int *token, DecState *state, int *history, int hist_cap, hipStream_t st);
 int tp_comm_geometry(const pie_comm *c, int *rank, int *world, size_t *max_elems);
+
+// paged_i8.hip: split-KV decode attention over int8 pages (a.slab = the layer's int8 slab, a.ctx_len / a.block_table as for T pages)
+int paged_attn_i8_launch(int dtype, int D, const AttnArgs &a, hipStream_t st);
 
 // prefill.hip: batched prompt processing (L >= prefill_min_rows() tokens): per layer the W4S weights are dequantised to T
 // and multiplied by hipBLASLt, with hand-written HIP kernels for RoPE + cache append, causal attention and SwiGLU.

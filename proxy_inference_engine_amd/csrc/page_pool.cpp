@@ -71,8 +71,17 @@ static uint32_t pop_free(pie_page_pool *p) {
 
 extern "C" {
 
+// int8 pages (the reference's own storage, page.hpp:25-32): int8 K block, int8 V block, then the per-head fp16 scales of K and of V
+// ([num_heads, 1] each); rounded up to 256 bytes so every page starts on a cache-line pair
+size_t pie_page_i8_bytes(int num_kv_heads, int head_dim) {
+    if (num_kv_heads <= 0 || head_dim <= 0) return 0;
+    const size_t raw = 2 * (size_t)PIE_PAGE_TOKENS * num_kv_heads * head_dim + 4 * (size_t)num_kv_heads;
+    return (raw + 255) & ~(size_t)255;
+}
+
 size_t pie_page_pool_slab_bytes(size_t num_pages, int num_kv_heads, int head_dim, int dtype) {
-    if (num_pages == 0 || num_kv_heads <= 0 || head_dim <= 0 || (dtype != PIE_BF16 && dtype != PIE_F16)) return 0;
+    if (num_pages == 0 || num_kv_heads <= 0 || head_dim <= 0 || (dtype != PIE_BF16 && dtype != PIE_F16 && dtype != PIE_I8)) return 0;
+    if (dtype == PIE_I8) return num_pages * pie_page_i8_bytes(num_kv_heads, head_dim);
     return num_pages * 2 * (size_t)PIE_PAGE_TOKENS * num_kv_heads * head_dim * 2;
 }
 
@@ -82,11 +91,12 @@ int pie_page_pool_create(size_t num_pages, int num_kv_heads, int head_dim, int d
     POOL_REQUIRE(num_pages < NIL, PIE_E_ARG, "pie_page_pool_create: too many pages");
     POOL_REQUIRE(num_kv_heads > 0, PIE_E_ARG, "num_heads must be positive.");
     POOL_REQUIRE(head_dim > 0, PIE_E_ARG, "head_dim must be positive.");
-    POOL_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_page_pool_create: dtype must be PIE_BF16 or PIE_F16");
+    POOL_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16 || dtype == PIE_I8, PIE_E_ARG, "pie_page_pool_create: dtype must be PIE_BF16, PIE_F16 or PIE_I8");
     pie_page_pool *p = new (std::nothrow) pie_page_pool();
     POOL_REQUIRE(p, PIE_E_HIP, "pie_page_pool_create: out of host memory");
     p->num_pages = num_pages, p->num_heads = num_kv_heads, p->head_dim = head_dim;
-    p->page_bytes = 2 * (size_t)PIE_PAGE_TOKENS * num_kv_heads * head_dim * 2;
+    p->elem_bytes = dtype == PIE_I8 ? 1 : 2;
+    p->page_bytes = dtype == PIE_I8 ? pie_page_i8_bytes(num_kv_heads, head_dim) : 2 * (size_t)PIE_PAGE_TOKENS * num_kv_heads * head_dim * 2;
     p->slab = (char *)slab;
     p->pages.reset(new (std::nothrow) PageMeta[num_pages]);
     if (!p->pages) {
@@ -172,7 +182,18 @@ int pie_page_ptrs(const pie_page_pool *p, uint32_t id, void **k, void **v) {
     POOL_REQUIRE(k && v, PIE_E_ARG, "pie_page_ptrs: null pointer");
     POOL_REQUIRE(p->slab, PIE_E_STATE, "pie_page_ptrs: the pool was created without a slab");
     *k = p->slab + (size_t)id * p->page_bytes;
-    *v = p->slab + (size_t)id * p->page_bytes + p->page_bytes / 2;
+    *v = p->slab + (size_t)id * p->page_bytes + (size_t)PIE_PAGE_TOKENS * p->num_heads * p->head_dim * p->elem_bytes;
+    return PIE_OK;
+}
+
+int pie_page_scale_ptrs(const pie_page_pool *p, uint32_t id, void **k_scale, void **v_scale) {
+    if (int rc = check_id(p, id, "pie_page_scale_ptrs")) return rc;
+    POOL_REQUIRE(k_scale && v_scale, PIE_E_ARG, "pie_page_scale_ptrs: null pointer");
+    POOL_REQUIRE(p->slab, PIE_E_STATE, "pie_page_scale_ptrs: the pool was created without a slab");
+    POOL_REQUIRE(p->elem_bytes == 1, PIE_E_STATE, "pie_page_scale_ptrs: only int8 pages carry scales");
+    char *s = p->slab + (size_t)id * p->page_bytes + 2 * (size_t)PIE_PAGE_TOKENS * p->num_heads * p->head_dim;
+    *k_scale = s;
+    *v_scale = s + 2 * (size_t)p->num_heads;
     return PIE_OK;
 }
 

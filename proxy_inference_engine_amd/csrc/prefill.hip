@@ -124,8 +124,10 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
                                                          int n_pages, const float *rope_cs, const int *ctx_len = nullptr, int bt_stride = 0,
                                                          u16 *slab = nullptr, const int *row_seq = nullptr, u16 *kc = nullptr, u16 *vc = nullptr,
-                                                         const float *part = nullptr, int S = 0, size_t MN = 0) {
+                                                         const float *part = nullptr, int S = 0, size_t MN = 0, size_t i8_page_bytes = 0) {
     // part != nullptr: the projection arrives as the fp32 slabs of a K-split GEMM (W4lSlabs) instead of qkv
+    // i8_page_bytes != 0 (with `slab`): int8 pages with per-head fp16 scales (paged_i8.hip): the rotated K / the V element x, already
+    // rounded to T, is stored as clamp(rint(x / s), -127, 127) with the scale of (its page, its kv-head)
     // row_seq / kc / vc (several prompts in one pass): row m belongs to sequence row_seq[m] (its block-table row), and the
     // rotated K and the V rows are also written to contiguous [n_kv_heads, rows, HD] buffers the attention of this pass reads
     // ctx_len != nullptr (multi-sequence decode step): row m is its own sequence at position ctx_len[m] - 1 with its own block
@@ -138,10 +140,20 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
     u16 *vdst = slab ? slab + (size_t)n_kv_heads * 64 * HD : reinterpret_cast<u16 *>(kv_table[n_layers + layer]);
     block_table = block_table ? block_table + (size_t)(row_seq ? row_seq[m] : m) * bt_stride : nullptr;
     const int n_rows = gridDim.x;
+    char *page8 = nullptr;  // int8 pages: this row's page
     if (block_table) {  // paged KV: the row goes to slot pos % 64 of page block_table[pos / 64]
-        const size_t pg_off = (size_t)min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u) * 2 * 64 * n_kv_heads * HD;
+        const unsigned pg = min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u);
+        const size_t pg_off = (size_t)pg * 2 * 64 * n_kv_heads * HD;
         kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
+        if (i8_page_bytes && slab) page8 = reinterpret_cast<char *>(slab) + (size_t)pg * i8_page_bytes;
     }
+    const size_t blk8 = (size_t)n_kv_heads * 64 * HD;
+    auto q8 = [](float x, float sc) {
+        float q = rintf(x / sc);
+        q = q < -127.0f ? -127.0f : (q > 127.0f ? 127.0f : q);
+        return (signed char)(q == q ? (int)q : 0);
+    };
+    auto f16f = [](u16 h) { return (float)__builtin_bit_cast(_Float16, h); };
     const u16 *row = qkv + (size_t)m * n_cols;
     for (int p = threadIdx.x; p < (n_cols >> 1); p += blockDim.x) {
         const int R = 2 * p;
@@ -161,14 +173,23 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
             const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
             const u16 o0 = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn))), o1 = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
-            dst[i0] = o0, dst[i1] = o1;
+            if (page8 && R >= q_cols) {
+                const float sk = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[head]);
+                signed char *kb = reinterpret_cast<signed char *>(page8) + ((size_t)head * 64 + kvrow) * HD;
+                kb[i0] = q8(T::to_f32(o0), sk), kb[i1] = q8(T::to_f32(o1), sk);
+            } else dst[i0] = o0, dst[i1] = o1;
             if (kc && R >= q_cols) {
                 u16 *c = kc + ((size_t)head * n_rows + m) * HD;
                 c[i0] = o0, c[i1] = o1;
             }
         } else {
             const int rr = R - q_cols - k_cols;
-            *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pr;
+            if (page8) {
+                const int head = rr / HD;
+                const float sv = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[n_kv_heads + head]);
+                signed char *vb = reinterpret_cast<signed char *>(page8) + blk8 + ((size_t)head * 64 + kvrow) * HD + rr % HD;
+                vb[0] = q8(ra, sv), vb[1] = q8(rb, sv);
+            } else *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pr;
             if (vc) *reinterpret_cast<u32 *>(vc + ((size_t)(rr / HD) * n_rows + m) * HD + rr % HD) = pr;
         }
     }
@@ -917,10 +938,12 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         W4mRope re = {s->rope_cs, nullptr, ctx_len, nullptr, (u16 *)slabs[li], block_tables, max_blocks, n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads,
                       D, c.rope_traditional, s->q, nullptr};
         bool roped = false;
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
+        const size_t i8pb = d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : 0;  // int8 pages: the append quantises, so it stays out of the GEMM epilogue
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, d->kv_i8 ? nullptr : &re))) return rc;
         if (!roped) {
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
-                               c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li]);
+                               c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li],
+                               (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, (const float *)nullptr, 0, (size_t)0, i8pb);
             PIE_LAUNCH_CHECK();
         }
         AttnArgs a = {};
@@ -928,7 +951,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         a.rows = B, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = splits, a.scale = 1.0f / sqrtf((float)D);
         a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;
         a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
-        if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+        if ((rc = d->kv_i8 ? paged_attn_i8_launch(c.dtype, D, a, st) : attn_decode_launch(c.dtype, D, a, true, st))) return rc;
         bool r32 = false;
         if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
         if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
@@ -988,7 +1011,8 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv))) return rc;
         hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(N), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                            c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, row_ctx, max_blocks, (u16 *)slabs[li],
-                           row_seq, s->kc, s->vc);
+                           row_seq, s->kc, s->vc, (const float *)nullptr, 0, (size_t)0,
+                           d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : (size_t)0);  // int8 pages: quantised on the way in; this pass's own attention reads the T copies
         PIE_LAUNCH_CHECK();
         PrefillAttnArgs pa = {};
         pa.q = s->q, pa.k = s->kc, pa.v = s->vc, pa.offset = 0, pa.cap = N, pa.seg_lo = seg_lo, pa.seg_hi = seg_hi;

@@ -320,6 +320,66 @@ def paged_attention_decode(q: torch.Tensor, slab: torch.Tensor, n_pages: int, bl
     return out
 
 
+def _i8_slab_check(slab: torch.Tensor, n_pages: int, Hkv: int, D: int, who: str) -> None:
+    if slab.numel() * slab.element_size() < n_pages * _ffi.load().pie_page_i8_bytes(Hkv, D):
+        raise ValueError(f"{who}: slab smaller than n_pages int8 pages")
+
+
+def page_i8_set_scales(slab: torch.Tensor, n_pages: int, n_kv_heads: int, head_dim: int, k_scales: torch.Tensor | None,
+                       v_scales: torch.Tensor | None, page_ids: torch.Tensor | None = None) -> None:
+    """Writes the per-head fp16 scales of int8 pages (page.hpp:31-32: key_cache_scale_ / value_cache_scale_, [heads, 1]; None = ones, the
+    reference constructor's value) into the pages `page_ids` (int32, device; None = all n_pages)."""
+    _dev(slab)
+    for t in (k_scales, v_scales):
+        if t is not None:
+            _dev(t)
+            if t.dtype != torch.float16 or t.numel() != n_kv_heads:
+                raise ValueError("page_i8_set_scales: scales are float16 [n_kv_heads]")
+    if page_ids is not None and page_ids.dtype != torch.int32:
+        raise TypeError("page_ids must be int32")
+    _i8_slab_check(slab, n_pages, n_kv_heads, head_dim, "page_i8_set_scales")
+    n = n_pages if page_ids is None else page_ids.numel()
+    _ffi.check(_ffi.load().pie_page_i8_set_scales(_ffi.p(slab), n_pages, n_kv_heads, head_dim, _ffi.p(page_ids), n, _ffi.p(k_scales), _ffi.p(v_scales),
+                                                  _ffi.stream()))
+
+
+def paged_kv_append_i8(k: torch.Tensor, v: torch.Tensor, slab: torch.Tensor, n_pages: int, block_table: torch.Tensor, positions: torch.Tensor) -> None:
+    """paged_kv_append onto int8 pages: each row is quantised with its page's per-head scale, q = clamp(rint(x / s), -127, 127)."""
+    for t in (k, v, slab, block_table, positions):
+        _dev(t)
+    if block_table.dtype != torch.int32 or positions.dtype != torch.int32:
+        raise TypeError("block_table and positions must be int32")
+    B, Hkv, D = k.shape
+    if v.shape != k.shape or block_table.shape[0] != B or positions.shape[0] != B:
+        raise ValueError("paged_kv_append_i8: k, v [B, Hkv, D]; block_table [B, max_blocks]; positions [B]")
+    _i8_slab_check(slab, n_pages, Hkv, D, "paged_kv_append_i8")
+    _ffi.check(_ffi.load().pie_paged_kv_append_i8(_ffi.p(k), _ffi.p(v), _ffi.p(slab), n_pages, _ffi.p(block_table), block_table.shape[1],
+                                                  _ffi.p(positions), B, Hkv, D, _ffi.dtype_code(k.dtype), _ffi.stream()))
+
+
+def paged_attention_decode_i8(q: torch.Tensor, slab: torch.Tensor, n_pages: int, block_table: torch.Tensor, context_lens: torch.Tensor,
+                              n_kv_heads: int, scale: float) -> torch.Tensor:
+    """paged_attention_decode over int8 pages: K / V rows are read as fp32(q) * fp32(scale of the page's head), the rest in fp32."""
+    for t in (q, slab, block_table, context_lens):
+        _dev(t)
+    if block_table.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise TypeError("block_table and context_lens must be int32")
+    B, Hq, D = q.shape
+    if block_table.shape[0] != B or context_lens.shape[0] != B:
+        raise ValueError("paged_attention_decode_i8: block_table [B, max_blocks]; context_lens [B]")
+    _i8_slab_check(slab, n_pages, n_kv_heads, D, "paged_attention_decode_i8")
+    key = ("paged", q.device, B, Hq, D)
+    ws = _sdpa_ws.get(key)
+    if ws is None:
+        ws = torch.empty(_ffi.load().pie_paged_attn_workspace_bytes(B, Hq, D), dtype=torch.uint8, device=q.device)
+        _sdpa_ws[key] = ws
+    out = torch.empty_like(q)
+    _ffi.check(_ffi.load().pie_paged_attn_decode_i8(_ffi.p(q), _ffi.p(slab), n_pages, _ffi.p(block_table), block_table.shape[1],
+                                                    _ffi.p(context_lens), B, Hq, n_kv_heads, D, float(scale), _ffi.dtype_code(q.dtype),
+                                                    _ffi.p(out), _ffi.p(ws), _ffi.stream()))
+    return out
+
+
 def silu_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """nn.silu(a) * b (models/llama/language.py:127)."""
     _dev(a), _dev(b)

@@ -244,11 +244,27 @@ class Model:
             return self.make_paged_cache(self._page_pool, max_blocks=self._page_blocks)
         return [ReusableKVCache() for _ in self.layers]
 
-    def enable_paged_kv(self, num_pages: int = 512, max_blocks: int = 16) -> PageAllocator:
+    def enable_paged_kv(self, num_pages: int = 512, max_blocks: int = 16, kv_dtype: torch.dtype | None = None,
+                        kv_scales: tuple[torch.Tensor, torch.Tensor] | None = None) -> PageAllocator:
         """From now on make_cache() (PromptCache.create_kv_cache, prompt_cache.py:34-41) hands out paged caches drawing
-        on one pool of `num_pages` 64-token pages (all layers).  Returns the pool."""
-        self._page_pool = PageAllocator(num_pages, self.n_kv_heads, self.head_dim, dtype=self.dtype, device=self.device,
+        on one pool of `num_pages` 64-token pages (all layers).  Returns the pool.
+        kv_dtype=torch.int8: the pages are the reference KVPage's own storage (page.hpp:25-32) -- int8 K / V rows with float16 per-head
+        scales; kv_scales = (k, v), each float16 [n_layers, n_kv_heads], is written into every page (None: ones, the reference
+        constructor's value -- far too coarse for real activations; pass amax / 127 of a calibration prompt).  Such a pool serves
+        prefill_batch / step_batch (the continuous-batching path); the single-sequence step() keeps T pages."""
+        kv_dtype = self.dtype if kv_dtype is None else kv_dtype
+        if kv_dtype not in (self.dtype, torch.int8):
+            raise ValueError(f"kv_dtype must be the model's dtype or torch.int8, got {kv_dtype}")
+        self._page_pool = PageAllocator(num_pages, self.n_kv_heads, self.head_dim, dtype=kv_dtype, device=self.device,
                                         num_layers=len(self.layers))
+        if kv_dtype == torch.int8 and kv_scales is not None:
+            ks, vs = (t.to(device=self.device, dtype=torch.float16).contiguous() for t in kv_scales)
+            if ks.shape != (len(self.layers), self.n_kv_heads) or vs.shape != ks.shape:
+                raise ValueError("kv_scales: two float16 tensors [n_layers, n_kv_heads]")
+            for li in range(len(self.layers)):
+                hip_ops.page_i8_set_scales(self._page_pool.slab[li], num_pages, self.n_kv_heads, self.head_dim, ks[li], vs[li])
+        _ffi.check(_ffi.load().pie_decoder_configure(self._dec, _ffi.PIE_OPT_KV_I8, int(kv_dtype == torch.int8)))
+        self._kv_key = None
         self._page_blocks = max_blocks
         return self._page_pool
 
@@ -259,8 +275,8 @@ class Model:
         if allocator is None:
             allocator = PageAllocator(num_pages, self.n_kv_heads, self.head_dim, dtype=self.dtype, device=self.device,
                                       num_layers=len(self.layers))
-        if (allocator.num_layers, allocator.num_heads, allocator.head_dim, allocator.dtype) != (
-                len(self.layers), self.n_kv_heads, self.head_dim, self.dtype) or allocator.slab is None:
+        if (allocator.num_layers, allocator.num_heads, allocator.head_dim) != (len(self.layers), self.n_kv_heads, self.head_dim) or \
+                allocator.dtype not in (self.dtype, torch.int8) or allocator.slab is None:
             raise ValueError("the allocator's geometry does not match this model")
         seq = PagedSequence(allocator, max_blocks)
         return [PagedKVCache(seq, i) for i in range(len(self.layers))]
@@ -271,6 +287,8 @@ class Model:
             raise TypeError("the layers of a paged cache must share one PagedSequence")
         seq.reserve(n_new)
         a = seq.allocator
+        if a.dtype == torch.int8:
+            raise TypeError("int8 pages serve prefill_batch / step_batch; the single-sequence step() reads pages of the model's dtype")
         key = ("paged", a.slab.data_ptr(), a.size(), seq.table.data_ptr(), seq.max_blocks)
         lib = _ffi.load()
         if key != self._kv_key:

@@ -435,3 +435,137 @@ def test_several_prompts_in_one_pass(golden_dir):
         assert_vec_close(la[i], lb[i], "bfloat16", what=f"decode after batched prefill, prompt {i}")
     with pytest.raises(ValueError, match="fresh"):
         model.prefill_batch([[1, 2]], [caches[0]])
+
+
+# ---------------------------------------------------------------- int8 pages with per-head scales (page.hpp:25-32)
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("Hq,Hkv,D,lens", [
+    (8, 2, 128, [1, 63, 64, 65, 300]),
+    (32, 8, 128, [777, 5, 1500]),
+    (6, 2, 64, [129, 0, 64, 31]),          # an idle slot (context 0) in the batch
+    (16, 2, 128, [200, 70]),               # 8 q-heads per kv-head: the 2-wave form
+    (4, 4, 64, [200]),
+])
+def test_int8_pages_append_and_attention_vs_oracle(ops, dt, Hq, Hkv, D, lens):
+    """The reference page's own storage: int8 K / V blocks + float16 per-head scales.  Appended rows equal the oracle's quantiser bit for
+    bit (every page has its own scales, some small enough to clip), attention over the pages follows the oracle's sdpa on the dequantised
+    rows, and a fresh pool's scales are ones (page.hpp:31-32)."""
+    from proxy_inference_engine_amd.cache.kv_cache.paged import PageAllocator
+    rng = np.random.default_rng(Hq * 100 + len(lens) + 7)
+    max_blocks = (max(lens) + 63) // 64 + 1
+    n_pages = sum((n + 63) // 64 for n in lens) + 3
+    alloc = PageAllocator(n_pages, Hkv, D, dtype=torch.int8, device="cuda")
+    assert alloc.page_bytes % 256 == 0 and alloc.page_bytes >= 2 * 64 * Hkv * D + 4 * Hkv
+    fresh = alloc.get_page(n_pages - 1)
+    assert torch.all(fresh.key_cache_scale() == 1) and torch.all(fresh.value_cache_scale() == 1) and fresh.key_cache_scale().shape == (Hkv, 1)
+    assert fresh.key_cache().dtype == torch.int8 and fresh.key_cache().shape == (64, Hkv, D)
+    # per-page scales: K rows are N(0,1): 1/32 covers +-4 sigma, 1/64 clips the tails; V likewise
+    ksc = rng.choice(np.array([1 / 32, 1 / 48, 1 / 64], np.float16), size=(n_pages, Hkv))
+    vsc = rng.choice(np.array([1 / 32, 1 / 40, 1 / 64], np.float16), size=(n_pages, Hkv))
+    for pg in range(n_pages):
+        ops.page_i8_set_scales(alloc.slab[0], n_pages, Hkv, D, torch.from_numpy(ksc[pg]).cuda(), torch.from_numpy(vsc[pg]).cuda(),
+                               torch.tensor([pg], dtype=torch.int32, device="cuda"))
+    B = len(lens)
+    table = np.zeros((B, max_blocks), np.int32)
+    need = [(n + 63) // 64 for n in lens]
+    for j in range(max(need)):
+        for s in rng.permutation(B):
+            if j < need[s]:
+                table[s, j] = alloc.allocate_page()
+    ks = [po.round_T(rng.standard_normal((n, Hkv, D)), dt) for n in lens]
+    vs = [po.round_T(rng.standard_normal((n, Hkv, D)), dt) for n in lens]
+    bt = torch.from_numpy(table).cuda()
+    for t in range(max(lens)):
+        kb, vb, pos = np.zeros((B, Hkv, D), np.float32), np.zeros((B, Hkv, D), np.float32), np.full(B, -1, np.int32)
+        for s in range(B):
+            if t < lens[s]:
+                kb[s], vb[s], pos[s] = ks[s][t], vs[s][t], t
+        ops.paged_kv_append_i8(to_dev(po.to_bits(kb, dt), dt), to_dev(po.to_bits(vb, dt), dt), alloc.slab[0], alloc.size(), bt, torch.from_numpy(pos).cuda())
+    q = po.round_T(rng.standard_normal((B, Hq, D)), dt)
+    got = to_bits(ops.paged_attention_decode_i8(to_dev(po.to_bits(q, dt), dt), alloc.slab[0], n_pages, bt,
+                                                torch.tensor(lens, dtype=torch.int32, device="cuda"), Hkv, D ** -0.5))
+    clipped = 0
+    for s, n in enumerate(lens):
+        if n == 0:
+            assert not got[s].any(), "an idle slot must produce zeros"
+            continue
+        pages = table[s, np.arange(n) // 64]                       # page of every token
+        kq = po.kv_i8_quantize(ks[s], ksc[pages])                   # [n, Hkv, D] with scales [n, Hkv]
+        vq = po.kv_i8_quantize(vs[s], vsc[pages])
+        clipped += int((np.abs(kq) == 127).sum())
+        for j in range(need[s]):                                    # the stored bytes, in the reference's logical [64, heads, head_dim] view
+            page, rows = alloc.get_page(int(table[s, j])), min(64, n - 64 * j)
+            assert np.array_equal(page.key_cache()[:rows].cpu().numpy(), kq[64 * j: 64 * j + rows]), f"K bytes of seq {s} block {j}"
+            assert np.array_equal(page.value_cache()[:rows].cpu().numpy(), vq[64 * j: 64 * j + rows]), f"V bytes of seq {s} block {j}"
+            assert np.array_equal(page.key_cache_scale().cpu().numpy()[:, 0], ksc[table[s, j]])
+        k = np.ascontiguousarray(po.kv_i8_dequantize(kq, ksc[pages]).transpose(1, 0, 2))    # [Hkv, n, D] fp32
+        v = np.ascontiguousarray(po.kv_i8_dequantize(vq, vsc[pages]).transpose(1, 0, 2))
+        want = po.sdpa(q[s][:, None, :], k, v, D ** -0.5, None, dt, True, T=n)
+        assert_dot_close(po.from_bits(got[s], dt), po.round_T(want, dt), dt, max_frac=0.03, what=f"int8 paged seq {s} len {n} {Hq}/{Hkv} D{D} {dt}")
+    assert clipped > 0 or max(lens) < 100, "the small scales were meant to exercise the clamp"
+
+
+def test_int8_pages_default_scale_is_one_like_the_reference(ops):
+    """KVPage's constructor sets both scales to ones (page.hpp:31-32): with them the stored byte is rint(x) clamped."""
+    from proxy_inference_engine_amd.cache.kv_cache.paged import PageAllocator
+    dt, Hkv, D = "bfloat16", 2, 64
+    alloc = PageAllocator(2, Hkv, D, dtype=torch.int8, device="cuda")
+    pid = alloc.allocate_page()
+    x = po.round_T(np.array([[-300.0, -2.5, -1.5, -0.5, 0.49, 0.5, 1.5, 2.5] * (D // 8)] * Hkv, np.float32) * np.ones((1, 1, 1), np.float32), dt)
+    bt = torch.tensor([[pid]], dtype=torch.int32, device="cuda")
+    ops.paged_kv_append_i8(to_dev(po.to_bits(x, dt), dt), to_dev(po.to_bits(x, dt), dt), alloc.slab[0], alloc.size(), bt, torch.tensor([3], dtype=torch.int32, device="cuda"))
+    row = alloc.get_page(pid).key_cache()[3].cpu().numpy()
+    assert np.array_equal(row[0, :8], np.array([-127, -2, -2, 0, 0, 0, 2, 2], np.int8))          # round-half-even, clamp at -127
+    assert np.array_equal(row, po.kv_i8_quantize(x[0], np.ones(Hkv, np.float16)))
+
+
+def test_decoder_batch_paths_on_int8_pages(golden_dir):
+    """PIE_OPT_KV_I8: prefill_batch / step_batch on a pool of int8 pages.  The prompt pass attends to its own T rows, so its logits are
+    bit-identical to the T-page run and EVERY layer's pages must hold exactly the oracle's quantisation of that run's K / V rows; the decode
+    step then reads the quantised rows back: layer 0's appended row is again exact (it does not depend on attention), the logits stay within
+    the quantisation noise of the T-page step, and the greedy tokens agree."""
+    from tests._util import assert_vec_close
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(23)
+    lens = [5, 33, 64, 97]
+    prompts = [rng.integers(0, cfg["vocab_size"], n).astype(np.int32).tolist() for n in lens]
+    L, Hkv = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
+    model.enable_paged_kv(num_pages=24)
+    ct = [model.make_cache() for _ in prompts]
+    _, _, lg_t = model.prefill_batch(prompts, ct)
+    lg_t = lg_t.clone()
+    rows = [[tuple(t.float().cpu().numpy()[0].transpose(1, 0, 2) for t in ct[i][l].state) for l in range(L)] for i in range(len(lens))]  # [n, Hkv, D]
+    amax = np.zeros((2, L, Hkv), np.float32)
+    for i in range(len(lens)):
+        for l in range(L):
+            for w in range(2):
+                amax[w, l] = np.maximum(amax[w, l], np.abs(rows[i][l][w]).max(axis=(0, 2)))
+    ks, vs = (torch.from_numpy((amax[w] * 1.25 / 127).astype(np.float16)) for w in range(2))   # headroom for the decode rows
+    feed = torch.tensor([3, 1, 4, 1], dtype=torch.int32)
+    tok_t, _, la_t = model.step_batch(feed, ct, graph=False)
+    tok_t, la_t = tok_t.clone(), la_t.float().cpu().numpy().copy()
+    new_t = [tuple(t.float().cpu().numpy()[0].transpose(1, 0, 2)[-1] for t in ct[i][0].state) for i in range(len(lens))]          # layer 0, the step's row
+
+    pool = model.enable_paged_kv(num_pages=24, kv_dtype=torch.int8, kv_scales=(ks, vs))
+    c8 = [model.make_cache() for _ in prompts]
+    _, _, lg_8 = model.prefill_batch(prompts, c8)
+    assert torch.equal(lg_8, lg_t), "the prompt pass reads its own T rows: identical logits"
+    ksn, vsn = ks.numpy(), vs.numpy()
+    for i, n in enumerate(lens):
+        for l in range(L):
+            k8, v8 = (t.cpu().numpy()[0].transpose(1, 0, 2) for t in c8[i][l].state)                                             # int8 [n, Hkv, D]
+            assert k8.dtype == np.int8
+            assert np.array_equal(k8, po.kv_i8_quantize(rows[i][l][0], np.broadcast_to(ksn[l], (n, Hkv)))), f"K codes, prompt {i} layer {l}"
+            assert np.array_equal(v8, po.kv_i8_quantize(rows[i][l][1], np.broadcast_to(vsn[l], (n, Hkv)))), f"V codes, prompt {i} layer {l}"
+    page = pool.get_page(c8[0][0].page_manager.pages[0])
+    assert np.array_equal(page.key_cache_scale(1).cpu().numpy()[:, 0], ksn[1])
+    tok_8, _, la_8 = model.step_batch(feed, c8, graph=False)
+    for i in range(len(lens)):
+        k8, v8 = (t.cpu().numpy()[0].transpose(1, 0, 2)[-1] for t in c8[i][0].state)
+        assert np.array_equal(k8, po.kv_i8_quantize(new_t[i][0], ksn[0])) and np.array_equal(v8, po.kv_i8_quantize(new_t[i][1], vsn[0]))
+        assert_vec_close(la_8.float().cpu().numpy()[i], la_t[i], "bfloat16", c_max=24.0, c_rms=16.0, what=f"int8-page decode step, sequence {i}")
+    assert torch.equal(tok_8.cpu(), tok_t.cpu())
+    with pytest.raises(TypeError, match="int8 pages"):
+        model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
+    model.enable_paged_kv(num_pages=8)   # back to T pages: the single-sequence path works again
+    model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())

@@ -277,3 +277,29 @@ def test_native_thread_stress(tmp_path, sanitize):
         pytest.skip("ThreadSanitizer cannot map its shadow in this container")
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "ok" in r.stdout
+
+
+def test_int8_page_geometry_and_oracle_quantiser():
+    """The reference page's own storage (page.hpp:25-32): int8 K / V blocks [64, heads, head_dim] + float16 scales [heads, 1] per block.
+    Geometry of the native pool for that dtype (no GPU needed) and the oracle's definition of the arithmetic the HIP kernels follow."""
+    import numpy as np
+    import torch
+    from oracle import pie_oracle as po
+    from proxy_inference_engine_amd import _ffi
+    lib = _ffi.load()
+    for heads, dim in ((8, 128), (2, 64), (1, 128)):
+        pb = lib.pie_page_i8_bytes(heads, dim)
+        assert pb % 256 == 0 and 0 <= pb - (2 * 64 * heads * dim + 4 * heads) < 256
+        assert lib.pie_page_pool_slab_bytes(5, heads, dim, _ffi.PIE_I8) == 5 * pb
+    pool = PageAllocator(4, 2, 64, dtype=torch.int8)          # bookkeeping only: the same allocator contract for int8 pages
+    assert pool.page_bytes == lib.pie_page_i8_bytes(2, 64) and pool.allocate_page() == 0 and pool.get_num_free_pages() == 3
+    x = np.array([[-300.0, -2.5, -1.5, -0.5, 0.49, 0.5, 1.5, 2.5, 126.5, 127.5]], np.float32)
+    assert po.kv_i8_quantize(x, np.ones(1, np.float16)).tolist() == [[-127, -2, -2, 0, 0, 0, 2, 2, 126, 127]]       # half-even, clamp
+    q = po.kv_i8_quantize(x, np.array([0.5], np.float16))
+    assert q.tolist() == [[-127, -5, -3, -1, 1, 1, 3, 5, 127, 127]]
+    assert np.array_equal(po.kv_i8_dequantize(q, np.array([0.5], np.float16)), q.astype(np.float32) * 0.5)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((7, 3, 16)).astype(np.float32)
+    s = np.full((7, 3), 1 / 32, np.float16)
+    err = np.abs(po.kv_i8_dequantize(po.kv_i8_quantize(y, s), s) - y)
+    assert err[np.abs(y) <= 127 / 32].max() <= 0.5 / 32 + 1e-7                                                          # half a step inside the range
