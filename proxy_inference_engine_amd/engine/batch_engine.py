@@ -27,9 +27,13 @@ class _Active:
 
 class BatchedEngine:
     def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
-                 sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096):
+                 sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096,
+                 kv_dtype: torch.dtype | None = None, kv_scales=None):
+        """kv_dtype=torch.int8 (+ kv_scales = (k, v) float16 [n_layers, n_kv_heads]): the pool holds the reference KVPage's int8 pages with
+        per-head scales (page.hpp:25-32) -- half the cache bytes per token, so twice the sequences / context per pool."""
         self.model = model
-        self.pool = model.enable_paged_kv(num_pages=num_pages)
+        self.pool = model.enable_paged_kv(num_pages=num_pages, kv_dtype=kv_dtype, kv_scales=kv_scales)
+        self._i8 = self.pool.dtype == torch.int8   # int8 pages are written by the batch paths only: lone prompts go through prefill_batch too
         self.max_batch = max_batch
         self.stop_tokens = set(int(t) for t in stop_tokens)
         self.sampler = sampler
@@ -66,7 +70,13 @@ class BatchedEngine:
                 reserved += n_pages
                 rows += len(prompt)
                 batch.append((idx, prompt, self.model.make_cache()))
-            if len(batch) == 1 or (batch and not self.batch_prefill):
+            if self._i8 and batch and (len(batch) == 1 or not self.batch_prefill):
+                for idx, prompt, cache in batch:
+                    toks, logprobs, _ = self.model.prefill_batch([prompt], [cache])
+                    if self.sampler is not None:
+                        toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                    active.append(_Active(idx, cache, toks[:1].clone()))
+            elif len(batch) == 1 or (batch and not self.batch_prefill):
                 for idx, prompt, cache in batch:
                     ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
                     tok, logprobs, _ = self.model.step(ids.to(self.model.device), cache)

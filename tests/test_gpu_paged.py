@@ -569,3 +569,27 @@ def test_decoder_batch_paths_on_int8_pages(golden_dir):
         model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
     model.enable_paged_kv(num_pages=8)   # back to T pages: the single-sequence path works again
     model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
+
+
+def test_continuous_batching_engine_on_int8_pages(golden_dir):
+    """BatchedEngine(kv_dtype=torch.int8): more requests than slots, prompts of mixed length (a lone admission goes through prefill_batch
+    as well: int8 pages are written by the batch paths only).  With scales from the T-page run's amax the generated ids equal the T-page
+    engine's for most requests; every request completes and the pool drains."""
+    from proxy_inference_engine_amd.engine.batch_engine import BatchedEngine
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(31)
+    prompts = [rng.integers(0, cfg["vocab_size"], n).tolist() for n in (9, 40, 3, 70, 21)]
+    ref = BatchedEngine(model, num_pages=16, max_batch=2).generate(prompts, 6)
+    L, Hkv = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
+    # calibration: amax of K / V over one prompt on T pages
+    model.enable_paged_kv(num_pages=8)
+    c = model.make_cache()
+    model.step(torch.tensor(prompts[3], dtype=torch.int32).cuda(), c)
+    ks = torch.stack([c[l].state[0].float().abs().amax(dim=(0, 2, 3)) for l in range(L)]) * (2.0 / 127)
+    vs = torch.stack([c[l].state[1].float().abs().amax(dim=(0, 2, 3)) for l in range(L)]) * (2.0 / 127)
+    eng = BatchedEngine(model, num_pages=16, max_batch=2, kv_dtype=torch.int8, kv_scales=(ks.half(), vs.half()))
+    got = eng.generate(prompts, 6)
+    assert [len(t) for t in got] == [6] * len(prompts) and eng.pool.get_num_free_pages() == eng.pool.size()
+    same = sum(a == b for a, b in zip(got, ref))
+    assert same >= len(prompts) - 1, f"int8 pages changed the greedy ids of {len(prompts) - same} of {len(prompts)} requests"
+    assert all(a[0] == b[0] for a, b in zip(got, ref)), "the first token comes from the prompt pass, which reads its own T rows"
