@@ -16,11 +16,11 @@ for name, N, K in (("qkv", 6144, 4096), ("o_proj", 4096, 4096), ("gate_up", 2867
     pw = ops.repack_w4s(*ops.quantize(w))
     w4m = ops.repack_w4m(pw)
     x = torch.randn(M, K, dtype=torch.bfloat16, device="cuda")
-    for _ in range(3):
+    for _ in range(3 if M > 512 else 50):
         ops.quantized_matmul_rows(x, pw, w4m)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
+    reps = 10 if M > 512 else 300
     e0.record()
     for _ in range(reps):
         ops.quantized_matmul_rows(x, pw, w4m)
