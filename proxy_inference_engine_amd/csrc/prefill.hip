@@ -1083,7 +1083,7 @@ extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, con
     // captured only for a call that repeats the previous call's buffers after that call allocated nothing, and is dropped when
     // either changes.  (First call with new buffers: eager, it may allocate; second: capture; from the third: replay.)
     std::vector<uintptr_t> key = {(uintptr_t)tokens, (uintptr_t)context_lens, (uintptr_t)block_tables, (uintptr_t)logits, (uintptr_t)logprobs,
-                                  (uintptr_t)next_tokens, (uintptr_t)n_pages, (uintptr_t)max_blocks, (uintptr_t)B};
+                                  (uintptr_t)next_tokens, (uintptr_t)n_pages, (uintptr_t)max_blocks, (uintptr_t)B, (uintptr_t)d->kv_i8 /* the page format is baked into the launches too */};
     for (int i = 0; i < d->cfg.n_layers; ++i) key.push_back((uintptr_t)slabs[i]);
     if (!d->prefill) d->prefill = new PrefillScratch();
     PrefillScratch *s = d->prefill;
