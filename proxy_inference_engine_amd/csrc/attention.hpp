@@ -210,6 +210,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
         for (int d = 0; d < DA; ++d) {
             const int b = base + d;
             if (b < n_blk) {  // wave-uniform; every block has at least one valid token (ts == 0)
+                // Long caches (8 waves, two per SIMD): the two waves of a SIMD take turns at the higher issue priority, two row blocks each --
+                // the GEMV's finding (w4_gemv.hpp) carries over where the scoring loop is long: 8B step at 32k cached positions 1.998 ->
+                // 1.945-1.956 ms, at 8k 1.527 -> 1.516, at 2k unchanged; turns of one or four blocks measured no gain.
+                if constexpr (WAVES == 8 && NTKV) {
+                    if (((b >> 1) + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 const bool valid = first + b * NSUB * TPW + ts < t_end;
                 const u32 kw[4] = {kq[d].x, kq[d].y, kq[d].z, kq[d].w};
                 float vf[8];

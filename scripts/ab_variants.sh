@@ -5,7 +5,7 @@ B=$R/tools/step_bench
 run() { # name, env...
   local name=$1; shift
   local out
-  out=$(env "$@" $B --model 8b --mode launch --no-mega --steps 1024 --warmup 64 2>&1 | grep "launch sequence")
+  out=$(env "$@" $B ${STEP_ARGS:---model 8b --mode launch --no-mega --steps 1024 --warmup 64} 2>&1 | grep "launch sequence")
   echo "$name: $out"
 }
 for rep in 1 2 3; do
