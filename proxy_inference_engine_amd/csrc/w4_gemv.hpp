@@ -36,7 +36,10 @@ constexpr int GEMV_ATTN_SPLITS = 4;  // split-KV factor the PRO_ATTN prologue me
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4, EPI_PARTIAL_F32 = 5 };
 
 constexpr int GEMV_WAVES = 8;        // waves per workgroup
-constexpr int GEMV_DEPTH = 2;        // units in flight per wave (swept 2..12 on MI355X: 2-3 best, deeper rings are slower)
+#ifndef PIE_GEMV_DEPTH
+#define PIE_GEMV_DEPTH 2
+#endif
+constexpr int GEMV_DEPTH = PIE_GEMV_DEPTH;  // units in flight per wave (round 1 swept 2..12: 2-3 best; re-checked with round 2's kernels: 1 / 2 / 3 / 4 -> 1.454 / 1.235 / 1.286 / 1.334 ms per 8B step)
 constexpr int GEMV_MAX_WAVES = 2048; // 256 CUs x ONE 8-wave workgroup: measured best (sweep 1024..6144 in DESIGN.md); the
                                      // activation staging is paid once per CU and no CU runs a second, later wave of groups
 constexpr int GEMV_MAX_RUN = 64;     // row pairs per wave (one epilogue lane each)
