@@ -88,23 +88,26 @@ struct W4lSlabs {
     int S = 0;
     size_t MN = 0;
 };
-// V = float2 / float4: one thread's NV vectors at element offsets off[]; the slabs are fetched four at a time (all 4 NV loads in flight
+#ifndef SLAB_BATCH
+#define SLAB_BATCH 4
+#endif
+// V = float2 / float4: one thread's NV vectors at element offsets off[]; the slabs are fetched BATCH at a time (all BATCH x NV loads in flight
 // before the first add -- a plain loop over the slabs waits out one memory latency per slab: 15 us instead of 5 for a 64-row o_proj
 // consumer) and added strictly in slab order.
-template <class V, int NV>
+template <class V, int NV, int BATCH = 4>
 __device__ __forceinline__ void slab_sum(const float *part, int S, size_t MN, const size_t (&off)[NV], V (&acc)[NV]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = *reinterpret_cast<const V *>(part + off[v]);
-    for (int z = 1; z < S; z += 4) {
-        V b[4][NV];
+    for (int z = 1; z < S; z += BATCH) {
+        V b[BATCH][NV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BATCH; ++u) {
             const size_t zz = (size_t)(z + u < S ? z + u : S - 1) * MN;  // clamp, never branch around a load
 #pragma unroll
             for (int v = 0; v < NV; ++v) b[u][v] = *reinterpret_cast<const V *>(part + zz + off[v]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BATCH; ++u)
             if (z + u < S) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
@@ -155,7 +158,8 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
     };
     auto f16f = [](u16 h) { return (float)__builtin_bit_cast(_Float16, h); };
     const u16 *row = qkv + (size_t)m * n_cols;
-    for (int p = threadIdx.x; p < (n_cols >> 1); p += blockDim.x) {
+    // gridDim.y workgroups share a row (few rows summing fp32 slabs: one workgroup per row cannot keep enough loads in flight)
+    for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < (n_cols >> 1); p += gridDim.y * blockDim.x) {
         const int R = 2 * p;
         u32 pr;
         if (part) {
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
                 if (part) {
                     const size_t o[2] = {(size_t)blockIdx.x * H + i, (size_t)blockIdx.x * H + i + 4};
                     float4 f[2];
-                    slab_sum<float4, 2>(part, S, MN, o, f);
+                    slab_sum<float4, 2, SLAB_BATCH>(part, S, MN, o, f);
                     f0 = f[0], f1 = f[1];
                 } else {
                     f0 = *reinterpret_cast<const float4 *>(r32r + i), f1 = *reinterpret_cast<const float4 *>(r32r + i + 4);
@@ -663,11 +667,12 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     if (slabs) *slabs = W4lSlabs();
     if (const char *e = getenv("PIE_W4L_SLABS"))  // 0: always reduce in the GEMM's own launch (A/B and the bit-equality test)
         if (e[0] == '0') slabs = nullptr;
-    // Below ~200 rows the consumers (one workgroup per row) have too few workgroups to fetch 8-16 slabs as fast as the reduce launch's
-    // M N / 1024 do: 8B prompt of 64 / 128 / 256 / 512 / 700 tokens, slabs vs reduce launch: 4.21 / 4.85 / 6.13 / 9.56 / 14.26 ms vs
-    // 3.92 / 4.78 / 6.20 / 9.75 / 14.38.
-    static const int slabs_min_rows = getenv("PIE_W4L_SLABS_MIN_ROWS") ? atoi(getenv("PIE_W4L_SLABS_MIN_ROWS")) : 192;
-    if (M < slabs_min_rows) slabs = nullptr;
+    // 8B prompt of 64 / 128 / 256 / 512 / 700 tokens, slabs summed by the consumers vs reduce launches: 3.70 / 4.56 / 6.13 / 9.56 / 14.26 ms
+    // vs 3.96 / 4.82 / 6.20 / 9.75 / 14.38.  (With ONE workgroup per row the RoPE consumer could not keep enough slab loads in flight
+    // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
+    // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
+    static const int slabs_min_rows = getenv("PIE_W4L_SLABS_MIN_ROWS") ? atoi(getenv("PIE_W4L_SLABS_MIN_ROWS")) : 0;
+    if (M < slabs_min_rows && !rope) slabs = nullptr;
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
     if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
@@ -823,7 +828,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
                 return rc;
             if (!roped) {
-                hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
+                const unsigned row_wgs = sq.S > 1 && M < 192 ? 4u : 1u;  // few rows of slabs: four workgroups per row
+                hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M, row_wgs), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                    c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs, (const int *)nullptr, 0,
                                    (u16 *)nullptr, (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN);
                 PIE_LAUNCH_CHECK();

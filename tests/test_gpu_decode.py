@@ -330,12 +330,12 @@ def test_batched_prefill_llama8b_shapes(monkeypatch):
         assert_vec_close(logits.float().cpu().numpy(), want, dtype, what="decode after batched prefill")
 
 
-@pytest.mark.parametrize("bias", [False, True])
-def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias):
+@pytest.mark.parametrize("bias,L", [(False, 200), (True, 200), (False, 70)])
+def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias, L):
     """Prompts of a few dozen to a few hundred rows split K in the many-row int4 GEMM; the fp32 partial slabs are summed by the kernels that
     consume the product (RoPE + append for q|k|v, residual add + RMSNorm for o_proj / down) instead of a reduce launch of their own.  Same
     arithmetic in the same order: logits, hidden state and the decode steps that follow are bit-identical to the reduce-launch form
-    (PIE_W4L_SLABS=0), and both follow the oracle.  Two Llama-3-8B-shaped layers, 200-token prompt; with Linear biases the q|k|v product
+    (PIE_W4L_SLABS=0), and both follow the oracle.  Two Llama-3-8B-shaped layers, 200- and 70-token prompts; with Linear biases the q|k|v product
     keeps its reduce launch and o_proj / down add the bias after their own rounding."""
     dtype = "bfloat16"
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
@@ -344,7 +344,7 @@ def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias):
            "attention_bias": bias, "mlp_bias": bias, "quantization": {"group_size": 64, "bits": 4}}
     w = po.synth_checkpoint(cfg, seed=5, dtype=dtype, lm_head_gain=4.0)
     orc = po.OracleLlama(cfg, w, dtype)
-    prompt = np.random.default_rng(21).integers(0, cfg["vocab_size"], 200)
+    prompt = np.random.default_rng(21).integers(0, cfg["vocab_size"], L)   # (70 rows: the RoPE consumer runs four workgroups per row)
     ocache = [po.OracleKVCache() for _ in orc.layers]
     want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
     outs = {}
