@@ -14,11 +14,17 @@
 // (head-major blocks like the 16-bit pages: one head's 64 rows are one 4-8 KB burst).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/pie_hip.h"
 #include "attention.hpp"
 #include "common.hpp"
 
 namespace {
+
+#ifndef I8_DEPTH
+#define I8_DEPTH 2  // row blocks in flight per wave
+#endif
 
 __device__ __forceinline__ float f16_bits_to_f32(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ float i8_to_f32(u32 word, int j) { return (float)(int)(signed char)(word >> (8 * j)); }
@@ -72,7 +78,8 @@ __global__ void __launch_bounds__(256) k_paged_kv_append_i8(const uint4 *k, cons
 // Split-KV decode attention over int8 pages: one workgroup per (kv-head g, split, sequence).  Same lane geometry as k_attn_decode
 // (D / 8 lanes per token row, 8 dims each -- here 8 bytes), every token group keeps its own online-softmax stream in the base-2 domain,
 // the streams meet in LDS and the split's partial (m, l, acc[D]) goes to the workspace k_attn_combine merges.  K's scale multiplies the
-// reduced score, V's scale the converted value: x' = fp32(q) * fp32(s) exactly, everything after it in fp32.
+// reduced score (q . q8 through v_dot2 on exact T copies of the codes), V's scale the converted value: x' = fp32(q8) * fp32(s) exactly,
+// everything after it in fp32.
 template <class T, int D, int REP>
 __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const AttnArgs a, size_t page_bytes) {
     constexpr int WAVES = REP > 4 ? 2 : 4;
@@ -91,14 +98,30 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
     const unsigned last_page = (unsigned)a.n_pages - 1u;
     const size_t blk = (size_t)a.Hkv * 64 * D;
 
-    float qf[REP][8];
+    // q stays packed (T pairs) for v_dot2; the K bytes enter as OFFSET codes u = q8 + 128 (one xor per word, then v_cvt_f32_ubyteN -- the
+    // signed route costs a bit-field extract more per element), so sum q (u - 128) = dot(q, u) - 128 sum q: the second term once per kernel
+    u32 qr[REP][4];
+    float q128[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
         const uint4 qv = *reinterpret_cast<const uint4 *>(a.q + ((size_t)row * a.Hq + g * REP + h) * D + dc * 8);
-        const u32 w[4] = {qv.x, qv.y, qv.z, qv.w};
+        qr[h][0] = qv.x, qr[h][1] = qv.y, qr[h][2] = qv.z, qr[h][3] = qv.w;
+        float sq = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) qf[h][2 * j] = lo_f32<T>(w[j]), qf[h][2 * j + 1] = hi_f32<T>(w[j]);
+        for (int j = 0; j < 4; ++j) sq += lo_f32<T>(qr[h][j]) + hi_f32<T>(qr[h][j]);
+        q128[h] = 128.0f * sq;
     }
+    auto ub = [](u32 w, int j) { return (float)((w >> (8 * j)) & 0xFFu); };  // v_cvt_f32_ubyteN
+    auto pk = [](float lo, float hi) {  // both exact in T (integers <= 255)
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        if constexpr (std::is_same<T, BF16>::value) {
+            typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+            return __builtin_bit_cast(u32, __builtin_convertvector((f2_t){lo, hi}, b2_t));
+        } else {
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            return __builtin_bit_cast(u32, __builtin_convertvector((f2_t){lo, hi}, h2_t));
+        }
+    };
     float m[REP], l[REP], acc[REP][8];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
@@ -108,8 +131,9 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
     }
     const int first = t_begin + wave * TPW;
     const int n_blk = first < t_end ? (t_end - first + WAVES * TPW - 1) / (WAVES * TPW) : 0;
-    uint2 kq[2], vq[2];
-    u32 sq[2];  // K scale | V scale << 16 of the block's page
+    constexpr int DA = I8_DEPTH;
+    uint2 kq[DA], vq[DA];
+    u32 sq[DA];  // K scale | V scale << 16 of the block's page
     auto issue = [&](int d, int b) {
         int t = first + b * WAVES * TPW + ts;
         t = t < t_end ? t : t_end - 1;  // clamp, never branch around a load
@@ -120,27 +144,28 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
         const u16 *sc = reinterpret_cast<const u16 *>(page + 2 * blk);
         sq[d] = (u32)sc[g] | ((u32)sc[a.Hkv + g] << 16);
     };
-    if (n_blk > 0) issue(0, 0);
-    if (n_blk > 1) issue(1, 1);
-    for (int base = 0; base < n_blk; base += 2) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < DA; ++d)
+        if (d < n_blk) issue(d, d);
+    for (int base = 0; base < n_blk; base += DA) {
+#pragma unroll
+        for (int d = 0; d < DA; ++d) {
             const int b = base + d;
             if (b < n_blk) {  // wave-uniform
                 const bool valid = first + b * WAVES * TPW + ts < t_end;
                 const float ks = f16_bits_to_f32((u16)(sq[d] & 0xFFFFu)), vs = f16_bits_to_f32((u16)(sq[d] >> 16));
-                float kf[8], vf[8];
+                const u32 kx = kq[d].x ^ 0x80808080u, ky = kq[d].y ^ 0x80808080u, vx = vq[d].x ^ 0x80808080u, vy = vq[d].y ^ 0x80808080u;
+                const u32 kp[4] = {pk(ub(kx, 0), ub(kx, 1)), pk(ub(kx, 2), ub(kx, 3)), pk(ub(ky, 0), ub(ky, 1)), pk(ub(ky, 2), ub(ky, 3))};
+                const float vneg = -128.0f * vs;  // (u - 128) * vs = fma(u, vs, -128 vs): exact, the product has <= 19 significant bits
+                float vf[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    kf[j] = i8_to_f32(kq[d].x, j), kf[4 + j] = i8_to_f32(kq[d].y, j);
-                    vf[j] = i8_to_f32(vq[d].x, j) * vs, vf[4 + j] = i8_to_f32(vq[d].y, j) * vs;
-                }
+                for (int j = 0; j < 4; ++j) vf[j] = fmaf(ub(vx, j), vs, vneg), vf[4 + j] = fmaf(ub(vy, j), vs, vneg);
                 float sc[REP];
 #pragma unroll
                 for (int h = 0; h < REP; ++h) {
-                    sc[h] = 0.0f;
+                    sc[h] = -q128[h];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sc[h] = fmaf(qf[h][j], kf[j], sc[h]);
+                    for (int j = 0; j < 4; ++j) sc[h] = T::dot2(qr[h][j], kp[j], sc[h]);
                 }
 #pragma unroll
                 for (int h = 0; h < REP; ++h) sc[h] += __builtin_amdgcn_update_dpp(0.0f, sc[h], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -176,7 +201,7 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(p, vf[j], acc[h][j]);
                 }
-                if (b + 2 < n_blk) issue(d, b + 2);
+                if (b + DA < n_blk) issue(d, b + DA);
             }
         }
     }
@@ -289,7 +314,9 @@ int pie_paged_attn_decode_i8(const void *q, const void *slab, size_t n_pages, co
     a.q = (const u16 *)q, a.slab = (const u16 *)slab, a.block_table = block_table, a.ctx_len = context_lens;
     a.bt_stride = max_blocks, a.n_pages = (int)n_pages, a.rows = B;
     a.Hq = Hq, a.Hkv = Hkv, a.scale = scale;
-    int splits = (512 + B * Hkv - 1) / (B * Hkv);  // enough workgroups for two per CU across the batch, never more than pages per sequence
+    // enough workgroups across the batch -- 1024 of these 4-wave workgroups put as many waves on the chip as 512 of the T-page kernel's 8-wave
+    // ones (with 512: 313 us instead of 223 at 64 sequences x 4096 positions) --, never more splits than pages per sequence
+    int splits = (1024 + B * Hkv - 1) / (B * Hkv);
     splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : splits;
     splits = splits > max_blocks ? max_blocks : splits;
     a.splits = splits < 1 ? 1 : splits;

@@ -919,7 +919,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
     if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
     // attention splits: enough workgroups for two per CU across the batch, never more than pages per sequence
-    int splits = (512 + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);
+    int splits = ((d->kv_i8 ? 1024 : 512) + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);  // (the int8-page kernel runs 4-wave workgroups: twice as many)
     splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
     splits = splits < 1 ? 1 : splits;
     int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
