@@ -318,9 +318,13 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_p(const char *w4m, 
                 const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
                 const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc = MfmaT<T>::run(w4m_dequant<T>(words[k], s, b), xf[d % XD][k], acc);
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 af = (W4M_ABL & 1) ? make_uint4(words[k], words[k] ^ sb[d], words[k] + 1, sb[d]) : w4m_dequant<T>(words[k], s, b);
+                    if (W4M_ABL & 4) acc[k] += __builtin_bit_cast(float, af.x ^ af.y ^ af.z ^ af.w ^ xf[d % XD][k].x);
+                    else acc = MfmaT<T>::run(af, xf[d % XD][k], acc);
+                }
                 W4M_WISSUE(d)
-                W4M_XISSUE(d % XD)
+                if (!(W4M_ABL & 2)) W4M_XISSUE(d % XD)
                 if (++cit == my_groups) {  // strip done for this wave: all eight waves meet here once per strip
                     const int buf = cj & 1, nt = (int)blockIdx.x + cj * (int)gridDim.x;
 #pragma unroll
