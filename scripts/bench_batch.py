@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--kv-int8", action="store_true", help="a second pass with the sequences on int8 pages (per-head scales 1/16; prompts through prefill_batch)")
     args = ap.parse_args()
     cfg = dict(LLAMA3_8B)
     if args.layers:
@@ -66,6 +67,26 @@ def main():
                           "vs_single": round(B / dt * single, 2)}), flush=True)
         for c in caches:
             c[0].page_manager.release()
+    if args.kv_int8:  # the same step on the reference page's own storage: int8 rows + per-head fp16 scales (half the cache bytes)
+        L, Hkv = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
+        sc = torch.full((L, Hkv), 1 / 16, dtype=torch.float16)
+        model.enable_paged_kv(num_pages=max(batches) * pages_per_seq + 4, max_blocks=pages_per_seq, kv_dtype=torch.int8, kv_scales=(sc, sc))
+        for B in batches:
+            caches = [model.make_cache() for _ in range(B)]
+            prompts = [torch.randint(0, cfg["vocab_size"], (args.prompt + (i % 7),), generator=g).tolist() for i in range(B)]
+            tokens, _, _ = model.prefill_batch(prompts, caches)
+            tokens = tokens.clone()
+            for _ in range(4):
+                tokens, _, _ = model.step_batch(tokens, caches)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tokens, _, _ = model.step_batch(tokens, caches)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            print(json.dumps({"mode": "step_batch on int8 pages", "sequences": B, "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(B / dt, 1)}), flush=True)
+            for c in caches:
+                c[0].page_manager.release()
 
 
 if __name__ == "__main__" and "--engine" not in sys.argv:
