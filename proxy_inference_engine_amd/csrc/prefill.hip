@@ -606,6 +606,7 @@ struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.h
     int bt_stride, n_pages, layer, n_layers, n_heads, n_kv_heads, HD, traditional;
     u16 *q_out;
     const u16 *bias;
+    size_t i8_page_bytes;  // != 0 (with slab): int8 pages with per-head scales (paged_i8.hip)
 };
 int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
                     const void *bias, const W4mRope *rope);
@@ -822,7 +823,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             // input_layernorm: layer 0 here; for the later layers it was fused with the previous block's residual add
             if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st))) return rc;
             W4mRope re = {s->rope_cs, d->state, nullptr, d->kv_table, nullptr, d->block_table, 0, d->n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads, D,
-                          c.rope_traditional, s->q, nullptr};
+                          c.rope_traditional, s->q, nullptr, 0};
             bool roped = false;
             W4lSlabs sq, so, sd;  // K-split products handed over as fp32 slabs (q|k|v only without a bias: RoPE takes T(x W^T + b))
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
@@ -941,11 +942,11 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     for (int li = 0; li < c.n_layers; ++li) {
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, B, H, c.dtype, s->xn, st))) return rc;
+        const size_t i8pb = d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : 0;  // int8 pages: the append (epilogue or row kernel) quantises
         W4mRope re = {s->rope_cs, nullptr, ctx_len, nullptr, (u16 *)slabs[li], block_tables, max_blocks, n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads,
-                      D, c.rope_traditional, s->q, nullptr};
+                      D, c.rope_traditional, s->q, nullptr, i8pb};
         bool roped = false;
-        const size_t i8pb = d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : 0;  // int8 pages: the append quantises, so it stays out of the GEMM epilogue
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, d->kv_i8 ? nullptr : &re))) return rc;
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
         if (!roped) {
             hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                                c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li],

@@ -120,6 +120,7 @@ struct W4mRope {
     int bt_stride, n_pages, layer, n_layers, n_heads, n_kv_heads, HD, traditional;
     u16 *q_out;                         // [M, n_heads, HD]
     const u16 *bias;                    // the Linear's bias (packed order), nullable
+    size_t i8_page_bytes;               // != 0 (with slab): the pages are int8 with per-head fp16 scales (paged_i8.hip): K / V are quantised on the way in
 };
 
 template <class T>
@@ -137,11 +138,21 @@ __device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt
     int cap = r.ctx_len ? 64 : r.state->cap, kvrow = pos;
     u16 *kdst = r.slab ? r.slab : reinterpret_cast<u16 *>(r.kv_table[r.layer]);
     u16 *vdst = r.slab ? r.slab + (size_t)r.n_kv_heads * 64 * HD : reinterpret_cast<u16 *>(r.kv_table[r.n_layers + r.layer]);
+    char *page8 = nullptr;  // int8 pages: this row's page (k_rope_append_rows' arithmetic: clamp(rint(x / s), -127, 127) of the T-rounded element)
     if (r.block_table) {
         const int *bt = r.block_table + (size_t)m * r.bt_stride;
-        const size_t pg_off = (size_t)min((unsigned)bt[pos >> 6], (unsigned)r.n_pages - 1u) * 2 * 64 * r.n_kv_heads * HD;
+        const unsigned pg = min((unsigned)bt[pos >> 6], (unsigned)r.n_pages - 1u);
+        const size_t pg_off = (size_t)pg * 2 * 64 * r.n_kv_heads * HD;
         kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
+        if (r.i8_page_bytes && r.slab) page8 = reinterpret_cast<char *>(r.slab) + (size_t)pg * r.i8_page_bytes;
     }
+    const size_t blk8 = (size_t)r.n_kv_heads * 64 * HD;
+    auto q8 = [](float x, float sc) {
+        float q = rintf(x / sc);
+        q = q < -127.0f ? -127.0f : (q > 127.0f ? 127.0f : q);
+        return (signed char)(q == q ? (int)q : 0);
+    };
+    auto f16f = [](u16 h) { return (float)__builtin_bit_cast(_Float16, h); };
     const int q_cols = r.n_heads * HD, k_cols = r.n_kv_heads * HD;
     if (R < q_cols + k_cols) {
         const int rr = R < q_cols ? R : R - q_cols;
@@ -149,11 +160,20 @@ __device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt
         const float2 csn = *reinterpret_cast<const float2 *>(r.rope_cs + ((size_t)m * half + ii) * 2);
         u16 *dst = R < q_cols ? r.q_out + ((size_t)m * r.n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
         const int i0 = r.traditional ? 2 * ii : ii, i1 = r.traditional ? 2 * ii + 1 : ii + half;
-        dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(a, csn.x), __fmul_rn(b, csn.y)));
-        dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(a, csn.y), __fmul_rn(b, csn.x)));
+        const u16 o0 = T::from_f32(__fsub_rn(__fmul_rn(a, csn.x), __fmul_rn(b, csn.y))), o1 = T::from_f32(__fadd_rn(__fmul_rn(a, csn.y), __fmul_rn(b, csn.x)));
+        if (page8 && R >= q_cols) {
+            const float sk = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[head]);
+            signed char *kb = reinterpret_cast<signed char *>(page8) + ((size_t)head * 64 + kvrow) * HD;
+            kb[i0] = q8(T::to_f32(o0), sk), kb[i1] = q8(T::to_f32(o1), sk);
+        } else dst[i0] = o0, dst[i1] = o1;
     } else {
         const int rr = R - q_cols - k_cols;
-        *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pack2<T>(a, b);
+        if (page8) {
+            const int head = rr / HD;
+            const float sv = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[r.n_kv_heads + head]);
+            signed char *vb = reinterpret_cast<signed char *>(page8) + blk8 + ((size_t)head * 64 + kvrow) * HD + rr % HD;
+            vb[0] = q8(a, sv), vb[1] = q8(b, sv);
+        } else *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pack2<T>(a, b);
     }
 }
 
