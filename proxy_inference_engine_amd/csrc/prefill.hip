@@ -829,7 +829,8 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
                 return rc;
             if (!roped) {
-                const unsigned row_wgs = sq.S > 1 && M < 192 ? 4u : 1u;  // few rows of slabs: four workgroups per row
+                static const int rw_env = getenv("PIE_ROPE_ROW_WGS") ? atoi(getenv("PIE_ROPE_ROW_WGS")) : 0;  // developer override
+                const unsigned row_wgs = sq.S > 1 ? (rw_env > 0 ? (unsigned)rw_env : (M < 512 ? 4u : 1u)) : 1u;  // few rows of slabs: four workgroups per row (256 tokens: 6.03 vs 6.20 ms; from 512 rows no difference)
                 hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M, row_wgs), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                    c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs, (const int *)nullptr, 0,
                                    (u16 *)nullptr, (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN);
