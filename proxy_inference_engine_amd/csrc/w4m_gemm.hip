@@ -450,6 +450,107 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
     else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
 }
 
+// The staged form for matrices with many strips (gate|up: 896, lm_head: 4008): one workgroup owns W4M_NS (= 4) consecutive strips and walks K
+// ONCE for all of them -- a round's x tile is staged once and its fragments are read once per wave, then multiplied into W4M_NS
+// accumulators.  With one strip per workgroup every strip re-reads the whole of x from L2: at 32 rows that is 256 KB per strip, 229 MB
+// per gate|up launch against 66 MB of weights (the 32-sequence step's gate|up: 35 us for what the decode GEMV streams in 12).
+// Same tiles per wave (groups wave, wave + 8, ...), same accumulation order per strip, same reduction: bit-identical results.
+// Used at every row count 2..32: gate|up 24.1-25.8 us against 32.6-37.2 (the persistent gather form below 24 rows) / 35.0 (staged, one strip);
+// 8B prompt suffix of 8 / 16 / 32 tokens 2.20 / 2.49 / 3.01 ms against 2.56 / 2.81 / 3.27, multi-sequence step at 8 / 16 / 32 sequences
+// 2.48 / 2.77 / 3.42 ms against 2.81 / 3.18 / 3.73.
+template <class T, int W4M_NS>
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias,
+                                                                 const W4mRope rope) {
+    __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kh = lane >> 5, groups = K >> 6, n_strips = N >> 5;
+    const int nt0 = blockIdx.x * W4M_NS;
+    const int rounds = (groups + W4M_WAVES - 1) / W4M_WAVES;
+    const int m_read = n < M ? n : M - 1;
+
+    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+    uint4 cw[2][W4M_NS];  // ring: two rounds ahead, one slot per strip
+    u32 sb[2][W4M_NS];
+#define W4M_WLOAD4(p, st, r)                                                                              \
+    {                                                                                                     \
+        int g_ = wave + ((r) < rounds ? (r) : rounds - 1) * W4M_WAVES;                                    \
+        g_ = g_ < groups ? g_ : groups - 1;                                                               \
+        const int nt_ = nt0 + (st) < n_strips ? nt0 + (st) : n_strips - 1;                                \
+        const char *tile_ = w4m + ((size_t)nt_ * groups + g_) * W4M_TILE_BYTES;                           \
+        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);  \
+        cw[p][st] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                   \
+        sb[p][st] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);           \
+    }
+    uint4 xs[4];
+    auto x_fetch = [&](int r) {
+        const int col = 512 * r + 8 * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wave + 8 * j;
+            xs[j] = (m < M && col < K) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wave + 8 * j;
+            if (m < M) *reinterpret_cast<uint4 *>(s_x[buf] + m * W4M_XROW + lane * 16) = xs[j];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int st = 0; st < W4M_NS; ++st) W4M_WLOAD4(p, st, p)
+    x_fetch(0);
+    x_store(0);
+    __syncthreads();
+
+    f32x16_t acc[W4M_NS];
+#pragma unroll
+    for (int st = 0; st < W4M_NS; ++st)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[st][i] = 0.0f;
+    for (int base = 0; base < rounds; base += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = base + p;
+            if (r < rounds) {  // uniform for the workgroup
+                if (r + 1 < rounds) x_fetch(r + 1);
+                const bool live = wave + r * W4M_WAVES < groups;  // wave-uniform: the last round may be short
+                uint4 xf[4];
+                const char *xr = s_x[r & 1] + m_read * W4M_XROW + wave * 128 + kh * 16;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xf[k] = *reinterpret_cast<const uint4 *>(xr + 32 * k);
+#pragma unroll
+                for (int st = 0; st < W4M_NS; ++st) {
+                    if (live) {
+                        const float sc = lo_f32<T>(sb[p][st]), bi = hi_f32<T>(sb[p][st]);
+                        const u32 words[4] = {cw[p][st].x, cw[p][st].y, cw[p][st].z, cw[p][st].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[st] = MfmaT<T>::run(w4m_dequant<T>(words[k], sc, bi), xf[k], acc[st]);
+                    }
+                    W4M_WLOAD4(p, st, r + 2)
+                }
+                if (r + 1 < rounds) x_store((r + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+#undef W4M_WLOAD4
+    float(*s_red)[16][64] = reinterpret_cast<float(*)[16][64]>(&s_x[0][0]);  // every wave is past its last fragment read (barrier above)
+#pragma unroll
+    for (int st = 0; st < W4M_NS; ++st) {
+        if (nt0 + st < n_strips) {  // uniform
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[st][i];
+            __syncthreads();
+            if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt0 + st, M, rope);
+            else w4m_epilogue<T>(s_red, nt0 + st, M, N, y, nullptr, swiglu != 0, bias);
+            __syncthreads();  // the next strip reuses the buffer
+        }
+    }
+}
+
 // ---------------------------------------------------------------- MANY rows (33 .. thousands): the prompt GEMM
 // y[M, N] = x[M, K] . dequant(W)[N, K]^T on the same W4M tiles, MFMA-bound (round 1 expanded the weights to a 16-bit copy --
 // 15 GB on the 8B model -- and called hipBLASLt).  One workgroup = 256 rows of x by 256 output columns:
@@ -1219,6 +1320,17 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
     const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     const int n_strips = N >> 5;
+    const char *ne = getenv("PIE_W4M_MULTI");  // 0: one strip per workgroup also for the wide matrices (A/B, bit-equality test)
+    if (!y32 && n_strips >= 512 && K >= 512 && !(ne && ne[0] == '0')) {  // at every row count: 24.1-25.8 us on gate|up against 32.6-37.2 (persistent form) / 35.0 (staged, one strip)
+        constexpr int NS = 4;  // strips per workgroup (8 measured worse: 256 VGPRs with spills, and gate|up left with 112 workgroups)
+        const dim3 mgrid((n_strips + NS - 1) / NS);
+        if (dtype == PIE_BF16)
+            hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+        else
+            hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
     const char *pe = getenv("PIE_W4M_PERSIST");  // 0: never use the persistent form (tuning / test knob)
     if (M < stage_min && !y32 && n_strips > 512 && K >= 512 && !(pe && pe[0] == '0')) {
         const int per = (n_strips + 511) / 512;                 // strips per workgroup, balanced: 896 -> 448 x 2, 4008 -> 501 x 8

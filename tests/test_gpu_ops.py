@@ -338,6 +338,27 @@ def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
         assert np.array_equal(to_bits(cols), po.to_bits(deq[:, :min(32, K)].T.copy(), dt))
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 16384 + 96, 1024), (32, 16512, 2048), (19, 16416, 576)])
+def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, monkeypatch, M, N, K):
+    """Matrices with 512+ strips of 32 columns (gate|up, lm_head): one workgroup walks K once for four strips (k_w4m_gemm_lds4) -- x is
+    staged once per workgroup instead of once per strip.  Same tiles per wave, same accumulation and reduction order: bit-identical to the
+    one-strip-per-workgroup forms (PIE_W4M_MULTI=0), and close to the oracle's qmm.  N not a multiple of 128: the last workgroup owns
+    fewer strips; K = 576: fewer groups than two rounds of waves."""
+    dt = "bfloat16"
+    rng = np.random.default_rng(M + N)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    wq, sc, bi = po.quantize(w, 64, 4, dt)
+    x = po.round_T(rng.standard_normal((M, K)), dt)
+    packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+    xd = to_dev(po.to_bits(x, dt), dt)
+    got = ops.quantized_matmul_rows(xd, packed)
+    monkeypatch.setenv("PIE_W4M_MULTI", "0")
+    ref = ops.quantized_matmul_rows(xd, packed)
+    assert torch.equal(got, ref), "four strips per workgroup must not change a bit"
+    want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w4m wide {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,K", [(33, 64, 64), (64, 256, 512), (100, 96, 4096), (256, 4096, 1408), (300, 6144, 4096), (513, 1024, 14336), (1000, 288, 192),
                                    (512, 2048, 4096), (1300, 8192, 1024), (257, 96, 256)])
