@@ -612,6 +612,8 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
                     const void *bias, const W4mRope *rope);
 int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
                     int *slabs);  // many rows (MFMA-bound)
+int w4m_slab_splits(int M, int N, int K);  // few rows, narrow matrix: K split into fp32 slabs (0 = shape not served)
+int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st);
 size_t w4l_workspace_bytes(int M, int N, int K);
 int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
                      const void *bias, bool *bias_done);  // 16-bit weights in W16M tiles
@@ -695,6 +697,24 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             static const int split_min_m = getenv("PIE_W4M_SPLIT_MIN_M") ? atoi(getenv("PIE_W4M_SPLIT_MIN_M")) : 24;
             static const int split_long_k = getenv("PIE_W4M_SPLIT_LONG_K") ? atoi(getenv("PIE_W4M_SPLIT_LONG_K")) : 8192;  // K from which any M splits
             const bool split = y32 && used32 && N / 32 < 256 && K >= split_min_k && (M >= split_min_m || K >= split_long_k) && split_k_enabled();
+            // o_proj / down whose consumer can sum fp32 slabs: two strips per workgroup and a deeper, still deterministic K split
+            // (k_w4m_gemm_lds4 with part): a quarter of x staged per workgroup for two strips instead of half of it for one
+            const char *s2e = getenv("PIE_W4M_SLABS");  // 0: the one-strip forms with the two-way fp32 atomic split (A/B)
+            const bool slab2_on = !(s2e && s2e[0] == '0');
+            const int slab_s = slabs && !rope && !act && slab2_on && split_k_enabled() ? w4m_slab_splits(M, N, K) : 0;
+            if (slab_s >= 2) {
+                const size_t wb = (size_t)slab_s * M * N * sizeof(float);
+                if (wb > s->w4l_ws_bytes) {
+                    if (s->w4l_ws) (void)hipFree(s->w4l_ws);
+                    s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
+                    PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
+                    s->w4l_ws_bytes = wb, ++s->alloc_gen;
+                }
+                const int rc = w4m_slab_gemm_launch(d->cfg.dtype, wm, x, M, N, K, (float *)s->w4l_ws, st);
+                if (rc) return rc;
+                slabs->part = (const float *)s->w4l_ws, slabs->S = slab_s, slabs->MN = (size_t)M * N;  // the consumer also adds the bias
+                return PIE_OK;
+            }
             if (rope && used_act) {
                 *used_act = true;
                 rope->bias = (const u16 *)bias;
@@ -961,8 +981,12 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
         if ((rc = d->kv_i8 ? paged_attn_i8_launch(c.dtype, D, a, st) : attn_decode_launch(c.dtype, D, a, true, st))) return rc;
         bool r32 = false;
-        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
+        W4lSlabs so, sd;  // o_proj / down handed over as K-split fp32 slabs where the shape qualifies
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                 H <= 8192 ? &so : nullptr)))
+            return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+            return rc;
         bool fused_act = false;
         if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
         if (!fused_act) {
@@ -970,9 +994,12 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
         }
-        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                 H <= 8192 ? &sd : nullptr)))
+            return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;  // final norm: language.py:187
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || sd.S > 1 ? w.bdown : nullptr, &sd)))
+            return rc;
     }
     if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, B, logits, st, false, nullptr, true))) return rc;
     return logits_tail_rows_launch(c.dtype, logits, c.vocab, B, s->tail_stats, logprobs, next_tokens, st);

@@ -458,13 +458,24 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m
 // Used at every row count 2..32: gate|up 24.1-25.8 us against 32.6-37.2 (the persistent gather form below 24 rows) / 35.0 (staged, one strip);
 // 8B prompt suffix of 8 / 16 / 32 tokens 2.20 / 2.49 / 3.01 ms against 2.56 / 2.81 / 3.27, multi-sequence step at 8 / 16 / 32 sequences
 // 2.48 / 2.77 / 3.42 ms against 2.81 / 3.18 / 3.73.
+// part != nullptr (the narrow matrices -- o_proj, down: 128 strips -- with W4M_NS = 2): K is split over gridDim.y workgroups at multiples of
+// 512 columns and every split stores its un-rounded fp32 tile sums to its own slab part[blockIdx.y][M][N]; the consumer adds the slabs in
+// slab order and rounds once (W4lSlabs, prefill.hip) -- deterministic at any split depth, where the two-way fp32 atomics of the one-strip
+// forms stop at two addends.  Four splits x two strips: 256 workgroups that each stage a quarter of x for two strips.
 template <class T, int W4M_NS>
 __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias,
-                                                                 const W4mRope rope) {
+                                                                 const W4mRope rope, float *part) {
     __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, groups = K >> 6, n_strips = N >> 5;
+    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6, n_strips = N >> 5;
     const int nt0 = blockIdx.x * W4M_NS;
+    // this workgroup's K groups: all of them, or (part != nullptr) the blockIdx.y-th run of per_z groups (a multiple of 8: whole rounds)
+    const int per_z = part ? ((all_groups + (int)gridDim.y - 1) / (int)gridDim.y + 7) & ~7 : all_groups;
+    const int g_lo = part ? (int)blockIdx.y * per_z : 0;
+    const int groups = all_groups - g_lo < per_z ? all_groups - g_lo : per_z;  // >= 1 (launcher)
+    w4m += (size_t)g_lo * W4M_TILE_BYTES;  // tile (strip, group) lives at (strip * all_groups + group): only the group offset moves
+    x += (size_t)g_lo * 64;
+    const int Kx = K - g_lo * 64;  // columns of x from there on (row stride stays K)
     const int rounds = (groups + W4M_WAVES - 1) / W4M_WAVES;
     const int m_read = n < M ? n : M - 1;
 
@@ -476,7 +487,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4
         int g_ = wave + ((r) < rounds ? (r) : rounds - 1) * W4M_WAVES;                                    \
         g_ = g_ < groups ? g_ : groups - 1;                                                               \
         const int nt_ = nt0 + (st) < n_strips ? nt0 + (st) : n_strips - 1;                                \
-        const char *tile_ = w4m + ((size_t)nt_ * groups + g_) * W4M_TILE_BYTES;                           \
+        const char *tile_ = w4m + ((size_t)nt_ * all_groups + g_) * W4M_TILE_BYTES;                       \
         const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);  \
         cw[p][st] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                   \
         sb[p][st] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);           \
@@ -487,7 +498,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = wave + 8 * j;
-            xs[j] = (m < M && col < K) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
+            xs[j] = (m < M && col < Kx) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
         }
     };
     auto x_store = [&](int buf) {
@@ -544,7 +555,17 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4
 #pragma unroll
             for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[st][i];
             __syncthreads();
-            if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt0 + st, M, rope);
+            if (part) {  // this split's fp32 sums (waves added in wave order), un-rounded
+                float *slab = part + (size_t)blockIdx.y * M * N;
+                for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
+                    const int i = o >> 6, l = o & 63;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
+                    const int mm = l & 31, nn = 32 * (nt0 + st) + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+                    if (mm < M) slab[(size_t)mm * N + nn] = v;
+                }
+            } else if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt0 + st, M, rope);
             else w4m_epilogue<T>(s_red, nt0 + st, M, N, y, nullptr, swiglu != 0, bias);
             __syncthreads();  // the next strip reuses the buffer
         }
@@ -1325,9 +1346,9 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
         constexpr int NS = 4;  // strips per workgroup (8 measured worse: 256 VGPRs with spills, and gate|up left with 112 workgroups)
         const dim3 mgrid((n_strips + NS - 1) / NS);
         if (dtype == PIE_BF16)
-            hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+            hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args, (float *)nullptr);
         else
-            hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+            hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args, (float *)nullptr);
         PIE_LAUNCH_CHECK();
         return PIE_OK;
     }
@@ -1347,6 +1368,30 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
         else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
     } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
     else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+// Few rows, narrow matrix (128-255 strips), long K: two strips per workgroup, K split into fp32 slabs part[S][M][N] that the consumer sums
+// (see k_w4m_gemm_lds4).  Returns the split count S (>= 2), or 0 when the shape does not qualify; workspace: S * M * N floats.
+int w4m_slab_splits(int M, int N, int K) {
+    const int n_strips = N >> 5, groups = K >> 6;
+    if (M < 1 || M > 32 || n_strips < 64 || n_strips >= 512 || (n_strips & 1) || groups < 32) return 0;
+    int S = 512 / n_strips;  // workgroups = n_strips / 2 * S ~ 256
+    S = S < 2 ? 2 : (S > 8 ? 8 : S);
+    while (S > 2 && (S - 1) * ((((groups + S - 1) / S) + 7) & ~7) >= groups) --S;  // every split must own at least one group
+    return (S - 1) * ((((groups + S - 1) / S) + 7) & ~7) < groups ? S : 0;
+}
+int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st) {
+    const int S = w4m_slab_splits(M, N, K);
+    PIE_REQUIRE(S >= 2 && part, PIE_E_ARG, "W4M slab GEMM: shape not served");
+    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(part, 16), PIE_E_ALIGN, "W4M slab GEMM: 16-byte alignment required");
+    const dim3 grid((unsigned)((N >> 5) / 2), (unsigned)S), block(W4M_WAVES * 64);
+    if (dtype == PIE_BF16)
+        hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, 2>), grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)nullptr, 0, (const u16 *)nullptr, W4mRope{}, part);
+    else if (dtype == PIE_F16)
+        hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, 2>), grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)nullptr, 0, (const u16 *)nullptr, W4mRope{}, part);
+    else return pie::fail(PIE_E_ARG, "W4M slab GEMM: dtype must be PIE_BF16 or PIE_F16");
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }

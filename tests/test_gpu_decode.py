@@ -367,6 +367,33 @@ def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias, 
             assert torch.equal(a, b), "slab-consuming kernels differ from the reduce launch"
 
 
+@pytest.mark.parametrize("L", [9, 24, 32])
+def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(monkeypatch, L):
+    """Prompt suffixes of up to 32 rows on the real layer shapes: gate|up walks K once for four strips per workgroup, o_proj / down run two
+    strips per workgroup with K split into four fp32 slabs that the residual-add + RMSNorm kernel sums (PIE_W4M_SLABS=0: the one-strip forms
+    with the two-way fp32 atomic split).  Both follow the oracle; the two differ only in the order of four fp32 additions."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=9, dtype=dtype, lm_head_gain=4.0)
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(L).integers(0, cfg["vocab_size"], L)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PIE_W4M_SLABS", mode)
+        model = build(cfg, w, dtype)
+        cache = model.make_cache()
+        tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
+        assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what=f"hidden, PIE_W4M_SLABS={mode}")
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"logits, PIE_W4M_SLABS={mode}")
+        outs[mode] = logits.float().cpu().numpy()
+    assert_vec_close(outs["1"], outs["0"], dtype, what="slab split vs atomic split")   # (a few bf16 roundings flip downstream of the reordered sums)
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
     """head_dim 128 prompts use the MFMA causal flash-attention kernel (prefill_attn.hpp).  One Llama-3-8B-shaped layer,
