@@ -1054,8 +1054,12 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         pa.M = N, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
         if ((rc = segment_attn_gqa_launch_t<T>(pa, D, st))) return rc;
         bool r32 = false;
-        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bo : nullptr))) return rc;
+        W4lSlabs so, sd;  // K-split products handed to their consumers as fp32 slabs (as in the single-prompt path)
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                 H <= 8192 ? &so : nullptr)))
+            return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+            return rc;
         bool fused_act = false;
         if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, N, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
         if (!fused_act) {
@@ -1063,9 +1067,12 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
         }
-        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, N, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32))) return rc;
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, N, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+                                 H <= 8192 ? &sd : nullptr)))
+            return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 ? w.bdown : nullptr))) return rc;
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || sd.S > 1 ? w.bdown : nullptr, &sd)))
+            return rc;
     }
     // the normalised last row of every prompt -> lm_head -> tail
     hipLaunchKernelGGL(k_gather_rows, dim3(S), dim3(256), 0, st, (const uint4 *)s->xn, last_rows, H / 8, (uint4 *)s->r);
