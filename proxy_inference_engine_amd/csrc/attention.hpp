@@ -144,6 +144,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
     const int cap = PAGED ? 64 : a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
     ATTN_STAMP(1);  // the position has arrived
+    if constexpr (PAGED) {
+        if (a.splits == 1 && a.ctx_len && sp.active == 0) {  // idle slot of a one-split batch: zeros, as k_attn_combine leaves it
+            for (int o = threadIdx.x; o < REP * D; o += NT) a.out[((size_t)row * a.Hq + g * REP) * D + o] = 0;
+            return;
+        }
+    }
     if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
     const int t_begin = split * sp.chunk;
     const int t_end = min(Ttot, t_begin + sp.chunk);
@@ -330,6 +336,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
             A0 = fmaf(w, av.x, A0), A1 = fmaf(w, av.y, A1);
         }
         const size_t hq = (size_t)row * a.Hq + g * REP + h;
+        if constexpr (PAGED) {
+            if (a.splits == 1 && a.ctx_len) {  // a batch of short sequences, one split each: the partial IS the result (k_attn_combine would
+                // compute fma(1, acc, 0) / fma(1, l, 0) -- the same bits) and the launcher skips the combine launch
+                *reinterpret_cast<u32 *>(a.out + hq * D + d) = pack2<T>(A0 / Lsum, A1 / Lsum);
+                continue;
+            }
+        }
         *reinterpret_cast<float2 *>(a.part_acc + (hq * a.splits + split) * D + d) = make_float2(A0, A1);
         if (d == 0) {
             a.part_ml[(hq * a.splits + split) * 2 + 0] = M;

@@ -28,7 +28,7 @@ static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t
     }
 #undef ATTN_GO
     PIE_LAUNCH_CHECK();
-    if (combine) {
+    if (combine && !(PAGED && a.splits == 1 && a.ctx_len)) {  // (one split per sequence of a paged batch: the kernel wrote `out` itself)
         hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, rows), dim3(256), 0, st, a, D);
         PIE_LAUNCH_CHECK();
     }

@@ -56,6 +56,7 @@ def _fill(ops, alloc, rng, lens, Hkv, D, dt, max_blocks):
     (32, 8, 128, [777, 5, 1500]),
     (6, 2, 64, [129, 0, 64, 31]),          # an idle slot (context 0) in the batch
     (4, 4, 64, [200]),
+    (16, 8, 128, [(7 * i) % 90 for i in range(64)]),   # 64 short sequences x 8 kv-heads: ONE split each, the kernel writes the result itself (no combine launch); idle slots among them
 ])
 def test_paged_attention_vs_oracle(ops, dt, Hq, Hkv, D, lens):
     from proxy_inference_engine_amd.cache.kv_cache.paged import PageAllocator
