@@ -90,6 +90,10 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ts = lane / LPT, dc = lane % LPT;
     const int Ttot = a.ctx_len[row];
     const AttnSplit sp = attn_split(Ttot, a.splits);
+    if (a.splits == 1 && sp.active == 0) {  // idle slot of a one-split batch: zeros, as k_attn_combine leaves it
+        for (int o = threadIdx.x; o < REP * D; o += NT) a.out[((size_t)row * a.Hq + g * REP) * D + o] = 0;
+        return;
+    }
     if (split >= sp.active) return;  // uniform; the combine only reads `active` partials (0 for an idle slot)
     const int t_begin = split * sp.chunk, t_end = min(Ttot, t_begin + sp.chunk);
     const float sl2 = a.scale * ATTN_LOG2E;
@@ -227,6 +231,10 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
             A0 = fmaf(w, av.x, A0), A1 = fmaf(w, av.y, A1);
         }
         const size_t hq = (size_t)row * a.Hq + g * REP + h;
+        if (a.splits == 1) {  // one split per sequence: the partial is the result (what k_attn_combine would compute, bit for bit); no combine launch
+            *reinterpret_cast<u32 *>(a.out + hq * D + d) = pack2<T>(A0 / Lsum, A1 / Lsum);
+            continue;
+        }
         *reinterpret_cast<float2 *>(a.part_acc + (hq * a.splits + split) * D + d) = make_float2(A0, A1);
         if (d == 0) {
             a.part_ml[(hq * a.splits + split) * 2 + 0] = M;
@@ -252,8 +260,10 @@ int attn_i8_launch(int rep, const AttnArgs &a, size_t page_bytes, hipStream_t st
     }
 #undef I8_GO
     PIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, a.rows), dim3(256), 0, st, a, D);
-    PIE_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        hipLaunchKernelGGL(k_attn_combine<T>, dim3(a.Hq, a.rows), dim3(256), 0, st, a, D);
+        PIE_LAUNCH_CHECK();
+    }
     return PIE_OK;
 }
 

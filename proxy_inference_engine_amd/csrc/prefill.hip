@@ -945,7 +945,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
     splits = splits < 1 ? 1 : splits;
     // short sequences (tables of at most 8 pages) in a batch that fills half the chip by itself: one split, and no combine launch
-    if (!d->kv_i8 && max_blocks <= 8 && B * c.n_kv_heads >= 128) splits = 1;
+    if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 128)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
     int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;

@@ -446,6 +446,7 @@ def test_several_prompts_in_one_pass(golden_dir):
     (6, 2, 64, [129, 0, 64, 31]),          # an idle slot (context 0) in the batch
     (16, 2, 128, [200, 70]),               # 8 q-heads per kv-head: the 2-wave form
     (4, 4, 64, [200]),
+    (16, 8, 128, [(11 * i) % 70 for i in range(128)]),   # 128 short sequences x 8 kv-heads: one split each, written directly; idle slots among them
 ])
 def test_int8_pages_append_and_attention_vs_oracle(ops, dt, Hq, Hkv, D, lens):
     """The reference page's own storage: int8 K / V blocks + float16 per-head scales.  Appended rows equal the oracle's quantiser bit for
