@@ -121,7 +121,9 @@ __device__ __forceinline__ void slab_sum(const float *part, int S, size_t MN, co
 // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:134-137) for M rows of the packed
 // q|k|v projection: packed columns (2i, 2i+1) of a q/k head are its dims (i, i + D/2); v columns are natural.
 // grid M, one thread per packed column pair.
-template <class T>
+// SLAB / I8: the two optional input / output forms as compile-time switches -- carried as run-time branches they cost the plain
+// 4096-row launch 7.6 us (34.4 vs 26.8 us per layer)
+template <class T, bool SLAB = false, bool I8 = false>
 __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_cols, const float *freqs, const DecState *state,
                                                          const unsigned long long *kv_table, int layer, int n_layers, int n_heads,
                                                          int n_kv_heads, int HD, int traditional, u16 *q_out, const int *block_table,
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
         const unsigned pg = min((unsigned)block_table[pos >> 6], (unsigned)n_pages - 1u);
         const size_t pg_off = (size_t)pg * 2 * 64 * n_kv_heads * HD;
         kdst += pg_off, vdst += pg_off, cap = 64, kvrow = pos & 63;
-        if (i8_page_bytes && slab) page8 = reinterpret_cast<char *>(slab) + (size_t)pg * i8_page_bytes;
+        if (I8 && i8_page_bytes && slab) page8 = reinterpret_cast<char *>(slab) + (size_t)pg * i8_page_bytes;
     }
     const size_t blk8 = (size_t)n_kv_heads * 64 * HD;
     auto q8 = [](float x, float sc) {
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
     for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < (n_cols >> 1); p += gridDim.y * blockDim.x) {
         const int R = 2 * p;
         u32 pr;
-        if (part) {
+        if (SLAB && part) {
             const size_t i[1] = {(size_t)m * n_cols + R};
             float2 a[1];
             slab_sum<float2, 1>(part, S, MN, i, a);
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             u16 *dst = R < q_cols ? q_out + ((size_t)m * n_heads + head) * HD : kdst + ((size_t)head * cap + kvrow) * HD;
             const int i0 = traditional ? 2 * ii : ii, i1 = traditional ? 2 * ii + 1 : ii + half;
             const u16 o0 = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn))), o1 = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
-            if (page8 && R >= q_cols) {
+            if (I8 && page8 && R >= q_cols) {
                 const float sk = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[head]);
                 signed char *kb = reinterpret_cast<signed char *>(page8) + ((size_t)head * 64 + kvrow) * HD;
                 kb[i0] = q8(T::to_f32(o0), sk), kb[i1] = q8(T::to_f32(o1), sk);
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(256) k_rope_append_rows(const u16 *qkv, int n_
             }
         } else {
             const int rr = R - q_cols - k_cols;
-            if (page8) {
+            if (I8 && page8) {
                 const int head = rr / HD;
                 const float sv = f16f(reinterpret_cast<const u16 *>(page8 + 2 * blk8)[n_kv_heads + head]);
                 signed char *vb = reinterpret_cast<signed char *>(page8) + blk8 + ((size_t)head * 64 + kvrow) * HD + rr % HD;
@@ -851,9 +853,11 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if (!roped) {
                 static const int rw_env = getenv("PIE_ROPE_ROW_WGS") ? atoi(getenv("PIE_ROPE_ROW_WGS")) : 0;  // developer override
                 const unsigned row_wgs = sq.S > 1 ? (rw_env > 0 ? (unsigned)rw_env : (M < 512 ? 4u : 1u)) : 1u;  // few rows of slabs: four workgroups per row (256 tokens: 6.03 vs 6.20 ms; from 512 rows no difference)
-                hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(M, row_wgs), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
+                decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
+                if (sq.S > 1) rope_k = &k_rope_append_rows<T, true, false>;
+                hipLaunchKernelGGL(rope_k, dim3(M, row_wgs), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,
                                    c.n_layers, c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, d->block_table, d->n_pages, s->rope_cs, (const int *)nullptr, 0,
-                                   (u16 *)nullptr, (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN);
+                                   (u16 *)nullptr, (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN, (size_t)0);
                 PIE_LAUNCH_CHECK();
             }
             if (mfma_attn) {  // causal flash attention on the MFMA units (prefill_attn.hpp)
@@ -971,7 +975,9 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         bool roped = false;
         if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
         if (!roped) {
-            hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+            decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
+            if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
+            hipLaunchKernelGGL(rope_k, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                                c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li],
                                (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, (const float *)nullptr, 0, (size_t)0, i8pb);
             PIE_LAUNCH_CHECK();
@@ -1046,7 +1052,9 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, N, H, c.dtype, s->xn, st))) return rc;
         if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv))) return rc;
-        hipLaunchKernelGGL(k_rope_append_rows<T>, dim3(N), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+        decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
+        if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
+        hipLaunchKernelGGL(rope_k, dim3(N), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                            c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, row_ctx, max_blocks, (u16 *)slabs[li],
                            row_seq, s->kc, s->vc, (const float *)nullptr, 0, (size_t)0,
                            d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : (size_t)0);  // int8 pages: quantised on the way in; this pass's own attention reads the T copies
