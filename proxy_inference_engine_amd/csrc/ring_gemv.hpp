@@ -1,0 +1,99 @@
+// ring_gemv.hpp -- the consumer side of the weight ring: W4S row-pair dot products out of LDS slots.
+//
+// Same arithmetic, in the same order, as the launched GEMV (k_w4s_gemv in w4_gemv.hpp): per unit the four v_dot2c chains of
+// w4s_unit_dot, per group one fma with {scale, bias}, a row pair's K slices accumulated in slice order in one register, the
+// 32-lane DPP sum -- so a row sum is bit-identical whichever path produced it.  What differs is where operands come from:
+// the unit's codes from a ring slot (filled by the loader wave's LDS-DMA), and, for matrices of two K slices (K <= 4096: q|k|v,
+// o_proj, gate|up, lm_head of the 8B geometry = 73 % of its bytes), the activations from REGISTERS: both slices' 64 values per
+// lane are read from the LDS image once per phase, so the loop's only LDS traffic is the slot itself (3 reads per unit instead
+// of 12; measured in tools/ring_probe).
+#pragma once
+#include "ring.hpp"
+#include "w4_gemv.hpp"
+
+// x of one K slice for this lane: its quantisation group's 64 activations (pre-scaled, as staged in the image) and their sum
+struct RingX {
+    u32 xr[32];
+    float sx;
+    bool valid;
+};
+template <class T>
+__device__ __forceinline__ void ring_load_x(const char *img, const GemvLds &L, int n_groups, int slice, int lane, RingX &x) {
+    const int g = slice * 32 + (lane & 31);
+    x.valid = g < n_groups;
+    const int gc = x.valid ? g : n_groups - 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(img + ((size_t)q * L.stride + gc) * 16);
+        x.xr[4 * q + 0] = v.x, x.xr[4 * q + 1] = v.y, x.xr[4 * q + 2] = v.z, x.xr[4 * q + 3] = v.w;
+    }
+    x.sx = reinterpret_cast<const float *>(img + L.off_sx)[gc];
+}
+template <class T>
+__device__ __forceinline__ float ring_unit_term(const RingUnit &un, const RingX &x) {
+    const float dd = w4s_unit_dot<T>(un.c0, un.c1, x.xr);
+    const float scale = lo_f32<T>(un.sb), bias = hi_f32<T>(un.sb);
+    const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * x.sx, bias * x.sx);
+    return x.valid ? pr : 0.0f;
+}
+
+// Consumes this wave's `n_pairs` row pairs of one [N, K] matrix from its ring; the two row sums of local pair p are left in
+// outp[2 p], outp[2 p + 1] (LDS, this wave's region).  NS2: K has exactly two slices and x lives in registers.
+// Returns false when a bounded wait gave up.
+template <class T, bool NS2>
+__device__ __forceinline__ bool ring_consume(RingCursor &cur, const char *smem, unsigned lds0, const char *img, const GemvLds &L, int K, int n_pairs,
+                                             float *outp, int lane, unsigned long long deadline) {
+    const int n_groups = K >> 6;
+    bool ok = true;
+    if constexpr (NS2) {
+        RingX x0, x1;
+        ring_load_x<T>(img, L, n_groups, 0, lane, x0);
+        ring_load_x<T>(img, L, n_groups, 1, lane, x1);
+        for (int p = 0; p < n_pairs; p += 2) {  // one slot = two row pairs
+            const unsigned slot = ring_wait_slot(cur, deadline, ok);
+            if (!ok) return false;
+            const bool two = p + 1 < n_pairs;  // wave-uniform
+            const RingUnit u0 = ring_read_unit(smem, lds0, slot, 0, lane), u1 = ring_read_unit(smem, lds0, slot, 1, lane);
+            RingUnit u2 = u0, u3 = u1;
+            if (two) u2 = ring_read_unit(smem, lds0, slot, 2, lane), u3 = ring_read_unit(smem, lds0, slot, 3, lane);
+            ring_release_slot(cur);  // LDS executes a wave's accesses in order: the reads above are ahead of this store
+            float acc = 0.0f + ring_unit_term<T>(u0, x0);  // 0 + term: the launched kernel's accumulator starts at +0 (matters for an all -0 row only)
+            acc += ring_unit_term<T>(u1, x1);
+            float tot = half_wave_sum(acc);
+            if ((lane & 31) == 31) outp[2 * p + (lane >> 5)] = tot;
+            if (two) {
+                acc = 0.0f + ring_unit_term<T>(u2, x0);
+                acc += ring_unit_term<T>(u3, x1);
+                tot = half_wave_sum(acc);
+                if ((lane & 31) == 31) outp[2 * (p + 1) + (lane >> 5)] = tot;
+            }
+        }
+    } else {
+        const int ns = w4s_slices(K), n_units = n_pairs * ns;
+        float acc = 0.0f;
+        int sl = 0, pl = 0;
+        for (int base = 0; base < n_units; base += RING_SLOT_UNITS) {
+            const unsigned slot = ring_wait_slot(cur, deadline, ok);
+            if (!ok) return false;
+            const int nu = n_units - base < RING_SLOT_UNITS ? n_units - base : RING_SLOT_UNITS;
+            RingUnit un[RING_SLOT_UNITS];
+#pragma unroll
+            for (int k = 0; k < RING_SLOT_UNITS; ++k) un[k] = ring_read_unit(smem, lds0, slot, k < nu ? k : 0, lane);
+            ring_release_slot(cur);
+#pragma unroll
+            for (int k = 0; k < RING_SLOT_UNITS; ++k) {
+                if (k < nu) {  // wave-uniform
+                    RingX x;
+                    ring_load_x<T>(img, L, n_groups, sl, lane, x);
+                    acc += ring_unit_term<T>(un[k], x);
+                    if (++sl == ns) {
+                        const float tot = half_wave_sum(acc);
+                        if ((lane & 31) == 31) outp[2 * pl + (lane >> 5)] = tot;
+                        acc = 0.0f, sl = 0, ++pl;
+                    }
+                }
+            }
+        }
+    }
+    return ok;
+}
