@@ -289,13 +289,17 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
 /* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
 size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
-/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_MEGA: 1 runs the
- * whole step as ONE persistent launch where the configuration allows (int4 weights, contiguous caches up to 1024 positions,
- * no Linear biases), 0 (default; env PIE_STEP_MEGA=1 flips it) keeps the per-kernel launch sequence; both produce identical bits.  Changing an option drops the
- * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of the persistent launch's bounded
- * grid barriers in *error (0 = none; the outputs of that step are then undefined). */
-enum { PIE_OPT_MEGA = 1, PIE_OPT_KV_I8 = 2 /* 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
-                                              pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back */ };
+/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_ENGINE: 1 (default; env
+ * PIE_STEP_ENGINE=0 flips it) runs the whole step as ONE persistent launch where the configuration allows (uniform int4 weights, hidden
+ * size <= 4096, contiguous caches of up to 512 positions, no Linear biases, no tensor parallelism), 0 keeps the per-kernel launch
+ * sequence; both produce the same logits, tokens and hidden state bit for bit (log-probabilities to fp32 rounding of their log-sum-exp).
+ * PIE_OPT_ATTN_HEADS: the decode attention plan "one workgroup per q-head, unsplit" (what the persistent launch runs): 1 / 0 force it
+ * on / off for the launch sequence, -1 (default) follows the persistent launch's availability.  Changing an option drops the captured
+ * graphs.  pie_decoder_status: synchronises the device and reports a give-up of the persistent launch's bounded waits in *error
+ * (0 = none; sticky; the outputs of that step are undefined). */
+enum { PIE_OPT_ENGINE = 1, PIE_OPT_KV_I8 = 2 /* 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
+                                              pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back */,
+       PIE_OPT_ATTN_HEADS = 3 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);
 

@@ -14,7 +14,8 @@ import torch
 _PKG = Path(__file__).resolve().parent
 PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
-PIE_OPT_MEGA = 1
+PIE_OPT_ENGINE = 1
+PIE_OPT_ATTN_HEADS = 3
 PIE_OPT_KV_I8 = 2
 PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "attention.hpp"
+#include "attn_head.hpp"
+#include "ring.hpp"
 #include "tail.hpp"
 #include "w4_gemv.hpp"
 #include "decoder.hpp"
@@ -49,8 +51,13 @@ static bool plan_attention(pie_decoder *d) {
         if (splits < GEMV_ATTN_SPLITS) splits = GEMV_ATTN_SPLITS;
     }
     const bool combine = splits > GEMV_ATTN_SPLITS;
-    const bool changed = splits != d->splits || combine != d->combine;
-    d->splits = splits, d->combine = combine;
+    // one workgroup per q-head, unsplit (attn_head.hpp): the persistent step's plan; the launch sequence follows it wherever that step
+    // could run, so that switching between the two never changes a bit
+    bool head_plan = d->head_plan_opt == 1;
+    if (d->head_plan_opt < 0) head_plan = engine_enabled(d) && engine_config_ok(d) && d->kv_cap > 0 && d->kv_cap <= ENGINE_MAX_CAP && !d->block_table;
+    if (d->block_table || d->tp() || c.kv_splits > 0) head_plan = false;
+    const bool changed = splits != d->splits || combine != d->combine || head_plan != d->head_plan;
+    d->splits = splits, d->combine = combine, d->head_plan = head_plan;
     d->pf_rows = d->pf_enable ? (256 - c.n_kv_heads * splits) / c.n_kv_heads : 0;  // fill the CUs attention leaves idle
     if (d->pf_rows < 0) d->pf_rows = 0;
     return changed;
@@ -102,6 +109,17 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
+            if (d->head_plan) {
+                AttnHeadArgs ha = {};
+                ha.q = d->qbuf, ha.kv_table = d->kv_table, ha.layer = li, ha.n_layers = c.n_layers, ha.Hq = c.n_heads, ha.Hkv = c.n_kv_heads, ha.state = d->state, ha.out = d->attn;
+                constexpr int NW = RING_CONSUMERS;
+                if (c.dtype == PIE_BF16 && D == 128) hipLaunchKernelGGL((k_attn_head<BF16, 128, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
+                else if (c.dtype == PIE_BF16) hipLaunchKernelGGL((k_attn_head<BF16, 64, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
+                else if (D == 128) hipLaunchKernelGGL((k_attn_head<F16, 128, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
+                else hipLaunchKernelGGL((k_attn_head<F16, 64, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
+                PIE_LAUNCH_CHECK();
+                return PIE_OK;
+            }
             AttnArgs a = {};
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
@@ -121,10 +139,11 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             // THEN the Linear's one rounding and the residual add
             const int epi = d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL;
             a.y32 = d->tp_part;
-            if (d->combine) a.x = d->attn;
+            const bool merged_attn = d->combine || d->head_plan;  // the attention output is already one T vector
+            if (merged_attn) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
-            const int rc = w4s_gemv_launch(c.dtype, d->combine ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
+            const int rc = w4s_gemv_launch(c.dtype, merged_attn ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
@@ -159,7 +178,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
 
 // The launch sequence of one step.  token_ptr: device int32 holding the input token id.
 static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
-    if (mega_supported(d, with_logits)) return mega_step_enqueue(d, token_ptr, with_logits, logits_dst, st);  // one persistent launch
+    if (engine_supported(d, with_logits)) return engine_step_enqueue(d, token_ptr, with_logits, logits_dst, st);  // one persistent launch
     int rc = enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
     if (rc) return rc;
     for (int li = 0; li < d->cfg.n_layers; ++li)
@@ -250,7 +269,7 @@ int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
     prefill_free(d);
-    mega_free(d);
+    engine_free(d);
     void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -279,7 +298,7 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
     prefill_free(d);  // resident T copies of the previous weights are stale
-    mega_invalidate(d);  // so is the persistent step's layer table
+    engine_invalidate(d);  // so is the persistent step's layer table
     drop_graphs(d);
     return PIE_OK;
 }
@@ -375,7 +394,7 @@ static int ready(pie_decoder *d) {
 int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
     int rc = ready(d);
     if (rc) return rc;
-    if ((rc = mega_prepare(d))) return rc;  // allocates once: must happen before stream capture
+    if ((rc = engine_prepare(d))) return rc;  // allocates once: must happen before stream capture
     hipStream_t st = (hipStream_t)stream;
     const bool with_logits = (flags & PIE_STEP_LOGITS) != 0;
     if (!(flags & PIE_STEP_GRAPH)) return enqueue_step(d, &d->state->token, with_logits, d->logits, st);
@@ -416,7 +435,7 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     if (rc) return rc;
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = mega_prepare(d))) return rc;
+    if ((rc = engine_prepare(d))) return rc;
     // a tensor-parallel shard feeds its prompt through the step kernels (2 all-reduces per layer and token); the many-row GEMM
     // path has no collective yet
     if (L >= prefill_min_rows() && !d->tp()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime
@@ -470,17 +489,19 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 
 // Developer hook (not in the public header): the decoder's internal scratch vectors, for tools/step_bench's bisection.
 void *pie_debug_buffer(pie_decoder *d, int which) {
-    if (which == 6) return (mega_prepare(d) == PIE_OK && mega_supported(d, true)) ? (void *)d : nullptr;  // would a step run as the persistent launch?
+    if (which == 6) return (engine_prepare(d) == PIE_OK && engine_supported(d, true)) ? (void *)d : nullptr;  // would a step run as the persistent launch?
     if (which == 7) return d->pf_sink;
-    void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, mega_prof_ptr(d)};
+    void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, engine_prof_ptr(d)};
     return which >= 0 && which < 6 ? p[which] : nullptr;
 }
 
 int pie_decoder_configure(pie_decoder *d, int option, int value) {
     PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_configure: null decoder");
-    PIE_REQUIRE(option == PIE_OPT_MEGA || option == PIE_OPT_KV_I8, PIE_E_ARG, "pie_decoder_configure: unknown option");
-    if (option == PIE_OPT_MEGA) mega_enable(d, value != 0);
+    PIE_REQUIRE(option == PIE_OPT_ENGINE || option == PIE_OPT_KV_I8 || option == PIE_OPT_ATTN_HEADS, PIE_E_ARG, "pie_decoder_configure: unknown option");
+    if (option == PIE_OPT_ENGINE) engine_enable(d, value != 0);
+    else if (option == PIE_OPT_ATTN_HEADS) d->head_plan_opt = value < 0 ? -1 : (value != 0);
     else d->kv_i8 = value != 0;
+    plan_attention(d);
     drop_graphs(d);
     return PIE_OK;
 }
@@ -505,7 +526,7 @@ int pie_decoder_status(pie_decoder *d, unsigned *error) {
         int rc = pie_comm_status(d->comm, error);
         if (rc || *error) return rc;
     }
-    return mega_status(d, error);
+    return engine_status(d, error);
 }
 
 static size_t lin_bytes(const pie_decoder *d, const void *m, size_t n, size_t k) {  // algorithmic bytes of one Linear's weights

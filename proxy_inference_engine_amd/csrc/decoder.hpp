@@ -42,7 +42,11 @@ struct pie_decoder {
     bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs of pie_decoder_step_batch / _prefill_batch hold int8 pages (paged_i8.hip)
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
-    struct MegaState *mega = nullptr;               // the persistent one-launch step (step_mega.hip), allocated on first use
+    struct EngineState *engine = nullptr;           // the persistent one-launch step (step_engine.hip), allocated on first use
+    // Attention plan "one workgroup per q-head, unsplit" (attn_head.hpp): what the persistent step runs; the launch sequence uses the
+    // same plan whenever the persistent step could run, so the two paths produce the same bits.  -1 = automatic, 0 / 1 = forced.
+    int head_plan_opt = -1;
+    bool head_plan = false;
     // tensor parallelism (cfg.tp_world > 1): this decoder is one rank's shard; comm is caller-owned (pie_decoder_set_comm)
     pie_comm *comm = nullptr;
     float *tp_part = nullptr;  // [hidden] fp32 partial of the row-parallel Linears, [hidden] = log-sum-exp of the step
@@ -78,12 +82,15 @@ int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int 
 void prefill_free(pie_decoder *d);
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st);
 
-// step_mega.hip: the whole decode step as one persistent launch (int4 checkpoints, contiguous caches up to the merged-split plan).
-bool mega_supported(pie_decoder *d, bool with_logits);
-int mega_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st);
-int mega_status(pie_decoder *d, unsigned *err);
-void *mega_prof_ptr(pie_decoder *d);
-int mega_prepare(pie_decoder *d);
-void mega_free(pie_decoder *d);
-void mega_invalidate(pie_decoder *d);
-void mega_enable(pie_decoder *d, bool on);
+// step_engine.hip: the whole decode step as one persistent launch on the LDS-DMA weight ring (int4 checkpoints, contiguous short caches).
+constexpr int ENGINE_MAX_CAP = 512;  // cache capacity up to which the per-q-head attention plan (and with it the persistent step) is used
+bool engine_config_ok(pie_decoder *d);  // static part of engine_supported(): geometry, formats, LDS budget
+bool engine_supported(pie_decoder *d, bool with_logits);
+int engine_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st);
+int engine_status(pie_decoder *d, unsigned *err);
+void *engine_prof_ptr(pie_decoder *d);
+int engine_prepare(pie_decoder *d);
+void engine_free(pie_decoder *d);
+void engine_invalidate(pie_decoder *d);
+void engine_enable(pie_decoder *d, bool on);
+bool engine_enabled(pie_decoder *d);

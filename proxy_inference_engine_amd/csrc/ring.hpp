@@ -12,6 +12,8 @@
 // Handshake: two monotonic counters per consumer wave in LDS -- FULL (fills landed, written by the loader behind a counted
 // s_waitcnt vmcnt) and FREE (slots released, written by the consumer once the slot's last unit sits in registers).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 #ifndef PIE_RING_CONSUMERS
@@ -57,6 +59,14 @@ __device__ __forceinline__ unsigned lds_add_rtn(unsigned addr, unsigned v) {
     return r;
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) { return (unsigned)(unsigned long long)p; }  // flat LDS address: low 32 bits = LDS offset
+
+__device__ __forceinline__ unsigned ring_uniform(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool ring_uniform(bool v) { return __builtin_amdgcn_readfirstlane((unsigned)v) != 0u; }
+__device__ __forceinline__ const char *ring_uniform(const char *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));  // unsigned first: the builtin returns int
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
 
 // One 1-KiB LDS-DMA piece: lane l's 16 bytes at gsrc land at lds_dst + 16 l.  Inline asm on purpose: hipcc does not count
 // it, so the loader's own LDS accesses do not drain it (guide 5.7 item 1); completion is the loader's counted vmcnt.
@@ -107,6 +117,7 @@ constexpr unsigned RING_CTL_FULL = 0, RING_CTL_FREE = 32, RING_CTL_USER = 64;
 // the first version (a loop of guarded single pieces, runtime wave selects) took ~1 us per fill = 2.3 TB/s chip-wide.
 __device__ __forceinline__ void glds_fill9_nt(const char *src_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
     unsigned keep;
+    src_uniform = ring_uniform(src_uniform), lds_dst_uniform = ring_uniform(lds_dst_uniform);
     const char *p1 = src_uniform + 4096, *p2 = src_uniform + 8192;
     const unsigned d1 = lds_dst_uniform + 4096, d2 = lds_dst_uniform + 8192;
     asm volatile(
@@ -129,21 +140,42 @@ __device__ __forceinline__ void glds_fill9_nt(const char *src_uniform, unsigned 
         : "memory");
 }
 
-// Loader side.  A `segment` is one consumer wave's byte range of one matrix; the engine / probe feeds segments in phase order
-// through next_segment(w, &ptr, &bytes) (returns false when that wave's stream is finished).  Everything here is wave-uniform
-// (SGPRs); the per-wave state is indexed by compile-time constants only.
+// Loader side.  A `segment` is one consumer wave's byte range of one matrix; the engine / probe describes them through the STATELESS
+// callback segment(w, m, &ptr, &bytes): consumer wave w's share of matrix number m (0 bytes = none), false once m is past the last
+// matrix.  Everything here is wave-uniform (SGPRs) and the per-wave state is indexed by compile-time constants only: a callback
+// that kept its own per-wave cursor in an array had it turned into a dynamically indexed scratch array -- VGPR values, and with
+// them the whole loader, off the scalar unit.
+template <int W, class F>
+__device__ __forceinline__ void ring_static_for(F &&f) {  // f(integral_constant<w>) for w = W, W + RING_LOADERS, ... < RING_CONSUMERS
+    if constexpr (W < RING_CONSUMERS) {
+        f(std::integral_constant<int, W>{});
+        ring_static_for<W + RING_LOADERS>(f);
+    }
+}
+
 template <int L0, class NextSeg>
 __device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, int lane, NextSeg next_segment, unsigned thin_word, unsigned long long deadline) {
     const char *ptr[RING_CONSUMERS];
     unsigned rem[RING_CONSUMERS], issued[RING_CONSUMERS], freec[RING_CONSUMERS];
     bool more[RING_CONSUMERS];
-#pragma unroll
-    for (int w = L0; w < RING_CONSUMERS; w += RING_LOADERS) {
-        issued[w] = freec[w] = 0, rem[w] = 0, ptr[w] = nullptr;
+    int seg[RING_CONSUMERS];
+    auto advance = [&](auto wc) {  // wave wc's next non-empty segment
+        constexpr int w = decltype(wc)::value;
         unsigned b = 0;
-        more[w] = next_segment(w, &ptr[w], &b);
-        rem[w] = b;
-    }
+        bool m = true;
+        const char *p = nullptr;
+        while (m && b == 0) {
+            m = ring_uniform(next_segment(w, seg[w], &p, &b));
+            b = m ? ring_uniform(b) : 0u;
+            ++seg[w];
+        }
+        more[w] = m, rem[w] = b, ptr[w] = ring_uniform(p);
+    };
+    ring_static_for<L0>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        issued[w] = freec[w] = 0, seg[w] = 0;
+        advance(wc);
+    });
     // in-flight fills, oldest in the low bits, 8 bits each: wave << 4 | pieces.  Branch-free push / pop (a register FIFO with
     // an if-chain on the fill count compiled to a page of branches, and the loader wave pays ~5 cycles per instruction).
     unsigned long long fifo = 0;
@@ -167,11 +199,11 @@ __device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, in
     for (;;) {
         bool any = false;
         const int max_inflight = (thin_word != 0xFFFFFFFFu && lds_ld_s(thin_word) != 0u) ? 1 : RING_INFLIGHT;  // thinned while this CU gathers
-#pragma unroll
-        for (int w = L0; w < RING_CONSUMERS; w += RING_LOADERS) {
-            if (!more[w]) continue;
+        ring_static_for<L0>([&](auto wc) {
+            constexpr int w = decltype(wc)::value;
+            if (!more[w]) return;
             if (issued[w] - freec[w] >= (unsigned)RING_SLOTS) freec[w] = lds_ld_s(ctl + RING_CTL_FREE + 4 * w);  // looks full: refresh
-            if (issued[w] - freec[w] >= (unsigned)RING_SLOTS) continue;
+            if (issued[w] - freec[w] >= (unsigned)RING_SLOTS) return;
             while (n_inflight >= max_inflight) retire();
             const unsigned dst = ring_base + (unsigned)w * RING_WAVE_BYTES + (issued[w] % RING_SLOTS) * RING_SLOT_BYTES;
             unsigned take = RING_SLOT_BYTES;
@@ -188,13 +220,9 @@ __device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, in
             fifo |= (unsigned long long)(((unsigned)w << 4) | pieces) << (8 * n_inflight);
             ++n_inflight, out_pieces += (int)pieces;
             ptr[w] += take, rem[w] -= take;
-            if (rem[w] == 0) {
-                unsigned b = 0;
-                more[w] = next_segment(w, &ptr[w], &b);
-                rem[w] = b;
-            }
+            if (rem[w] == 0) advance(wc);
             any = true;
-        }
+        });
         if (!any) {
             if (n_inflight > 0) retire();  // every ring full or finished: publish what is in flight, the consumers may be waiting for exactly that
             else if (!any_more()) break;

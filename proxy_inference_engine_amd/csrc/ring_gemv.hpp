@@ -38,34 +38,36 @@ __device__ __forceinline__ float ring_unit_term(const RingUnit &un, const RingX 
 }
 
 // Consumes this wave's `n_pairs` row pairs of one [N, K] matrix from its ring; the two row sums of local pair p are left in
-// outp[2 p], outp[2 p + 1] (LDS, this wave's region).  NS2: K has exactly two slices and x lives in registers.
+// outp[2 p], outp[2 p + 1] (LDS, this wave's region).  NSX = 1 / 2: K has exactly that many slices and x lives in registers
+// (a slot then holds 4 / NSX whole row pairs: straight-line code); NSX = 0: any K, x re-read from the LDS image per unit.
 // Returns false when a bounded wait gave up.
-template <class T, bool NS2>
+template <class T, int NSX>
 __device__ __forceinline__ bool ring_consume(RingCursor &cur, const char *smem, unsigned lds0, const char *img, const GemvLds &L, int K, int n_pairs,
                                              float *outp, int lane, unsigned long long deadline) {
     const int n_groups = K >> 6;
     bool ok = true;
-    if constexpr (NS2) {
-        RingX x0, x1;
-        ring_load_x<T>(img, L, n_groups, 0, lane, x0);
-        ring_load_x<T>(img, L, n_groups, 1, lane, x1);
-        for (int p = 0; p < n_pairs; p += 2) {  // one slot = two row pairs
+    if constexpr (NSX > 0) {
+        constexpr int PPS = RING_SLOT_UNITS / NSX;  // row pairs per slot
+        RingX x[NSX];
+#pragma unroll
+        for (int s = 0; s < NSX; ++s) ring_load_x<T>(img, L, n_groups, s, lane, x[s]);
+        for (int p = 0; p < n_pairs; p += PPS) {
             const unsigned slot = ring_wait_slot(cur, deadline, ok);
             if (!ok) return false;
-            const bool two = p + 1 < n_pairs;  // wave-uniform
-            const RingUnit u0 = ring_read_unit(smem, lds0, slot, 0, lane), u1 = ring_read_unit(smem, lds0, slot, 1, lane);
-            RingUnit u2 = u0, u3 = u1;
-            if (two) u2 = ring_read_unit(smem, lds0, slot, 2, lane), u3 = ring_read_unit(smem, lds0, slot, 3, lane);
+            const int np = n_pairs - p < PPS ? n_pairs - p : PPS;  // wave-uniform
+            RingUnit un[RING_SLOT_UNITS];
+#pragma unroll
+            for (int k = 0; k < RING_SLOT_UNITS; ++k) un[k] = ring_read_unit(smem, lds0, slot, k < np * NSX ? k : 0, lane);
             ring_release_slot(cur);  // LDS executes a wave's accesses in order: the reads above are ahead of this store
-            float acc = 0.0f + ring_unit_term<T>(u0, x0);  // 0 + term: the launched kernel's accumulator starts at +0 (matters for an all -0 row only)
-            acc += ring_unit_term<T>(u1, x1);
-            float tot = half_wave_sum(acc);
-            if ((lane & 31) == 31) outp[2 * p + (lane >> 5)] = tot;
-            if (two) {
-                acc = 0.0f + ring_unit_term<T>(u2, x0);
-                acc += ring_unit_term<T>(u3, x1);
-                tot = half_wave_sum(acc);
-                if ((lane & 31) == 31) outp[2 * (p + 1) + (lane >> 5)] = tot;
+#pragma unroll
+            for (int q = 0; q < PPS; ++q) {
+                if (q < np) {
+                    float acc = 0.0f;  // 0 + term first, as the launched kernel's accumulator (matters for an all -0 row only)
+#pragma unroll
+                    for (int s = 0; s < NSX; ++s) acc += ring_unit_term<T>(un[q * NSX + s], x[s]);
+                    const float tot = half_wave_sum(acc);
+                    if ((lane & 31) == 31) outp[2 * (p + q) + (lane >> 5)] = tot;
+                }
             }
         }
     } else {

@@ -5,11 +5,14 @@ B=$R/tools/step_bench
 run() { # name, env...
   local name=$1; shift
   local out
-  out=$(env "$@" $B ${STEP_ARGS:---model 8b --mode launch --no-mega --steps 1024 --warmup 64} 2>&1 | grep "launch sequence")
+  out=$(env "$@" $B ${STEP_ARGS:---model 8b --mode launch --no-mega --steps 1024 --warmup 64} 2>&1 | grep -E "launch sequence|persistent step|library")
   echo "$name: $out"
 }
 for rep in 1 2 3; do
   run base X=1
-  for v in "$@"; do run $v LD_LIBRARY_PATH=$R/tools/variants/$v; done
+  for v in "$@"; do
+    [ -f $R/tools/variants/$v/libpie_hip.so ] || { echo "no such variant: tools/variants/$v/libpie_hip.so (scripts/build_variant.sh $v ...)"; exit 1; }
+    run $v LD_LIBRARY_PATH=$R/tools/variants/$v   # step_bench prints the library it loaded
+  done
   run nopf PIE_PREFETCH_MB=-1
 done

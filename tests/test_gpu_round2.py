@@ -251,7 +251,7 @@ def test_batched_step_after_trim_and_regrow(tiny):
 
 
 def test_persistent_step_equals_launch_sequence():
-    """pie_decoder_configure(PIE_OPT_MEGA): the whole step as one persistent launch (csrc/step_mega.hip) must reproduce the launch
+    """pie_decoder_configure(PIE_OPT_ENGINE): the whole step as one persistent launch (csrc/step_mega.hip) must reproduce the launch
     sequence bit for bit -- logits, logprobs, tokens, hidden state -- on an 8B-geometry model cut to 2 layers, eager and
     graph-replayed, and report no give-up of its bounded grid barriers."""
     import ctypes as C
@@ -265,7 +265,7 @@ def test_persistent_step_equals_launch_sequence():
     runs = {}
     for mega in (0, 1):
         for graph in (False, True):
-            _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_MEGA, mega))
+            _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_ENGINE, mega))
             cache = model.make_cache()
             tok, _, _ = model.step(prompt, cache, graph=False)
             out = []
@@ -281,7 +281,7 @@ def test_persistent_step_equals_launch_sequence():
         for i, (a, b) in enumerate(zip(base, out)):
             assert a[0] == b[0], (key, i)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)) and np.array_equal(a[3], b[3]), (key, i)
-    _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_MEGA, 0))
+    _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_ENGINE, 0))
 
 
 def test_model_call_accepts_the_causal_mask_it_would_build_itself(tiny):

@@ -91,19 +91,11 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
     __syncthreads();
     const int n_cus = gridDim.x, cu = blockIdx.x;
     if (wave < RING_LOADERS) {
-        int seg[RING_CONSUMERS] = {};
-        auto next = [&](int w, const char **p, unsigned *bytes) -> bool {
-            int s = 0;
-#pragma unroll
-            for (int j = 0; j < RING_CONSUMERS; ++j)
-                if (j == w) s = seg[j];
+        auto next = [&](int w, int m, const char **p, unsigned *bytes) -> bool {
+            if (m >= a.reps) return false;
             const RingRun r = ring_run(a.n_pairs, 1, n_cus, cu, w);
-            if (s >= a.reps || r.count == 0) return false;
-            *p = a.w + (size_t)((a.abl & 2) ? 0 : s) * a.mat_bytes + (size_t)r.first * a.ns * W4S_UNIT_BYTES;
+            *p = a.w + (size_t)((a.abl & 2) ? 0 : m) * a.mat_bytes + (size_t)r.first * a.ns * W4S_UNIT_BYTES;
             *bytes = (unsigned)(r.count * a.ns * W4S_UNIT_BYTES);
-#pragma unroll
-            for (int j = 0; j < RING_CONSUMERS; ++j)
-                if (j == w) seg[j] = s + 1;
             return true;
         };
         const unsigned long long dl = __builtin_amdgcn_s_memrealtime() + 300000000ull;
@@ -127,8 +119,8 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
             }
             continue;
         }
-        if (a.ns == 2 && !(a.abl & 8)) ok = ring_consume<T, true>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
-        else ok = ring_consume<T, false>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
+        if (a.ns == 2 && !(a.abl & 8)) ok = ring_consume<T, 2>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
+        else ok = ring_consume<T, 0>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
         if (lane < r.count) *reinterpret_cast<float2 *>(a.y + (size_t)rep * 2 * a.n_pairs + 2 * (r.first + lane)) = *reinterpret_cast<const float2 *>(outp + 2 * lane);
     }
     if (!ok && lane == 0) atomicAdd(a.err, 1u);
