@@ -30,8 +30,13 @@ template <class T, int D, int NW, int DA>
 __device__ __forceinline__ void attn_head_issue(AttnHeadRing<DA> &r, int d, int b, const u16 *kbase, const u16 *vbase, int pos, int wv, int ts) {
     int t = ah_token<D, NW>(b, wv, ts);
     t = t < pos ? t : (pos > 0 ? pos - 1 : 0);  // clamp, never branch around a load; pos == 0: row 0 is read and ignored
-    r.kq[d] = *reinterpret_cast<const uint4 *>(kbase + (size_t)t * D);
-    r.vq[d] = *reinterpret_cast<const uint4 *>(vbase + (size_t)t * D);
+    // global address space, explicitly: a pointer that came out of a table is a FLAT pointer to hipcc, and flat loads count on
+    // lgkmcnt as well as vmcnt -- every LDS wait behind them would wait for the cache rows
+    typedef u32 ah_u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const ah_u32x4 g_u32x4;
+    const ah_u32x4 kv = *(g_u32x4 *)(unsigned long long)(kbase + (size_t)t * D), vv = *(g_u32x4 *)(unsigned long long)(vbase + (size_t)t * D);
+    r.kq[d] = make_uint4(kv.x, kv.y, kv.z, kv.w);
+    r.vq[d] = make_uint4(vv.x, vv.y, vv.z, vv.w);
 }
 // kbase / vbase: this kv-head's [cap, D] rows + the lane's column chunk (dc * 8)
 template <class T, int D, int NW, int DA>

@@ -78,18 +78,15 @@ __device__ __forceinline__ void glds16_nt(const char *gsrc_lane, unsigned lds_ds
                  : "memory");
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant)
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n <= N (the immediate must be a constant): a short compare chain, N + 1 waits of code
+template <int N>
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-#define PIE_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {
-        PIE_VMW(0) PIE_VMW(1) PIE_VMW(2) PIE_VMW(3) PIE_VMW(4) PIE_VMW(5) PIE_VMW(6) PIE_VMW(7) PIE_VMW(8) PIE_VMW(9)
-        PIE_VMW(10) PIE_VMW(11) PIE_VMW(12) PIE_VMW(13) PIE_VMW(14) PIE_VMW(15) PIE_VMW(16) PIE_VMW(17) PIE_VMW(18) PIE_VMW(19)
-        PIE_VMW(20) PIE_VMW(21) PIE_VMW(22) PIE_VMW(23) PIE_VMW(24) PIE_VMW(25) PIE_VMW(26) PIE_VMW(27) PIE_VMW(28) PIE_VMW(29)
-        PIE_VMW(30) PIE_VMW(31) PIE_VMW(32) PIE_VMW(33) PIE_VMW(34) PIE_VMW(35) PIE_VMW(36) PIE_VMW(37) PIE_VMW(38) PIE_VMW(39)
-        PIE_VMW(40) PIE_VMW(41) PIE_VMW(42) PIE_VMW(43) PIE_VMW(44) PIE_VMW(45)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // never reached: out_pieces <= 9 (RING_INFLIGHT - 1) <= 45
+    if constexpr (N == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (n >= N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        else wait_vmcnt_dyn<N - 1>(n);
     }
-#undef PIE_VMW
 }
 
 // ---- how a matrix's row pairs are dealt to the chip's consumer waves
@@ -185,8 +182,7 @@ __device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, in
         const unsigned e = (unsigned)fifo & 255u;
         fifo >>= 8;
         out_pieces -= (int)(e & 15u);
-        if (out_pieces == 9 * (RING_INFLIGHT - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 * (RING_INFLIGHT - 1)) : "memory");
-        else wait_vmcnt_dyn(out_pieces);
+        wait_vmcnt_dyn<9 * (RING_INFLIGHT - 1)>(out_pieces);  // first test = the steady state (whole slots in flight)
         lds_inc(ctl + RING_CTL_FULL + 4u * (e >> 4), lane_one);
         --n_inflight;
     };

@@ -52,11 +52,11 @@ struct EngArgs {
     const unsigned long long *kv_table;
     u16 *h, *logits;
     LogitStat *stats;
-    unsigned long long *gran;                  // granule buffers; per edge two (layer parity) of n granules
-    unsigned g_off[5], g_n[5];                 // offset of buffer [0] / granules per buffer, by edge
+    unsigned long long *gran;                  // granule buffers: buffer (edge, layer parity) at gran + (2 edge + parity) g_stride
+    unsigned g_stride;                         // granules per buffer (the longest edge vector, rounded up)
     int with_logits, rope_traditional;
     EngSync *sync;
-    unsigned lds_r0, lds_r1, lds_out, lds_ctl, lds_rope, lds_stage, lds_ring;  // byte offsets in dynamic LDS
+    unsigned lds_r0, lds_r1, lds_out, lds_ctl, lds_rope, lds_stage, lds_tab, lds_ring, lds_prof;  // byte offsets in dynamic LDS
     unsigned long long *prof;  // developer build (-DPIE_ENGINE_PROF): per-phase stamps of one workgroup
     int prof_block;
 };
@@ -64,6 +64,10 @@ struct EngArgs {
 typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) u32 gu32;
+typedef __attribute__((address_space(1))) u16 gu16;
+// plain stores through pointers that came out of a table: global, not flat (flat accesses count on lgkmcnt too)
+__device__ __forceinline__ void gst32(void *p, u32 v) { *(gu32 *)(unsigned long long)p = v; }
+__device__ __forceinline__ void gst16(void *p, u16 v) { *(gu16 *)(unsigned long long)p = v; }
 
 // wave-uniform pointers re-loaded from memory become VGPRs to the compiler and put waterfall loops around buffer accesses: pin them
 __device__ __forceinline__ const void *uniform_ptr(const void *p) {
@@ -82,18 +86,37 @@ __device__ __forceinline__ uint4 coh_ld16(__amdgpu_buffer_rsrc_t r, unsigned off
 __device__ __forceinline__ void store_granule(unsigned long long *g, unsigned tag, unsigned value) {
     __hip_atomic_store((gu64 *)(unsigned long long)g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// host-written tables no kernel modifies: scalar loads through the constant address space
-template <class U>
-__device__ __forceinline__ U const_load(const U *p) {
-    return *(const __attribute__((address_space(4))) U *)(unsigned long long)p;
+// Values the loop needs again and again, made opaque once: hipcc otherwise RE-LOADS kernel arguments from memory wherever it runs out
+// of SGPRs (80 s_load sites in the first build), and a scalar load that misses while every CU streams costs microseconds
+// (MI355X_MICROARCH.md, polling-cost row) -- the epilogues and the norm pass, a few dozen instructions each, took 1.3-1.6 us.
+// An opaque value can only be kept or spilled to a VGPR lane, never re-fetched.
+__device__ __forceinline__ int opq(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
 }
-__device__ __forceinline__ EngLayer load_layer(const EngLayer *p) {
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    EngLayer l;
-    l.wqkv = reinterpret_cast<const char *>(const_load(q + 0)), l.wo = reinterpret_cast<const char *>(const_load(q + 1));
-    l.wgateup = reinterpret_cast<const char *>(const_load(q + 2)), l.wdown = reinterpret_cast<const char *>(const_load(q + 3));
-    l.attn_norm = reinterpret_cast<const u16 *>(const_load(q + 4)), l.mlp_norm = reinterpret_cast<const u16 *>(const_load(q + 5));
-    return l;
+__device__ __forceinline__ unsigned opq(unsigned v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ float opq(float v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+template <class U>
+__device__ __forceinline__ U *opq(U *p) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<U *>(v);
+}
+// Per-layer pointer table in LDS (filled once per launch from the host-written tables): [layer][8] = wqkv, wo, wgateup, wdown,
+// attn_norm, mlp_norm, K buffer, V buffer.  Read with one ds_read_b64: no scalar-memory access inside the layer loop.
+enum { T_WQKV = 0, T_WO = 1, T_WGATEUP = 2, T_WDOWN = 3, T_ATTN_NORM = 4, T_MLP_NORM = 5, T_KBUF = 6, T_VBUF = 7 };
+__device__ __forceinline__ const char *tab_ptr(unsigned tab_lds, int layer, int field) {
+    unsigned long long v;
+    const unsigned addr = tab_lds + (unsigned)(layer * 8 + field) * 8u;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
 }
 
 // The CU that runs q-head h's attention: heads spread over the CUs in steps of n_cus / n_heads, offset so that consecutive heads
@@ -115,12 +138,23 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
     const int n_cus = gridDim.x, cu = blockIdx.x;
     const unsigned lds0 = lds_addr_of(smem);
     const unsigned ctl = lds0 + a.lds_ctl, ring = lds0 + a.lds_ring;
-    const int H = a.H, QD = a.n_heads * HD, KVD = a.n_kv * HD, NQ = QD + 2 * KVD;
+    const int n_layers = opq(a.n_layers), H = opq(a.H), I = opq(a.I), n_heads = opq(a.n_heads), n_kv = opq(a.n_kv), V = opq(a.V);
+    const int with_logits = opq(a.with_logits), rope_trad = opq(a.rope_traditional);
+    const float eps = opq(a.eps);
+    unsigned long long *const gran = opq(a.gran);
+    const unsigned g_stride = opq(a.g_stride), tab = lds0 + a.lds_tab, a_lds_ctl = opq(a.lds_ctl);
+    const char *const lm_head = opq(a.lm_head);
+    const int QD = n_heads * HD, KVD = n_kv * HD, NQ = QD + 2 * KVD;
     if (threadIdx.x < CTL_BYTES / 4) lds_st(ctl + 4 * threadIdx.x, 0u);
+    for (int i = threadIdx.x; i < n_layers * 8; i += ENG_THREADS) {  // the per-layer pointer table (vector loads of host-written memory)
+        const int li = i >> 3, f = i & 7;
+        const unsigned long long v = f < 6 ? reinterpret_cast<const unsigned long long *>(a.layers)[li * 6 + f] : a.kv_table[(f - 6) * n_layers + li];
+        *reinterpret_cast<unsigned long long *>(smem + a.lds_tab + (size_t)i * 8) = v;
+    }
     const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + ENG_SPIN_TICKS;
-    const int pos = __builtin_amdgcn_readfirstlane(a.state->pos), cap = __builtin_amdgcn_readfirstlane(a.state->cap);
+    const int pos = opq(__builtin_amdgcn_readfirstlane(a.state->pos)), cap = opq(__builtin_amdgcn_readfirstlane(a.state->cap));
     const unsigned seq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned *>(&a.sync->seq));
-    const unsigned tag0 = ((seq & 0x1FFFFFu) << 11) + 1u;  // + 8 layer + edge; never 0 (the buffers are zeroed once, at creation)
+    const unsigned tag0 = opq(((seq & 0x1FFFFFu) << 11) + 1u);  // + 8 layer + edge; never 0 (the buffers are zeroed once, at creation)
     if (threadIdx.x < HD / 2) {  // cos / sin of pos / freqs[i] (llama/utils.py:42-50), as k_embedding_w4g64 computes them
         float *s_rope = reinterpret_cast<float *>(smem + a.lds_rope);
         const float theta = (float)pos * (1.0f / a.freqs[threadIdx.x]);
@@ -128,6 +162,9 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
         sincosf(theta, &sn, &cs);
         s_rope[2 * threadIdx.x] = cs, s_rope[2 * threadIdx.x + 1] = sn;
     }
+#ifdef PIE_ENGINE_PROF
+    for (int i = threadIdx.x; i < 160 * 8; i += ENG_THREADS) lds_st(lds0 + a.lds_prof + 4u * i, 0u);
+#endif
     __syncthreads();  // the only workgroup barrier: before any LDS-DMA is in flight
 
     auto give_up = [&](unsigned code) {
@@ -139,21 +176,21 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
 
     // ================================================================== loader waves
     if (wave < RING_LOADERS) {
-        const int n_mats = 4 * a.n_layers + (a.with_logits ? 1 : 0);
+        const int n_mats = 4 * n_layers + (with_logits ? 1 : 0);
         auto next = [&](int w, int m, const char **p, unsigned *bytes) -> bool {  // stateless: consumer wave w's share of matrix m
             if (m >= n_mats) return false;
-            const int li = m >> 2, kind = m < 4 * a.n_layers ? (m & 3) : K_LMHEAD;
-            int n_pairs, K, gran = 1;
+            const int li = m >> 2, kind = m < 4 * n_layers ? (m & 3) : K_LMHEAD;
+            int n_pairs, K, gran_pairs = 1;
             const char *base;
-            if (kind == K_LMHEAD) n_pairs = a.V >> 1, K = H, base = a.lm_head;
+            if (kind == K_LMHEAD) n_pairs = V >> 1, K = H, base = lm_head;
             else {
-                const EngLayer L = load_layer(a.layers + li);
-                if (kind == K_QKV) n_pairs = NQ >> 1, K = H, base = L.wqkv;
-                else if (kind == K_OPROJ) n_pairs = H >> 1, K = QD, base = L.wo;
-                else if (kind == K_GATEUP) n_pairs = a.I, K = H, base = L.wgateup, gran = 2;
-                else n_pairs = H >> 1, K = a.I, base = L.wdown;
+                base = tab_ptr(tab, li, kind);  // T_WQKV .. T_WDOWN = K_QKV .. K_DOWN
+                if (kind == K_QKV) n_pairs = NQ >> 1, K = H;
+                else if (kind == K_OPROJ) n_pairs = H >> 1, K = QD;
+                else if (kind == K_GATEUP) n_pairs = I, K = H, gran_pairs = 2;
+                else n_pairs = H >> 1, K = I;
             }
-            const RingRun r = ring_run(n_pairs, gran, n_cus, cu, w);
+            const RingRun r = ring_run(n_pairs, gran_pairs, n_cus, cu, w);
             const int ns = w4s_slices(K);
             *p = base + (size_t)r.first * ns * W4S_UNIT_BYTES;
             *bytes = (unsigned)(r.count * ns * W4S_UNIT_BYTES);
@@ -173,6 +210,9 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
 
     // ================================================================== consumer waves
     const int cw = wave - RING_LOADERS;           // 0 .. RING_CONSUMERS-1
+    const u16 *const final_norm = opq(a.final_norm);
+    u16 *const logits = opq(a.logits);
+    LogitStat *const stats = opq(a.stats);
     const int ctid = cw * 64 + lane;
     RingCursor cur = ring_cursor(ring, ctl, cw);
     char *img0 = smem + a.lds_r0, *img1 = smem + a.lds_r1;
@@ -184,7 +224,9 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
     int prof_phase = 0;
     auto stamp = [&](int slot) {
 #ifdef PIE_ENGINE_PROF
-        if (a.prof && cu == a.prof_block && lane == 0 && cw == 0 && prof_phase < 1024) a.prof[prof_phase * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        // into LDS, dumped once at the end: a global store here would sit in vmcnt and be waited for by the next counted wait,
+        // charging its write-through latency (~1 us while the chip streams) to whatever segment comes next
+        if (a.prof && cu == a.prof_block && cw == 0 && prof_phase < 160) lds_st(lds0 + a.lds_prof + (unsigned)(prof_phase * 8 + slot) * 4u, (unsigned)__builtin_amdgcn_s_memrealtime());
 #endif
     };
     // rendezvous of this CU's consumer waves (the loaders never take part): one LDS counter, monotonic
@@ -202,8 +244,8 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
     };
 
     // this wave's row pairs of each kind of matrix
-    const RingRun run_qkv = ring_run(NQ >> 1, 1, n_cus, cu, cw), run_h = ring_run(H >> 1, 1, n_cus, cu, cw), run_gu = ring_run(a.I, 2, n_cus, cu, cw),
-                  run_v = ring_run(a.V >> 1, 1, n_cus, cu, cw);
+    const RingRun run_qkv = ring_run(NQ >> 1, 1, n_cus, cu, cw), run_h = ring_run(H >> 1, 1, n_cus, cu, cw), run_gu = ring_run(I, 2, n_cus, cu, cw),
+                  run_v = ring_run(V >> 1, 1, n_cus, cu, cw);
 
     // ---- the activation gather: pieces (8 elements = 4 granules) p = 64 c + lane of pass c = cw + 6 i
     uint4 xv[ENG_MAXP];
@@ -304,18 +346,20 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
                 }
             }
         }
+        stamp(5);
         cons_sync();  // every wave of this CU is through the previous phase (its image is free) and the partial sums are in LDS
+        stamp(6);
 #ifdef PIE_ENGINE_THIN
         if (!local_embed && cw == 0 && lane == 0) lds_st(ctl + CTL_THIN, 0u);
 #endif
         if (!alive) return;
         float inv = 1.0f;
         if (norm_w) {
-            float r[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = __builtin_bit_cast(float, lds_ld(ctl + CTL_RED + 4 * k));
+            // the 8 partial sums with ONE wait: an LDS round trip costs ~0.1 us while the DMA and five other waves use the LDS
+            const float4 ra = *reinterpret_cast<const float4 *>(smem + a_lds_ctl + CTL_RED), rb = *reinterpret_cast<const float4 *>(smem + a_lds_ctl + CTL_RED + 16);
+            const float r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
             const float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            inv = 1.0f / sqrtf(tot / (float)K + a.eps);
+            inv = 1.0f / sqrtf(tot / (float)K + eps);
         }
         float *sxs = reinterpret_cast<float *>(img + L.off_sx);
 #pragma unroll
@@ -341,12 +385,13 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
                 }
             }
         }
+        stamp(7);
         cons_sync();  // the image is complete
     };
 
     // ---- layer 0's residual rows of this wave: the embedding (language.py:176), dequantised per element
     int token = __builtin_amdgcn_readfirstlane(*a.token_ptr);
-    token = token < 0 ? 0 : (token >= a.V ? a.V - 1 : token);
+    token = token < 0 ? 0 : (token >= V ? V - 1 : token);
     u32 resid = 0;  // the residual stream's rows (R, R + 1) of lane < run_h.count, R = 2 (run_h.first + lane)
     if (lane < run_h.count) {
         const int R = 2 * (run_h.first + lane);
@@ -357,18 +402,17 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
     }
 
     // ---- attention role of this CU
-    const int a_s = n_cus / a.n_heads;
+    const int a_s = n_cus / n_heads;
     const int a_head = cu / a_s;
-    const bool attn_wg = a_head < a.n_heads && cu == eng_attn_cu(a_head, a.n_heads, n_cus);
-    const int a_kvh = a_head / (a.n_heads / a.n_kv);
+    const bool attn_wg = a_head < n_heads && cu == eng_attn_cu(a_head, n_heads, n_cus);
+    const int a_kvh = a_head / (n_heads / n_kv);
 
-    const int n_ph = 4 * a.n_layers + (a.with_logits ? 1 : 0);
+    const int n_ph = 4 * n_layers + (with_logits ? 1 : 0);
     for (int ph = 0; ph < n_ph && alive; ++ph) {
-        const int li = ph >> 2, kind = ph < 4 * a.n_layers ? (ph & 3) : K_LMHEAD;
+        const int li = ph >> 2, kind = ph < 4 * n_layers ? (ph & 3) : K_LMHEAD;
         const int par = li & 1;
         const unsigned tagL = tag0 + 8u * (unsigned)li;
-        const EngLayer Lw = load_layer(a.layers + (kind == K_LMHEAD ? 0 : li));
-        auto gbuf = [&](int edge, int parity) { return a.gran + a.g_off[edge] + (size_t)parity * a.g_n[edge]; };
+        auto gbuf = [&](int edge, int parity) { return gran + (size_t)(2 * edge + parity) * g_stride; };
         stamp(0);
         // ------------------------------------------------------------ the phase's input vector -> LDS image
         int K = H, count = 0, first = 0;
@@ -377,19 +421,19 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
         unsigned gtag = 0;
         const u16 *norm_w = nullptr;
         if (kind == K_QKV) {  // input_layernorm (language.py:149); layer 0 reads the embedding row itself
-            gsrc = gbuf(E_H2, par ^ 1), gtag = tagL - 8u + E_H2, norm_w = Lw.attn_norm;
+            gsrc = gbuf(E_H2, par ^ 1), gtag = tagL - 8u + E_H2, norm_w = reinterpret_cast<const u16 *>(tab_ptr(tab, li, T_ATTN_NORM));
             first = run_qkv.first, count = run_qkv.count;
         } else if (kind == K_OPROJ) {
             K = QD, gsrc = gbuf(E_ATTN, par), gtag = tagL + E_ATTN;
             first = run_h.first, count = run_h.count;
         } else if (kind == K_GATEUP) {  // post_attention_layernorm (language.py:152)
-            gsrc = gbuf(E_H1, par), gtag = tagL + E_H1, norm_w = Lw.mlp_norm;
+            gsrc = gbuf(E_H1, par), gtag = tagL + E_H1, norm_w = reinterpret_cast<const u16 *>(tab_ptr(tab, li, T_MLP_NORM));
             first = run_gu.first, count = run_gu.count;
         } else if (kind == K_DOWN) {
-            K = a.I, img = img1, gsrc = gbuf(E_ACT, par), gtag = tagL + E_ACT;
+            K = I, img = img1, gsrc = gbuf(E_ACT, par), gtag = tagL + E_ACT;
             first = run_h.first, count = run_h.count;
         } else {  // final norm (language.py:187)
-            gsrc = gbuf(E_H2, (a.n_layers - 1) & 1), gtag = tag0 + 8u * (unsigned)(a.n_layers - 1) + E_H2, norm_w = a.final_norm;
+            gsrc = gbuf(E_H2, (n_layers - 1) & 1), gtag = tag0 + 8u * (unsigned)(n_layers - 1) + E_H2, norm_w = final_norm;
             first = run_v.first, count = run_v.count;
         }
         gather(gsrc, gtag, K, norm_w, img, ph == 0, token);
@@ -419,8 +463,8 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
         if (kind == K_QKV) {  // RoPE (llama/utils.py:42-50, offset = cache.offset) + cache append (reusable.py:136-137)
             if (live) {
                 const float ra = round_T<T>(va), rb = round_T<T>(vb);
-                u16 *kdst = reinterpret_cast<u16 *>(const_load(a.kv_table + li));
-                u16 *vdst = reinterpret_cast<u16 *>(const_load(a.kv_table + a.n_layers + li));
+                u16 *kdst = reinterpret_cast<u16 *>(const_cast<char *>(tab_ptr(tab, li, T_KBUF)));
+                u16 *vdst = reinterpret_cast<u16 *>(const_cast<char *>(tab_ptr(tab, li, T_VBUF)));
                 u32 val;
                 if (R < QD + KVD) {
                     const int rr = R < QD ? R : R - QD;
@@ -429,14 +473,14 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
                     const u16 o0 = T::from_f32(__fsub_rn(__fmul_rn(ra, cs), __fmul_rn(rb, sn))), o1 = T::from_f32(__fadd_rn(__fmul_rn(ra, sn), __fmul_rn(rb, cs)));
                     if (R >= QD) {
                         u16 *dst = kdst + ((size_t)head * cap + pos) * HD;
-                        const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + HD / 2;
-                        dst[i0] = o0, dst[i1] = o1;
+                        const int i0 = rope_trad ? 2 * ii : ii, i1 = rope_trad ? 2 * ii + 1 : ii + HD / 2;
+                        gst16(dst + i0, o0), gst16(dst + i1, o1);
                     }
                     val = (u32)o0 | ((u32)o1 << 16);
                 } else {
                     const int rr = R - QD - KVD;
                     val = pack2<T>(ra, rb);
-                    *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + pos) * HD + rr % HD) = val;
+                    gst32(vdst + ((size_t)(rr / HD) * cap + pos) * HD + rr % HD, val);
                 }
                 store_granule(gbuf(E_QKV, par) + pair, tagL + E_QKV, val);
             }
@@ -456,7 +500,7 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
             if (live && !(lane & 1)) store_granule(gbuf(E_ACT, par) + (pair >> 1), tagL + E_ACT, act | (nb << 16));
         } else {  // logits + per-wave log-softmax partials, as the launched EPI_LOGITS epilogue
             const float oa = round_T<T>(va), ob = round_T<T>(vb);
-            if (live) *reinterpret_cast<u32 *>(a.logits + R) = pack2<T>(oa, ob);
+            if (live) gst32(logits + R, pack2<T>(oa, ob));
             const float mx = live ? fmaxf(oa, ob) : -INFINITY;
             const int ix = live ? (ob > oa ? R + 1 : R) : 0x7fffffff;
             const float wmax = wave_max(mx);
@@ -466,9 +510,9 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
             float se = live ? expf(oa - wmax) + expf(ob - wmax) : 0.0f;
             se = wave_sum(se);
             if (lane == 0) {
-                LogitStat st;
-                st.max = wmax, st.sumexp = se, st.argmax = cand, st.pad = 0;
-                a.stats[cu * RING_CONSUMERS + cw] = st;
+                typedef __attribute__((address_space(1))) u32x4_t g_u32x4;
+                const u32x4_t sv = {__builtin_bit_cast(u32, wmax), __builtin_bit_cast(u32, se), (u32)cand, 0u};
+                *(g_u32x4 *)(unsigned long long)(stats + cu * RING_CONSUMERS + cw) = sv;
             }
         }
         stamp(3);
@@ -477,8 +521,8 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
             constexpr int LPT = HD / 8, TPW = 64 / LPT, NSTR = RING_CONSUMERS * TPW;
             float *s_m = reinterpret_cast<float *>(img1), *s_l = s_m + NSTR, *s_acc = s_l + NSTR;  // aliases the down_proj image: idle until this layer's down phase
             const int ts = lane / LPT, dc = lane % LPT;
-            const u16 *kb = reinterpret_cast<const u16 *>(const_load(a.kv_table + li)) + (size_t)a_kvh * cap * HD + dc * 8;
-            const u16 *vb2 = reinterpret_cast<const u16 *>(const_load(a.kv_table + a.n_layers + li)) + (size_t)a_kvh * cap * HD + dc * 8;
+            const u16 *kb = reinterpret_cast<const u16 *>(tab_ptr(tab, li, T_KBUF)) + (size_t)a_kvh * cap * HD + dc * 8;
+            const u16 *vb2 = reinterpret_cast<const u16 *>(tab_ptr(tab, li, T_VBUF)) + (size_t)a_kvh * cap * HD + dc * 8;
             AttnHeadRing<AH_DEPTH> ringr;
             attn_head_preload<T, HD, RING_CONSUMERS, AH_DEPTH>(ringr, kb, vb2, pos, cw, ts);  // old rows: requested before q exists
             if (cw == 0) {  // q, the new K row and the new V row of this head: HD / 2 granules each, packed pairs
@@ -496,7 +540,7 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
                     if (__all(t0 == tg && t1 == tg && t2 == tg)) {
                         if (lane < HD / 2) {
                             const u32 d0 = v[0].x, d1 = v[1].x, d2 = v[2].x;
-                            const int i0 = a.rope_traditional ? 2 * lane : lane, i1 = a.rope_traditional ? 2 * lane + 1 : lane + HD / 2;
+                            const int i0 = rope_trad ? 2 * lane : lane, i1 = rope_trad ? 2 * lane + 1 : lane + HD / 2;
                             stage[i0] = (u16)d0, stage[i1] = (u16)(d0 >> 16);
                             stage[HD + i0] = (u16)d1, stage[HD + i1] = (u16)(d1 >> 16);
                             *reinterpret_cast<u32 *>(stage + 2 * HD + 2 * lane) = d2;
@@ -521,11 +565,15 @@ __global__ void __launch_bounds__(ENG_THREADS, 1) k_step_engine(const EngArgs a)
         }
         ++prof_phase;
     }
+#ifdef PIE_ENGINE_PROF
+    if (a.prof && cu == a.prof_block && cw == 0)
+        for (int i = lane; i < 160 * 8; i += 64) a.prof[i] = lds_ld(lds0 + a.lds_prof + 4u * i);
+#endif
     // the hidden state (bind_outputs' `hidden`), as the launch sequence leaves it
-    if (alive && lane < run_h.count) *reinterpret_cast<u32 *>(a.h + 2 * (run_h.first + lane)) = resid;
+    if (alive && lane < run_h.count) gst32(a.h + 2 * (run_h.first + lane), resid);
     if (cu == 0 && cw == 0 && lane == 0) {
         *reinterpret_cast<unsigned *>(&a.sync->seq) = seq + 1u;  // plain store: read by the NEXT launch
-        if (!a.with_logits) a.state->pos = pos + 1;              // a prompt token before the last: only the caches were filled
+        if (!with_logits) a.state->pos = pos + 1;              // a prompt token before the last: only the caches were filled
     }
 }
 
@@ -576,8 +624,16 @@ void engine_enable(pie_decoder *d, bool on) {
     if (EngineState *m = engine_state(d)) m->enabled = on && m->n_cus > 0;
 }
 
+// granules per hand-off buffer: the longest edge vector (q|k|v pairs, or inter / 2), in whole 64-byte lines
+static unsigned engine_gran_stride(const pie_decoder_config &c) {
+    const unsigned nq = (unsigned)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim / 2, ni = (unsigned)c.inter / 2, nh = (unsigned)c.hidden / 2;
+    unsigned n = nq > ni ? nq : ni;
+    n = n > nh ? n : nh;
+    return (n + 7u) & ~7u;
+}
+
 struct EngLdsPlan {
-    unsigned r0, r1, out, ctl, rope, stage, ring, total;
+    unsigned r0, r1, out, ctl, rope, stage, tab, ring, prof, total;
 };
 static EngLdsPlan engine_lds(const pie_decoder_config &c) {
     const int QD = c.n_heads * c.head_dim;
@@ -597,7 +653,12 @@ static EngLdsPlan engine_lds(const pie_decoder_config &c) {
     p.ctl = take(CTL_BYTES);
     p.rope = take((unsigned)c.head_dim * 4);
     p.stage = take(3u * (unsigned)c.head_dim * 2);
+    p.tab = take(64u * (unsigned)c.n_layers);
     p.ring = take(RING_BYTES);
+    p.prof = off;
+#ifdef PIE_ENGINE_PROF
+    p.prof = take(160 * 8 * 4);
+#endif
     p.total = off;
     return p;
 }
@@ -655,15 +716,14 @@ int engine_prepare(pie_decoder *d) {
         PIE_HIP_TRY(hipMemset(m->sync, 0, sizeof(EngSync)));
     }
     if (!m->gran) {
-        const int QD = c.n_heads * c.head_dim, NQ = QD + 2 * c.n_kv_heads * c.head_dim;
-        m->gran_count = 2 * ((size_t)NQ / 2 + QD / 2 + c.hidden / 2 + c.inter / 2 + c.hidden / 2) + 64;
+        m->gran_count = (size_t)10 * engine_gran_stride(c);  // 5 edges x 2 layer parities
         PIE_HIP_TRY(hipMalloc((void **)&m->gran, m->gran_count * 8));
         PIE_HIP_TRY(hipMemset(m->gran, 0, m->gran_count * 8));  // tag 0 = never published; the kernel's tags start at 1
     }
 #ifdef PIE_ENGINE_PROF
     if (!m->prof) {
-        PIE_HIP_TRY(hipMalloc((void **)&m->prof, 1024 * 8 * 8));
-        PIE_HIP_TRY(hipMemset(m->prof, 0, 1024 * 8 * 8));
+        PIE_HIP_TRY(hipMalloc((void **)&m->prof, 160 * 8 * 8));
+        PIE_HIP_TRY(hipMemset(m->prof, 0, 160 * 8 * 8));
     }
 #endif
     return PIE_OK;
@@ -703,17 +763,8 @@ int engine_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, 
     a.state = d->state, a.token_ptr = token_ptr, a.kv_table = d->kv_table;
     a.h = d->h, a.logits = logits_dst, a.stats = d->stats;
     a.gran = m->gran;
-    {
-        const int QD = c.n_heads * c.head_dim, NQ = QD + 2 * c.n_kv_heads * c.head_dim;
-        const unsigned n[5] = {(unsigned)NQ / 2, (unsigned)QD / 2, (unsigned)c.hidden / 2, (unsigned)c.inter / 2, (unsigned)c.hidden / 2};
-        unsigned off = 0;
-        for (int e = 0; e < 5; ++e) {
-            a.g_off[e] = off, a.g_n[e] = n[e];
-            off += 2 * n[e];
-            off = (off + 7u) & ~7u;  // 64-byte lines per buffer pair
-        }
-        PIE_REQUIRE(off <= m->gran_count, PIE_E_STATE, "persistent step: granule arena too small");
-    }
+    a.g_stride = engine_gran_stride(c);
+    PIE_REQUIRE((size_t)10 * a.g_stride <= m->gran_count, PIE_E_STATE, "persistent step: granule arena too small");
     a.with_logits = with_logits ? 1 : 0, a.rope_traditional = c.rope_traditional;
     a.sync = m->sync;
     a.prof = m->prof;
@@ -722,7 +773,7 @@ int engine_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, 
         a.prof_block = e ? atoi(e) : 0;
     }
     const EngLdsPlan p = engine_lds(c);
-    a.lds_r0 = p.r0, a.lds_r1 = p.r1, a.lds_out = p.out, a.lds_ctl = p.ctl, a.lds_rope = p.rope, a.lds_stage = p.stage, a.lds_ring = p.ring;
+    a.lds_r0 = p.r0, a.lds_r1 = p.r1, a.lds_out = p.out, a.lds_ctl = p.ctl, a.lds_rope = p.rope, a.lds_stage = p.stage, a.lds_tab = p.tab, a.lds_ring = p.ring, a.lds_prof = p.prof;
     const int nsh = w4s_slices(c.hidden);
     int rc;
     if (c.dtype == PIE_BF16) rc = engine_launch_t<BF16>(a, c.head_dim, nsh, m->n_cus, p.total, st);

@@ -350,27 +350,28 @@ int main(int argc, char **argv) {
                    (q[6] - q[0]) * 0.01);
     }
     if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_ENGINE_PROF build of the library: stamps of one workgroup (consumer wave 0) during the LAST step
-        std::vector<unsigned long long> t(1024 * 8);
+        std::vector<unsigned long long> t(160 * 8);
         CK(hipMemcpy(t.data(), pp, t.size() * 8, hipMemcpyDeviceToHost));
         const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
-        double sum[5][5] = {}, cnt[5] = {};
+        double sum[5][8] = {}, cnt[5] = {};
         const int n_ph = 4 * g.L + 1;
-        for (int ph = 0; ph < n_ph && ph < 1024; ++ph) {
+        auto dt = [](unsigned long long b, unsigned long long a2) { return (double)(unsigned)((unsigned)b - (unsigned)a2); };  // 32-bit stamps (100 MHz)
+        for (int ph = 0; ph < n_ph && ph < 160; ++ph) {
             const unsigned long long *c = &t[ph * 8];
             if (!c[0]) continue;
             const int kd = ph == n_ph - 1 ? 4 : ph % 4;
-            const double total = ph + 1 < n_ph && t[(ph + 1) * 8] ? (double)(t[(ph + 1) * 8] - c[0]) : (double)(c[3] - c[0]);
-            const double v[5] = {(double)(c[1] - c[0]), (double)(c[2] - c[1]), (double)(c[3] - c[2]), c[4] > c[3] ? (double)(c[4] - c[3]) : 0.0, total};
-            for (int i = 0; i < 5; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
+            const double total = ph + 1 < n_ph && ph + 1 < 160 && t[(ph + 1) * 8] ? dt(t[(ph + 1) * 8], c[0]) : dt(c[3], c[0]);
+            const double v[8] = {dt(c[1], c[0]), dt(c[2], c[1]), dt(c[3], c[2]), c[4] ? dt(c[4], c[3]) : 0.0, total, dt(c[5], c[0]), dt(c[6], c[5]), dt(c[7], c[6])};
+            for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
             cnt[kd] += 1;
         }
-        printf("per-phase timeline of workgroup %s, consumer wave 0 (us, mean over layers): input gather | weight stream | epilogue + publish | attention | TOTAL\n",
+        printf("per-phase timeline of workgroup %s, consumer wave 0 (us, mean over layers): input gather | weight stream | epilogue + publish | attention | TOTAL || gather: sweep | rendezvous | norm + image\n",
                getenv("PIE_ENGINE_PROF_BLOCK") ? getenv("PIE_ENGINE_PROF_BLOCK") : "0");
         double layer = 0.0;
         for (int kd = 0; kd < 5; ++kd)
             if (cnt[kd] > 0) {
                 printf("  %-7s", names[kd]);
-                for (int i = 0; i < 5; ++i) printf(" %7.2f", sum[kd][i] / cnt[kd]);
+                for (int i = 0; i < 8; ++i) printf(i == 5 ? " || %7.2f" : " %7.2f", sum[kd][i] / cnt[kd]);
                 printf("\n");
                 if (kd < 4) layer += sum[kd][4] / cnt[kd];
             }
