@@ -289,8 +289,8 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
 /* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
 size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
-/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_ENGINE: 1 (default; env
- * PIE_STEP_ENGINE=0 flips it) runs the whole step as ONE persistent launch where the configuration allows (uniform int4 weights, hidden
+/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_ENGINE: 1 (env PIE_STEP_ENGINE=1 makes it
+ * the default) runs the whole step as ONE persistent launch where the configuration allows (uniform int4 weights, hidden
  * size <= 4096, contiguous caches of up to 512 positions, no Linear biases, no tensor parallelism), 0 keeps the per-kernel launch
  * sequence; both produce the same logits, tokens and hidden state bit for bit (log-probabilities to fp32 rounding of their log-sum-exp).
  * PIE_OPT_ATTN_HEADS: the decode attention plan "one workgroup per q-head, unsplit" (what the persistent launch runs): 1 / 0 force it
@@ -302,6 +302,10 @@ enum { PIE_OPT_ENGINE = 1, PIE_OPT_KV_I8 = 2 /* 1: the slabs handed to pie_decod
        PIE_OPT_ATTN_HEADS = 3 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);
+/* What the next pie_decoder_step would run: PIE_QUERY_ENGINE -> 1 when it is the persistent launch, PIE_QUERY_ATTN_HEADS -> 1 when the
+ * decode attention uses the per-q-head plan; negative = error. */
+enum { PIE_QUERY_ENGINE = 1, PIE_QUERY_ATTN_HEADS = 2 };
+int pie_decoder_query(pie_decoder *d, int what);
 
 /* ---------------------------------------------------------------- tensor-parallel communicator (SURVEY.md 8 row e)
  * The reference has no multi-GPU path; BASELINE.json configs[4] (Llama-3-70B over the 8 GPUs of one node) needs

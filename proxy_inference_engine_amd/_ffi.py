@@ -16,6 +16,8 @@ PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
 PIE_OPT_ENGINE = 1
 PIE_OPT_ATTN_HEADS = 3
+PIE_QUERY_ENGINE = 1
+PIE_QUERY_ATTN_HEADS = 2
 PIE_OPT_KV_I8 = 2
 PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
@@ -29,7 +31,7 @@ EXPORTS = [
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
     "pie_decoder_set_kv", "pie_decoder_set_paged_kv", "pie_decoder_step_batch", "pie_decoder_prefill_batch", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill", "pie_decoder_prefill_embeds",
     "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
-    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status",
+    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status", "pie_decoder_query",
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
@@ -95,6 +97,7 @@ def load() -> C.CDLL:
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    lib.pie_decoder_query.argtypes = [C.c_void_p, C.c_int]
     lib.pie_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pie_sample_workspace_bytes.argtypes = [C.c_int, C.c_int]

@@ -506,6 +506,13 @@ int pie_decoder_configure(pie_decoder *d, int option, int value) {
     return PIE_OK;
 }
 
+int pie_decoder_query(pie_decoder *d, int what) {
+    if (!d) return -1;
+    if (what == PIE_QUERY_ENGINE) return engine_prepare(d) == PIE_OK && engine_supported(d, true) ? 1 : 0;
+    if (what == PIE_QUERY_ATTN_HEADS) return d->head_plan ? 1 : 0;
+    return -1;
+}
+
 int pie_decoder_set_comm(pie_decoder *d, pie_comm *c) {
     PIE_REQUIRE(d && c, PIE_E_ARG, "pie_decoder_set_comm: null pointer");
     int rank = 0, world = 0;

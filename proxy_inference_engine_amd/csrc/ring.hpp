@@ -245,8 +245,9 @@ __device__ __forceinline__ RingCursor ring_cursor(unsigned ring_base, unsigned c
 }
 // Blocks until fill number c.fills has landed; returns its LDS address.  `give_up` bounds the spin (s_memrealtime ticks).
 __device__ __forceinline__ unsigned ring_wait_slot(const RingCursor &c, unsigned long long deadline, bool &ok) {
+    unsigned spins = 0;
     while ((int)(lds_ld_s(c.full_word) - c.fills) <= 0) {
-        if (__builtin_amdgcn_s_memrealtime() > deadline) {
+        if ((++spins & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) {  // the clock is read through scalar memory: not on every poll
             ok = false;
             break;
         }

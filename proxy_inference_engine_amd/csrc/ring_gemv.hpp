@@ -71,9 +71,14 @@ __device__ __forceinline__ bool ring_consume(RingCursor &cur, const char *smem, 
             }
         }
     } else {
+        // x of the NEXT unit's slice is requested before the current unit is multiplied (two register sets, ping-pong): with one LDS
+        // round trip per unit exposed (~0.1-0.2 us while the DMA and the other waves use the LDS) the down_proj stream drained at
+        // 25 GB/s per CU, slower than the loaders deliver.
         const int ns = w4s_slices(K), n_units = n_pairs * ns;
         float acc = 0.0f;
         int sl = 0, pl = 0;
+        RingX xa, xb;
+        if (n_units > 0) ring_load_x<T>(img, L, n_groups, 0, lane, xa);
         for (int base = 0; base < n_units; base += RING_SLOT_UNITS) {
             const unsigned slot = ring_wait_slot(cur, deadline, ok);
             if (!ok) return false;
@@ -85,9 +90,14 @@ __device__ __forceinline__ bool ring_consume(RingCursor &cur, const char *smem, 
 #pragma unroll
             for (int k = 0; k < RING_SLOT_UNITS; ++k) {
                 if (k < nu) {  // wave-uniform
-                    RingX x;
-                    ring_load_x<T>(img, L, n_groups, sl, lane, x);
-                    acc += ring_unit_term<T>(un[k], x);
+                    const int nsl = sl + 1 == ns ? 0 : sl + 1;
+                    if (k & 1) {
+                        ring_load_x<T>(img, L, n_groups, nsl, lane, xa);
+                        acc += ring_unit_term<T>(un[k], xb);
+                    } else {
+                        ring_load_x<T>(img, L, n_groups, nsl, lane, xb);
+                        acc += ring_unit_term<T>(un[k], xa);
+                    }
                     if (++sl == ns) {
                         const float tot = half_wave_sum(acc);
                         if ((lane & 31) == 31) outp[2 * pl + (lane >> 5)] = tot;

@@ -250,40 +250,6 @@ def test_batched_step_after_trim_and_regrow(tiny):
         assert_vec_close(logits[i].float().cpu().numpy(), want, DT, what=f"sequence {i} after trim + regrow")
 
 
-def test_persistent_step_equals_launch_sequence():
-    """pie_decoder_configure(PIE_OPT_ENGINE): the whole step as one persistent launch (csrc/step_mega.hip) must reproduce the launch
-    sequence bit for bit -- logits, logprobs, tokens, hidden state -- on an 8B-geometry model cut to 2 layers, eager and
-    graph-replayed, and report no give-up of its bounded grid barriers."""
-    import ctypes as C
-    from proxy_inference_engine_amd import _ffi
-    from proxy_inference_engine_amd.models.utils import LLAMA3_8B, synthetic_checkpoint
-    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
-    cfg = dict(LLAMA3_8B, num_hidden_layers=2, vocab_size=8192)
-    model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=5, dtype=torch.bfloat16))
-    lib = _ffi.load()
-    prompt = torch.randint(0, cfg["vocab_size"], (40,), generator=torch.Generator().manual_seed(2)).to(torch.int32).cuda()
-    runs = {}
-    for mega in (0, 1):
-        for graph in (False, True):
-            _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_ENGINE, mega))
-            cache = model.make_cache()
-            tok, _, _ = model.step(prompt, cache, graph=False)
-            out = []
-            for _ in range(6):
-                tok, lp, logits = model.step(tok.reshape(1), cache, graph=graph)
-                out.append((int(tok.item()), to_bits(logits).copy(), lp.cpu().numpy().copy(), to_bits(model.hidden).copy()))
-            err = C.c_uint(0)
-            _ffi.check(lib.pie_decoder_status(model._dec, C.byref(err)))
-            assert err.value == 0, f"persistent launch gave up at grid barrier {err.value}"
-            runs[(mega, graph)] = out
-    base = runs[(0, False)]
-    for key, out in runs.items():
-        for i, (a, b) in enumerate(zip(base, out)):
-            assert a[0] == b[0], (key, i)
-            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)) and np.array_equal(a[3], b[3]), (key, i)
-    _ffi.check(lib.pie_decoder_configure(model._dec, _ffi.PIE_OPT_ENGINE, 0))
-
-
 def test_model_call_accepts_the_causal_mask_it_would_build_itself(tiny):
     """Model.__call__(inputs, mask=...) (language.py:199-204): the reference builds create_attention_mask(h, cache) when mask is None
     and passes a caller's mask through to sdpa; here the causal mask is implicit in the kernels, so that very mask (additive array,

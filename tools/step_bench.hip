@@ -350,23 +350,24 @@ int main(int argc, char **argv) {
                    (q[6] - q[0]) * 0.01);
     }
     if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_ENGINE_PROF build of the library: stamps of one workgroup (consumer wave 0) during the LAST step
-        std::vector<unsigned long long> t(160 * 8);
-        CK(hipMemcpy(t.data(), pp, t.size() * 8, hipMemcpyDeviceToHost));
+        const int PB = getenv("PIE_ENGINE_PROF_BLOCK") ? atoi(getenv("PIE_ENGINE_PROF_BLOCK")) : 0;
+        std::vector<unsigned long long> all((size_t)n_cus * 132 * 8);
+        CK(hipMemcpy(all.data(), pp, all.size() * 8, hipMemcpyDeviceToHost));
+        const unsigned long long *t = &all[(size_t)PB * 132 * 8];
         const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
         double sum[5][8] = {}, cnt[5] = {};
         const int n_ph = 4 * g.L + 1;
-        auto dt = [](unsigned long long b, unsigned long long a2) { return (double)(unsigned)((unsigned)b - (unsigned)a2); };  // 32-bit stamps (100 MHz)
-        for (int ph = 0; ph < n_ph && ph < 160; ++ph) {
+        auto dt = [](unsigned long long b, unsigned long long a2) { return (double)(int)((unsigned)b - (unsigned)a2); };  // 32-bit stamps (100 MHz)
+        for (int ph = 0; ph < n_ph && ph < 132; ++ph) {
             const unsigned long long *c = &t[ph * 8];
             if (!c[0]) continue;
             const int kd = ph == n_ph - 1 ? 4 : ph % 4;
-            const double total = ph + 1 < n_ph && ph + 1 < 160 && t[(ph + 1) * 8] ? dt(t[(ph + 1) * 8], c[0]) : dt(c[3], c[0]);
+            const double total = ph + 1 < n_ph && ph + 1 < 132 && t[(ph + 1) * 8] ? dt(t[(ph + 1) * 8], c[0]) : dt(c[3], c[0]);
             const double v[8] = {dt(c[1], c[0]), dt(c[2], c[1]), dt(c[3], c[2]), c[4] ? dt(c[4], c[3]) : 0.0, total, dt(c[5], c[0]), dt(c[6], c[5]), dt(c[7], c[6])};
             for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
             cnt[kd] += 1;
         }
-        printf("per-phase timeline of workgroup %s, consumer wave 0 (us, mean over layers): input gather | weight stream | epilogue + publish | attention | TOTAL || gather: sweep | rendezvous | norm + image\n",
-               getenv("PIE_ENGINE_PROF_BLOCK") ? getenv("PIE_ENGINE_PROF_BLOCK") : "0");
+        printf("per-phase timeline of workgroup %d, consumer wave 0 (us, mean over layers): input gather | weight stream | epilogue + publish | attention | TOTAL || gather: sweep | rendezvous | norm + image\n", PB);
         double layer = 0.0;
         for (int kd = 0; kd < 5; ++kd)
             if (cnt[kd] > 0) {
@@ -376,6 +377,54 @@ int main(int argc, char **argv) {
                 if (kd < 4) layer += sum[kd][4] / cnt[kd];
             }
         printf("  one layer: %.2f us\n", layer);
+        // across ALL workgroups: when does each one publish (epilogue done) relative to the first, per kind of phase -- the skew every gather waits out
+        printf("skew over the %d workgroups (us after the first one, mean over layers): input complete: median / p90 / max | outputs published: median / p90 / max | stream time min / median / max\n", n_cus);
+        for (int kd = 0; kd < 4; ++kd) {
+            double acc[9] = {};
+            int n = 0;
+            for (int ph = kd; ph < 4 * g.L && ph < 132; ph += 4) {
+                std::vector<double> rdy, pub, str;
+                unsigned r0 = 0, p0 = 0;
+                bool first = true;
+                for (int cu2 = 0; cu2 < n_cus; ++cu2) {
+                    const unsigned long long *c = &all[((size_t)cu2 * 132 + ph) * 8];
+                    if (!c[0]) continue;
+                    if (first) r0 = (unsigned)c[1], p0 = (unsigned)c[3], first = false;
+                    rdy.push_back(dt(c[1], r0) * 0.01), pub.push_back(dt(c[3], p0) * 0.01), str.push_back(dt(c[2], c[1]) * 0.01);
+                }
+                if (rdy.size() < 8) continue;
+                std::sort(rdy.begin(), rdy.end()), std::sort(pub.begin(), pub.end()), std::sort(str.begin(), str.end());
+                const size_t m = rdy.size();
+                acc[0] += rdy[m / 2] - rdy[0], acc[1] += rdy[m * 9 / 10] - rdy[0], acc[2] += rdy[m - 1] - rdy[0];
+                acc[3] += pub[m / 2] - pub[0], acc[4] += pub[m * 9 / 10] - pub[0], acc[5] += pub[m - 1] - pub[0];
+                acc[6] += str[0], acc[7] += str[m / 2], acc[8] += str[m - 1];
+                ++n;
+            }
+            if (kd == 2) {  // the longest loader-bound phase: who is slow?  mean stream time by blockIdx % 8 (the XCD under round-robin placement) and the slowest workgroups
+                double xs[8] = {}, xn[8] = {};
+                std::vector<std::pair<double, int>> per(n_cus, {0.0, 0});
+                for (int cu2 = 0; cu2 < n_cus; ++cu2) {
+                    double sm = 0.0;
+                    int k = 0;
+                    for (int ph = kd; ph < 4 * g.L && ph < 132; ph += 4) {
+                        const unsigned long long *c = &all[((size_t)cu2 * 132 + ph) * 8];
+                        if (c[0]) sm += dt(c[2], c[1]) * 0.01, ++k;
+                    }
+                    per[cu2] = {k ? sm / k : 0.0, cu2};
+                    xs[cu2 % 8] += per[cu2].first, xn[cu2 % 8] += 1;
+                }
+                printf("  gateup stream time by blockIdx %% 8:");
+                for (int k = 0; k < 8; ++k) printf(" %.2f", xn[k] ? xs[k] / xn[k] : 0.0);
+                std::sort(per.begin(), per.end());
+                printf("\n  slowest workgroups (mean over layers):");
+                for (int k = n_cus - 10; k < n_cus; ++k) printf(" %d:%.2f", per[k].second, per[k].first);
+                printf("\n  fastest:");
+                for (int k = 0; k < 10; ++k) printf(" %d:%.2f", per[k].second, per[k].first);
+                printf("\n");
+            }
+            if (n) printf("  %-7s %6.2f / %5.2f / %5.2f | %6.2f / %5.2f / %5.2f | %5.2f / %5.2f / %5.2f\n", names[kd], acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n,
+                          acc[6] / n, acc[7] / n, acc[8] / n);
+        }
     }
     PK(pie_decoder_destroy(dec));
     return rc;
