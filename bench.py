@@ -123,7 +123,8 @@ def cpu_baseline(cfg, weights_host, n_tokens, model=None):
               "vs_float32_oracle": {"hip_max_eps": hip_exact[0], "hip_rms_eps": hip_exact[1], "bf16_oracle_max_eps": orc_exact[0], "bf16_oracle_rms_eps": orc_exact[1]},
               "tolerance_eps": tol, "tolerance_rule": "HIP vs float32 oracle <= max(1.5 x (bf16 oracle vs float32 oracle), 8) ulps of the largest logit",
               "reference": "oracle/pie_oracle.c (parity unpinned: the reference holds no fixture for this path)",
-              "ok": bool(equal == checked and checked > 0 and hip_exact[0] <= tol)}
+              "min_ids_checked": min(16, n_tokens // 2),
+              "ok": bool(equal == checked and checked >= min(16, n_tokens // 2) and hip_exact[0] <= tol)}
     return base, parity
 
 
@@ -182,7 +183,9 @@ def main():
                     t.copy_(h)
         comm = HipComm(cfg["hidden_size"])
     else:
-        weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16)
+        # heavy-tailed lm_head rows: the parity gate's id comparison needs steps whose greedy token is decided by more than rounding noise
+        # (models/utils.py: synthetic_checkpoint); same shapes and bytes, so the timing is that of any Llama-3-8B int4 checkpoint
+        weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16, lm_head_tail=1.0)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b" and args.bits == 4
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
@@ -244,10 +247,16 @@ def main():
     k_bytes = model.kernel_bytes("gate_up", T_mid)
     k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes over the product step (tools/step_bench under rocprofv3 --pmc,
+    # scripts/profile_r03.sh, profiles/README.md).  The file names the library build it was measured on; any other build gets null
+    # rather than last round's kernels' traffic.
     traffic = None
-    tf = ROOT / "profiles" / "r02_traffic.json"  # PMC passes over the product step (tools/step_bench under rocprofv3 --pmc), see profiles/README.md
+    tf = ROOT / "profiles" / "r03_traffic.json"
     if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
-        traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+        from proxy_inference_engine_amd import _ffi
+        rec = json.loads(tf.read_text())
+        if rec.get("library") == _ffi.load().pie_version().decode():
+            traffic = rec.get("hbm_bytes_per_launch")
 
     shape_cfg = full_cfg if tp else cfg
     out = {

@@ -37,6 +37,17 @@ def _stale() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 over the sources the library is built from: pie_version() carries its first 12 digits, and the counter files under
+    profiles/ name the build they were measured on (bench.py refuses a stale one)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.cpp")) + [PKG.parent / "include" / "pie_hip.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not _stale():
         return LIB
@@ -47,7 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = obj_dir / (src + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        extra = [f'-DPIE_BUILD_HASH="{source_hash()}"'] if src == "decoder.hip" else []
+        cmd = [hipcc, *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-6000:]}")

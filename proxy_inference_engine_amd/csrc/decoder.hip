@@ -196,7 +196,10 @@ static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, 
 extern "C" {
 
 const char *pie_hello(void) { return "pie_core \xe2\x9c\x93"; }
-const char *pie_version(void) { return "pie_hip 0.1.0 (gfx950)"; }
+#ifndef PIE_BUILD_HASH
+#define PIE_BUILD_HASH "unhashed"
+#endif
+const char *pie_version(void) { return "pie_hip 0.3.0 (gfx950) " PIE_BUILD_HASH; }  // the hash of the sources: proxy_inference_engine_amd/build.py
 const char *pie_last_error(void) { return g_last_error.c_str(); }
 
 int pie_device_info(char *name, int name_len, int *n_cus, size_t *hbm_bytes) {

@@ -103,10 +103,14 @@ QWEN2VL_7B_TEXT = {
 
 
 def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch.bfloat16, device=None,
-                         lm_head_gain: float = 1.0) -> dict[str, torch.Tensor]:
+                         lm_head_gain: float = 1.0, lm_head_tail: float = 0.0) -> dict[str, torch.Tensor]:
     """Random-weight checkpoint in the reference's on-disk layout, generated and quantised ON the GPU
     (hip_ops.quantize = the HIP restatement of mx.quantize).  Linear/Embedding W ~ N(0, 0.02^2) cast to `dtype`
-    then int4 g=64 quantised -- or left dense when the config has no "quantization" entry; norm weights 1 + N(0, 0.02^2)."""
+    then int4 g=64 quantised -- or left dense when the config has no "quantization" entry; norm weights 1 + N(0, 0.02^2).
+    lm_head_tail = s > 0 multiplies row v of lm_head by exp(s * N(0, 1)): a heavy-tailed logit distribution, so that the greedy
+    token is decided by a clear margin on most steps, as in a trained model.  (A uniform gain cannot do that: it scales the top-2
+    gap and the 16-bit error of the logits alike.  With i.i.d. rows the gap between the two largest of 128k logits is ~0.2 sigma,
+    the same size as a few bf16 ulps of the largest one: an id comparison would be decided by rounding noise.)"""
     device = device or _ffi.require_gpu()
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -116,10 +120,13 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
     D = config.get("head_dim") or H // nh
     out: dict[str, torch.Tensor] = {}
 
-    def put_linear(name: str, N: int, K: int, gain: float = 1.0, bias: bool = False) -> None:
+    def put_linear(name: str, N: int, K: int, gain: float = 1.0, bias: bool = False, row_tail: float = 0.0) -> None:
         if bias:
             out[f"{name}.bias"] = (torch.randn(N, generator=gen, device=device, dtype=torch.float32) * 0.1).to(dtype)
-        w = (torch.randn((N, K), generator=gen, device=device, dtype=torch.float32) * (0.02 * gain)).to(dtype)
+        w = torch.randn((N, K), generator=gen, device=device, dtype=torch.float32) * (0.02 * gain)
+        if row_tail > 0.0:
+            w *= torch.exp(row_tail * torch.randn((N, 1), generator=gen, device=device, dtype=torch.float32))
+        w = w.to(dtype)
         if config.get("quantization"):
             out[f"{name}.weight"], out[f"{name}.scales"], out[f"{name}.biases"] = hip_ops.quantize(w, bits=int(config["quantization"]["bits"]))
         else:
@@ -143,5 +150,5 @@ def synthetic_checkpoint(config: dict, seed: int = 0, dtype: torch.dtype = torch
         put_linear(f"{p}.mlp.down_proj", H, I, bias=mb)
     out["model.norm.weight"] = norm_w()
     if not config.get("tie_word_embeddings", True):
-        put_linear("lm_head", V, H, gain=lm_head_gain)
+        put_linear("lm_head", V, H, gain=lm_head_gain, row_tail=lm_head_tail)
     return out

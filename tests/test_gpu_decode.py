@@ -499,6 +499,49 @@ def test_dense_checkpoint_prefill_and_decode(dtype):
     assert model.step_bytes(100) > 2 * sum(v.size for k, v in w.items() if k.endswith("proj.weight"))  # 2 B per parameter
 
 
+def test_llama8b_dense_bf16_layers_vs_oracle():
+    """BASELINE.json configs[2] at ITS geometry: two Llama-3-8B-shaped UNQUANTISED bf16 layers (H=4096, I=14336, 32/8 heads, D=128:
+    W16S units of 512-wide K slices -> 8 and 28 slices per row; a config without a "quantization" entry keeps nn.Linear,
+    models/utils.py:96-97), V=8192.  A 48-token and a 512-token prompt through the batched GEMM path (every 64th position and the
+    last against the oracle), then 3 decode steps through the W16S streaming GEMV, same tolerances as the int4 test above."""
+    dtype = "bfloat16"
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False}
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    from proxy_inference_engine_amd.models.utils import synthetic_checkpoint
+    wd = synthetic_checkpoint(cfg, seed=31, dtype=torch.bfloat16, lm_head_gain=4.0)  # 470 M parameters: generated on the GPU, the oracle gets host copies
+    assert "model.layers.0.mlp.down_proj.scales" not in wd
+    w = {k: v.view(torch.int16).cpu().numpy().view(np.uint16) for k, v in wd.items()}
+    model = Model(ModelArgs(**cfg), wd)
+    del wd
+    assert model.dense
+    orc = po.OracleLlama(cfg, w, dtype)
+    rng = np.random.default_rng(12)
+    for L in (48, 512):
+        prompt = rng.integers(0, cfg["vocab_size"], L)
+        ocache = [po.OracleKVCache() for _ in orc.layers]
+        want_all = orc.forward(prompt, ocache)
+        cache = model.make_cache()
+        got_all = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+        for l in sorted(set(range(0, L, 64)) | {L - 1}):
+            assert_vec_close(got_all[l], want_all[l], dtype, what=f"dense 8B geometry, L={L}, position {l}")
+        tok = model.token
+        matched = 0
+        for i in range(3):
+            want = orc.forward(np.array([int(tok.item())]), ocache)[0]
+            otok, olp = po.logprobs_argmax(want)
+            tok, lp, logits = model.step(None, cache)
+            assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"dense 8B geometry, decode step {i} after L={L}")
+            top2 = np.sort(olp)[-2:]
+            if top2[1] - top2[0] > margin_bound(want, dtype):
+                assert int(tok.item()) == otok
+                matched += 1
+        assert matched >= 1
+    n_lin = sum(v.size for k, v in w.items() if k.endswith("proj.weight"))
+    assert model.step_bytes(100) > 2 * n_lin  # 2 B per parameter: 436 M parameters in two layers
+
+
 def test_llama32_3b_shaped_layer():
     """Llama-3.2-3B geometry: H = 3072 (1.5 K-slices of 2048: ragged), I = 8192, 24/8 heads (3 q-heads per kv-head), D = 128,
     tied embeddings; one layer, f16."""

@@ -92,6 +92,14 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
     const int n_cus = gridDim.x, cu = blockIdx.x;
     if (wave < RING_LOADERS) {
         auto next = [&](int w, int m, const char **p, unsigned *bytes) -> bool {
+            if (a.abl & 16) {  // slot-interleaved: the chip's streams form one compact window sweeping through the matrix (two K slices only)
+                const int S = n_cus * RING_CONSUMERS, n_slots = a.n_pairs / 2, kmax = (n_slots + S - 1) / S;
+                const int rep = m / kmax, k = m % kmax, slot = k * S + ((a.abl & 32) ? w * n_cus + cu : cu * RING_CONSUMERS + w);
+                if (rep >= a.reps) return false;
+                *p = a.w + (size_t)rep * a.mat_bytes + (size_t)slot * RING_SLOT_BYTES;
+                *bytes = slot < n_slots ? (unsigned)RING_SLOT_BYTES : 0u;
+                return true;
+            }
             if (m >= a.reps) return false;
             const RingRun r = ring_run(a.n_pairs, 1, n_cus, cu, w);
             *p = a.w + (size_t)((a.abl & 2) ? 0 : m) * a.mat_bytes + (size_t)r.first * a.ns * W4S_UNIT_BYTES;
@@ -106,7 +114,12 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
     }
     const int cw = wave - RING_LOADERS;
     RingCursor cur = ring_cursor(ring, ctl, cw);
-    const RingRun r = ring_run(a.n_pairs, 1, n_cus, cu, cw);
+    RingRun r = ring_run(a.n_pairs, 1, n_cus, cu, cw);
+    const int S = n_cus * RING_CONSUMERS, sidx = (a.abl & 32) ? cw * n_cus + cu : cu * RING_CONSUMERS + cw;
+    if (a.abl & 16) {
+        const int n_slots = a.n_pairs / 2;
+        r.first = 0, r.count = sidx < n_slots ? 2 * ((n_slots - sidx + S - 1) / S) : 0;
+    }
     const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + 200000000ull;  // 2 s
     float *outp = reinterpret_cast<float *>(smem + img_bytes + 64) + cw * 2 * GEMV_MAX_RUN;
     bool ok = true;
@@ -121,7 +134,8 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
         }
         if (a.ns == 2 && !(a.abl & 8)) ok = ring_consume<T, 2>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
         else ok = ring_consume<T, 0>(cur, smem, lds0, smem, L, a.K, r.count, outp, lane, deadline);
-        if (lane < r.count) *reinterpret_cast<float2 *>(a.y + (size_t)rep * 2 * a.n_pairs + 2 * (r.first + lane)) = *reinterpret_cast<const float2 *>(outp + 2 * lane);
+        const int gpair = (a.abl & 16) ? 2 * ((lane >> 1) * S + sidx) + (lane & 1) : r.first + lane;
+        if (lane < r.count) *reinterpret_cast<float2 *>(a.y + (size_t)rep * 2 * a.n_pairs + 2 * gpair) = *reinterpret_cast<const float2 *>(outp + 2 * lane);
     }
     if (!ok && lane == 0) atomicAdd(a.err, 1u);
 }
