@@ -236,16 +236,18 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
  * include/engine/batch_details.hpp:10-88; Scheduler and the paged attention kernel are skeletons there).  Independent of
  * pie_decoder_set_kv / set_state / bind_outputs; all device arrays are caller-owned.  flags: PIE_STEP_GRAPH replays a captured
  * hipGraph of the step while the caller passes the same buffers (their contents may change) -- captured on the second such call. */
-int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
+int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages, size_t slab_bytes,
                            const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
                            int flags, void *stream);
 /* Several FRESH prompts in one pass (the prefill-state half of BatchDetails, batch_details.hpp:10-88): their N rows are
  * concatenated -- ids [N]; per row: row_context_lens (position + 1), row_seq (which prompt, = its block-table row), seg_lo
  * (index of its prompt's first row), seg_hi (row index + 1: causal); per prompt: last_rows [S] (index of its last row).  K / V
  * go to each prompt's pages; attention reads this pass's own rows.  Outputs per prompt as in pie_decoder_step_batch.
- * All index arrays are device int32. */
+ * All index arrays are device int32.  slab_bytes (here and in pie_decoder_step_batch): the size of EACH layer's slab; it must hold
+ * n_pages pages of the ACTIVE page format (T pages, or int8 pages under PIE_OPT_KV_I8) -- a pool of the other format is refused
+ * instead of being indexed with the wrong page stride. */
 int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
-                              const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, size_t n_pages,
+                              const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, size_t n_pages, size_t slab_bytes,
                               const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */

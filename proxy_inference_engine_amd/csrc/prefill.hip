@@ -679,6 +679,10 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     static const int slabs_min_rows = getenv("PIE_W4L_SLABS_MIN_ROWS") ? atoi(getenv("PIE_W4L_SLABS_MIN_ROWS")) : 0;
     if (M < slabs_min_rows && !rope) slabs = nullptr;
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
+    // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the
+    // streaming GEMV with the rows' images side by side -- one pass over the weights, each row with the batch-1 arithmetic.
+    if (is_int4 && M <= GEMV_ROWS_MAX && K % 64 == 0 && N % 2 == 0 && gemv_rows_lds_bytes(K, 1) <= 160u * 1024u)
+        return w4s_gemv_rows_launch(d->cfg.dtype, packed, N, K, x, M, y, (const u16 *)bias, st);
     if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
@@ -1091,15 +1095,18 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
     return logits_tail_rows_launch(c.dtype, logits, c.vocab, S, s->tail_stats, logprobs, next_tokens, st);
 }
 
+static size_t active_page_bytes(const pie_decoder *d);
 extern "C" int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
                                          const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *last_rows, int N, int S,
-                                         const void *const *slabs, size_t n_pages, const int32_t *block_tables, int max_blocks, void *logits,
+                                         const void *const *slabs, size_t n_pages, size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits,
                                          float *logprobs, int32_t *next_tokens, void *stream) {
     PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
                 PIE_E_ARG, "pie_decoder_prefill_batch: null pointer");
     PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch: set_globals must be called first");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_prefill_batch: a layer has no weights (pie_decoder_set_layer)");
     PIE_REQUIRE(S >= 1 && N >= S && N <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_prefill_batch: bad batch shape");
+    PIE_REQUIRE(slab_bytes >= n_pages * active_page_bytes(d), PIE_E_SHAPE,
+                "pie_decoder_prefill_batch: the slabs are smaller than n_pages pages of the active page format (an int8 pool needs PIE_OPT_KV_I8, a T pool must not have it)");
     PIE_REQUIRE(d->cfg.hidden % 8 == 0 && d->cfg.hidden <= 8192, PIE_E_SHAPE, "pie_decoder_prefill_batch: hidden must be a multiple of 8, at most 8192");
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
     PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_prefill_batch: n_heads / n_kv_heads must be between 1 and 8");
@@ -1118,7 +1125,13 @@ static int decode_batch(pie_decoder *d, const int32_t *tokens, const int32_t *ct
                : decode_batch_t<F16>(d, tokens, ctx_len, slabs, n_pages, block_tables, max_blocks, B, (u16 *)logits, logprobs, next_tokens, st);
 }
 
-extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages,
+// bytes one page of the active format takes in a layer's slab: K block + V block of T rows, or the int8 page with its scales
+static size_t active_page_bytes(const pie_decoder *d) {
+    const pie_decoder_config &c = d->cfg;
+    return d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, c.head_dim) : (size_t)2 * PIE_PAGE_TOKENS * c.n_kv_heads * c.head_dim * 2;
+}
+
+extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t *context_lens, const void *const *slabs, size_t n_pages, size_t slab_bytes,
                                       const int32_t *block_tables, int max_blocks, int B, void *logits, float *logprobs, int32_t *next_tokens,
                                       int flags, void *stream) {
     PIE_REQUIRE(d && tokens && context_lens && slabs && block_tables && logits && logprobs && next_tokens, PIE_E_ARG, "pie_decoder_step_batch: null pointer");
@@ -1126,6 +1139,8 @@ extern "C" int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, con
     PIE_REQUIRE(!d->tp(), PIE_E_STATE, "pie_decoder_step_batch: not available on a tensor-parallel shard");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_step_batch: a layer has no weights (pie_decoder_set_layer)");
     PIE_REQUIRE(B >= 1 && B <= 4096 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_step_batch: bad batch shape");
+    PIE_REQUIRE(slab_bytes >= n_pages * active_page_bytes(d), PIE_E_SHAPE,
+                "pie_decoder_step_batch: the slabs are smaller than n_pages pages of the active page format (an int8 pool needs PIE_OPT_KV_I8, a T pool must not have it)");
     const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
     PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_step_batch: n_heads / n_kv_heads must be between 1 and 8");
     for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_step_batch: null or misaligned slab");

@@ -296,6 +296,52 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
 }
 
+template <class T, int MR>
+static int rows_launch_t(const GemvRowsArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PIE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_w4s_gemv_rows<T, MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_w4s_gemv_rows<T, MR>), grid, dim3(GEMV_WAVES * 64), lds, st, a);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 *x, int M, u16 *y, const u16 *lin_bias, hipStream_t stream) {
+    PIE_REQUIRE(packed && x && y, PIE_E_ARG, "w4s_gemv_rows: null pointer");
+    PIE_REQUIRE(K % 64 == 0 && K > 0 && K <= 32768 && N % 2 == 0 && N > 0, PIE_E_SHAPE, "w4s_gemv_rows: K must be a multiple of 64 (<= 32768), N even");
+    PIE_REQUIRE(M >= 1 && M <= GEMV_ROWS_MAX, PIE_E_SHAPE, "w4s_gemv_rows: 1 .. 5 rows");
+    if (M == 1) {
+        GemvArgs g = {};
+        g.w = (const char *)packed, g.K = K, g.N = N, g.x = x, g.y = y, g.lin_bias = lin_bias;
+        return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, g, 1, stream);
+    }
+    GemvRowsArgs a = {};
+    a.w = (const char *)packed, a.K = K, a.N = N, a.M = M, a.x = x, a.y = y, a.lin_bias = lin_bias;
+    a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
+    PIE_REQUIRE((size_t)a.n_pairs * a.n_slices * W4S_UNIT_BYTES < ((size_t)1 << 32) - 8192, PIE_E_SHAPE, "w4s_gemv_rows: one matrix must stay below 4 GiB");
+    // rows per workgroup: all of them where their LDS images fit, else the fewest equal chunks (K = 14336: 5 rows -> 3 + 2)
+    int mr_fit = GEMV_ROWS_MAX;
+    while (mr_fit > 1 && gemv_rows_lds_bytes(K, mr_fit) > 160u * 1024u) --mr_fit;
+    PIE_REQUIRE(gemv_rows_lds_bytes(K, mr_fit) <= 160u * 1024u, PIE_E_SHAPE, "w4s_gemv_rows: activation vector does not fit LDS");
+    const int chunks = (M + mr_fit - 1) / mr_fit, mr = (M + chunks - 1) / chunks;
+    const unsigned lds = gemv_rows_lds_bytes(K, mr);
+    const dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, chunks);
+#define PIE_ROWS(TT)                                                   \
+    switch (mr) {                                                      \
+        case 1: return rows_launch_t<TT, 1>(a, grid, lds, stream);    \
+        case 2: return rows_launch_t<TT, 2>(a, grid, lds, stream);    \
+        case 3: return rows_launch_t<TT, 3>(a, grid, lds, stream);    \
+        case 4: return rows_launch_t<TT, 4>(a, grid, lds, stream);    \
+        default: return rows_launch_t<TT, 5>(a, grid, lds, stream);   \
+    }
+    if (dtype == PIE_BF16) { PIE_ROWS(BF16) }
+    if (dtype == PIE_F16) { PIE_ROWS(F16) }
+#undef PIE_ROWS
+    return pie::fail(PIE_E_ARG, "w4s_gemv_rows: dtype must be PIE_BF16 or PIE_F16");
+}
+
 // ---------------------------------------------------------------- C ABI
 int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype,
                      void *out, const float *freqs, const DecState *state, float *rope_cs, int half, hipStream_t st, int bits);

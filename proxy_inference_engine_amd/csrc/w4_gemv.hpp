@@ -470,7 +470,148 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     GEMV_STAMP(3);
 }
 
+// ---------------------------------------------------------------- a few activation rows against ONE pass over the weights
+// y[m, :] = T(x[m, :] @ W^T) (+ bias) for 2 .. 5 rows (MLX's qmv regime: below 6 rows nn.QuantizedLinear multiplies row by row in
+// exact fp32, mx.quantized_matmul): the same persistent-wave stream as k_w4s_gemv with the MR rows' activation images side by side
+// in LDS -- every weight unit is fetched once and multiplied MR times, each row with the batch-1 kernel's arithmetic in the
+// batch-1 kernel's order, so a row's result is bit-identical to that row multiplied alone.  (k_w4s_gemv with blockIdx.y = row
+// streams the matrix once per row: two sequences cost two batch-1 steps.)  W4S only; no prologue, plain-store epilogue.
+struct GemvRowsArgs {
+    const char *w;
+    int n_pairs, n_slices, n_waves, K, N, M;
+    const u16 *x;  // [M, K]
+    u16 *y;        // [M, N]
+    const u16 *lin_bias;
+};
+static inline __host__ __device__ unsigned gemv_rows_image_bytes(int K) { return (unsigned)((gemv_lds(K).off_red + 15) & ~15); }
+static inline __host__ __device__ unsigned gemv_rows_lds_bytes(int K, int MR) {
+    return (unsigned)MR * (gemv_rows_image_bytes(K) + GEMV_WAVES * 2 * GEMV_MAX_RUN * 4);
+}
+
+template <class T, int MR>
+__global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const GemvRowsArgs a) {
+    constexpr int D = GEMV_DEPTH, UB = W4S_UNIT_BYTES, NT = GEMV_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ns = a.n_slices;
+    const GemvLds L = gemv_lds(a.K);
+    const unsigned img = gemv_rows_image_bytes(a.K);
+    const int row0 = blockIdx.y * MR;
+    const int nr = a.M - row0 < MR ? a.M - row0 : MR;  // rows of this chunk (wave-uniform)
+    float *outp = reinterpret_cast<float *>(smem + (size_t)MR * img) + wave * (2 * GEMV_MAX_RUN);  // + r * GEMV_WAVES * 2 * GEMV_MAX_RUN per row
+
+    const int gw = blockIdx.x * GEMV_WAVES + wave;
+    const int W = a.n_waves;
+    const int run = gw < a.n_pairs ? (a.n_pairs - gw + W - 1) / W : 0;
+    const int n_units = run * ns;
+    typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
+    const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * UB);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.w), 0, (int)w_bytes, 0x00020000);
+    const unsigned woff0 = (unsigned)((size_t)gw * ns * UB) + lane * 16;
+    const unsigned pstride32 = (unsigned)((size_t)W * ns * UB);
+    const int my_chunks = (a.K + 63) >> 6;
+    const bool ragged = (my_chunks & 31) != 0;
+    int iss_sl = 0, iss_pl = 0;
+    uint4 c0[D], c1[D];
+    u32 sb[D];
+    auto issue = [&](int d) {
+        unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
+        if (ragged && iss_sl * 32 + (lane & 31) >= my_chunks) off = 0xFFFFF000u;
+        if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
+        const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
+        const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, 2);
+        c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+        c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+        sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, 2);
+    };
+    // the rows' activations first (their loads retire before the weight stream's), then the head of the stream
+    const int n_pieces = a.K >> 3;
+    const int n_iter = (n_pieces + NT - 1) / NT;
+    for (int r = 0; r < nr; ++r) {
+        const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + r) * a.K);
+        char *im = smem + (size_t)r * img;
+        float *sxs = reinterpret_cast<float *>(im + L.off_sx);
+        for (int i = 0; i < n_iter; ++i) {
+            const int j = threadIdx.x + i * NT;
+            const bool ok = j < n_pieces;
+            const uint4 v = xg[ok ? j : n_pieces - 1];
+            float ps = ok ? sum8<T>(v) : 0.0f;
+            ps = lanes8_sum(ps);
+            if (ok) {
+                *reinterpret_cast<uint4 *>(im + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = scale8<T>(v);
+                if ((j & 7) == 0) sxs[j >> 3] = ps;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d);
+    __syncthreads();
+
+    const int n_groups = a.K >> 6;
+    float acc[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) acc[r] = 0.0f;
+    int sl = 0, pl = 0;
+    for (int base = 0; base < n_units; base += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (base + d < n_units) {  // wave-uniform
+                if (((((base + d) >> 1) + (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1);  // the two waves of a SIMD take turns (k_w4s_gemv)
+                else __builtin_amdgcn_s_setprio(0);
+                const int g = sl * 32 + (lane & 31);
+                const bool gvalid = g < n_groups;
+                const int gc = gvalid ? g : n_groups - 1;
+                const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
+#pragma unroll
+                for (int r = 0; r < MR; ++r) {
+                    if (r < nr) {
+                        const char *im = smem + (size_t)r * img;
+                        u32 xr[32];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint4 v = *reinterpret_cast<const uint4 *>(im + ((size_t)q * L.stride + gc) * 16);
+                            xr[4 * q + 0] = v.x, xr[4 * q + 1] = v.y, xr[4 * q + 2] = v.z, xr[4 * q + 3] = v.w;
+                        }
+                        const float sx = reinterpret_cast<const float *>(im + L.off_sx)[gc];
+                        const float dd = w4s_unit_dot<T>(c0[d], c1[d], xr);
+                        const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
+                        acc[r] += gvalid ? pr : 0.0f;
+                    }
+                }
+                if (++sl == ns) {
+#pragma unroll
+                    for (int r = 0; r < MR; ++r) {
+                        const float tot = half_wave_sum(acc[r]);
+                        if ((lane & 31) == 31) outp[r * (GEMV_WAVES * 2 * GEMV_MAX_RUN) + 2 * pl + (lane >> 5)] = tot;
+                        acc[r] = 0.0f;
+                    }
+                    sl = 0, ++pl;
+                }
+            }
+            issue(d);
+        }
+    }
+    // epilogue: lane l owns local pair l (rows R, R + 1 of the packed order) of every activation row
+    const bool live = lane < run;
+    const int R = 2 * (gw + lane * W);
+    u32 pre_b = 0;
+    if (a.lin_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        if (r < nr && live) {
+            const float2 o = *reinterpret_cast<const float2 *>(outp + r * (GEMV_WAVES * 2 * GEMV_MAX_RUN) + 2 * lane);
+            float oa = round_T<T>(o.x), ob = round_T<T>(o.y);
+            if (a.lin_bias) oa = round_T<T>(oa + lo_f32<T>(pre_b)), ob = round_T<T>(ob + hi_f32<T>(pre_b));  // y = T(T(x W^T) + b)
+            *reinterpret_cast<u32 *>(a.y + (size_t)(row0 + r) * a.N + R) = pack2<T>(oa, ob);
+        }
+    }
+}
+
 // Host-side launch: sizes the persistent grid for (N, K) and dispatches the template.
 int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t stream);
 // Number of waves (= log-softmax partials with EPI_LOGITS) the launcher uses for an [N, K] weight.
 int w4s_gemv_waves(int N, int K);
+// y[M, N] = T(x[M, K] @ W^T) (+ bias) for 1 <= M <= GEMV_ROWS_MAX rows of one W4S matrix in one pass over the weights (see k_w4s_gemv_rows)
+constexpr int GEMV_ROWS_MAX = 5;
+int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 *x, int M, u16 *y, const u16 *lin_bias, hipStream_t stream);

@@ -1415,10 +1415,11 @@ int pie_repack_w16m(const void *weight_rows, int N, int K, void *w16m, void *str
     return w16m_repack_launch(nullptr, weight_rows, N, K, w16m, (hipStream_t)stream);
 }
 
-size_t pie_linear_w16m_workspace_bytes(int M, int N, int K) { return M > 0 && N > 0 && K > 0 ? w16l_workspace_bytes(M, N, K) : 0; }
+size_t pie_linear_w16m_workspace_bytes(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0 ? w16l_workspace_bytes(M, N, K) : 0; }
 
 int pie_linear_w16m(const void *x, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, void *workspace, void *stream) {
     PIE_REQUIRE(x && w16m && y, PIE_E_ARG, "pie_linear_w16m: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0, PIE_E_SHAPE, "pie_linear_w16m: M > 0, N a multiple of 4, K a multiple of 8");
     hipStream_t st = (hipStream_t)stream;
     bool bias_done = false;
     const int rc = w16l_gemm_launch(dtype, w16m, x, M, N, K, y, workspace, st, nullptr, nullptr, bias, &bias_done);
@@ -1428,6 +1429,8 @@ int pie_linear_w16m(const void *x, const void *w16m, const void *bias, int M, in
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
+    // before any plan or workspace arithmetic: with N < 32 a plan has no column tiles and divides by zero on the host
+    PIE_REQUIRE(M > 0 && N >= 32 && N % 32 == 0 && K >= 64 && K % 64 == 0, PIE_E_SHAPE, "pie_qgemm_w4m: M > 0, N a multiple of 32, K a multiple of 64");
     if (M > 32) {  // the prompt GEMM; a K-split shape takes stream-ordered scratch for its fp32 partial tiles
         hipStream_t st = (hipStream_t)stream;
         void *ws = nullptr;

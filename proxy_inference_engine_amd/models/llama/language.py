@@ -264,6 +264,7 @@ class Model:
             for li in range(len(self.layers)):
                 hip_ops.page_i8_set_scales(self._page_pool.slab[li], num_pages, self.n_kv_heads, self.head_dim, ks[li], vs[li])
         _ffi.check(_ffi.load().pie_decoder_configure(self._dec, _ffi.PIE_OPT_KV_I8, int(kv_dtype == torch.int8)))
+        self._kv_i8 = kv_dtype == torch.int8
         self._kv_key = None
         self._page_blocks = max_blocks
         return self._page_pool
@@ -280,6 +281,14 @@ class Model:
             raise ValueError("the allocator's geometry does not match this model")
         seq = PagedSequence(allocator, max_blocks)
         return [PagedKVCache(seq, i) for i in range(len(self.layers))]
+
+    def _match_page_format(self, allocator: PageAllocator) -> None:
+        """The decoder indexes the slabs with the page stride of ITS page format (PIE_OPT_KV_I8); a pool handed to make_cache(allocator=...)
+        may be of the other one.  The batch entry points therefore follow the pool they are given (and the C ABI checks the slab size)."""
+        want = allocator.dtype == torch.int8
+        if getattr(self, "_kv_i8", None) != want:
+            _ffi.check(_ffi.load().pie_decoder_configure(self._dec, _ffi.PIE_OPT_KV_I8, int(want)))
+            self._kv_i8 = want
 
     def _sync_paged(self, cache: list[PagedKVCache], n_new: int) -> None:
         seq = cache[0].page_manager
@@ -493,7 +502,8 @@ class Model:
         buf["ctx"].copy_(torch.tensor([s.offset + 1 for s in seqs], dtype=torch.int32))
         n = len(self.layers)
         slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
-        _ffi.check(_ffi.load().pie_decoder_step_batch(self._dec, _ffi.p(buf["tokens"]), _ffi.p(buf["ctx"]), slabs, a.size(), _ffi.p(buf["table"]),
+        self._match_page_format(a)
+        _ffi.check(_ffi.load().pie_decoder_step_batch(self._dec, _ffi.p(buf["tokens"]), _ffi.p(buf["ctx"]), slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(buf["table"]),
                                                       buf["table"].shape[1], B, _ffi.p(buf["logits"]), _ffi.p(buf["logprobs"]), _ffi.p(buf["next"]),
                                                       _ffi.PIE_STEP_GRAPH if graph else 0, _ffi.stream()))
         nxt, logprobs, logits = buf["next"], buf["logprobs"], buf["logits"]
@@ -542,8 +552,9 @@ class Model:
         nxt = torch.empty(S, dtype=torch.int32, device=self.device)
         n = len(self.layers)
         slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
+        self._match_page_format(a)
         _ffi.check(_ffi.load().pie_decoder_prefill_batch(self._dec, _ffi.p(t_ids), _ffi.p(t_ctx), _ffi.p(t_seq), _ffi.p(t_lo), _ffi.p(t_hi), _ffi.p(t_last),
-                                                         N, S, slabs, a.size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt),
+                                                         N, S, slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt),
                                                          _ffi.stream()))
         for s, k in zip(seqs, lens):
             s.advance(k)

@@ -42,6 +42,20 @@ def test_hello_and_size_helpers_without_gpu():
     assert lib.pie_qkv_row_map(4, 2, 63, arr) != 0 and b"pie_qkv_row_map" in lib.pie_last_error()
 
 
+def test_shape_errors_come_before_any_planning_without_gpu():
+    """Entry points must refuse a bad shape with PIE_E_SHAPE before any plan or workspace arithmetic (a host-side division by zero in
+    the many-row int4 GEMM's plan for N < 32 was a SIGFPE, not an error code)."""
+    from proxy_inference_engine_amd import _ffi
+    lib = _ffi.load()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    for M, N, K in ((64, 16, 256), (64, 48, 256), (64, 64, 100), (0, 64, 256), (4, 16, 256)):
+        rc = lib.pie_qgemm_w4m(p, p, M, N, K, _ffi.PIE_BF16, p, None)
+        assert rc == -2 and b"pie_qgemm_w4m" in lib.pie_last_error(), (M, N, K, rc)
+    assert lib.pie_linear_w16m_workspace_bytes(64, 0, 256) == 0 and lib.pie_linear_w16m_workspace_bytes(64, 30, 256) == 0
+    assert lib.pie_linear_w16m(p, p, None, 64, 30, 256, _ffi.PIE_BF16, p, None, None) == -2  # PIE_E_SHAPE
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for f in (ROOT / "proxy_inference_engine_amd").rglob("*"):
