@@ -251,17 +251,10 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
     PIE_ALLOC(d->pf_sink, 8192);  // 16 bytes of sink + room for the developer builds' stamps (attention: words 2..9; GEMVs: 16 + 4 kind ..)
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
-    {
-        const char *e = getenv("PIE_PREFETCH_MB");
-        // tuning knob: the attention launch's idle workgroups warm the Infinity Cache with what runs next -- 0 (default) = o_proj's weights,
-        // N > 0 = also N MB of gate/up's (measured slower), -1 = no warm-up.  Round 1: +1 % for the default; with round 2's kernels
-        // +0.3-0.4 % (1.232-1.236 vs 1.237-1.241 ms per step on two boxes), for 10 MB of additional memory-side fetches per layer.
-        const long mb = e ? atol(e) : 0;
-        const size_t gu = c.weight_format == PIE_W_DENSE ? pie_w16s_bytes(2 * c.inter, c.hidden)
-                          : (c.weight_format == PIE_W_INT8_G64 ? pie_w8s_bytes(2 * c.inter, c.hidden) : pie_w4s_bytes(2 * c.inter, c.hidden));
-        d->pf_gateup_bytes = mb <= 0 ? 0 : ((size_t)mb << 20 < gu ? (size_t)mb << 20 : gu);
-        d->pf_enable = mb >= 0;
-    }
+    // The split-KV attention launch's idle workgroups warm the Infinity Cache with o_proj's weights (round 1: +1 %, round 2's kernels:
+    // +0.3-0.4 % -- 1.232-1.236 vs 1.237-1.241 ms per step on two boxes -- for 10 MB of additional memory-side fetches per layer);
+    // warming part of gate|up's as well measured slower.
+    d->pf_gateup_bytes = 0, d->pf_enable = true;
 #undef PIE_ALLOC
     plan_attention(d);
     *out = d;

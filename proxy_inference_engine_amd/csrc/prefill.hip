@@ -402,10 +402,7 @@ int gemm_xwt_impl(int dtype, const void *x, const void *w, void *y, int M, int N
         constexpr int MAX_ALGOS = 8;
         hipblasLtMatmulHeuristicResult_t res[MAX_ALGOS];
         int n_res = 0;
-        const char *te = getenv("PIE_PREFILL_TUNE");  // 0: take the heuristic's first choice without timing the candidates
-        const char *ts = getenv("PIE_PREFILL_TUNE_MIN_ROWS");  // experiment knob: smallest M whose candidates are timed
-        const int tune_min = ts ? atoi(ts) : 64;
-        const int want = (te && te[0] == '0') || M < tune_min ? 1 : MAX_ALGOS;
+        const int want = M < 64 ? 1 : MAX_ALGOS;  // from 64 rows the heuristic's candidates are timed once per shape, below its first choice is taken
         const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, want, res, &n_res);
         PIE_REQUIRE(hs == HIPBLAS_STATUS_SUCCESS && n_res > 0, PIE_E_HIP, "prefill: hipBLASLt has no kernel for this GEMM shape");
         int best = 0;
@@ -624,11 +621,8 @@ size_t w16m_bytes(int N, int K);
 int w16m_repack_launch(const void *w16s, const void *rows, int N, int K, void *w16m, hipStream_t st);
 
 // int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
-// copy of the weights, no hipBLASLt.  PIE_W4L=0 restores round 1's dequantise-to-T + hipBLASLt path (kept for A/B timing).
-static bool w4l_enabled() {
-    const char *e = getenv("PIE_W4L");
-    return !(e && e[0] == '0');
-}
+// copy of the weights, no hipBLASLt (which remains the path of shapes the tile kernels do not take: N not a multiple of 32).
+static bool w4l_enabled() { return true; }
 // dense (16-bit) modules: PIE_W16L=1 takes the hand-written prompt GEMM on W16M tiles (k_w16l_gemm, w4m_gemm.hip) instead of the
 // unpack-to-T + hipBLASLt path.  Off by default on measurement: for 16-bit weights the library GEMM is a plain GEMM done well -- the own
 // kernel ties it up to 128 rows and is 13-20 % slower from 256 rows (8B dense prefill: 8.8 vs 7.8 ms at 256 tokens, 64.9 vs 53.8 at
@@ -645,10 +639,7 @@ static int small_rows() {
     return v < 0 ? 0 : (v > 32 ? 32 : v);
 }
 
-static bool split_k_enabled() {  // PIE_W4M_SPLITK=0: never split (tuning / test knob)
-    const char *e = getenv("PIE_W4M_SPLITK");
-    return !(e && e[0] == '0');
-}
+static bool split_k_enabled() { return true; }
 
 template <class T>
 static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
@@ -676,8 +667,6 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // vs 3.96 / 4.82 / 6.20 / 9.75 / 14.38.  (With ONE workgroup per row the RoPE consumer could not keep enough slab loads in flight
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
-    static const int slabs_min_rows = getenv("PIE_W4L_SLABS_MIN_ROWS") ? atoi(getenv("PIE_W4L_SLABS_MIN_ROWS")) : 0;
-    if (M < slabs_min_rows && !rope) slabs = nullptr;
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
     // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the
     // streaming GEMV with the rows' images side by side -- one pass over the weights, each row with the batch-1 arithmetic.
@@ -699,9 +688,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             // K split over two workgroups per strip where the strips alone cannot fill the chip (N / 32 < 256) and K is long enough
             // (measured on the 8B shapes: down, K = 14336, gains at every row count -- 8 rows 3.05 -> 2.85 ms per prompt, half the
             // chip is VALU-bound on its dequantisation; o_proj, K = 4096, only from ~24 rows, below that its halves are too short)
-            static const int split_min_k = getenv("PIE_W4M_SPLIT_MIN_K") ? atoi(getenv("PIE_W4M_SPLIT_MIN_K")) : 2048;  // tuning knobs
-            static const int split_min_m = getenv("PIE_W4M_SPLIT_MIN_M") ? atoi(getenv("PIE_W4M_SPLIT_MIN_M")) : 24;
-            static const int split_long_k = getenv("PIE_W4M_SPLIT_LONG_K") ? atoi(getenv("PIE_W4M_SPLIT_LONG_K")) : 8192;  // K from which any M splits
+            constexpr int split_min_k = 2048, split_min_m = 24, split_long_k = 8192;  // split_long_k: K from which any M splits
             const bool split = y32 && used32 && N / 32 < 256 && K >= split_min_k && (M >= split_min_m || K >= split_long_k) && split_k_enabled();
             // o_proj / down whose consumer can sum fp32 slabs: two strips per workgroup and a deeper, still deterministic K split
             // (k_w4m_gemm_lds4 with part): a quarter of x staged per workgroup for two strips instead of half of it for one
@@ -855,8 +842,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
                 return rc;
             if (!roped) {
-                static const int rw_env = getenv("PIE_ROPE_ROW_WGS") ? atoi(getenv("PIE_ROPE_ROW_WGS")) : 0;  // developer override
-                const unsigned row_wgs = sq.S > 1 ? (rw_env > 0 ? (unsigned)rw_env : (M < 512 ? 4u : 1u)) : 1u;  // few rows of slabs: four workgroups per row (256 tokens: 6.03 vs 6.20 ms; from 512 rows no difference)
+                const unsigned row_wgs = sq.S > 1 ? (M < 512 ? 4u : 1u) : 1u;  // few rows of slabs: four workgroups per row (256 tokens: 6.03 vs 6.20 ms; from 512 rows no difference)
                 decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
                 if (sq.S > 1) rope_k = &k_rope_append_rows<T, true, false>;
                 hipLaunchKernelGGL(rope_k, dim3(M, row_wgs), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, d->state, d->kv_table, li,

@@ -792,7 +792,8 @@ int engine_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, 
     else rc = engine_launch_t<F16>(a, c.head_dim, nsh, m->n_cus, p.total, st);
     if (rc || !with_logits) return rc;
     // log-softmax + greedy argmax (inference_engine.py:268-271): the launched tail, over one (max, sum exp, argmax) partial per consumer wave
-    return logits_tail_launch(c.dtype, logits_dst, c.vocab, d->stats, m->n_cus * RING_CONSUMERS, d->logprobs, d->token_out, d->state, d->history, d->hist_cap, st);
+    return logits_tail_launch(c.dtype, logits_dst, c.vocab, d->stats, m->n_cus * RING_CONSUMERS, d->logprobs, d->token_out, d->state, d->history, d->hist_cap, st,
+                              &m->sync->error);  // sticky give-up word: the tail then reports token -1
 }
 
 void *engine_prof_ptr(pie_decoder *d) { return d->engine ? (void *)d->engine->prof : nullptr; }

@@ -51,7 +51,7 @@ constexpr int TAIL_MAX_STATS = 4096;  // 256 threads x 16 register-resident part
 
 template <class T>
 __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V, const LogitStat *stats, int n_stats, float *logprobs,
-                                                       int *token, DecState *state, int *history, int hist_cap) {
+                                                       int *token, DecState *state, int *history, int hist_cap, const unsigned *err_word) {
     __shared__ float s_max[4], s_sum[4];
     __shared__ int s_arg[4];
     logits += (size_t)blockIdx.y * V, stats += (size_t)blockIdx.y * n_stats, logprobs += (size_t)blockIdx.y * V, token += blockIdx.y;  // batch row
@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(256) k_logits_finish(const u16 *logits, int V,
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (err_word && *err_word != 0u) tok = -1;  // the persistent launch gave up a bounded wait (sticky): no plausible-looking id from garbage
         *token = tok;
         if (state) {
             const int next_pos = state->pos + 1;  // the position the chosen token will occupy
@@ -120,10 +121,10 @@ static inline int logits_tail_rows_launch(int dtype, const u16 *logits, int V, i
     const dim3 g1(TAIL_STAT_TILES, rows), g2(TAIL_FINISH_BLOCKS, rows);
     if (dtype == PIE_BF16) {
         hipLaunchKernelGGL(k_logits_stats<BF16>, g1, dim3(256), 0, st, logits, V, stats_buf);
-        hipLaunchKernelGGL(k_logits_finish<BF16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0);
+        hipLaunchKernelGGL(k_logits_finish<BF16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0, (const unsigned *)nullptr);
     } else {
         hipLaunchKernelGGL(k_logits_stats<F16>, g1, dim3(256), 0, st, logits, V, stats_buf);
-        hipLaunchKernelGGL(k_logits_finish<F16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0);
+        hipLaunchKernelGGL(k_logits_finish<F16>, g2, dim3(256), 0, st, logits, V, stats_buf, TAIL_STAT_TILES, logprobs, tokens, nullptr, nullptr, 0, (const unsigned *)nullptr);
     }
     PIE_LAUNCH_CHECK();
     return PIE_OK;
@@ -132,7 +133,7 @@ static inline int logits_tail_rows_launch(int dtype, const u16 *logits, int V, i
 // stats == nullptr (op-level API): the per-tile partials are computed from the logits first, into
 // stream-ordered scratch (hipMallocAsync; the decoder path passes its own stats and never allocates).
 static inline int logits_tail_launch(int dtype, const u16 *logits, int V, const LogitStat *stats, int n_stats, float *logprobs,
-                                     int *token, DecState *state, int *history, int hist_cap, hipStream_t st) {
+                                     int *token, DecState *state, int *history, int hist_cap, hipStream_t st, const unsigned *err_word = nullptr) {
     if (dtype != PIE_BF16 && dtype != PIE_F16) return pie::fail(PIE_E_ARG, "logits tail: dtype must be PIE_BF16 or PIE_F16");
     if (stats && n_stats > TAIL_MAX_STATS) return pie::fail(PIE_E_SHAPE, "logits tail: too many partials");
     LogitStat *tmp = nullptr;
@@ -145,9 +146,9 @@ static inline int logits_tail_launch(int dtype, const u16 *logits, int V, const 
         stats = tmp, n_stats = TAIL_STAT_TILES;
     }
     if (dtype == PIE_BF16)
-        hipLaunchKernelGGL(k_logits_finish<BF16>, dim3(TAIL_FINISH_BLOCKS), dim3(256), 0, st, logits, V, stats, n_stats, logprobs, token, state, history, hist_cap);
+        hipLaunchKernelGGL(k_logits_finish<BF16>, dim3(TAIL_FINISH_BLOCKS), dim3(256), 0, st, logits, V, stats, n_stats, logprobs, token, state, history, hist_cap, err_word);
     else
-        hipLaunchKernelGGL(k_logits_finish<F16>, dim3(TAIL_FINISH_BLOCKS), dim3(256), 0, st, logits, V, stats, n_stats, logprobs, token, state, history, hist_cap);
+        hipLaunchKernelGGL(k_logits_finish<F16>, dim3(TAIL_FINISH_BLOCKS), dim3(256), 0, st, logits, V, stats, n_stats, logprobs, token, state, history, hist_cap, err_word);
     PIE_LAUNCH_CHECK();
     if (tmp) PIE_HIP_TRY(hipFreeAsync(tmp, st));
     return PIE_OK;

@@ -168,6 +168,8 @@ __global__ void __launch_bounds__(256) k_tp_tail_stats(unsigned long long *const
             if (gm[r] == GM) gtok = min(gtok, __float_as_int(ga[r]));
         }
         *lse_out = GM + logf(S);
+        // a collective of this step gave up (sticky error word): the sums are not sums -- the host sees token -1 instead of a plausible id
+        if (__hip_atomic_load(epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) gtok = -1;
         *token = gtok;
         if (state) {
             const int next_pos = state->pos + 1;
@@ -237,6 +239,13 @@ int pie_comm_create(int rank, int world, size_t max_elems, pie_comm **out) {
     hipError_t e = hipExtMallocWithFlags((void **)&c->recv, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        // A peer's stores into coarse-grained memory are not guaranteed visible to a kernel that is polling it: every collective
+        // would spin for its whole bounded wait and then reduce zeros.  Only a single-rank communicator (nobody writes remotely) may
+        // fall back; with peers this is an error at creation, not a 2-second timeout per step later.
+        if (world > 1) {
+            (void)pie_comm_destroy(c);
+            return pie::fail(PIE_E_HIP, "pie_comm_create: fine-grained device memory (hipDeviceMallocFinegrained) is unavailable; peers' stores would not be visible to a polling kernel");
+        }
         e = hipMalloc((void **)&c->recv, bytes);
     }
     if (e != hipSuccess || hipMemset(c->recv, 0, bytes) != hipSuccess || hipMalloc((void **)&c->epoch, 16) != hipSuccess ||

@@ -253,11 +253,7 @@ static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
 // Persistent grid: one wave per row pair until the chip is full (16 waves per CU), then longer runs per wave.
 int w4s_gemv_waves(int N, int K) {
     (void)K;
-    static const int max_waves = [] {  // tuning knob for experiments: PIE_GEMV_MAX_WAVES overrides the resident-wave budget
-        const char *e = getenv("PIE_GEMV_MAX_WAVES");
-        const int v = e ? atoi(e) : 0;
-        return v >= 256 ? v : GEMV_MAX_WAVES;
-    }();
+    constexpr int max_waves = GEMV_MAX_WAVES;
     const int n_pairs = N / 2;
     int waves = n_pairs < max_waves ? n_pairs : max_waves;
     const int need = (n_pairs + GEMV_MAX_RUN - 1) / GEMV_MAX_RUN;  // a wave's run must fit its epilogue lanes

@@ -1110,16 +1110,6 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const char *w16m, const u16 *
 static void w16l_plan(int M, int N, int K, int *mt_out, int *s_out) {
     const int groups = (K + 255) / 256 * 4, col_t = ((N + 31) / 32 + 7) / 8;
     const int mt_max = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-    {  // developer override for sweeps: PIE_W16L_MT (64 / 128 / 256), PIE_W16L_S (a valid split)
-        const char *em = getenv("PIE_W16L_MT"), *es = getenv("PIE_W16L_S");
-        if (em && es) {
-            const int mt = atoi(em), sp = atoi(es);
-            if ((mt == 64 || mt == 128 || mt == 256) && mt <= mt_max && sp >= 1 && sp <= 16 && groups % (4 * sp) == 0) {
-                *mt_out = mt, *s_out = sp;
-                return;
-            }
-        }
-    }
     int best_mt = mt_max, best_s = 1, best_wgs = 0;
     for (int mt = mt_max; mt >= 64; mt >>= 1) {
         const int row_t = (M + mt - 1) / mt;
@@ -1193,21 +1183,10 @@ struct W4lPlan {
     bool v2;
 };
 static W4lPlan w4l_plan(int M, int N, int K) {
-    static const bool v2_on = [] {
-        const char *e = getenv("PIE_W4L2");  // A/B switch: 0 = the 8-wave register-staged form only
-        return !(e && e[0] == '0');
-    }();
     const int groups = K >> 6, col_t = (N / 32 + 7) / 8;
     const int mt_max = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-    if (v2_on && groups % 4 == 0 && M > 32) {
-        {  // developer override for sweeps: PIE_W4L_MT (64 / 128 / 256) and PIE_W4L_S (a valid split)
-            const char *em = getenv("PIE_W4L_MT"), *es = getenv("PIE_W4L_S");
-            if (em && es) {
-                const int mt = atoi(em), sp = atoi(es);
-                if ((mt == 64 || mt == 128 || mt == 256) && mt <= mt_max && sp >= 1 && sp <= 16 && groups % (4 * sp) == 0) return {mt, sp, true};
-            }
-        }
-        // a small cost model, calibrated on the 8B shapes at 512 / 1024 / 2048 rows (scripts/bench_w4l.py with PIE_W4L_MT / PIE_W4L_S):
+    if (groups % 4 == 0 && M > 32) {
+        // a small cost model, calibrated on the 8B shapes at 512 / 1024 / 2048 rows (scripts/bench_w4l.py, swept with a developer override of the plan):
         // a K step costs ~1.30 / 0.85 / 0.75 us for 256 / 128 / 64-row tiles (below 256 rows the conversion of the weights, which does
         // not shrink with the tile, bounds the step), workgroups run in rounds of 256, a K split pays an fp32 write + read of S + 1
         // [M, N] slabs at ~1.3 TB/s.  The plan is the cheapest (row tile, split) under it.
@@ -1338,8 +1317,7 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     PIE_REQUIRE(!y32 || K >= 1024, PIE_E_SHAPE, "W4M GEMM: the K-split form needs K >= 1024 (both halves non-empty)");
     const dim3 grid(N >> 5, y32 ? 2 : 1), block(W4M_WAVES * 64);
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
-    const char *e = getenv("PIE_W4M_STAGE_MIN");  // rows from which x is staged through LDS (tuning / test knob)
-    const int stage_min = e ? atoi(e) : 24;  // measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
+    constexpr int stage_min = 24;  // rows from which x is staged through LDS; measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     const int n_strips = N >> 5;
     const char *ne = getenv("PIE_W4M_MULTI");  // 0: one strip per workgroup also for the wide matrices (A/B, bit-equality test)
     if (!y32 && n_strips >= 512 && K >= 512 && !(ne && ne[0] == '0')) {  // at every row count: 24.1-25.8 us on gate|up against 32.6-37.2 (persistent form) / 35.0 (staged, one strip)
@@ -1352,8 +1330,7 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
         PIE_LAUNCH_CHECK();
         return PIE_OK;
     }
-    const char *pe = getenv("PIE_W4M_PERSIST");  // 0: never use the persistent form (tuning / test knob)
-    if (M < stage_min && !y32 && n_strips > 512 && K >= 512 && !(pe && pe[0] == '0')) {
+    if (M < stage_min && !y32 && n_strips > 512 && K >= 512) {
         const int per = (n_strips + 511) / 512;                 // strips per workgroup, balanced: 896 -> 448 x 2, 4008 -> 501 x 8
         const dim3 pgrid((n_strips + per - 1) / per);
         if (dtype == PIE_BF16)

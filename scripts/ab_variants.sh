@@ -14,5 +14,5 @@ for rep in 1 2 3; do
     [ -f $R/tools/variants/$v/libpie_hip.so ] || { echo "no such variant: tools/variants/$v/libpie_hip.so (scripts/build_variant.sh $v ...)"; exit 1; }
     run $v LD_LIBRARY_PATH=$R/tools/variants/$v   # step_bench prints the library it loaded
   done
-  run nopf PIE_PREFETCH_MB=-1
+
 done
