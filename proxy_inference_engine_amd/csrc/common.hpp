@@ -49,6 +49,12 @@ struct BF16 {
     // per word instead of three.
     static constexpr float ODD_SCALE = 0.0625f;
     static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]);
+    // the same in two steps, for kernels that multiply one code word with several activation rows: the four dot2 operands of a word
+    // (the masking, 5 of the 9 instructions per word) are formed once and reused per row
+    static __device__ __forceinline__ void word_ops(u32 w, u32 (&e)[4]) {
+        const u32 w8 = w >> 8;
+        e[0] = w & 0x000F000Fu, e[1] = w & 0x00F000F0u, e[2] = w8 & 0x000F000Fu, e[3] = w8 & 0x00F000F0u;
+    }
     static __device__ __forceinline__ u32 bytes2(u32 masked) { return masked; }  // two 8-bit codes in the 16-bit halves, as operands
     static __device__ __forceinline__ float to_f32(u16 b) { return __builtin_bit_cast(float, (u32)b << 16); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (__bf16)f); }  // v_cvt_pk_bf16_f32, RNE
@@ -74,6 +80,9 @@ struct F16 {
     }
     static constexpr float ODD_SCALE = 1.0f;
     static __device__ __forceinline__ u32 bytes2(u32 masked) { return codes2(masked); }  // 0x6400|q = 1024+q is exact up to q = 1023
+    static __device__ __forceinline__ void word_ops(u32 w, u32 (&e)[4]) {
+        e[0] = codes2(w & 0x000F000Fu), e[1] = codes2((w >> 4) & 0x000F000Fu), e[2] = codes2((w >> 8) & 0x000F000Fu), e[3] = codes2((w >> 12) & 0x000F000Fu);
+    }
     static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]) {
         d[0] = dot2(codes2(w & 0x000F000Fu), x0, d[0]);
         d[1] = dot2(codes2((w >> 4) & 0x000F000Fu), x1, d[1]);

@@ -940,14 +940,66 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     splits = splits < 1 ? 1 : splits;
     // short sequences (tables of at most 8 pages) in a batch that fills half the chip by itself: one split, and no combine launch
     if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 128)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
+    // a handful of short sequences: one split as well -- the split kernel + its combine launch cost 10.6 us per layer against 5.5 for the
+    // batch-1 step's attention, and a few hundred positions are a handful of row blocks per wave
+    if (B <= GEMV_ROWS_MAX && max_blocks <= 4 && !d->kv_i8) splits = 1;
     int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
+    const int lm_waves = w4s_gemv_waves(c.vocab, H);  // the fused few-sequence form: one log-softmax partial per GEMV wave and row
+    const size_t stats_per_row = (size_t)(lm_waves > TAIL_STAT_TILES ? lm_waves : TAIL_STAT_TILES);
     if (s->tail_rows < B) {
         if (s->tail_stats) (void)hipFree(s->tail_stats);
         s->tail_stats = nullptr, s->tail_rows = 0;
-        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)B));
+        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * stats_per_row * (size_t)B));
         s->tail_rows = B, ++s->alloc_gen;
+    }
+    // Up to 5 sequences on an int4 checkpoint: the batch-1 launch sequence, once, with every GEMV multiplying all rows per weight
+    // unit (k_w4s_gemv_rows: RMSNorm prologues; RoPE + page append, residual, SwiGLU and logits epilogues, per row) -- 6 launches per
+    // layer instead of 9-10, each row in MLX's row-by-row fp32 regime.  Biases, int8 pages and hidden sizes beyond 8192 take the
+    // general path below.
+    bool fused_rows = B <= GEMV_ROWS_MAX && d->uniform_int4() && !d->kv_i8 && H <= 8192 && lm_waves <= TAIL_MAX_STATS;
+    for (const pie_layer_weights &w : d->layers)
+        if (w.bqkv || w.bo || w.bgateup || w.bdown) fused_rows = false;
+    if (fused_rows) {
+        rc = embedding_launch(tokens, B, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr, nullptr, 0, st, 4);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rope_cs_rows, dim3(B), dim3(64), 0, st, d->glob.rope_freqs, nullptr, ctx_len, D / 2, s->rope_cs);
+        PIE_LAUNCH_CHECK();
+        for (int li = 0; li < c.n_layers; ++li) {
+            const pie_layer_weights &w = d->layers[li];
+            GemvRowsArgs g = {};
+            g.w = (const char *)w.wqkv, g.K = H, g.N = NQKV, g.M = B, g.x = s->x, g.norm_w = (const u16 *)w.attn_norm, g.eps = c.rms_eps;
+            g.rope_cs = s->rope_cs, g.ctx_len = ctx_len, g.block_table = block_tables, g.slab = (u16 *)slabs[li], g.q_out = s->q;
+            g.bt_stride = max_blocks, g.n_pages = n_pages, g.n_heads = c.n_heads, g.n_kv_heads = c.n_kv_heads, g.head_dim = D, g.rope_traditional = c.rope_traditional;
+            if ((rc = w4s_gemv_rows_fused_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, g, st))) return rc;
+            AttnArgs a = {};
+            a.q = s->q, a.slab = (const u16 *)slabs[li], a.block_table = block_tables, a.ctx_len = ctx_len, a.bt_stride = max_blocks, a.n_pages = n_pages;
+            a.rows = B, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = splits, a.scale = 1.0f / sqrtf((float)D);
+            a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;
+            a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
+            if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+            g = GemvRowsArgs();
+            g.w = (const char *)w.wo, g.K = QD, g.N = H, g.M = B, g.x = s->attn, g.resid = s->x;
+            if ((rc = w4s_gemv_rows_fused_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, g, st))) return rc;
+            g = GemvRowsArgs();
+            g.w = (const char *)w.wgateup, g.K = H, g.N = 2 * I, g.M = B, g.x = s->x, g.norm_w = (const u16 *)w.mlp_norm, g.eps = c.rms_eps, g.y = s->act;
+            if ((rc = w4s_gemv_rows_fused_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, g, st))) return rc;
+            g = GemvRowsArgs();
+            g.w = (const char *)w.wdown, g.K = I, g.N = H, g.M = B, g.x = s->act, g.resid = s->x;
+            if ((rc = w4s_gemv_rows_fused_launch(c.dtype, PRO_NONE, EPI_RESIDUAL, g, st))) return rc;
+        }
+        GemvRowsArgs g = {};
+        g.w = (const char *)d->glob.lm_head, g.K = H, g.N = c.vocab, g.M = B, g.x = s->x, g.norm_w = (const u16 *)d->glob.final_norm, g.eps = c.rms_eps;
+        g.y = logits, g.stats = s->tail_stats;
+        if ((rc = w4s_gemv_rows_fused_launch(c.dtype, PRO_RMSNORM, EPI_LOGITS, g, st))) return rc;
+        const dim3 fg(TAIL_FINISH_BLOCKS, B);
+        if (c.dtype == PIE_BF16)
+            hipLaunchKernelGGL(k_logits_finish<BF16>, fg, dim3(256), 0, st, logits, c.vocab, s->tail_stats, lm_waves, logprobs, next_tokens, (DecState *)nullptr, (int *)nullptr, 0, (const unsigned *)nullptr);
+        else
+            hipLaunchKernelGGL(k_logits_finish<F16>, fg, dim3(256), 0, st, logits, c.vocab, s->tail_stats, lm_waves, logprobs, next_tokens, (DecState *)nullptr, (int *)nullptr, 0, (const unsigned *)nullptr);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
     }
     rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(tokens, B, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)

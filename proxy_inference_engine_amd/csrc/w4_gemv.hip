@@ -292,21 +292,63 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
 }
 
-template <class T, int MR>
+template <class T, int MR, int PRO, int EPI>
 static int rows_launch_t(const GemvRowsArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        PIE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_w4s_gemv_rows<T, MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        PIE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_w4s_gemv_rows<T, MR, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_w4s_gemv_rows<T, MR>), grid, dim3(GEMV_WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((k_w4s_gemv_rows<T, MR, PRO, EPI>), grid, dim3(GEMV_WAVES * 64), lds, st, a);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
+template <class T, int PRO, int EPI>
+static int rows_launch_mr(const GemvRowsArgs &a, int mr, dim3 grid, unsigned lds, hipStream_t st) {
+    switch (mr) {
+        case 1: return rows_launch_t<T, 1, PRO, EPI>(a, grid, lds, st);
+        case 2: return rows_launch_t<T, 2, PRO, EPI>(a, grid, lds, st);
+        case 3: return rows_launch_t<T, 3, PRO, EPI>(a, grid, lds, st);
+        case 4: return rows_launch_t<T, 4, PRO, EPI>(a, grid, lds, st);
+        default: return rows_launch_t<T, 5, PRO, EPI>(a, grid, lds, st);
+    }
+}
+template <class T>
+static int rows_launch_pe(int pro, int epi, const GemvRowsArgs &a, int mr, dim3 grid, unsigned lds, hipStream_t st) {
+    if (pro == PRO_NONE && epi == EPI_STORE) return rows_launch_mr<T, PRO_NONE, EPI_STORE>(a, mr, grid, lds, st);
+    if (pro == PRO_NONE && epi == EPI_RESIDUAL) return rows_launch_mr<T, PRO_NONE, EPI_RESIDUAL>(a, mr, grid, lds, st);
+    if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) return rows_launch_mr<T, PRO_RMSNORM, EPI_SWIGLU>(a, mr, grid, lds, st);
+    if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) return rows_launch_mr<T, PRO_RMSNORM, EPI_ROPE_KV>(a, mr, grid, lds, st);
+    if (pro == PRO_RMSNORM && epi == EPI_LOGITS) return rows_launch_mr<T, PRO_RMSNORM, EPI_LOGITS>(a, mr, grid, lds, st);
+    return pie::fail(PIE_E_ARG, "w4s_gemv_rows: prologue / epilogue combination not instantiated");
+}
+
+int w4s_gemv_rows_fused_launch(int dtype, int pro, int epi, GemvRowsArgs &a, hipStream_t stream) {
+    PIE_REQUIRE(a.w && a.x, PIE_E_ARG, "w4s_gemv_rows: null pointer");
+    PIE_REQUIRE(a.K % 64 == 0 && a.K > 0 && a.K <= 32768 && a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv_rows: K must be a multiple of 64 (<= 32768), N even");
+    PIE_REQUIRE(a.M >= 1 && a.M <= GEMV_ROWS_MAX, PIE_E_SHAPE, "w4s_gemv_rows: 1 .. 5 rows");
+    // every pointer the chosen prologue / epilogue dereferences, checked here so that a null can never reach the kernel
+    PIE_REQUIRE(pro != PRO_RMSNORM || (a.norm_w && a.K <= 8192), PIE_E_ARG, "w4s_gemv_rows: the RMSNorm prologue needs its weight and K <= 8192");
+    PIE_REQUIRE((epi != EPI_STORE && epi != EPI_LOGITS && epi != EPI_SWIGLU) || a.y, PIE_E_ARG, "w4s_gemv_rows: null output");
+    PIE_REQUIRE(epi != EPI_RESIDUAL || a.resid, PIE_E_ARG, "w4s_gemv_rows: EPI_RESIDUAL without a residual stream");
+    PIE_REQUIRE(epi != EPI_LOGITS || a.stats, PIE_E_ARG, "w4s_gemv_rows: EPI_LOGITS without a partials buffer");
+    PIE_REQUIRE(epi != EPI_ROPE_KV || (a.rope_cs && a.ctx_len && a.block_table && a.slab && a.q_out && a.n_pages > 0 && a.bt_stride > 0 && a.head_dim > 0), PIE_E_ARG,
+                "w4s_gemv_rows: EPI_ROPE_KV needs the rows' RoPE table, context lengths, block tables, the slab and q_out");
+    a.n_slices = w4s_slices(a.K), a.n_pairs = a.N / 2, a.n_waves = w4s_gemv_waves(a.N, a.K);
+    PIE_REQUIRE((size_t)a.n_pairs * a.n_slices * W4S_UNIT_BYTES < ((size_t)1 << 32) - 8192, PIE_E_SHAPE, "w4s_gemv_rows: one matrix must stay below 4 GiB");
+    // rows per workgroup: all of them where their LDS images fit, else the fewest equal chunks (K = 14336: 5 rows -> 3 + 2)
+    int mr_fit = GEMV_ROWS_MAX;
+    while (mr_fit > 1 && gemv_rows_lds_bytes(a.K, mr_fit) > 160u * 1024u) --mr_fit;
+    PIE_REQUIRE(gemv_rows_lds_bytes(a.K, mr_fit) <= 160u * 1024u, PIE_E_SHAPE, "w4s_gemv_rows: activation vector does not fit LDS");
+    const int chunks = (a.M + mr_fit - 1) / mr_fit, mr = (a.M + chunks - 1) / chunks;
+    const unsigned lds = gemv_rows_lds_bytes(a.K, mr);
+    const dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, chunks);
+    if (dtype == PIE_BF16) return rows_launch_pe<BF16>(pro, epi, a, mr, grid, lds, stream);
+    if (dtype == PIE_F16) return rows_launch_pe<F16>(pro, epi, a, mr, grid, lds, stream);
+    return pie::fail(PIE_E_ARG, "w4s_gemv_rows: dtype must be PIE_BF16 or PIE_F16");
+}
 
 int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 *x, int M, u16 *y, const u16 *lin_bias, hipStream_t stream) {
-    PIE_REQUIRE(packed && x && y, PIE_E_ARG, "w4s_gemv_rows: null pointer");
-    PIE_REQUIRE(K % 64 == 0 && K > 0 && K <= 32768 && N % 2 == 0 && N > 0, PIE_E_SHAPE, "w4s_gemv_rows: K must be a multiple of 64 (<= 32768), N even");
     PIE_REQUIRE(M >= 1 && M <= GEMV_ROWS_MAX, PIE_E_SHAPE, "w4s_gemv_rows: 1 .. 5 rows");
     if (M == 1) {
         GemvArgs g = {};
@@ -315,27 +357,7 @@ int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 
     }
     GemvRowsArgs a = {};
     a.w = (const char *)packed, a.K = K, a.N = N, a.M = M, a.x = x, a.y = y, a.lin_bias = lin_bias;
-    a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
-    PIE_REQUIRE((size_t)a.n_pairs * a.n_slices * W4S_UNIT_BYTES < ((size_t)1 << 32) - 8192, PIE_E_SHAPE, "w4s_gemv_rows: one matrix must stay below 4 GiB");
-    // rows per workgroup: all of them where their LDS images fit, else the fewest equal chunks (K = 14336: 5 rows -> 3 + 2)
-    int mr_fit = GEMV_ROWS_MAX;
-    while (mr_fit > 1 && gemv_rows_lds_bytes(K, mr_fit) > 160u * 1024u) --mr_fit;
-    PIE_REQUIRE(gemv_rows_lds_bytes(K, mr_fit) <= 160u * 1024u, PIE_E_SHAPE, "w4s_gemv_rows: activation vector does not fit LDS");
-    const int chunks = (M + mr_fit - 1) / mr_fit, mr = (M + chunks - 1) / chunks;
-    const unsigned lds = gemv_rows_lds_bytes(K, mr);
-    const dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, chunks);
-#define PIE_ROWS(TT)                                                   \
-    switch (mr) {                                                      \
-        case 1: return rows_launch_t<TT, 1>(a, grid, lds, stream);    \
-        case 2: return rows_launch_t<TT, 2>(a, grid, lds, stream);    \
-        case 3: return rows_launch_t<TT, 3>(a, grid, lds, stream);    \
-        case 4: return rows_launch_t<TT, 4>(a, grid, lds, stream);    \
-        default: return rows_launch_t<TT, 5>(a, grid, lds, stream);   \
-    }
-    if (dtype == PIE_BF16) { PIE_ROWS(BF16) }
-    if (dtype == PIE_F16) { PIE_ROWS(F16) }
-#undef PIE_ROWS
-    return pie::fail(PIE_E_ARG, "w4s_gemv_rows: dtype must be PIE_BF16 or PIE_F16");
+    return w4s_gemv_rows_fused_launch(dtype, PRO_NONE, EPI_STORE, a, stream);
 }
 
 // ---------------------------------------------------------------- C ABI

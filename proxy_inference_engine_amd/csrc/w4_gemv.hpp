@@ -102,6 +102,29 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
     return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
 }
 
+// The same dot product in two steps (several activation rows per code word): operands once, four chains per row -- bit-identical to
+// w4s_unit_dot (the same operands enter the same v_dot2c chains in the same order).
+template <class T>
+__device__ __forceinline__ void w4s_unit_ops(const uint4 &c0, const uint4 &c1, u32 (&e)[32]) {
+    const u32 w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u32 q[4];
+        T::word_ops(w[t], q);
+        e[4 * t] = q[0], e[4 * t + 1] = q[1], e[4 * t + 2] = q[2], e[4 * t + 3] = q[3];
+    }
+}
+template <class T>
+__device__ __forceinline__ float w4s_ops_dot(const u32 (&e)[32], const u32 (&xr)[32]) {
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = T::dot2(e[4 * t + i], xr[4 * t + i], d[i]);
+    }
+    return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
+}
+
 // W8S: 16 code words (4 codes each) against the group's 32 packed activation pairs; word i covers pairs 2i, 2i+1.
 template <class T>
 __device__ __forceinline__ float w8s_unit_dot(const uint4 &c0, const uint4 &c1, const uint4 &c2, const uint4 &c3, const u32 (&xr)[32]) {
@@ -471,26 +494,38 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
 }
 
 // ---------------------------------------------------------------- a few activation rows against ONE pass over the weights
-// y[m, :] = T(x[m, :] @ W^T) (+ bias) for 2 .. 5 rows (MLX's qmv regime: below 6 rows nn.QuantizedLinear multiplies row by row in
-// exact fp32, mx.quantized_matmul): the same persistent-wave stream as k_w4s_gemv with the MR rows' activation images side by side
-// in LDS -- every weight unit is fetched once and multiplied MR times, each row with the batch-1 kernel's arithmetic in the
-// batch-1 kernel's order, so a row's result is bit-identical to that row multiplied alone.  (k_w4s_gemv with blockIdx.y = row
-// streams the matrix once per row: two sequences cost two batch-1 steps.)  W4S only; no prologue, plain-store epilogue.
+// y[m, :] = T(x[m, :] @ W^T) for 2 .. 5 rows (MLX's qmv regime: below 6 rows nn.QuantizedLinear multiplies row by row in exact
+// fp32, mx.quantized_matmul): the same persistent-wave stream as k_w4s_gemv with the MR rows' activation images side by side in
+// LDS -- every weight unit is fetched once and multiplied MR times, each row with the batch-1 kernel's arithmetic in the batch-1
+// kernel's order, so a row's result is bit-identical to that row multiplied alone.  (k_w4s_gemv with blockIdx.y = row streams
+// the matrix once per row: two sequences cost two batch-1 steps.)  W4S only.  The same prologues / epilogues as the batch-1
+// kernel, per row: RMSNorm; plain store (+ bias) | residual add | SwiGLU | RoPE + append to the row's own page | logits + per-wave
+// log-softmax partials -- the multi-sequence decode step of up to 5 sequences is then the batch-1 launch sequence, once.
 struct GemvRowsArgs {
     const char *w;
     int n_pairs, n_slices, n_waves, K, N, M;
-    const u16 *x;  // [M, K]
-    u16 *y;        // [M, N]
-    const u16 *lin_bias;
+    const u16 *x;        // [M, K]
+    const u16 *norm_w;   // PRO_RMSNORM
+    float eps;
+    u16 *y;              // EPI_STORE / EPI_LOGITS [M, N]; EPI_SWIGLU act [M, N / 2]
+    const u16 *lin_bias; // EPI_STORE only
+    u16 *resid;          // EPI_RESIDUAL [M, N], updated in place
+    LogitStat *stats;    // EPI_LOGITS [M, n_waves]
+    // EPI_ROPE_KV: every row is its own sequence (pie_decoder_step_batch): position ctx_len[m] - 1 (< 0: idle slot), K / V rows to page
+    // block_table[m * bt_stride + pos / 64] of this layer's slab (K block then V block, each [n_kv_heads, 64, head_dim])
+    const float *rope_cs;  // [M, head_dim / 2, 2] (cos, sin) of every row's position (k_rope_cs_rows)
+    const int *ctx_len, *block_table;
+    u16 *slab, *q_out;     // q_out [M, n_heads, head_dim]
+    int bt_stride, n_pages, n_heads, n_kv_heads, head_dim, rope_traditional;
 };
 static inline __host__ __device__ unsigned gemv_rows_image_bytes(int K) { return (unsigned)((gemv_lds(K).off_red + 15) & ~15); }
 static inline __host__ __device__ unsigned gemv_rows_lds_bytes(int K, int MR) {
-    return (unsigned)MR * (gemv_rows_image_bytes(K) + GEMV_WAVES * 2 * GEMV_MAX_RUN * 4);
+    return (unsigned)MR * (gemv_rows_image_bytes(K) + GEMV_WAVES * 2 * GEMV_MAX_RUN * 4) + 64u * (unsigned)MR;  // images | row sums | RMSNorm partials
 }
 
-template <class T, int MR>
+template <class T, int MR, int PRO, int EPI>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const GemvRowsArgs a) {
-    constexpr int D = GEMV_DEPTH, UB = W4S_UNIT_BYTES, NT = GEMV_WAVES * 64;
+    constexpr int D = GEMV_DEPTH, UB = W4S_UNIT_BYTES, NT = GEMV_WAVES * 64, NPT = 2;  // NPT: activation pieces per thread of a NORMALISED input (K <= 8192)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -499,7 +534,9 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
     const unsigned img = gemv_rows_image_bytes(a.K);
     const int row0 = blockIdx.y * MR;
     const int nr = a.M - row0 < MR ? a.M - row0 : MR;  // rows of this chunk (wave-uniform)
-    float *outp = reinterpret_cast<float *>(smem + (size_t)MR * img) + wave * (2 * GEMV_MAX_RUN);  // + r * GEMV_WAVES * 2 * GEMV_MAX_RUN per row
+    constexpr int OUT_ROW = GEMV_WAVES * 2 * GEMV_MAX_RUN;
+    float *outp = reinterpret_cast<float *>(smem + (size_t)MR * img) + wave * (2 * GEMV_MAX_RUN);  // + r * OUT_ROW per activation row
+    float *red = reinterpret_cast<float *>(smem + (size_t)MR * img) + MR * OUT_ROW;                // [MR][16]
 
     const int gw = blockIdx.x * GEMV_WAVES + wave;
     const int W = a.n_waves;
@@ -525,30 +562,107 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
         c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
         sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, 2);
     };
-    // the rows' activations first (their loads retire before the weight stream's), then the head of the stream
+    // 1. the rows' activations (their loads retire before the weight stream's), then the head of the stream
     const int n_pieces = a.K >> 3;
-    const int n_iter = (n_pieces + NT - 1) / NT;
-    for (int r = 0; r < nr; ++r) {
-        const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + r) * a.K);
+    auto publish = [&](int r, int j, const uint4 &v) {  // piece j of row r -> its LDS image, group sums by DPP over 8 lanes
         char *im = smem + (size_t)r * img;
-        float *sxs = reinterpret_cast<float *>(im + L.off_sx);
-        for (int i = 0; i < n_iter; ++i) {
-            const int j = threadIdx.x + i * NT;
-            const bool ok = j < n_pieces;
-            const uint4 v = xg[ok ? j : n_pieces - 1];
-            float ps = ok ? sum8<T>(v) : 0.0f;
-            ps = lanes8_sum(ps);
-            if (ok) {
-                *reinterpret_cast<uint4 *>(im + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = scale8<T>(v);
-                if ((j & 7) == 0) sxs[j >> 3] = ps;
+        const bool ok = j < n_pieces;
+        float ps = ok ? sum8<T>(v) : 0.0f;
+        ps = lanes8_sum(ps);
+        if (ok) {
+            *reinterpret_cast<uint4 *>(im + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = scale8<T>(v);
+            if ((j & 7) == 0) reinterpret_cast<float *>(im + L.off_sx)[j >> 3] = ps;
+        }
+    };
+    if constexpr (PRO == PRO_RMSNORM) {  // mx.fast.rms_norm per row, with the batch-1 prologue's summation tree
+        uint4 xv[MR][NPT], nv[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            int j = threadIdx.x + i * NT;
+            j = j < n_pieces ? j : n_pieces - 1;
+            nv[i] = reinterpret_cast<const uint4 *>(a.norm_w)[j];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) xv[r][i] = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + (r < nr ? r : 0)) * a.K)[j];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            float ssq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const bool ok = threadIdx.x + i * NT < n_pieces;
+                const u32 v[4] = {xv[r][i].x, xv[r][i].y, xv[r][i].z, xv[r][i].w};
+                float q = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = lo_f32<T>(v[k]), hi = hi_f32<T>(v[k]);
+                    q = fmaf(lo, lo, q);
+                    q = fmaf(hi, hi, q);
+                }
+                ssq += ok ? q : 0.0f;
+            }
+            ssq = half_wave_sum(ssq);
+            ssq = lane_value(ssq, 31) + lane_value(ssq, 63);
+            if (lane == 0) red[r * 16 + wave] = ssq;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float4 ra = *reinterpret_cast<const float4 *>(red + r * 16), rb = *reinterpret_cast<const float4 *>(red + r * 16 + 4);
+            const float tot = ((ra.x + ra.y) + (ra.z + ra.w)) + ((rb.x + rb.y) + (rb.z + rb.w));
+            const float inv = 1.0f / sqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const u32 v[4] = {xv[r][i].x, xv[r][i].y, xv[r][i].z, xv[r][i].w}, g[4] = {nv[i].x, nv[i].y, nv[i].z, nv[i].w};
+                u32 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = pack2<T>(round_T<T>(lo_f32<T>(v[k]) * inv) * lo_f32<T>(g[k]), round_T<T>(hi_f32<T>(v[k]) * inv) * hi_f32<T>(g[k]));
+                if (r < nr && i * NT < n_pieces) publish(r, threadIdx.x + i * NT, make_uint4(o[0], o[1], o[2], o[3]));
             }
         }
-    }
+    } else {
+        const int n_iter = (n_pieces + NT - 1) / NT;
+        for (int r = 0; r < nr; ++r) {
+            const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + r) * a.K);
+            for (int i = 0; i < n_iter; ++i) {
+                const int j = threadIdx.x + i * NT;
+                publish(r, j, xg[j < n_pieces ? j : n_pieces - 1]);
+            }
+        }
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(d);
+        for (int d = 0; d < D; ++d) issue(d);
+    }
     __syncthreads();
 
+    // 2. the stream: every unit once; its dot2 operands are formed once (5 of the 9 VALU instructions per code word) and multiplied
+    //    with every row.  XREG: for K of at most two slices and at most two rows the rows' activations live in registers (2 x MR x 33),
+    //    otherwise they are re-read from the LDS images per unit (8 x ds_read_b128 per row).
     const int n_groups = a.K >> 6;
+    constexpr bool XREG = MR <= 2 && D == 2;
+    const bool xreg = XREG && ns == 2;  // wave-uniform; with two slices per row and a ring of two, ring slot d always holds slice d: static indexing
+    u32 xc[XREG ? 2 : 1][XREG ? MR : 1][32];
+    float sxc[XREG ? 2 : 1][XREG ? MR : 1];
+    auto load_x = [&](int r, int slice, u32 (&xr)[32], float &sx) {
+        const int g2 = slice * 32 + (lane & 31);
+        const int gc2 = g2 < n_groups ? g2 : n_groups - 1;
+        const char *im = smem + (size_t)r * img;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(im + ((size_t)q * L.stride + gc2) * 16);
+            xr[4 * q + 0] = v.x, xr[4 * q + 1] = v.y, xr[4 * q + 2] = v.z, xr[4 * q + 3] = v.w;
+        }
+        sx = reinterpret_cast<const float *>(im + L.off_sx)[gc2];
+    };
+    if constexpr (XREG) {
+        if (xreg) {
+#pragma unroll
+            for (int sl2 = 0; sl2 < 2; ++sl2)
+#pragma unroll
+                for (int r = 0; r < MR; ++r) load_x(r < nr ? r : 0, sl2, xc[sl2][r], sxc[sl2][r]);
+        }
+    }
     float acc[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) acc[r] = 0.0f;
@@ -559,22 +673,26 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
             if (base + d < n_units) {  // wave-uniform
                 if (((((base + d) >> 1) + (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1);  // the two waves of a SIMD take turns (k_w4s_gemv)
                 else __builtin_amdgcn_s_setprio(0);
-                const int g = sl * 32 + (lane & 31);
-                const bool gvalid = g < n_groups;
-                const int gc = gvalid ? g : n_groups - 1;
+                const bool gvalid = sl * 32 + (lane & 31) < n_groups;
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
+                u32 e[32];
+                w4s_unit_ops<T>(c0[d], c1[d], e);
 #pragma unroll
                 for (int r = 0; r < MR; ++r) {
                     if (r < nr) {
-                        const char *im = smem + (size_t)r * img;
-                        u32 xr[32];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const uint4 v = *reinterpret_cast<const uint4 *>(im + ((size_t)q * L.stride + gc) * 16);
-                            xr[4 * q + 0] = v.x, xr[4 * q + 1] = v.y, xr[4 * q + 2] = v.z, xr[4 * q + 3] = v.w;
+                        float dd, sx;
+                        bool done = false;
+                        if constexpr (XREG) {
+                            if (xreg) {
+                                dd = w4s_ops_dot<T>(e, xc[d & 1][r]), sx = sxc[d & 1][r];
+                                done = true;
+                            }
                         }
-                        const float sx = reinterpret_cast<const float *>(im + L.off_sx)[gc];
-                        const float dd = w4s_unit_dot<T>(c0[d], c1[d], xr);
+                        if (!done) {
+                            u32 xr[32];
+                            load_x(r, sl, xr, sx);
+                            dd = w4s_ops_dot<T>(e, xr);
+                        }
                         const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
                         acc[r] += gvalid ? pr : 0.0f;
                     }
@@ -583,7 +701,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
 #pragma unroll
                     for (int r = 0; r < MR; ++r) {
                         const float tot = half_wave_sum(acc[r]);
-                        if ((lane & 31) == 31) outp[r * (GEMV_WAVES * 2 * GEMV_MAX_RUN) + 2 * pl + (lane >> 5)] = tot;
+                        if ((lane & 31) == 31) outp[r * OUT_ROW + 2 * pl + (lane >> 5)] = tot;
                         acc[r] = 0.0f;
                     }
                     sl = 0, ++pl;
@@ -592,18 +710,72 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
             issue(d);
         }
     }
-    // epilogue: lane l owns local pair l (rows R, R + 1 of the packed order) of every activation row
+    // 3. epilogue: lane l owns local pair l (rows R, R + 1 of the packed order) of every activation row
     const bool live = lane < run;
-    const int R = 2 * (gw + lane * W);
+    const int pair = gw + lane * W, R = 2 * pair;
     u32 pre_b = 0;
-    if (a.lin_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
+    if (EPI == EPI_STORE && a.lin_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-        if (r < nr && live) {
-            const float2 o = *reinterpret_cast<const float2 *>(outp + r * (GEMV_WAVES * 2 * GEMV_MAX_RUN) + 2 * lane);
-            float oa = round_T<T>(o.x), ob = round_T<T>(o.y);
-            if (a.lin_bias) oa = round_T<T>(oa + lo_f32<T>(pre_b)), ob = round_T<T>(ob + hi_f32<T>(pre_b));  // y = T(T(x W^T) + b)
-            *reinterpret_cast<u32 *>(a.y + (size_t)(row0 + r) * a.N + R) = pack2<T>(oa, ob);
+        if (r >= nr) continue;  // wave-uniform
+        const int row = row0 + r;
+        float va = 0.0f, vb = 0.0f;
+        if (live) {
+            const float2 o = *reinterpret_cast<const float2 *>(outp + r * OUT_ROW + 2 * lane);
+            va = o.x, vb = o.y;
+        }
+        if constexpr (EPI == EPI_STORE || EPI == EPI_LOGITS) {
+            float oa = round_T<T>(va), ob = round_T<T>(vb);
+            if (EPI == EPI_STORE && a.lin_bias) oa = round_T<T>(oa + lo_f32<T>(pre_b)), ob = round_T<T>(ob + hi_f32<T>(pre_b));  // y = T(T(x W^T) + b)
+            if (live) *reinterpret_cast<u32 *>(a.y + (size_t)row * a.N + R) = pack2<T>(oa, ob);
+            if constexpr (EPI == EPI_LOGITS) {  // per-wave log-softmax partial of this row: max, first argmax, sum exp(x - max)
+                const float mx = live ? fmaxf(oa, ob) : -INFINITY;
+                const int ix = live ? (ob > oa ? R + 1 : R) : 0x7fffffff;
+                const float wmax = wave_max(mx);
+                int cand = (live && mx == wmax) ? ix : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+                float se = live ? expf(oa - wmax) + expf(ob - wmax) : 0.0f;
+                se = wave_sum(se);
+                if (lane == 0 && gw < a.n_waves) {
+                    LogitStat st;
+                    st.max = wmax, st.sumexp = se, st.argmax = cand, st.pad = 0;
+                    a.stats[(size_t)row * a.n_waves + gw] = st;
+                }
+            }
+        } else if constexpr (EPI == EPI_RESIDUAL) {  // h = x + r: Linear output rounded to T, then the add rounded to T
+            if (live) {
+                u32 *hp = reinterpret_cast<u32 *>(a.resid + (size_t)row * a.N + R);
+                const u32 h2 = *hp;
+                *hp = pack2<T>(lo_f32<T>(h2) + round_T<T>(va), hi_f32<T>(h2) + round_T<T>(vb));
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {  // nn.silu(gate) * up; packed rows (2 i, 2 i + 1) = (gate_i, up_i)
+            if (live) {
+                const float gte = round_T<T>(va), up = round_T<T>(vb);
+                const float slu = round_T<T>(gte / (1.0f + expf(-gte)));
+                a.y[(size_t)row * (a.N >> 1) + pair] = T::from_f32(slu * up);
+            }
+        } else if constexpr (EPI == EPI_ROPE_KV) {  // RoPE at the row's own position + append to the row's own page
+            const int pos = a.ctx_len[row] - 1;
+            if (live && pos >= 0) {
+                const int HD = a.head_dim, half = HD >> 1, q_rows = a.n_heads * HD, k_rows = a.n_kv_heads * HD;
+                const unsigned pg = min((unsigned)a.block_table[(size_t)row * a.bt_stride + (pos >> 6)], (unsigned)a.n_pages - 1u);
+                u16 *kdst = a.slab + (size_t)pg * 2 * 64 * a.n_kv_heads * HD, *vdst = kdst + (size_t)a.n_kv_heads * 64 * HD;
+                const int kvrow = pos & 63;
+                const float ra = round_T<T>(va), rb = round_T<T>(vb);
+                if (R < q_rows + k_rows) {
+                    const int rr = R < q_rows ? R : R - q_rows;
+                    const int head = rr / HD, ii = (rr % HD) >> 1;
+                    const float2 csn = *reinterpret_cast<const float2 *>(a.rope_cs + ((size_t)row * half + ii) * 2);
+                    u16 *dst = R < q_rows ? a.q_out + ((size_t)row * a.n_heads + head) * HD : kdst + ((size_t)head * 64 + kvrow) * HD;
+                    const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + half;
+                    dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, csn.x), __fmul_rn(rb, csn.y)));
+                    dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, csn.y), __fmul_rn(rb, csn.x)));
+                } else {
+                    const int rr = R - q_rows - k_rows;
+                    *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * 64 + kvrow) * HD + rr % HD) = pack2<T>(ra, rb);
+                }
+            }
         }
     }
 }
@@ -615,3 +787,6 @@ int w4s_gemv_waves(int N, int K);
 // y[M, N] = T(x[M, K] @ W^T) (+ bias) for 1 <= M <= GEMV_ROWS_MAX rows of one W4S matrix in one pass over the weights (see k_w4s_gemv_rows)
 constexpr int GEMV_ROWS_MAX = 5;
 int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 *x, int M, u16 *y, const u16 *lin_bias, hipStream_t stream);
+// the fused forms (pro: PRO_NONE / PRO_RMSNORM; epi: EPI_STORE / EPI_RESIDUAL / EPI_SWIGLU / EPI_ROPE_KV / EPI_LOGITS): w, K, N, M and the operands of the
+// chosen prologue / epilogue set by the caller
+int w4s_gemv_rows_fused_launch(int dtype, int pro, int epi, GemvRowsArgs &a, hipStream_t stream);
