@@ -151,7 +151,7 @@ __device__ __forceinline__ void ring_static_for(F &&f) {  // f(integral_constant
 }
 
 template <int L0, class NextSeg>
-__device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, int lane, NextSeg next_segment, unsigned thin_word, unsigned long long deadline) {
+__device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, int lane, NextSeg next_segment, unsigned long long deadline) {
     const char *ptr[RING_CONSUMERS];
     unsigned rem[RING_CONSUMERS], issued[RING_CONSUMERS], freec[RING_CONSUMERS];
     bool more[RING_CONSUMERS];
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool ring_loader(unsigned ring_base, unsigned ctl, in
     };
     for (;;) {
         bool any = false;
-        const int max_inflight = (thin_word != 0xFFFFFFFFu && lds_ld_s(thin_word) != 0u) ? 1 : RING_INFLIGHT;  // thinned while this CU gathers
+        constexpr int max_inflight = RING_INFLIGHT;
         ring_static_for<L0>([&](auto wc) {
             constexpr int w = decltype(wc)::value;
             if (!more[w]) return;

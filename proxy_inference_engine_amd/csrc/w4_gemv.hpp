@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
 #pragma unroll
                 for (int r = 0; r < MR; ++r) {
                     if (r < nr) {
-                        float dd, sx;
+                        float dd = 0.0f, sx = 0.0f;
                         bool done = false;
                         if constexpr (XREG) {
                             if (xreg) {

@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(RING_WAVES * 64, 1) k_ring_probe(const ProbeAr
         };
         const unsigned long long dl = __builtin_amdgcn_s_memrealtime() + 300000000ull;
         if (a.abl & 4) __builtin_amdgcn_s_setprio(3);
-        if (wave == 0) ring_loader<0>(ring, ctl, lane, next, 0xFFFFFFFFu, dl);
-        if (RING_LOADERS > 1 && wave == 1) ring_loader<(RING_LOADERS > 1 ? 1 : 0)>(ring, ctl, lane, next, 0xFFFFFFFFu, dl);
+        if (wave == 0) ring_loader<0>(ring, ctl, lane, next, dl);
+        if (RING_LOADERS > 1 && wave == 1) ring_loader<(RING_LOADERS > 1 ? 1 : 0)>(ring, ctl, lane, next, dl);
         return;
     }
     const int cw = wave - RING_LOADERS;
