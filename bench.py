@@ -185,7 +185,7 @@ def main():
     else:
         # heavy-tailed lm_head rows: the parity gate's id comparison needs steps whose greedy token is decided by more than rounding noise
         # (models/utils.py: synthetic_checkpoint); same shapes and bytes, so the timing is that of any Llama-3-8B int4 checkpoint
-        weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16, lm_head_tail=1.0)
+        weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16, lm_head_tail=1.5)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b" and args.bits == 4
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
