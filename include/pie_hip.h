@@ -64,7 +64,8 @@ int pie_repack_w4g64(const uint32_t *codes, const void *scales, const void *bias
  * transpose=True, group_size=64, bits=4) via nn.QuantizedLinear.__call__ (K1).
  * Call sites: models/llama/language.py:83 (q,k,v), :108 (o), :127 (gate,up,down), :207/:209 (lm_head).
  * x [M,K] T, packed = W4S of a [N,K] weight, lin_bias T [N] or NULL (nn.QuantizedLinear bias), y [M,N] T.
- * Weights are re-streamed once per row of x (M is the prompt length at prefill, 1 at decode). */
+ * Row-by-row exact-fp32 arithmetic (MLX's qmv regime) for every M; the weights are streamed once per up to 5 rows of x
+ * (k_w4s_gemv_rows), each row bit-identical to that row multiplied alone. */
 int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y,
                     int dtype, void *stream);
 

@@ -326,7 +326,7 @@ static int rows_launch_pe(int pro, int epi, const GemvRowsArgs &a, int mr, dim3 
 int w4s_gemv_rows_fused_launch(int dtype, int pro, int epi, GemvRowsArgs &a, hipStream_t stream) {
     PIE_REQUIRE(a.w && a.x, PIE_E_ARG, "w4s_gemv_rows: null pointer");
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0 && a.K <= 32768 && a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv_rows: K must be a multiple of 64 (<= 32768), N even");
-    PIE_REQUIRE(a.M >= 1 && a.M <= GEMV_ROWS_MAX, PIE_E_SHAPE, "w4s_gemv_rows: 1 .. 5 rows");
+    PIE_REQUIRE(a.M >= 1 && a.M <= 65535, PIE_E_SHAPE, "w4s_gemv_rows: M out of range");  // more than GEMV_ROWS_MAX rows: chunks of rows over blockIdx.y
     // every pointer the chosen prologue / epilogue dereferences, checked here so that a null can never reach the kernel
     PIE_REQUIRE(pro != PRO_RMSNORM || (a.norm_w && a.K <= 8192), PIE_E_ARG, "w4s_gemv_rows: the RMSNorm prologue needs its weight and K <= 8192");
     PIE_REQUIRE((epi != EPI_STORE && epi != EPI_LOGITS && epi != EPI_SWIGLU) || a.y, PIE_E_ARG, "w4s_gemv_rows: null output");
@@ -349,11 +349,11 @@ int w4s_gemv_rows_fused_launch(int dtype, int pro, int epi, GemvRowsArgs &a, hip
 }
 
 int w4s_gemv_rows_launch(int dtype, const void *packed, int N, int K, const u16 *x, int M, u16 *y, const u16 *lin_bias, hipStream_t stream) {
-    PIE_REQUIRE(M >= 1 && M <= GEMV_ROWS_MAX, PIE_E_SHAPE, "w4s_gemv_rows: 1 .. 5 rows");
-    if (M == 1) {
+    PIE_REQUIRE(M >= 1 && M <= 65535, PIE_E_SHAPE, "w4s_gemv_rows: M out of range");
+    if (M == 1 || gemv_rows_lds_bytes(K, 1) > 160u * 1024u) {  // one row, or a K whose image does not fit next to the row sums: the batch-1 kernel, one pass per row
         GemvArgs g = {};
         g.w = (const char *)packed, g.K = K, g.N = N, g.x = x, g.y = y, g.lin_bias = lin_bias;
-        return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, g, 1, stream);
+        return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, g, M, stream);
     }
     GemvRowsArgs a = {};
     a.w = (const char *)packed, a.K = K, a.N = N, a.M = M, a.x = x, a.y = y, a.lin_bias = lin_bias;
@@ -533,13 +533,8 @@ int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, cons
     PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w4g64: null pointer");
     PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w4g64: M out of range");
     PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w4g64: misaligned pointer");
-    GemvArgs a = {};
-    a.w = (const char *)packed;
-    a.K = K, a.N = N;
-    a.x = (const u16 *)x;
-    a.y = (u16 *)y;
-    a.lin_bias = (const u16 *)lin_bias;
-    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
+    // one pass over the weights per up to GEMV_ROWS_MAX rows (k_w4s_gemv_rows); every row with the batch-1 arithmetic
+    return w4s_gemv_rows_launch(dtype, packed, N, K, (const u16 *)x, M, (u16 *)y, (const u16 *)lin_bias, (hipStream_t)stream);
 }
 
 int pie_embedding_w4g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,

@@ -63,6 +63,28 @@ def test_qgemv_shapes_vs_oracle(ops, dt, N, K, M):
     assert_bits_close(to_bits(got), po.to_bits(want, dt), what=f"qgemv {N}x{K} M={M} {dt}")
 
 
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("N,K", [(2, 64), (6, 192), (34, 2112), (130, 2048), (4098, 4096), (258, 5632), (66, 8192), (40, 14336), (4100, 14336), (20, 16384),
+                                 (18, 28672)])
+def test_qgemv_several_rows_in_one_pass_equal_each_row_alone(ops, dt, N, K):
+    """k_w4s_gemv_rows (pie_qgemv_w4g64 from two rows on: one pass over the weights per up to 5 rows) against the batch-1 kernel on each
+    row alone: BIT-identical, for 1..8 and 14 K slices (incl. ragged last slices), pair counts that leave waves without a pair, several
+    pairs per wave (N = 4098 / 4100 on 2048 waves), row counts that split into chunks of rows (7 -> 4 + 3, 11 -> 4 + 4 + 3; K = 14336:
+    chunks of three), a linear bias."""
+    rng = np.random.default_rng(N + K)
+    w = po.round_T(rng.standard_normal((N, K)) * 0.03, dt)
+    wq, s, b = po.quantize(w, 64, 4, dt)
+    lb = po.to_bits(rng.standard_normal(N) * 0.1, dt) if N % 4 == 0 else None
+    wt = ops.repack_w4s(codes_dev(wq), to_dev(s, dt), to_dev(b, dt), lin_bias=None if lb is None else to_dev(lb, dt))
+    x = po.round_T(rng.standard_normal((11, K)) * np.exp(rng.standard_normal((11, 1))), dt)
+    xd = to_dev(po.to_bits(x, dt), dt)
+    alone = torch.cat([ops.quantized_matmul(xd[i:i + 1], wt) for i in range(11)])
+    for M in (2, 3, 4, 5, 7, 11):
+        got = ops.quantized_matmul(xd[:M], wt)
+        assert got.shape == (M, N)
+        assert np.array_equal(to_bits(got), to_bits(alone[:M])), f"{N}x{K} {dt}: {M} rows in one pass differ from the rows alone"
+
+
 def test_qgemv_row_map_and_linearity(ops):
     """row_map reorders rows; y(x1 + x2) == y(x1) + y(x2) up to rounding (size-independent property)."""
     rng = np.random.default_rng(9)
