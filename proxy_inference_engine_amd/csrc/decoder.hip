@@ -78,7 +78,7 @@ static void drop_graphs(pie_decoder *d) {
 }
 
 // One launch of the step's sequence (PIE_K_* of include/pie_hip.h); `li` is the layer for per-layer kernels.
-int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st) {
+int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st, bool embed_here) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D;
     const pie_layer_weights &w = d->layers[li];
@@ -106,6 +106,12 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             a.block_table = d->block_table, a.n_pages = d->n_pages;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 16;
+            if (embed_here) {  // the step's embedding launch folded into this one (embed_in_qkv): x = the token's row, dequantised by every workgroup
+                a.x = nullptr, a.rope_cs = nullptr, a.rope_cs_out = d->rope_cs, a.h_out = d->h, a.token = token_ptr;
+                a.emb_codes = (const u32 *)d->glob.embed_codes, a.emb_scales = (const u16 *)d->glob.embed_scales, a.emb_biases = (const u16 *)d->glob.embed_biases;
+                a.emb_vocab = d->embed_vocab();
+                return w4s_gemv_launch(c.dtype, PRO_EMBED, EPI_ROPE_KV, a, 1, st);
+            }
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
@@ -179,11 +185,14 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
 // The launch sequence of one step.  token_ptr: device int32 holding the input token id.
 static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
     if (engine_supported(d, with_logits)) return engine_step_enqueue(d, token_ptr, with_logits, logits_dst, st);  // one persistent launch
-    int rc = enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
+    // An int4 embedding table in front of an int4 q|k|v matrix: no embedding launch, layer 0's q|k|v launch dequantises the row itself
+    // (4.4 us of kernel + a launch boundary per step; same bits: the same dequantisation, RMSNorm tree and RoPE table).
+    const bool embed_in_qkv = d->mat_fmt(d->glob.embed_codes) == PIE_W_INT4_G64 && d->mat_fmt(d->layers[0].wqkv) == PIE_W_INT4_G64 && !d->tp() && d->cfg.hidden <= 8 * 8 * GEMV_WAVES * 64;
+    int rc = embed_in_qkv ? PIE_OK : enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
     if (rc) return rc;
     for (int li = 0; li < d->cfg.n_layers; ++li)
         for (int k : {PIE_K_QKV, PIE_K_ATTN, PIE_K_OPROJ, PIE_K_GATEUP, PIE_K_DOWN})
-            if ((rc = enqueue_kernel(d, k, li, token_ptr, logits_dst, st))) return rc;
+            if ((rc = enqueue_kernel(d, k, li, token_ptr, logits_dst, st, embed_in_qkv && li == 0 && k == PIE_K_QKV))) return rc;
     if (!with_logits) {
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, d->state);
         PIE_LAUNCH_CHECK();

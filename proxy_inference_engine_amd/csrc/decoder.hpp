@@ -80,7 +80,7 @@ int paged_attn_i8_launch(int dtype, int D, const AttnArgs &a, hipStream_t st);
 int prefill_min_rows();
 int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st);
 void prefill_free(pie_decoder *d);
-int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st);
+int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st, bool embed_here = false);  // embed_here: PIE_K_QKV of layer 0 also embeds the token
 
 // step_engine.hip: the whole decode step as one persistent launch on the LDS-DMA weight ring (int4 checkpoints, contiguous short caches).
 constexpr int ENGINE_MAX_CAP = 512;  // cache capacity up to which the per-q-head attention plan (and with it the persistent step) is used

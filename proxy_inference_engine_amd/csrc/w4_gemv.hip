@@ -57,17 +57,10 @@ __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *sc
     }
 }
 
-// out[n,k] = T(scale*q + bias): separate multiply and add roundings, like the oracle.
+// out[n,k] = T(scale*q + bias): separate multiply and add roundings, like the oracle (dequant_word_u4, w4_gemv.hpp).
 template <class T>
 __device__ __forceinline__ void dequant_word(u32 word, float s, float b, u16 *out8) {
-    u32 o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float lo = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j)) & 0xFu)), b);
-        float hi = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j + 4)) & 0xFu)), b);
-        o[j] = pack2<T>(lo, hi);
-    }
-    *reinterpret_cast<uint4 *>(out8) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4 *>(out8) = dequant_word_u4<T>(word, s, b);
 }
 
 // 8-bit codes: 4 per word (byte i = code 4w + i), 16 words per group of 64.
@@ -228,6 +221,10 @@ static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_ATTN && epi == EPI_PARTIAL_F32) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_PARTIAL_F32, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_EMBED && epi == EPI_ROPE_KV) {
+        if constexpr (FMT == FMT_W4S) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_EMBED, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
+        else return pie::fail(PIE_E_ARG, "w4s_gemv: the embedding prologue is built for int4 q|k|v weights");
+    }
     else if (pro == PRO_RMSNORM && epi == EPI_SWIGLU) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_SWIGLU, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_LOGITS) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_LOGITS, NPT, 0, FMT>), grid, block, lds, st, a);
     else return pie::fail(PIE_E_ARG, "w4s_gemv: unsupported prologue/epilogue combination");
@@ -270,8 +267,11 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     // Every pointer the chosen prologue / epilogue dereferences, checked HERE so that a null can never reach a kernel (a dense
     // checkpoint legitimately leaves embed scales / biases and rope_cs null; see DESIGN.md "the 00:40 fault").
     PIE_REQUIRE(a.w, PIE_E_ARG, "w4s_gemv: null weight stream");
-    PIE_REQUIRE(pro == PRO_ATTN ? (a.part_acc && a.part_ml && a.state) : a.x != nullptr, PIE_E_ARG, "w4s_gemv: null activation input");
-    PIE_REQUIRE(pro != PRO_RMSNORM || a.norm_w, PIE_E_ARG, "w4s_gemv: RMSNorm prologue without a norm weight");
+    PIE_REQUIRE(pro == PRO_ATTN ? (a.part_acc && a.part_ml && a.state) : (pro == PRO_EMBED || a.x != nullptr), PIE_E_ARG, "w4s_gemv: null activation input");
+    PIE_REQUIRE((pro != PRO_RMSNORM && pro != PRO_EMBED) || a.norm_w, PIE_E_ARG, "w4s_gemv: RMSNorm prologue without a norm weight");
+    PIE_REQUIRE(pro != PRO_EMBED || (a.emb_codes && a.emb_scales && a.emb_biases && a.token && a.emb_vocab > 0 && a.h_out && a.rope_cs_out && a.state && a.freqs && M == 1 &&
+                                     epi == EPI_ROPE_KV && !a.rope_cs),
+                PIE_E_ARG, "w4s_gemv: the embedding prologue needs the int4 triplet, the token, the row / RoPE-table destinations and the q|k|v epilogue");
     PIE_REQUIRE((epi != EPI_STORE && epi != EPI_LOGITS && epi != EPI_SWIGLU) || a.y, PIE_E_ARG, "w4s_gemv: null output");
     PIE_REQUIRE(epi != EPI_LOGITS || a.stats, PIE_E_ARG, "w4s_gemv: EPI_LOGITS without a partials buffer");
     PIE_REQUIRE(epi != EPI_PARTIAL_F32 || a.y32, PIE_E_ARG, "w4s_gemv: EPI_PARTIAL_F32 without an fp32 output");

@@ -30,7 +30,10 @@
 #include "common.hpp"
 
 // PRO_ATTN: x is the merge of the split-KV attention partials (o_proj input, language.py:107-108)
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
+// PRO_EMBED: x is the embedding row of the step's token, dequantised by every workgroup itself, then RMSNorm as PRO_RMSNORM: the first
+//            layer's q|k|v launch, which saves the step its embedding launch (workgroup 0 also leaves the row in the residual stream
+//            and the step's RoPE table for the later layers)
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2, PRO_EMBED = 3 };
 constexpr int GEMV_ATTN_SPLITS = 4;  // split-KV factor the PRO_ATTN prologue merges (register budget: 10 floats per split and piece)
 // EPI_PARTIAL_F32: the un-rounded fp32 row sums (row-parallel Linear of a tensor-parallel shard: summed over ranks, THEN rounded)
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4, EPI_PARTIAL_F32 = 5 };
@@ -75,7 +78,27 @@ struct GemvArgs {
     LogitStat *stats;     // EPI_LOGITS: one entry per wave of the grid
     const float *part_acc, *part_ml;  // PRO_ATTN: split-KV partials [Hq, splits, D] / [Hq, splits, 2]
     int splits;
+    // PRO_EMBED: the int4 g=64 embedding triplet (nn.QuantizedEmbedding, language.py:176), the token, where the row and the RoPE table go
+    const u32 *emb_codes;
+    const u16 *emb_scales, *emb_biases;
+    const int *token;
+    int emb_vocab;
+    u16 *h_out;
+    float *rope_cs_out;
 };
+
+// out[0..8) = T(scale * q + bias) of one code word: separate multiply and add roundings, like the oracle (mx.dequantize)
+template <class T>
+__device__ __forceinline__ uint4 dequant_word_u4(u32 word, float s, float b) {
+    u32 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float lo = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j)) & 0xFu)), b);
+        const float hi = __fadd_rn(__fmul_rn(s, (float)((word >> (8 * j + 4)) & 0xFu)), b);
+        o[j] = pack2<T>(lo, hi);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // LDS carve-up (dynamic, 16-byte aligned): x image | group sums | block reduction scratch | per-wave row sums
 struct GemvLds {
@@ -220,8 +243,8 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         for (int i = 0; i < NPT; ++i) {
             int j = threadIdx.x + i * NT;
             j = j < n_pieces ? j : n_pieces - 1;  // clamp, never branch around a load
-            xv[i] = xg[j];
-            if (PRO == PRO_RMSNORM) nv[i] = reinterpret_cast<const uint4 *>(a.norm_w)[j];
+            if (PRO != PRO_EMBED) xv[i] = xg[j];
+            if (PRO == PRO_RMSNORM || PRO == PRO_EMBED) nv[i] = reinterpret_cast<const uint4 *>(a.norm_w)[j];
         }
     }
     // epilogue-side operands, fetched now so their latency hides under the stream (lane l owns pair gw + l*W)
@@ -297,6 +320,31 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d, d);
+    if constexpr (PRO == PRO_EMBED) {  // behind the head of the stream: the row's address hangs on a scalar load of the token
+        int id = *a.token;
+        id = id < 0 ? 0 : (id >= a.emb_vocab ? a.emb_vocab - 1 : id);
+        const u32 *row = a.emb_codes + (size_t)id * n_pieces;
+        const u16 *srow = a.emb_scales + (size_t)id * (a.K >> 6), *brow = a.emb_biases + (size_t)id * (a.K >> 6);
+        u32 wd[NPT];
+        u16 sc[NPT], bi[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            int j = threadIdx.x + i * NT;
+            j = j < n_pieces ? j : n_pieces - 1;
+            wd[i] = row[j], sc[i] = srow[j >> 3], bi[i] = brow[j >> 3];
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            xv[i] = dequant_word_u4<T>(wd[i], T::to_f32(sc[i]), T::to_f32(bi[i]));
+            const int j = threadIdx.x + i * NT;
+            if (blockIdx.x == 0 && j < n_pieces) reinterpret_cast<uint4 *>(a.h_out)[j] = xv[i];  // h = embed_tokens(inputs): the residual stream of o_proj's epilogue
+        }
+        if (blockIdx.x == 0 && (int)threadIdx.x < (a.head_dim >> 1)) {  // cos / sin of pos / freqs[i] for the later layers' q|k|v epilogues
+            float sn, cs;
+            sincosf((float)a.state->pos * (1.0f / a.freqs[threadIdx.x]), &sn, &cs);
+            a.rope_cs_out[2 * threadIdx.x] = cs, a.rope_cs_out[2 * threadIdx.x + 1] = sn;
+        }
+    }
 
     // 2. stage x through LDS once per workgroup, with the fused mx.fast.rms_norm
     //    (nn.RMSNorm, language.py:137-141,168): w * T(x * rsqrt(mean(x^2) + eps)), or the split-KV merge.
@@ -309,7 +357,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 xv[i] = make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
             }
         }
-        if (PRO == PRO_RMSNORM) {
+        if (PRO == PRO_RMSNORM || PRO == PRO_EMBED) {
             float ssq = 0.0f;
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
