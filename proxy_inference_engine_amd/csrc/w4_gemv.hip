@@ -287,6 +287,8 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     const unsigned lds = (unsigned)gemv_lds(a.K).total;
     PIE_REQUIRE(lds <= 65536u, PIE_E_SHAPE, "w4s_gemv: activation vector does not fit the 64 KB LDS image");
     dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, M);
+    a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs - a.full_rounds * a.n_waves;
+    a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (int)grid.x : 0;  // whole workgroups only: every wave that gets a leftover pair also has a slot in stats[]
     if (dtype == PIE_BF16) return launch_t<BF16>(pro, epi, a, grid, lds, stream);
     if (dtype == PIE_F16) return launch_t<F16>(pro, epi, a, grid, lds, stream);
     return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");

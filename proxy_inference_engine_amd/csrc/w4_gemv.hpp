@@ -56,6 +56,7 @@ struct GemvArgs {
     int fmt;        // FMT_W4S (int4 g=64 units) or FMT_W16S (dense 16-bit units)
     const char *w;  // W4S / W16S
     int n_pairs, n_slices, n_waves, K, N;
+    int full_rounds, rem_pairs, n_blocks;  // launcher: n_pairs = full_rounds * n_waves + rem_pairs; workgroups the leftover pairs are dealt over (0: the first waves); see k_w4s_gemv
     const u16 *x;         // [M,K]
     const u16 *norm_w;    // PRO_RMSNORM
     float eps;
@@ -219,7 +220,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     // streams -- measured faster on HBM (tools/w4s_bench).
     const int gw = blockIdx.x * GEMV_WAVES + wave;
     const int W = a.n_waves;
-    const int run = gw < a.n_pairs ? (a.n_pairs - gw + W - 1) / W : 0;  // <= GEMV_MAX_RUN (host-checked)
+    // The pairs that do not fill a whole round of W waves are dealt over the WORKGROUPS, not over the first waves: q|k|v of the 8B
+    // model is 3072 pairs on 2048 waves, and with the leftover 1024 on waves 0..1023 half of the CUs streamed twice what the other half
+    // did (a launch lasts as long as its busiest CU's ingest).  Leftover pair r goes to wave r / n_blocks of workgroup r % n_blocks.
+    const int kf = a.full_rounds;
+    const int rem_r = a.n_blocks > 0 ? wave * a.n_blocks + (int)blockIdx.x : gw;  // this wave's leftover pair, if r < rem_pairs (n_blocks 0: dealt over the first waves)
+    const bool has_rem = rem_r < a.rem_pairs;
+    const int run = (gw < W ? kf : 0) + (has_rem ? 1 : 0);       // <= GEMV_MAX_RUN (host-checked)
+    const int last_pair = kf * W + rem_r;                        // local pair kf, when has_rem
     const int n_units = run * ns;
     const size_t pstride = (size_t)W * ns * UB;  // bytes between consecutive pairs of this wave
 
@@ -249,7 +257,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     }
     // epilogue-side operands, fetched now so their latency hides under the stream (lane l owns pair gw + l*W)
     const bool live = lane < run;
-    const int pair = gw + lane * W;
+    const int pair = lane < kf ? gw + lane * W : last_pair;
     const int R = 2 * pair;  // packed row index; the pair is rows R, R+1
     u32 pre_u = 0;           // EPI_RESIDUAL: the residual pair
     u32 pre_b = 0;           // the linear bias pair
@@ -284,6 +292,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * UB);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.w), 0, (int)w_bytes, 0x00020000);
     const unsigned woff0 = (unsigned)((size_t)gw * ns * UB) + lane * 16;  // this wave's first unit, this lane's piece
+    const unsigned woff_last = (unsigned)((size_t)last_pair * ns * UB) + lane * 16;
     const unsigned pstride32 = (unsigned)pstride;
     int iss_sl = 0, iss_pl = 0;  // slice / local pair of the next unit to issue
     // K that is not a multiple of the slice width leaves zero-padded lanes in every row's last unit (Llama-3.2-3B: H = 3072 ->
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const int my_chunks = FMT == FMT_W16S ? (a.K + 15) >> 4 : (a.K + 63) >> 6;  // valid per-lane column chunks (16 weights / one 64-group)
     const bool ragged = (my_chunks & 31) != 0;                                    // wave-uniform
     auto issue = [&](int d, int) {  // ring slot d <- next unit of this wave
-        unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
+        unsigned off = iss_pl < run ? (iss_pl < kf ? woff0 + (unsigned)iss_pl * pstride32 : woff_last) + (unsigned)iss_sl * UB : 0xFFFFF000u;
         if (ragged && iss_sl * 32 + (lane & 31) >= my_chunks) off = 0xFFFFF000u;
         if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
         if (ABL & 1) {

@@ -158,6 +158,7 @@ int main(int argc, char **argv) {
             GemvArgs a = {};
             a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
             a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
+            a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs % a.n_waves, a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (a.n_waves / GEMV_WAVES) : 0;
             return a;
         };
         const unsigned lds = (unsigned)gemv_lds(K).total;
@@ -187,6 +188,7 @@ int main(int argc, char **argv) {
             GemvArgs a = {};
             a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
             a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
+            a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs % a.n_waves, a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (a.n_waves / GEMV_WAVES) : 0;
             return a;
         };
         const unsigned lds = (unsigned)gemv_lds(K).total;
