@@ -268,7 +268,7 @@ def main():
         "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{shape_cfg['hidden_size']} L{n_l} {shape_cfg['num_attention_heads']}/{shape_cfg['num_key_value_heads']} heads I{shape_cfg['intermediate_size']} V{shape_cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": f"TP={tp}" if tp else ("replicas" if world > 1 else "single GPU"),
-                   "launches_per_step": (4 + 7 * n_l) if tp else 3 + 5 * n_l,
+                   "launches_per_step": (4 + 7 * n_l) if tp else (3 if args.dense or args.bits != 4 else 2) + 5 * n_l,  # int4: the embedding rides in layer 0's q|k|v launch
                    "hipgraph": True, "kv": "paged (64-token pages)" if args.paged else "contiguous"},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,

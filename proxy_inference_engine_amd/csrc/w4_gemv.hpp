@@ -42,7 +42,8 @@ constexpr int GEMV_WAVES = 8;        // waves per workgroup
 #ifndef PIE_GEMV_DEPTH
 #define PIE_GEMV_DEPTH 2
 #endif
-constexpr int GEMV_DEPTH = PIE_GEMV_DEPTH;  // units in flight per wave (round 1 swept 2..12: 2-3 best; re-checked with round 2's kernels: 1 / 2 / 3 / 4 -> 1.454 / 1.235 / 1.286 / 1.334 ms per 8B step)
+constexpr int GEMV_DEPTH = PIE_GEMV_DEPTH;  // units in flight per wave (round 1 swept 2..12: 2-3 best; re-checked with round 2's kernels: 1 / 2 / 3 / 4 -> 1.454 / 1.235 / 1.286 / 1.334 ms per 8B step;
+                                            // round 3, the q|k|v launch alone at 3 / 4 with its pairs balanced over the CUs: 1.247 / 1.261 against 1.217)
 constexpr int GEMV_MAX_WAVES = 2048; // 256 CUs x ONE 8-wave workgroup: measured best (sweep 1024..6144 in DESIGN.md); the
                                      // activation staging is paid once per CU and no CU runs a second, later wave of groups
 constexpr int GEMV_MAX_RUN = 64;     // row pairs per wave (one epilogue lane each)
