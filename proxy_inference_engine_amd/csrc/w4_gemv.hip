@@ -345,6 +345,8 @@ int w4s_gemv_rows_fused_launch(int dtype, int pro, int epi, GemvRowsArgs &a, hip
     const int chunks = (a.M + mr_fit - 1) / mr_fit, mr = (a.M + chunks - 1) / chunks;
     const unsigned lds = gemv_rows_lds_bytes(a.K, mr);
     const dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, chunks);
+    a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs - a.full_rounds * a.n_waves;
+    a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (int)grid.x : 0;
     if (dtype == PIE_BF16) return rows_launch_pe<BF16>(pro, epi, a, mr, grid, lds, stream);
     if (dtype == PIE_F16) return rows_launch_pe<F16>(pro, epi, a, mr, grid, lds, stream);
     return pie::fail(PIE_E_ARG, "w4s_gemv_rows: dtype must be PIE_BF16 or PIE_F16");

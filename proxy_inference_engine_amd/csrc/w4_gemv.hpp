@@ -562,6 +562,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
 struct GemvRowsArgs {
     const char *w;
     int n_pairs, n_slices, n_waves, K, N, M;
+    int full_rounds, rem_pairs, n_blocks;  // launcher: the row-pair map of k_w4s_gemv (GemvArgs)
     const u16 *x;        // [M, K]
     const u16 *norm_w;   // PRO_RMSNORM
     float eps;
@@ -598,12 +599,18 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
 
     const int gw = blockIdx.x * GEMV_WAVES + wave;
     const int W = a.n_waves;
-    const int run = gw < a.n_pairs ? (a.n_pairs - gw + W - 1) / W : 0;
+    // leftover pairs dealt over the workgroups, as in k_w4s_gemv (here the busiest CU's VALU work, not only its ingest, sets the launch's time)
+    const int kf = a.full_rounds;
+    const int rem_r = a.n_blocks > 0 ? wave * a.n_blocks + (int)blockIdx.x : gw;
+    const bool has_rem = rem_r < a.rem_pairs;
+    const int run = (gw < W ? kf : 0) + (has_rem ? 1 : 0);
+    const int last_pair = kf * W + rem_r;
     const int n_units = run * ns;
     typedef __attribute__((ext_vector_type(4))) u32 u32x4_t;
     const unsigned w_bytes = (unsigned)((size_t)a.n_pairs * ns * UB);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.w), 0, (int)w_bytes, 0x00020000);
     const unsigned woff0 = (unsigned)((size_t)gw * ns * UB) + lane * 16;
+    const unsigned woff_last = (unsigned)((size_t)last_pair * ns * UB) + lane * 16;
     const unsigned pstride32 = (unsigned)((size_t)W * ns * UB);
     const int my_chunks = (a.K + 63) >> 6;
     const bool ragged = (my_chunks & 31) != 0;
@@ -611,7 +618,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
     uint4 c0[D], c1[D];
     u32 sb[D];
     auto issue = [&](int d) {
-        unsigned off = iss_pl < run ? woff0 + (unsigned)iss_pl * pstride32 + (unsigned)iss_sl * UB : 0xFFFFF000u;
+        unsigned off = iss_pl < run ? (iss_pl < kf ? woff0 + (unsigned)iss_pl * pstride32 : woff_last) + (unsigned)iss_sl * UB : 0xFFFFF000u;
         if (ragged && iss_sl * 32 + (lane & 31) >= my_chunks) off = 0xFFFFF000u;
         if (++iss_sl == ns) iss_sl = 0, ++iss_pl;
         const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2);
@@ -770,7 +777,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
     }
     // 3. epilogue: lane l owns local pair l (rows R, R + 1 of the packed order) of every activation row
     const bool live = lane < run;
-    const int pair = gw + lane * W, R = 2 * pair;
+    const int pair = lane < kf ? gw + lane * W : last_pair, R = 2 * pair;
     u32 pre_b = 0;
     if (EPI == EPI_STORE && a.lin_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
 #pragma unroll
