@@ -125,8 +125,10 @@ int main(int argc, char **argv) {
     size_t hbm = 0;
     PK(pie_device_info(name, sizeof name, &n_cus, &hbm));
     {
+        // through dlsym: &pie_hello in this executable is its PLT stub, which dladdr attributes to step_bench itself
         Dl_info di;
-        if (dladdr((void *)&pie_hello, &di) && di.dli_fname) printf("library %s\n", di.dli_fname);
+        void *sym = dlsym(RTLD_DEFAULT, "pie_hello");
+        if (sym && dladdr(sym, &di) && di.dli_fname) printf("library %s (%s)\n", di.dli_fname, pie_version());
     }
     printf("device %s, %d CUs, %.0f GB; model H=%d I=%d heads=%d/%d D=%d V=%d L=%d; ctx %d cap %d\n", name, n_cus, hbm / 1e9, g.H, g.I, g.heads, g.kv,
            g.D, g.V, g.L, ctx, cap);
