@@ -688,18 +688,58 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
             }
         }
     } else {
+        // every row's pieces of a pass are requested before the first is published: written row by row (load, publish, next row) each
+        // row paid its own L2 round trip -- ~1.5 us per row and launch, most of what a second row cost the o_proj launch
         const int n_iter = (n_pieces + NT - 1) / NT;
-        for (int r = 0; r < nr; ++r) {
-            const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + r) * a.K);
-            for (int i = 0; i < n_iter; ++i) {
-                const int j = threadIdx.x + i * NT;
-                publish(r, j, xg[j < n_pieces ? j : n_pieces - 1]);
-            }
-        }
+        constexpr int NI = 2;  // passes in flight (K <= 8192: all of them)
+        for (int i0 = 0; i0 < n_iter; i0 += NI) {
+            uint4 xs[MR][NI];
 #pragma unroll
-        for (int d = 0; d < D; ++d) issue(d);
+            for (int r = 0; r < MR; ++r) {
+                const uint4 *xg = reinterpret_cast<const uint4 *>(a.x + (size_t)(row0 + (r < nr ? r : 0)) * a.K);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = threadIdx.x + (i0 + i) * NT;
+                    xs[r][i] = xg[j < n_pieces ? j : n_pieces - 1];
+                }
+            }
+            if (i0 == 0) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) issue(d);
+            }
+#pragma unroll
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (r < nr && i0 + i < n_iter) publish(r, threadIdx.x + (i0 + i) * NT, xs[r][i]);
+        }
     }
     __syncthreads();
+
+    // epilogue-side operands, requested now so that their latency hides under the stream (lane l owns local pair l of every row): in the
+    // epilogue itself each row's loads waited behind the previous row's stores
+    const bool live = lane < run;
+    const int pair = lane < kf ? gw + lane * W : last_pair, R = 2 * pair;
+    u32 pre_u[EPI == EPI_RESIDUAL ? MR : 1];
+    int pre_pos[EPI == EPI_ROPE_KV ? MR : 1];
+    unsigned pre_pg[EPI == EPI_ROPE_KV ? MR : 1];
+    float2 pre_cs[EPI == EPI_ROPE_KV ? MR : 1];
+    if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) pre_u[r] = (r < nr && live) ? *reinterpret_cast<const u32 *>(a.resid + (size_t)(row0 + r) * a.N + R) : 0u;
+    }
+    if constexpr (EPI == EPI_ROPE_KV) {
+        const int HD = a.head_dim, q_rows = a.n_heads * HD, k_rows = a.n_kv_heads * HD;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int row = row0 + (r < nr ? r : 0);
+            pre_pos[r] = a.ctx_len[row] - 1;
+            const int pc = pre_pos[r] < 0 ? 0 : pre_pos[r];
+            pre_pg[r] = min((unsigned)a.block_table[(size_t)row * a.bt_stride + (pc >> 6)], (unsigned)a.n_pages - 1u);
+            pre_cs[r] = make_float2(1.0f, 0.0f);
+            if (live && R < q_rows + k_rows) pre_cs[r] = *reinterpret_cast<const float2 *>(a.rope_cs + ((size_t)row * (HD >> 1) + ((R % HD) >> 1)) * 2);
+        }
+    }
 
     // 2. the stream: every unit once; its dot2 operands are formed once (5 of the 9 VALU instructions per code word) and multiplied
     //    with every row.  XREG: for K of at most two slices and at most two rows the rows' activations live in registers (2 x MR x 33),
@@ -776,8 +816,6 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
         }
     }
     // 3. epilogue: lane l owns local pair l (rows R, R + 1 of the packed order) of every activation row
-    const bool live = lane < run;
-    const int pair = lane < kf ? gw + lane * W : last_pair, R = 2 * pair;
     u32 pre_b = 0;
     if (EPI == EPI_STORE && a.lin_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
 #pragma unroll
@@ -810,9 +848,8 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
             }
         } else if constexpr (EPI == EPI_RESIDUAL) {  // h = x + r: Linear output rounded to T, then the add rounded to T
             if (live) {
-                u32 *hp = reinterpret_cast<u32 *>(a.resid + (size_t)row * a.N + R);
-                const u32 h2 = *hp;
-                *hp = pack2<T>(lo_f32<T>(h2) + round_T<T>(va), hi_f32<T>(h2) + round_T<T>(vb));
+                const u32 h2 = pre_u[r];
+                *reinterpret_cast<u32 *>(a.resid + (size_t)row * a.N + R) = pack2<T>(lo_f32<T>(h2) + round_T<T>(va), hi_f32<T>(h2) + round_T<T>(vb));
             }
         } else if constexpr (EPI == EPI_SWIGLU) {  // nn.silu(gate) * up; packed rows (2 i, 2 i + 1) = (gate_i, up_i)
             if (live) {
@@ -821,17 +858,17 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 2) k_w4s_gemv_rows(const Gemv
                 a.y[(size_t)row * (a.N >> 1) + pair] = T::from_f32(slu * up);
             }
         } else if constexpr (EPI == EPI_ROPE_KV) {  // RoPE at the row's own position + append to the row's own page
-            const int pos = a.ctx_len[row] - 1;
+            const int pos = pre_pos[r];
             if (live && pos >= 0) {
                 const int HD = a.head_dim, half = HD >> 1, q_rows = a.n_heads * HD, k_rows = a.n_kv_heads * HD;
-                const unsigned pg = min((unsigned)a.block_table[(size_t)row * a.bt_stride + (pos >> 6)], (unsigned)a.n_pages - 1u);
+                const unsigned pg = pre_pg[r];
                 u16 *kdst = a.slab + (size_t)pg * 2 * 64 * a.n_kv_heads * HD, *vdst = kdst + (size_t)a.n_kv_heads * 64 * HD;
                 const int kvrow = pos & 63;
                 const float ra = round_T<T>(va), rb = round_T<T>(vb);
                 if (R < q_rows + k_rows) {
                     const int rr = R < q_rows ? R : R - q_rows;
                     const int head = rr / HD, ii = (rr % HD) >> 1;
-                    const float2 csn = *reinterpret_cast<const float2 *>(a.rope_cs + ((size_t)row * half + ii) * 2);
+                    const float2 csn = pre_cs[r];
                     u16 *dst = R < q_rows ? a.q_out + ((size_t)row * a.n_heads + head) * HD : kdst + ((size_t)head * 64 + kvrow) * HD;
                     const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + half;
                     dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, csn.x), __fmul_rn(rb, csn.y)));
