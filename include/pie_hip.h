@@ -286,7 +286,9 @@ int pie_decoder_set_token_from(pie_decoder *d, const int32_t *token_dev, void *s
 /* The step's launches by name.  pie_decoder_launch_kernel() enqueues ONE of them with exactly the arguments
  * the step uses (for per-kernel timing with events / rocprof; it does not advance the decode state, and
  * PIE_K_TAIL, which does, is refused).  pie_decoder_kernel_bytes() is that launch's algorithmic HBM traffic
- * (weights 0.5625 B/parameter + norm weights + KV rows; activations of a few KB are excluded). */
+ * (weights 0.5625 B/parameter + norm weights + KV rows; activations of a few KB are excluded).
+ * Inside pie_decoder_step an int4 checkpoint has no PIE_K_EMBED launch: layer 0's PIE_K_QKV launch dequantises the token's row itself;
+ * launched by name they remain two kernels with the same results (tests/test_gpu_decode.py::test_step_equals_its_kernels_launched_by_name). */
 enum { PIE_K_EMBED = 0, PIE_K_QKV = 1, PIE_K_ATTN = 2, PIE_K_OPROJ = 3, PIE_K_GATEUP = 4, PIE_K_DOWN = 5, PIE_K_LMHEAD = 6, PIE_K_TAIL = 7 };
 int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream);
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);

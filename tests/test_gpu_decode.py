@@ -112,6 +112,28 @@ def test_teacher_forced_steps_and_graph_replay_identical(tiny):
     assert checked >= 3
 
 
+def test_step_equals_its_kernels_launched_by_name(tiny):
+    """pie_decoder_step on an int4 checkpoint folds the embedding launch into layer 0's q|k|v launch (PRO_EMBED: every workgroup dequantises
+    the token's row itself, workgroup 0 leaves the row in the residual stream and the step's RoPE table).  Launched by name
+    (pie_decoder_launch_kernel) the embedding and layer 0's q|k|v are still two kernels: the logits of both routes must be the same bits."""
+    g, cfg, w, model = tiny
+    cache = model.make_cache()
+    model.step(torch.from_numpy(g["prompt"]).cuda(), cache)
+    for _ in range(3):
+        # by name: does not advance the state, appends the same K / V rows the step will write again
+        model.launch_kernel("embed")
+        for li in range(cfg["num_hidden_layers"]):
+            for name in ("qkv", "attn", "o_proj", "gate_up", "down"):
+                model.launch_kernel(name, li)
+        model.launch_kernel("lm_head")
+        torch.cuda.synchronize()
+        by_name = to_bits(model.logits).copy()
+        hidden_by_name = to_bits(model.hidden).copy()
+        tok, lp, logits = model.step(None, cache)
+        assert np.array_equal(to_bits(logits), by_name), "the step's logits differ from its kernels launched one by one"
+        assert np.array_equal(to_bits(model.hidden), hidden_by_name)
+
+
 @pytest.mark.parametrize("merge_cap", [None, "256"])
 def test_cache_growth_across_step_boundary(tiny, merge_cap, monkeypatch):
     """Decode across the 256-position capacity boundary: the cache re-allocates (256 -> 512) and the decoder must
