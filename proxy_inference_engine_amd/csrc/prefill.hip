@@ -938,8 +938,10 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     int splits = ((d->kv_i8 ? 1024 : 512) + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);  // (the int8-page kernel runs 4-wave workgroups: twice as many)
     splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
     splits = splits < 1 ? 1 : splits;
-    // short sequences (tables of at most 8 pages) in a batch that fills half the chip by itself: one split, and no combine launch
-    if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 128)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
+    // short sequences (tables of at most 8 pages) in a batch of 64+ (sequence, kv-head) workgroups: one split, and no combine launch
+    // (threshold 128 -> 64, i.e. from 8 sequences of the 8B model: 8 / 12 sequences 2.46 / 2.57 -> 2.40 / 2.46 ms at ~170 positions,
+    // 2.59 / 2.78 -> 2.57 / 2.61 at ~420; at 48 the 6-sequence step lost 1 % at ~420 positions)
+    if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 64)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
     // a handful of short sequences: one split as well -- the split kernel + its combine launch cost 10.6 us per layer against 5.5 for the
     // batch-1 step's attention, and a few hundred positions are a handful of row blocks per wave
     if (B <= GEMV_ROWS_MAX && max_blocks <= 4 && !d->kv_i8) splits = 1;
