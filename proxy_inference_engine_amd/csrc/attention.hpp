@@ -150,7 +150,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
             return;
         }
     }
-    if (split >= sp.active) return;  // uniform for the workgroup; consumers only read `active` partials
+    if (split >= sp.active) {  // uniform for the workgroup
+        // an idle split leaves the NEUTRAL partial (max = ATTN_NEG, sum = 0, accumulator = 0: weight exp2(ATTN_NEG - M) = 0 in every merge),
+        // so that the consumer that merges in its prologue (o_proj, w4_gemv.hpp) can read all `splits` slots without first loading the
+        // position to learn how many are active: one dependent load less at the head of that launch.  k_attn_combine still masks by count.
+        if (!(PAGED && a.splits == 1))
+            for (int o = threadIdx.x; o < REP * (D / 2); o += NT) {
+                const int h = o / (D / 2), d = (o % (D / 2)) * 2;
+                const size_t hq = (size_t)row * a.Hq + g * REP + h;
+                *reinterpret_cast<float2 *>(a.part_acc + (hq * a.splits + split) * D + d) = make_float2(0.0f, 0.0f);
+                if (d == 0) a.part_ml[(hq * a.splits + split) * 2 + 0] = ATTN_NEG, a.part_ml[(hq * a.splits + split) * 2 + 1] = 0.0f;
+            }
+        return;
+    }
     const int t_begin = split * sp.chunk;
     const int t_end = min(Ttot, t_begin + sp.chunk);
 

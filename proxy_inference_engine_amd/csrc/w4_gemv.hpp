@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     AttnMergeRegs<GEMV_ATTN_SPLITS> mr[PRO == PRO_ATTN ? NPT : 1];
     int attn_active = 1;
     if (PRO == PRO_ATTN) {
-        attn_active = attn_split(a.state->pos + 1, a.splits).active;
+        attn_active = a.splits;  // idle splits hold the neutral partial (k_attn_decode): no wait for the position here
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             int j = threadIdx.x + i * NT;
