@@ -177,6 +177,15 @@ __device__ __forceinline__ float sum8(const uint4 &v) {
            ((lo_f32<T>(v.z) + hi_f32<T>(v.z)) + (lo_f32<T>(v.w) + hi_f32<T>(v.w)));
 }
 
+// A wave-uniform pointer made opaque to the compiler at this point: it has to be in SGPRs here and can only be kept (or spilled to a
+// VGPR lane) afterwards, never re-fetched from the kernel-argument segment later.
+template <class U>
+__device__ __forceinline__ U *gemv_pin(U *p) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<U *>(v);
+}
+
 __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-uniform broadcast of one lane (v_readlane)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -257,6 +266,17 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
     // epilogue-side operands, fetched now so their latency hides under the stream (lane l owns pair gw + l*W)
+    // ... including the kernel ARGUMENTS only the epilogue uses: hipcc sinks their s_load to the first use, i.e. behind the stream, where
+    // a scalar-cache miss costs several hundred cycles while every CU streams (gate|up: `s_load_dwordx2 .., 0x48` twenty instructions ahead
+    // of its store; lm_head: two of them).  Pinned in SGPRs here.
+    u16 *y_out = a.y + (size_t)m * a.N;
+    float *y32_out = a.y32 + (size_t)m * a.N;
+    LogitStat *stats_out = a.stats + (size_t)m * a.n_waves;
+    u16 *q_dst = a.q_out;
+    if (EPI == EPI_STORE || EPI == EPI_LOGITS || EPI == EPI_SWIGLU) y_out = gemv_pin(y_out);
+    if (EPI == EPI_PARTIAL_F32) y32_out = gemv_pin(y32_out);
+    if (EPI == EPI_LOGITS) stats_out = gemv_pin(stats_out);
+    if (EPI == EPI_ROPE_KV) q_dst = gemv_pin(q_dst);
     const bool live = lane < run;
     const int pair = lane < kf ? gw + lane * W : last_pair;
     const int R = 2 * pair;  // packed row index; the pair is rows R, R+1
@@ -499,7 +519,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             oa = round_T<T>(oa + lo_f32<T>(pre_b));
             ob = round_T<T>(ob + hi_f32<T>(pre_b));
         }
-        if (live) *reinterpret_cast<u32 *>(a.y + (size_t)m * a.N + R) = pack2<T>(oa, ob);
+        if (live) *reinterpret_cast<u32 *>(y_out + R) = pack2<T>(oa, ob);
         if (EPI == EPI_LOGITS) {  // per-wave log-softmax partial: max, first argmax, sum exp(x - max)
             const float mx = live ? fmaxf(oa, ob) : -INFINITY;
             const int ix = live ? (ob > oa ? R + 1 : R) : 0x7fffffff;
@@ -512,11 +532,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             if (lane == 0 && gw < a.n_waves) {
                 LogitStat st;
                 st.max = wmax, st.sumexp = se, st.argmax = cand, st.pad = 0;
-                a.stats[(size_t)m * a.n_waves + gw] = st;
+                stats_out[gw] = st;
             }
         }
     } else if (EPI == EPI_PARTIAL_F32) {
-        if (live) *reinterpret_cast<float2 *>(a.y32 + (size_t)m * a.N + R) = make_float2(va, vb);
+        if (live) *reinterpret_cast<float2 *>(y32_out + R) = make_float2(va, vb);
     } else if (EPI == EPI_RESIDUAL) {
         // h = x + r (language.py:151,153): Linear output rounded to T, then the add rounded to T
         if (live) *reinterpret_cast<u32 *>(a.resid + R) = pack2<T>(lo_f32<T>(pre_u) + round_T<T>(va), hi_f32<T>(pre_u) + round_T<T>(vb));
@@ -525,7 +545,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         if (live) {
             const float gte = round_T<T>(va), up = round_T<T>(vb);
             const float slu = round_T<T>(gte / (1.0f + expf(-gte)));
-            a.y[pair] = T::from_f32(slu * up);
+            y_out[pair] = T::from_f32(slu * up);
         }
     } else if (EPI == EPI_ROPE_KV) {
         // packed rows of [q;k;v]: for q/k heads (2i, 2i+1) = dims (i, i + D/2) of one head; v rows natural.
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             if (R < q_rows + k_rows) {
                 const int rr = R < q_rows ? R : R - q_rows;
                 const int head = rr / HD, ii = (rr % HD) >> 1;
-                u16 *dst = R < q_rows ? a.q_out + (size_t)head * HD : kdst + ((size_t)head * cap + kvrow) * HD;
+                u16 *dst = R < q_rows ? q_dst + (size_t)head * HD : kdst + ((size_t)head * cap + kvrow) * HD;
                 const int i0 = a.rope_traditional ? 2 * ii : ii, i1 = a.rope_traditional ? 2 * ii + 1 : ii + half;
                 dst[i0] = T::from_f32(__fsub_rn(__fmul_rn(ra, pre_cs), __fmul_rn(rb, pre_sn)));
                 dst[i1] = T::from_f32(__fadd_rn(__fmul_rn(ra, pre_sn), __fmul_rn(rb, pre_cs)));
