@@ -14,7 +14,10 @@ Prints ONE JSON line on rank 0 with the driver's contract plus:
   roofline     -- the dominant kernel (gate/up W4S GEMV): algorithmic bytes per launch / mean launch duration,
                   measured here with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
                   `step` = the same fraction for the whole decode step (the north-star figure).
-  cpu_baseline -- the CPU oracle (oracle/pie_oracle.c, OpenMP) timed on this box's host cores on a bounded sample.
+                  `stream_peak` / `frac_of_stream`: the same against a bare streaming read measured in this run (pie_stream_read).
+  repetitions  -- 5 repetitions of the K timed steps (the first is `value`): median and min ms per step.
+  cpu_baseline -- the CPU oracle (oracle/pie_oracle.c, OpenMP) timed on this box's host cores on a bounded sample, at the GPU run's
+                  context (the same 128-token prompt).
   parity       -- the same oracle steps teacher-forced through the HIP model (full 32 layers, V = 128256), outside the timed
                   region: greedy ids where the oracle's top-2 margin exceeds the bound, max / rms logit error in bf16 ulps of
                   the largest logit; the process exits non-zero when it fails.
@@ -64,8 +67,9 @@ def _err_eps(got, ref):
             float(np.sqrt(np.mean((got - ref) ** 2))) / (eps * float(np.sqrt(np.mean(ref ** 2)))))
 
 
-def cpu_baseline(cfg, weights_host, n_tokens, model=None):
-    """Oracle decode tokens/s on the host cores: 4-token prompt (last_only lm_head), then `n_tokens` timed steps.
+def cpu_baseline(cfg, weights_host, n_tokens, model=None, prompt=None, what="Llama-3-8B int4"):
+    """Oracle decode tokens/s on the host cores AT THE GPU RUN'S CONTEXT: the benchmark's own prompt (last_only lm_head, untimed), then
+    `n_tokens` timed steps, each timed by itself (median and minimum step time reported beside the aggregate).
     With `model` (the HIP model on the same weights) the same steps are then teacher-forced on the GPU and compared:
     the parity gate of the benchmarked configuration itself (full depth, full vocabulary).
 
@@ -80,21 +84,26 @@ def cpu_baseline(cfg, weights_host, n_tokens, model=None):
     po.set_threads(threads)
     orc = po.OracleLlama(cfg, weights_host, "bfloat16")
     cache = [po.OracleKVCache() for _ in orc.layers]
-    rng = np.random.default_rng(1)
-    prompt = rng.integers(0, cfg["vocab_size"], 4)
-    orc.forward(prompt, cache, last_only=True)
-    tok = 1
-    fed, want = [], []
+    if prompt is None:
+        prompt = np.random.default_rng(1).integers(0, cfg["vocab_size"], 4)
+    prompt = np.asarray(prompt, np.int64)
+    P = len(prompt)
     t0 = time.perf_counter()
+    tok, _ = po.logprobs_argmax(orc.forward(prompt, cache, last_only=True))
+    t_prompt = time.perf_counter() - t0
+    fed, want, step_s = [], [], []
     for _ in range(n_tokens):
-        fed.append(tok)
+        fed.append(int(tok))
+        t0 = time.perf_counter()
         logits = orc.forward(np.array([tok]), cache, last_only=True)
+        step_s.append(time.perf_counter() - t0)
         tok, _ = po.logprobs_argmax(logits)
         want.append((np.asarray(logits, np.float32).reshape(-1).copy(), int(tok)))
-    dt = time.perf_counter() - t0
+    dt = float(np.sum(step_s))
     base = {"value": n_tokens / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/pie_oracle.c (OpenMP, {threads} threads), same synthetic Llama-3-8B int4 weights, "
-                      f"{n_tokens} greedy decode steps at context 4..{4 + n_tokens} ({dt:.1f} s)"}
+            "median_ms_per_step": 1e3 * float(np.median(step_s)), "min_ms_per_step": 1e3 * float(np.min(step_s)),
+            "sample": f"oracle/pie_oracle.c (OpenMP, {threads} threads), same synthetic {what} weights, {P}-token prompt ({t_prompt:.1f} s, untimed), "
+                      f"then {n_tokens} greedy decode steps at context {P + 1}..{P + n_tokens} ({dt:.1f} s)"}
     if model is None:
         return base, None
     del orc, cache
@@ -103,7 +112,7 @@ def cpu_baseline(cfg, weights_host, n_tokens, model=None):
     ecache = [po.OracleKVCache() for _ in exact.layers]
     exact.forward(prompt, ecache, last_only=True)
     gcache = model.make_cache()
-    model.step(torch.from_numpy(prompt).to(torch.int32).cuda(), gcache)
+    model.step(torch.from_numpy(prompt).to(torch.int32).cuda(), gcache)  # the batched prompt path (MLX's qmm regime from 6 rows, as the oracle's)
     hip_exact = orc_exact = hip_orc = (0.0, 0.0)
     checked = equal = 0
     for t, (ref, otok) in zip(fed, want):
@@ -186,7 +195,10 @@ def main():
         # heavy-tailed lm_head rows: the parity gate's id comparison needs steps whose greedy token is decided by more than rounding noise
         # (models/utils.py: synthetic_checkpoint); same shapes and bytes, so the timing is that of any Llama-3-8B int4 checkpoint
         weights = synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16, lm_head_tail=1.5)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dense and args.model == "8b" and args.bits == 4
+    # the CPU oracle + the teacher-forced parity gate run for every one-card configuration except the 70B model (its oracle step takes 3 s and
+    # 120 GB of host memory twice over); dense weights: 8 oracle steps (15 GB per step at 16 bits + 30 GB in float32)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.model in ("8b", "qv", "3b")
+    cpu_tokens = min(args.cpu_tokens, 8) if args.dense else args.cpu_tokens
     weights_host = None
     if want_cpu:  # the oracle reads the same checkpoint, in the reference's on-disk layout, from host memory
         weights_host = {k: (v.cpu().numpy().view(np.uint32) if v.dtype == torch.int32 else v.view(torch.int16).cpu().numpy().view(np.uint16))
@@ -217,6 +229,22 @@ def main():
         next(gen)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    launches_per_step = model.graph_launches(True)  # kernel nodes of the captured step graph (hipGraphGetNodes), not a formula
+    # 5 repetitions, median and min.  `value` stays the driver's contract (the K steps just timed); four more repetitions of
+    # the same K steps from the same prompt (the prefix cache makes the re-prefill one token) are reported beside it.
+    rep_ms = [1e3 * elapsed / args.steps]
+    if world == 1 and not args.layers:
+        for _ in range(4):
+            gen = eng.generate_step(prompt)
+            next(gen)
+            for _ in range(args.warmup):
+                next(gen)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                next(gen)
+            torch.cuda.synchronize()
+            rep_ms.append(1e3 * (time.perf_counter() - t1) / args.steps)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,13 +275,31 @@ def main():
     k_bytes = model.kernel_bytes("gate_up", T_mid)
     k_gbps = k_bytes / (k_ms * 1e-3) / 1e9
 
+    # The measured-stream denominator: a BARE streaming read of 1 GiB shaped like the GEMV's stream (pie_stream_read: one
+    # 8-wave workgroup per CU, non-temporal 16-byte loads, nothing computed), timed here with HIP events; best of 5.
+    from proxy_inference_engine_amd import _ffi
+    sbuf = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    sbuf.random_(0, 255)
+    lib = _ffi.load()
+    _ffi.check(lib.pie_stream_read(sbuf.data_ptr(), sbuf.numel(), _ffi.stream()))
+    torch.cuda.synchronize()
+    s_ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ffi.check(lib.pie_stream_read(sbuf.data_ptr(), sbuf.numel(), _ffi.stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        s_ms.append(e0.elapsed_time(e1))
+    stream_gbps = sbuf.numel() / (min(s_ms) * 1e-3) / 1e9
+    del sbuf
+
     # HBM bytes per launch of the dominant kernel from the PMC passes over the product step (tools/step_bench under rocprofv3 --pmc,
     # scripts/profile_r03.sh, profiles/README.md).  The file names the library build it was measured on; any other build gets null
     # rather than last round's kernels' traffic.
     traffic = None
-    tf = ROOT / "profiles" / "r03_traffic.json"
+    tf = ROOT / "profiles" / "r04_traffic.json"
     if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
-        from proxy_inference_engine_amd import _ffi
         rec = json.loads(tf.read_text())
         if rec.get("library") == _ffi.load().pie_version().decode():
             traffic = rec.get("hbm_bytes_per_launch")
@@ -261,25 +307,30 @@ def main():
     shape_cfg = full_cfg if tp else cfg
     out = {
         "metric": (f"decode tokens/sec, Llama-3-{args.model.upper()} int4 g=64 batch=1, TP={tp}; achieved HBM GB/s per GPU" if tp else
-                   "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s"),
+                   "decode tokens/sec, Llama-3-8B int4 g=64 batch=1; achieved HBM GB/s" if (args.model == "8b" and args.bits == 4 and not args.dense) else
+                   f"decode tokens/sec, {'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()} "
+                   f"{'dense bf16' if args.dense else f'int{args.bits} g=64'} batch=1; achieved HBM GB/s (NOT the BASELINE.json metric's workload)"),
         "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
         "dtype": "bf16", "dtype_detail": ("bf16 weights" if args.dense else f"uint{args.bits} g=64 weights") + " x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
         "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{shape_cfg['hidden_size']} L{n_l} {shape_cfg['num_attention_heads']}/{shape_cfg['num_key_value_heads']} heads I{shape_cfg['intermediate_size']} V{shape_cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
                    "parallelism": f"TP={tp}" if tp else ("replicas" if world > 1 else "single GPU"),
-                   "launches_per_step": (4 + 7 * n_l) if tp else (3 if args.dense or args.bits != 4 else 2) + 5 * n_l,  # int4: the embedding rides in layer 0's q|k|v launch
+                   "launches_per_step": launches_per_step,  # kernel nodes of the captured hipGraph
                    "hipgraph": True, "kv": "paged (64-token pages)" if args.paged else "contiguous"},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,
                      "ms_per_launch": k_ms,
-                     "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "bytes_per_step": step_bytes}},
+                     "stream_peak": stream_gbps, "frac_of_stream": k_gbps / stream_gbps,  # measured in this run: pie_stream_read over 1 GiB
+                     "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "frac_of_stream": step_gbps / stream_gbps, "bytes_per_step": step_bytes}},
+        "repetitions": {"ms_per_step": rep_ms, "median_ms_per_step": float(np.median(rep_ms)), "min_ms_per_step": float(np.min(rep_ms))},
     }
     if rank == 0:
         if want_cpu:
             del eng, gen
             try:
-                out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, weights_host, args.cpu_tokens, model)
+                what = ("Qwen2-VL-7B text tower" if args.model == "qv" else "Llama-3-" + args.model.upper()) + (" dense bf16" if args.dense else f" int{args.bits}")
+                out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, weights_host, cpu_tokens, model, prompt=prompt.numpy(), what=what)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
                 out["parity"] = {"ok": False, "error": str(e)}

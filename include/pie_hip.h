@@ -140,6 +140,10 @@ int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *st
  * engine/inference_engine.py:268-271 + samplers/__init__.py:37-38: logprobs = f32(logits) - logsumexp,
  * token = first argmax.  logits [V] T, logprobs fp32 [V], token device int32 [1]. */
 int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, int32_t *token, void *stream);
+/* Measurement aid (no reference counterpart; SURVEY.md 8d "fraction of a measured device-copy bandwidth"): a bare streaming read of `bytes`
+ * shaped like the weight GEMV's stream (one 8-wave workgroup per CU, non-temporal 16-byte loads, nothing computed).  bench.py times it for
+ * roofline.stream_peak. */
+int pie_stream_read(const void *p, size_t bytes, void *stream);
 
 /* The stochastic branches of make_sampler (samplers/__init__.py:39-46) over fp32 log-probabilities [rows, V], one kernel, no sort:
  * every branch scales by 1 / temp, filters, and draws argmax(x + Gumbel) like mx.random.categorical.
@@ -259,6 +263,9 @@ int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);
  * PIE_STEP_LOGITS, the device-side token is the greedy choice. */
 enum { PIE_STEP_LOGITS = 1, PIE_STEP_GRAPH = 2 };
 int pie_decoder_step(pie_decoder *d, int flags, void *stream);
+/* Kernel nodes of the captured step graph (read back with hipGraphGetNodes when it was instantiated); -1 while no step with these flags has
+ * been captured.  bench.py reports it as config.launches_per_step. */
+int pie_decoder_graph_launches(const pie_decoder *d, int flags);
 /* Prompt processing: Model.__call__(inputs[1, L]) from the current device-side offset, ids[0..L) device int32, all
  * launches queued back to back with no host round trip.  L >= 6 (env PIE_PREFILL_MIN): batched, in chunks of
  * PIE_PREFILL_CHUNK (4096) rows -- per layer the W4S weights are dequantised to T and multiplied by hipBLASLt (MLX's
@@ -294,23 +301,13 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 size_t pie_decoder_kernel_bytes(const pie_decoder *d, int which, int T);
 /* Algorithmic HBM bytes one decode step moves at context length T (SURVEY.md 8d formula). */
 size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
-/* How the step is scheduled (no reference counterpart: MLX schedules its own graph).  PIE_OPT_ENGINE: 1 (env PIE_STEP_ENGINE=1 makes it
- * the default) runs the whole step as ONE persistent launch where the configuration allows (uniform int4 weights, hidden
- * size <= 4096, contiguous caches of up to 512 positions, no Linear biases, no tensor parallelism), 0 keeps the per-kernel launch
- * sequence; both produce the same logits, tokens and hidden state bit for bit (log-probabilities to fp32 rounding of their log-sum-exp).
- * PIE_OPT_ATTN_HEADS: the decode attention plan "one workgroup per q-head, unsplit" (what the persistent launch runs): 1 / 0 force it
- * on / off for the launch sequence, -1 (default) follows the persistent launch's availability.  Changing an option drops the captured
- * graphs.  pie_decoder_status: synchronises the device and reports a give-up of the persistent launch's bounded waits in *error
- * (0 = none; sticky; the outputs of that step are undefined). */
-enum { PIE_OPT_ENGINE = 1, PIE_OPT_KV_I8 = 2 /* 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
-                                              pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back */,
-       PIE_OPT_ATTN_HEADS = 3 };
+/* Decoder options.  PIE_OPT_KV_I8 = 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
+ * pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back.  Changing an option drops the
+ * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of a bounded wait of the tensor-parallel collectives in
+ * *error (0 = none; sticky; that step's token is -1). */
+enum { PIE_OPT_KV_I8 = 2 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);
-/* What the next pie_decoder_step would run: PIE_QUERY_ENGINE -> 1 when it is the persistent launch, PIE_QUERY_ATTN_HEADS -> 1 when the
- * decode attention uses the per-q-head plan; negative = error. */
-enum { PIE_QUERY_ENGINE = 1, PIE_QUERY_ATTN_HEADS = 2 };
-int pie_decoder_query(pie_decoder *d, int what);
 
 /* ---------------------------------------------------------------- tensor-parallel communicator (SURVEY.md 8 row e)
  * The reference has no multi-GPU path; BASELINE.json configs[4] (Llama-3-70B over the 8 GPUs of one node) needs

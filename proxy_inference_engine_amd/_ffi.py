@@ -14,10 +14,6 @@ import torch
 _PKG = Path(__file__).resolve().parent
 PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
-PIE_OPT_ENGINE = 1
-PIE_OPT_ATTN_HEADS = 3
-PIE_QUERY_ENGINE = 1
-PIE_QUERY_ATTN_HEADS = 2
 PIE_OPT_KV_I8 = 2
 PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
@@ -27,11 +23,11 @@ EXPORTS = [
     "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_w8s_bytes", "pie_repack_w8g64", "pie_qgemv_w8g64", "pie_quantize_g64", "pie_dequantize_g64", "pie_embedding_g64",
     "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64", "pie_qgemv_w4g64_f32",
     "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode", "pie_sdpa_prefill",
-    "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_qkv_row_map", "pie_gateup_row_map",
+    "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_stream_read", "pie_decoder_graph_launches", "pie_qkv_row_map", "pie_gateup_row_map",
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
     "pie_decoder_set_kv", "pie_decoder_set_paged_kv", "pie_decoder_step_batch", "pie_decoder_prefill_batch", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill", "pie_decoder_prefill_embeds",
     "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
-    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status", "pie_decoder_query",
+    "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status",
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
@@ -96,8 +92,9 @@ def load() -> C.CDLL:
     lib.pie_decoder_step_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_kernel_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pie_decoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pie_decoder_graph_launches.argtypes = [C.c_void_p, C.c_int]
+    lib.pie_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pie_decoder_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
-    lib.pie_decoder_query.argtypes = [C.c_void_p, C.c_int]
     lib.pie_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pie_sample_workspace_bytes.argtypes = [C.c_int, C.c_int]

@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libpie_hip.so"
-SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "step_engine.hip", "prefill.hip", "vision.hip", "w4m_gemm.hip", "tp_comm.hip", "sampler.hip", "paged_i8.hip", "page_pool.cpp"]
+SOURCES = ["w4_gemv.hip", "ops.hip", "decoder.hip", "prefill.hip", "vision.hip", "w4m_gemm.hip", "tp_comm.hip", "sampler.hip", "paged_i8.hip", "page_pool.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
 

@@ -56,8 +56,6 @@ struct AttnArgs {
     float *part_acc;  // [Hq, splits, D]
     float *part_ml;   // [Hq, splits, 2]
     u16 *out;         // [Hq, D]
-    // Infinity-Cache warm-up riding on the idle CUs of this launch: blocks with blockIdx.y >= splits stream these
-    // byte ranges (the next kernels' weights) and discard them, so the small GEMVs that follow start from MALL hits.
     // Paged KV (PAGED instantiation, block_table != nullptr): token t of row / sequence r lives in page
     // block_table[r * bt_stride + t / 64] at row t % 64.  Page layout: K block then V block, each [Hkv, 64, D] (one kv-head's
     // 64 rows contiguous: 16 KB bursts at D = 128).  Op level: `slab` = the layer's slab, blockIdx.z = sequence, sequence s
@@ -66,10 +64,7 @@ struct AttnArgs {
     const u16 *slab;
     const int *block_table, *ctx_len;
     int bt_stride, n_pages;
-    const char *pf_ptr[2];
-    unsigned long long pf_bytes[2];
-    int pf_rows;      // extra blockIdx.y rows doing prefetch (0 = none)
-    unsigned *pf_sink;
+    unsigned *prof;   // developer build (-DPIE_ATTN_PROF): stamps of workgroup (0, 0, 0), words 2..9 of the decoder's scratch; nullptr otherwise
 };
 
 constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VALU scoring overlaps the other's loads)
@@ -95,8 +90,8 @@ __device__ __forceinline__ uint4 attn_load_row(const u16 *p) {
 }
 
 #ifdef PIE_ATTN_PROF  // developer build: s_memrealtime stamps (100 MHz) of workgroup (0, 0, 0), read by tools/step_bench
-// stamps go to the decoder's 128-byte pf_sink scratch, words 2..9 (pie_debug_buffer(d, 7) hands it out)
-#define ATTN_STAMP(i) if (a.pf_sink && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(a.pf_sink)[2 + (i)] = __builtin_amdgcn_s_memrealtime()
+// stamps go to the decoder's stamp scratch, words 2..9 (pie_debug_buffer(d, 7) hands it out)
+#define ATTN_STAMP(i) if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(a.prof)[2 + (i)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define ATTN_STAMP(i)
 #endif
@@ -121,21 +116,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
 
     ATTN_STAMP(0);
     const int g = blockIdx.x, split = blockIdx.y;
-    if (split >= a.splits) {  // prefetch role (uniform per workgroup)
-        const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
-        unsigned acc = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned long long n16 = a.pf_bytes[r] >> 4;  // 16-byte pieces
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr[r]);
-            for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
-                const uint4 v = src[i];
-                acc ^= v.x ^ v.y ^ v.z ^ v.w;
-            }
-        }
-        if (acc == 0x9e3779b9u) a.pf_sink[0] = acc;  // keeps the loads alive; practically never taken
-        return;
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;
@@ -219,7 +199,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
     }
 
 #ifdef PIE_ATTN_PROF
-    if (kq[0].x == 0x12345678u && vq[0].x == 0x9abcdef0u && a.pf_sink) a.pf_sink[1] = 1;  // forces a wait for the first K / V rows: stamp 2 = they have landed
+    if (kq[0].x == 0x12345678u && vq[0].x == 0x9abcdef0u && a.prof) a.prof[1] = 1;  // forces a wait for the first K / V rows: stamp 2 = they have landed
     ATTN_STAMP(2);
 #endif
     // Reductions: DPP inside a 16-lane row; v_permlane{16,32}_swap across rows only in the post-loop merge -- no LDS traffic.

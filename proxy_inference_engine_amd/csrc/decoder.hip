@@ -10,8 +10,6 @@
 #include <vector>
 
 #include "attention.hpp"
-#include "attn_head.hpp"
-#include "ring.hpp"
 #include "tail.hpp"
 #include "w4_gemv.hpp"
 #include "decoder.hpp"
@@ -51,15 +49,8 @@ static bool plan_attention(pie_decoder *d) {
         if (splits < GEMV_ATTN_SPLITS) splits = GEMV_ATTN_SPLITS;
     }
     const bool combine = splits > GEMV_ATTN_SPLITS;
-    // one workgroup per q-head, unsplit (attn_head.hpp): the persistent step's plan; the launch sequence follows it wherever that step
-    // could run, so that switching between the two never changes a bit
-    bool head_plan = d->head_plan_opt == 1;
-    if (d->head_plan_opt < 0) head_plan = engine_enabled(d) && engine_config_ok(d) && d->kv_cap > 0 && d->kv_cap <= ENGINE_MAX_CAP && !d->block_table;
-    if (d->block_table || d->tp() || c.kv_splits > 0) head_plan = false;
-    const bool changed = splits != d->splits || combine != d->combine || head_plan != d->head_plan;
-    d->splits = splits, d->combine = combine, d->head_plan = head_plan;
-    d->pf_rows = d->pf_enable ? (256 - c.n_kv_heads * splits) / c.n_kv_heads : 0;  // fill the CUs attention leaves idle
-    if (d->pf_rows < 0) d->pf_rows = 0;
+    const bool changed = splits != d->splits || combine != d->combine;
+    d->splits = splits, d->combine = combine;
     return changed;
 }
 
@@ -74,6 +65,7 @@ static void drop_graphs(pie_decoder *d) {
         if (d->graph[i]) {
             (void)hipGraphExecDestroy(d->graph[i]);
             d->graph[i] = nullptr;
+            d->graph_kernels[i] = -1;
         }
 }
 
@@ -85,10 +77,6 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     auto gfmt = [d](const void *m) {  // streaming format of one matrix (per-module quantisation: models/utils.py:99-109)
         const int f = d->mat_fmt(m);
         return f == PIE_W_DENSE ? FMT_W16S : (f == PIE_W_INT8_G64 ? FMT_W8S : FMT_W4S);
-    };
-    auto mat_bytes = [d](const void *m, int n, int k) {
-        const int f = d->mat_fmt(m);
-        return f == PIE_W_DENSE ? pie_w16s_bytes(n, k) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(n, k) : pie_w4s_bytes(n, k));
     };
     const int efmt = d->mat_fmt(d->glob.embed_codes);
     const bool dense_embed = efmt == PIE_W_DENSE;
@@ -115,27 +103,13 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
-            if (d->head_plan) {
-                AttnHeadArgs ha = {};
-                ha.q = d->qbuf, ha.kv_table = d->kv_table, ha.layer = li, ha.n_layers = c.n_layers, ha.Hq = c.n_heads, ha.Hkv = c.n_kv_heads, ha.state = d->state, ha.out = d->attn;
-                constexpr int NW = RING_CONSUMERS;
-                if (c.dtype == PIE_BF16 && D == 128) hipLaunchKernelGGL((k_attn_head<BF16, 128, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
-                else if (c.dtype == PIE_BF16) hipLaunchKernelGGL((k_attn_head<BF16, 64, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
-                else if (D == 128) hipLaunchKernelGGL((k_attn_head<F16, 128, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
-                else hipLaunchKernelGGL((k_attn_head<F16, 64, NW>), dim3(c.n_heads), dim3(NW * 64), 0, st, ha);
-                PIE_LAUNCH_CHECK();
-                return PIE_OK;
-            }
             AttnArgs a = {};
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
             a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
             a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
             a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
-            // warm the Infinity Cache with what runs next: o_proj's weights and the head of gate/up's
-            a.pf_rows = d->pf_rows, a.pf_sink = d->pf_sink;
-            a.pf_ptr[0] = (const char *)w.wo, a.pf_bytes[0] = mat_bytes(w.wo, H, QD);
-            a.pf_ptr[1] = (const char *)w.wgateup, a.pf_bytes[1] = d->pf_gateup_bytes;
+            a.prof = d->pf_sink;
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
@@ -145,7 +119,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             // THEN the Linear's one rounding and the residual add
             const int epi = d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL;
             a.y32 = d->tp_part;
-            const bool merged_attn = d->combine || d->head_plan;  // the attention output is already one T vector
+            const bool merged_attn = d->combine;  // the attention output is already one T vector
             if (merged_attn) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
@@ -184,7 +158,6 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
 
 // The launch sequence of one step.  token_ptr: device int32 holding the input token id.
 static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
-    if (engine_supported(d, with_logits)) return engine_step_enqueue(d, token_ptr, with_logits, logits_dst, st);  // one persistent launch
     // An int4 embedding table in front of an int4 q|k|v matrix: no embedding launch, layer 0's q|k|v launch dequantises the row itself
     // (4.4 us of kernel + a launch boundary per step; same bits: the same dequantisation, RMSNorm tree and RoPE table).
     const bool embed_in_qkv = d->mat_fmt(d->glob.embed_codes) == PIE_W_INT4_G64 && d->mat_fmt(d->layers[0].wqkv) == PIE_W_INT4_G64 && !d->tp() && d->cfg.hidden <= 8 * 8 * GEMV_WAVES * 64;
@@ -258,12 +231,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->part_ml, 4 * (size_t)c.n_heads * ATTN_MAX_SPLITS * 2);
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
-    PIE_ALLOC(d->pf_sink, 8192);  // 16 bytes of sink + room for the developer builds' stamps (attention: words 2..9; GEMVs: 16 + 4 kind ..)
+    PIE_ALLOC(d->pf_sink, 8192);  // the developer builds' stamps (-DPIE_ATTN_PROF: words 2..9; -DPIE_GEMV_PROF: 16 + 4 kind ..)
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
-    // The split-KV attention launch's idle workgroups warm the Infinity Cache with o_proj's weights (round 1: +1 %, round 2's kernels:
-    // +0.3-0.4 % -- 1.232-1.236 vs 1.237-1.241 ms per step on two boxes -- for 10 MB of additional memory-side fetches per layer);
-    // warming part of gate|up's as well measured slower.
-    d->pf_gateup_bytes = 0, d->pf_enable = true;
 #undef PIE_ALLOC
     plan_attention(d);
     *out = d;
@@ -274,7 +243,6 @@ int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
     prefill_free(d);
-    engine_free(d);
     void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -303,7 +271,6 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
     d->layers[layer] = *w;
     d->layer_set[layer] = 1;
     prefill_free(d);  // resident T copies of the previous weights are stale
-    engine_invalidate(d);  // so is the persistent step's layer table
     drop_graphs(d);
     return PIE_OK;
 }
@@ -399,7 +366,6 @@ static int ready(pie_decoder *d) {
 int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
     int rc = ready(d);
     if (rc) return rc;
-    if ((rc = engine_prepare(d))) return rc;  // allocates once: must happen before stream capture
     hipStream_t st = (hipStream_t)stream;
     const bool with_logits = (flags & PIE_STEP_LOGITS) != 0;
     if (!(flags & PIE_STEP_GRAPH)) return enqueue_step(d, &d->state->token, with_logits, d->logits, st);
@@ -427,6 +393,21 @@ int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
             return rc;
         }
         if (e != hipSuccess) return pie::fail(PIE_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        {  // what the graph really holds, for the benchmark's launches_per_step (not a formula)
+            size_t n_nodes = 0;
+            d->graph_kernels[gi] = -1;
+            if (hipGraphGetNodes(g, nullptr, &n_nodes) == hipSuccess) {
+                std::vector<hipGraphNode_t> nodes(n_nodes);
+                int k = 0;
+                if (n_nodes && hipGraphGetNodes(g, nodes.data(), &n_nodes) == hipSuccess) {
+                    for (size_t i = 0; i < n_nodes; ++i) {
+                        hipGraphNodeType t;
+                        if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+                    }
+                    d->graph_kernels[gi] = k;
+                }
+            }
+        }
         e = hipGraphInstantiate(&d->graph[gi], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return pie::fail(PIE_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
@@ -435,12 +416,17 @@ int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
     return PIE_OK;
 }
 
+int pie_decoder_graph_launches(const pie_decoder *d, int flags) {
+    if (!d) return -1;
+    const int gi = (flags & PIE_STEP_LOGITS) ? 1 : 0;
+    return d->graph[gi] ? d->graph_kernels[gi] : -1;
+}
+
 int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream) {
     int rc = ready(d);
     if (rc) return rc;
     PIE_REQUIRE(ids && L > 0, PIE_E_ARG, "pie_decoder_prefill: need at least one token");
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = engine_prepare(d))) return rc;
     // a tensor-parallel shard feeds its prompt through the step kernels (2 all-reduces per layer and token); the many-row GEMM
     // path has no collective yet
     if (L >= prefill_min_rows() && !d->tp()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime
@@ -494,28 +480,18 @@ int pie_decoder_launch_kernel(pie_decoder *d, int which, int layer, void *stream
 
 // Developer hook (not in the public header): the decoder's internal scratch vectors, for tools/step_bench's bisection.
 void *pie_debug_buffer(pie_decoder *d, int which) {
-    if (which == 6) return (engine_prepare(d) == PIE_OK && engine_supported(d, true)) ? (void *)d : nullptr;  // would a step run as the persistent launch?
     if (which == 7) return d->pf_sink;
-    void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, engine_prof_ptr(d)};
-    return which >= 0 && which < 6 ? p[which] : nullptr;
+    void *p[] = {d->qbuf, d->attn, d->act, d->part_acc, d->part_ml};
+    return which >= 0 && which < 5 ? p[which] : nullptr;
 }
 
 int pie_decoder_configure(pie_decoder *d, int option, int value) {
     PIE_REQUIRE(d, PIE_E_ARG, "pie_decoder_configure: null decoder");
-    PIE_REQUIRE(option == PIE_OPT_ENGINE || option == PIE_OPT_KV_I8 || option == PIE_OPT_ATTN_HEADS, PIE_E_ARG, "pie_decoder_configure: unknown option");
-    if (option == PIE_OPT_ENGINE) engine_enable(d, value != 0);
-    else if (option == PIE_OPT_ATTN_HEADS) d->head_plan_opt = value < 0 ? -1 : (value != 0);
-    else d->kv_i8 = value != 0;
+    PIE_REQUIRE(option == PIE_OPT_KV_I8, PIE_E_ARG, "pie_decoder_configure: unknown option");
+    d->kv_i8 = value != 0;
     plan_attention(d);
     drop_graphs(d);
     return PIE_OK;
-}
-
-int pie_decoder_query(pie_decoder *d, int what) {
-    if (!d) return -1;
-    if (what == PIE_QUERY_ENGINE) return engine_prepare(d) == PIE_OK && engine_supported(d, true) ? 1 : 0;
-    if (what == PIE_QUERY_ATTN_HEADS) return d->head_plan ? 1 : 0;
-    return -1;
 }
 
 int pie_decoder_set_comm(pie_decoder *d, pie_comm *c) {
@@ -534,11 +510,8 @@ int pie_decoder_set_comm(pie_decoder *d, pie_comm *c) {
 int pie_decoder_status(pie_decoder *d, unsigned *error) {
     PIE_REQUIRE(d && error, PIE_E_ARG, "pie_decoder_status: null pointer");
     PIE_HIP_TRY(hipDeviceSynchronize());
-    if (d->comm) {
-        int rc = pie_comm_status(d->comm, error);
-        if (rc || *error) return rc;
-    }
-    return engine_status(d, error);
+    *error = 0;
+    return d->comm ? pie_comm_status(d->comm, error) : PIE_OK;
 }
 
 static size_t lin_bytes(const pie_decoder *d, const void *m, size_t n, size_t k) {  // algorithmic bytes of one Linear's weights

@@ -22,10 +22,7 @@ struct pie_decoder {
     int n_pages = 0;
     u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
-    unsigned *pf_sink = nullptr;
-    int pf_rows = 0;
-    bool pf_enable = true;
-    size_t pf_gateup_bytes = 0;
+    unsigned *pf_sink = nullptr;  // scratch for the developer builds' in-kernel stamps
     // caller-owned outputs (pie_decoder_bind_outputs)
     u16 *h = nullptr, *logits = nullptr;
     float *logprobs = nullptr;
@@ -41,12 +38,8 @@ struct pie_decoder {
     int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
     bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs of pie_decoder_step_batch / _prefill_batch hold int8 pages (paged_i8.hip)
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
+    int graph_kernels[2] = {-1, -1};                // kernel nodes of each captured graph (hipGraphGetNodes)
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
-    struct EngineState *engine = nullptr;           // the persistent one-launch step (step_engine.hip), allocated on first use
-    // Attention plan "one workgroup per q-head, unsplit" (attn_head.hpp): what the persistent step runs; the launch sequence uses the
-    // same plan whenever the persistent step could run, so the two paths produce the same bits.  -1 = automatic, 0 / 1 = forced.
-    int head_plan_opt = -1;
-    bool head_plan = false;
     // tensor parallelism (cfg.tp_world > 1): this decoder is one rank's shard; comm is caller-owned (pie_decoder_set_comm)
     pie_comm *comm = nullptr;
     float *tp_part = nullptr;  // [hidden] fp32 partial of the row-parallel Linears, [hidden] = log-sum-exp of the step
@@ -81,16 +74,3 @@ int prefill_min_rows();
 int prefill_batched(pie_decoder *d, const int32_t *ids, const void *embeds, int L, void *logits_all, hipStream_t st);
 void prefill_free(pie_decoder *d);
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st, bool embed_here = false);  // embed_here: PIE_K_QKV of layer 0 also embeds the token
-
-// step_engine.hip: the whole decode step as one persistent launch on the LDS-DMA weight ring (int4 checkpoints, contiguous short caches).
-constexpr int ENGINE_MAX_CAP = 512;  // cache capacity up to which the per-q-head attention plan (and with it the persistent step) is used
-bool engine_config_ok(pie_decoder *d);  // static part of engine_supported(): geometry, formats, LDS budget
-bool engine_supported(pie_decoder *d, bool with_logits);
-int engine_step_enqueue(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st);
-int engine_status(pie_decoder *d, unsigned *err);
-void *engine_prof_ptr(pie_decoder *d);
-int engine_prepare(pie_decoder *d);
-void engine_free(pie_decoder *d);
-void engine_invalidate(pie_decoder *d);
-void engine_enable(pie_decoder *d, bool on);
-bool engine_enabled(pie_decoder *d);

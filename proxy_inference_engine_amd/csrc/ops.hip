@@ -8,7 +8,7 @@
 template <class T, int D, bool PAGED, bool NT, bool SHORT = false>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
-    const dim3 grid(a.Hkv, a.splits + a.pf_rows, rows);
+    const dim3 grid(a.Hkv, a.splits, rows);
 #define ATTN_GO(R)                                                                                                                      \
     {                                                                                                                                   \
         constexpr int W_ = SHORT ? attn_short_waves(R) : ATTN_WAVES;                                                                    \
@@ -272,6 +272,30 @@ int pie_silu_mul(const void *a, const void *b, size_t n, int dtype, void *y, voi
 }
 int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *stream) {
     return binary(1, a, b, n, dtype, y, stream, "pie_add");
+}
+
+// The yardstick of bench.py's roofline.stream_peak: what this chip gives a BARE streaming read shaped like the weight GEMV's -- one 8-wave
+// workgroup per CU, every wave instruction a contiguous KB of non-temporal 16-byte loads, four in flight per lane, nothing computed.
+__global__ void __launch_bounds__(512) k_stream_read(const uint4 *p, size_t n16, unsigned *sink) {
+    const size_t stride = (size_t)gridDim.x * 512;
+    size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride), c = __builtin_nontemporal_load(p + i + 2 * stride),
+                    d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i).x;
+    if (acc == 0x9e3779b9u && sink) *sink = acc;  // keeps the loads alive; practically never taken
+}
+int pie_stream_read(const void *p, size_t bytes, void *stream) {
+    PIE_REQUIRE(p && bytes >= 16 && pie_aligned(p, 16), PIE_E_ARG, "pie_stream_read: need a 16-byte aligned buffer");
+    int dev = 0, n_cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
+    hipLaunchKernelGGL(k_stream_read, dim3(n_cus), dim3(512), 0, (hipStream_t)stream, (const uint4 *)p, bytes / 16, (unsigned *)nullptr);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
 }
 
 int pie_logprobs_argmax(const void *logits, int V, int dtype, float *logprobs, int32_t *token, void *stream) {

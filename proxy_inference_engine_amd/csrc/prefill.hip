@@ -459,8 +459,8 @@ struct PrefillScratch {
     std::map<const void *, u16 *> resident;
     // W4M tile copies (w4m_gemm.hip) of int4 layer matrices for prompts of at most small_rows() rows: 0.5625 B per weight each
     std::map<const void *, void *> resident_w4m;
-    LogitStat *tail_stats = nullptr;  // multi-sequence step: per-row tail partials
-    int tail_rows = 0;
+    LogitStat *tail_stats = nullptr;  // multi-sequence step / several prompts per pass: per-row tail partials
+    size_t tail_entries = 0;           // its capacity in ENTRIES (rows x partials per row: the two users need 256 and max(lm_head waves, 256) per row)
     // Captured multi-sequence step (pie_decoder_step_batch with PIE_STEP_GRAPH): valid while the caller's buffers (key) and every
     // device allocation baked into the launches (alloc_gen) stay what they were at capture time.
     unsigned alloc_gen = 0;
@@ -473,6 +473,17 @@ struct PrefillScratch {
     size_t resident_left = 0; // bytes still available for resident copies
 };
 
+// The tail partials are sized in entries, not rows: a prompt pass needs 256 per row, the fused few-sequence step one per lm_head GEMV
+// wave (2048 at V = 128256) -- a buffer sized by the first and reused by the second was overrun 8 x.
+static int tail_stats_reserve(PrefillScratch *s, size_t entries) {
+    if (s->tail_entries >= entries) return PIE_OK;
+    if (s->tail_stats) (void)hipFree(s->tail_stats);
+    s->tail_stats = nullptr, s->tail_entries = 0;
+    PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * entries));
+    s->tail_entries = entries, ++s->alloc_gen;
+    return PIE_OK;
+}
+
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
     void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->y32, s->kc, s->vc};
     for (void *p : ptrs)
@@ -480,7 +491,7 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
     auto keep = std::move(s->resident);
     auto keep_m = std::move(s->resident_w4m);
     LogitStat *keep_ts = s->tail_stats;
-    const int keep_tr = s->tail_rows;
+    const size_t keep_tr = s->tail_entries;
     const unsigned gen = s->alloc_gen + 1;  // the chunk buffers move: captured launches are stale
     if (s->batch_graph) (void)hipGraphExecDestroy(s->batch_graph);
     const int mode = s->resident_mode;
@@ -490,7 +501,7 @@ static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident
     *s = PrefillScratch();
     s->w4l_ws = keep_ws, s->w4l_ws_bytes = keep_wsb;
     s->resident = std::move(keep), s->resident_w4m = std::move(keep_m), s->resident_mode = mode, s->resident_left = left;
-    s->tail_stats = keep_ts, s->tail_rows = keep_tr, s->alloc_gen = gen;
+    s->tail_stats = keep_ts, s->tail_entries = keep_tr, s->alloc_gen = gen;
 }
 
 void prefill_free(pie_decoder *d) {
@@ -950,12 +961,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     PrefillScratch *s = d->prefill;
     const int lm_waves = w4s_gemv_waves(c.vocab, H);  // the fused few-sequence form: one log-softmax partial per GEMV wave and row
     const size_t stats_per_row = (size_t)(lm_waves > TAIL_STAT_TILES ? lm_waves : TAIL_STAT_TILES);
-    if (s->tail_rows < B) {
-        if (s->tail_stats) (void)hipFree(s->tail_stats);
-        s->tail_stats = nullptr, s->tail_rows = 0;
-        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * stats_per_row * (size_t)B));
-        s->tail_rows = B, ++s->alloc_gen;
-    }
+    if ((rc = tail_stats_reserve(s, stats_per_row * (size_t)B))) return rc;
     // Up to 5 sequences on an int4 checkpoint: the batch-1 launch sequence, once, with every GEMV multiplying all rows per weight
     // unit (k_w4s_gemv_rows: RMSNorm prologues; RoPE + page append, residual, SwiGLU and logits epilogues, per row) -- 6 launches per
     // layer instead of 9-10, each row in MLX's row-by-row fp32 regime.  Biases, int8 pages and hidden sizes beyond 8192 take the
@@ -1079,12 +1085,7 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
     int rc = scratch_reserve(d, N > S ? N : S, w_elems, d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
-    if (s->tail_rows < S) {
-        if (s->tail_stats) (void)hipFree(s->tail_stats);
-        s->tail_stats = nullptr, s->tail_rows = 0;
-        PIE_HIP_TRY(hipMalloc((void **)&s->tail_stats, sizeof(LogitStat) * TAIL_STAT_TILES * (size_t)S));
-        s->tail_rows = S, ++s->alloc_gen;
-    }
+    if ((rc = tail_stats_reserve(s, (size_t)TAIL_STAT_TILES * (size_t)S))) return rc;
     rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(ids, N, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
              : embedding_launch(ids, N, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,

@@ -296,11 +296,9 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
 
 template <class T, int MR, int PRO, int EPI>
 static int rows_launch_t(const GemvRowsArgs &a, dim3 grid, unsigned lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PIE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_w4s_gemv_rows<T, MR, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = true;
-    }
+    // per call: the attribute belongs to the (function, device) pair, a process-wide "done" flag would leave a second device without it
+    // (ADVICE r3); the call is cheap and legal during stream capture
+    PIE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_w4s_gemv_rows<T, MR, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     hipLaunchKernelGGL((k_w4s_gemv_rows<T, MR, PRO, EPI>), grid, dim3(GEMV_WAVES * 64), lds, st, a);
     PIE_LAUNCH_CHECK();
     return PIE_OK;

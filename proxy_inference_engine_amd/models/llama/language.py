@@ -568,6 +568,10 @@ class Model:
         """Enqueues ONE launch of the step's sequence (for per-kernel timing); needs a prior step() for valid state."""
         _ffi.check(_ffi.load().pie_decoder_launch_kernel(self._dec, _ffi.KERNELS[name], int(layer), _ffi.stream()))
 
+    def graph_launches(self, with_logits: bool = True) -> int:
+        """Kernel nodes of the captured step graph (hipGraphGetNodes); -1 before the first graph-replayed step."""
+        return int(_ffi.load().pie_decoder_graph_launches(self._dec, 1 if with_logits else 0))
+
     def kernel_bytes(self, name: str, T: int) -> int:
         return int(_ffi.load().pie_decoder_kernel_bytes(self._dec, _ffi.KERNELS[name], int(T)))
 

@@ -439,6 +439,43 @@ def test_several_prompts_in_one_pass(golden_dir):
         model.prefill_batch([[1, 2]], [caches[0]])
 
 
+def test_prompt_pass_then_few_sequence_step_with_a_large_vocabulary():
+    """the serving order `prefill_batch` of S <= 5 prompts, then `step_batch` of B <= S sequences, with a vocabulary whose
+    lm_head GEMV runs more than 256 waves (V = 4096: 2048 waves).  The prompt pass sizes the tail partials at 256 per row; the fused
+    few-sequence step writes one per GEMV wave -- the buffer's capacity is tracked in entries now (it was tracked in rows: an 8 x overrun).
+    Every row must equal that sequence served alone, and a neighbouring allocation made right after the prompt pass must stay intact."""
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    from proxy_inference_engine_amd.models.utils import synthetic_checkpoint
+    from tests._util import assert_vec_close
+    cfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2, "intermediate_size": 704, "num_attention_heads": 4,
+           "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 4096, "rope_theta": 10000.0, "max_position_embeddings": 2048,
+           "tie_word_embeddings": False, "quantization": {"group_size": 64, "bits": 4}}
+    model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=5, lm_head_gain=4.0))
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, cfg["vocab_size"], n).astype(np.int32) for n in (9, 40, 23)]
+    model.enable_paged_kv(num_pages=16)
+    alone, alone_next = [], []
+    for p in prompts:  # each sequence alone: prompt, then one decode step on its own greedy token
+        c = model.make_cache()
+        tok, _, _ = model.step(torch.from_numpy(p).cuda(), c)
+        alone_next.append(int(tok.item()))
+        _, lp, lg = model.step(None, c)
+        alone.append((lg.float().cpu().numpy().copy(), lp.cpu().numpy().copy()))
+        c[0].page_manager.release()
+    caches = [model.make_cache() for _ in prompts]
+    toks, _, _ = model.prefill_batch([p.tolist() for p in prompts], caches)   # sizes the partials for a prompt pass: 256 per row
+    guard = torch.full((1 << 20,), 0x5A, dtype=torch.uint8, device="cuda")   # neighbours of whatever the pass allocated
+    feed = torch.tensor(alone_next, dtype=torch.int32, device="cuda")
+    _, logprobs, logits = model.step_batch(feed, caches, graph=False)
+    torch.cuda.synchronize()
+    assert bool((guard == 0x5A).all())
+    got, got_lp = logits.float().cpu().numpy(), logprobs.cpu().numpy()
+    for i in range(len(prompts)):
+        assert_vec_close(got[i], alone[i][0], "bfloat16", what=f"row {i} of the step after the prompt pass")
+        assert abs(float(np.exp(got_lp[i].astype(np.float64)).sum()) - 1.0) < 1e-4
+        assert np.abs(got_lp[i] - alone[i][1]).max() < 0.05
+
+
 # ---------------------------------------------------------------- int8 pages with per-head scales (page.hpp:25-32)
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 @pytest.mark.parametrize("Hq,Hkv,D,lens", [

@@ -141,6 +141,74 @@ def test_vision_tower_vs_oracle(cfg, grid):
     assert torch.equal(model(dev(other), torch.tensor(grid), graph=True), model(dev(other), torch.tensor(grid)))
 
 
+# BASELINE.json configs[3] at ITS geometry: the Qwen2.5-VL-7B tower's shapes -- hidden 1280, 16 heads of 80 (zero-padded
+# to 128 inside the attention kernel), SwiGLU 3420 (not a multiple of 64: the K = 3420 GEMM rows), patch 14 x 14 x 2 frames, 112-pixel windows,
+# merger 5120 -> 3584 -- with 2 of its 32 blocks: one windowed, one full-attention (vision.py:87-442).
+CFG7B = dict(depth=2, hidden_size=1280, intermediate_size=3420, out_hidden_size=3584, num_heads=16, patch_size=14, in_channels=3,
+             spatial_merge_size=2, temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1])
+
+
+@pytest.mark.parametrize("grid", [[(1, 16, 16)], [(1, 32, 32)]])
+def test_vision_tower_at_the_qwen25vl_7b_geometry(grid):
+    w, model = _tower(CFG7B, seed=11)
+    N = sum(t * h * ww for t, h, ww in grid)
+    pix = po.round_T(np.random.default_rng(N).standard_normal((N, 3 * 2 * 14 * 14)), DT)
+    want, states = vo.vision_forward(CFG7B, w, pix, grid, DT, want_states=True)
+    got, got_states = model(dev(pix), torch.tensor(grid), output_hidden_states=True)
+    assert got.shape == (N // 4, 3584) and len(got_states) == len(states)
+    for i, (a, b) in enumerate(zip(got_states, states)):
+        assert_vec_close(a.float().cpu().numpy(), b, DT, c_max=6.0, c_rms=5.0, what=f"7B-geometry tower, grid {grid}, hidden state {i}")
+    assert_vec_close(got.float().cpu().numpy(), want, DT, c_max=6.0, c_rms=5.0, what=f"7B-geometry tower output, grid {grid}")
+    for _ in range(3):                                       # eager, capture, replay: bit for bit
+        assert torch.equal(model(dev(pix), torch.tensor(grid), graph=True), got)
+
+
+def test_image_at_7b_geometry_into_a_256_token_prompt_through_the_engine():
+    """configs[3] end to end at geometry: a 16 x 16-patch image through the 7B-shaped tower (64 image tokens), scattered into a 256-token prompt,
+    through InferenceEngine.generate_step(prompt_ids, pixel_values=...) (inference_engine.py:228-252; intern/ensemble.py:62-91) into a text tower
+    with Qwen2-VL-7B's layer geometry (hidden 3584, 28 / 4 heads of 128, MLP 18944, q/k/v bias; ONE layer and an 8192-row vocabulary to keep the
+    CPU oracle in seconds).  First-token logits against the two oracles chained, then greedy tokens while the oracle's margins are safe."""
+    from proxy_inference_engine_amd import InferenceEngine
+    from proxy_inference_engine_amd.models.intern import Model as Ensemble, ModelArgs as EnsembleArgs
+    from tests.test_gpu_decode import build, margin_bound
+    tcfg = {"model_type": "llama", "hidden_size": 3584, "num_hidden_layers": 1, "intermediate_size": 18944, "num_attention_heads": 28,
+            "num_key_value_heads": 4, "rms_norm_eps": 1e-6, "vocab_size": 8192, "rope_theta": 1000000.0, "max_position_embeddings": 32768,
+            "tie_word_embeddings": False, "attention_bias": True, "quantization": {"group_size": 64, "bits": 4}}
+    tw = po.synth_checkpoint(tcfg, seed=9, dtype=DT, lm_head_gain=4.0)
+    lm = build(tcfg, tw, DT)
+    vw, tower = _tower(CFG7B, seed=12)
+    grid = [(1, 16, 16)]
+    n_img, IMG = 16 * 16 // 4, 7
+    rng = np.random.default_rng(13)
+    ids = np.concatenate([rng.integers(10, 8000, 96), np.full(n_img, IMG), rng.integers(10, 8000, 256 - 96 - n_img)]).astype(np.int64)
+    assert len(ids) == 256
+    pix = po.round_T(rng.standard_normal((256, 1176)), DT)
+    ens = Ensemble(EnsembleArgs(image_token_id=IMG, video_token_id=IMG + 1), lm, vision_tower=lambda pv, g: tower(pv, torch.tensor(grid)))
+    eng = InferenceEngine(model=ens)
+    eng.prepare_engine(ids, temp=0)
+    gen = eng.generate_step(torch.from_numpy(ids), pixel_values=dev(pix))
+    feats = vo.vision_forward(CFG7B, vw, pix, grid, DT)
+    table = po.dequantize(tw["model.embed_tokens.weight"], tw["model.embed_tokens.scales"], tw["model.embed_tokens.biases"], dtype=DT)[ids].copy()
+    table[ids == IMG] = feats
+    orc = po.OracleLlama(tcfg, tw, DT)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(None, ocache, inputs_embeds=table, last_only=True)
+    checked = 0
+    for step in range(4):
+        tok, lp = next(gen)
+        olp = po.logprobs_argmax(want)[1]
+        # the image rows carry the tower's own rounding noise into the text tower: one more factor on the end-to-end bound
+        assert float(np.abs(lp.cpu().numpy() - olp).max()) <= 8.0 * EPS[DT] * float(np.abs(want).max()) + 1e-3, f"step {step}: log-probabilities"
+        top2 = np.sort(want)[-2:]
+        if top2[1] - top2[0] <= 2.0 * margin_bound(want):
+            break
+        assert int(tok.item()) == int(np.argmax(want)), f"step {step}"
+        checked += 1
+        want = orc.forward(np.array([int(tok.item())]), ocache, last_only=True)
+    assert checked >= 1
+    assert eng.prompt_cache.computed_ids[:len(ids)] == [int(i) for i in ids]
+
+
 def test_vision_tower_mlx_ordered_conv_weight_and_errors():
     from proxy_inference_engine_amd.models.intern.vision import VisionConfig, VisionModel
     w = vo.synth_vision_checkpoint(CFG80, 1, DT)

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../proxy_inference_engine_amd/csrc/ring_gemv.hpp"
+#include "ring_gemv.hpp"  // build with -Iproxy_inference_engine_amd/csrc -Itools/engine
 
 namespace pie {
 void set_error(const std::string &) {}

@@ -3,10 +3,10 @@
 // Builds a synthetic Llama-shaped int4 g=64 model (random weights, quantised and repacked on the device through
 // pie_quantize_w4g64 / pie_repack_w4g64), then replays pie_decoder_step.  Because it is a plain binary it can sit directly
 // after `rocprofv3 ... --` (kernel trace or --pmc passes on the PRODUCT step; a Python host crashed the profiler in round 1).
-//   step_bench [--model 8b|70b|tiny] [--layers N] [--steps K] [--warmup W] [--ctx P] [--cap C] [--mode mega|launch|both]
-//              [--graph 0|1] [--check N] [--prefill N [--prefill-reps R]]
-// --check N: runs N steps with the launch sequence and N with the persistent launch from the same state and compares
-//            logits / logprobs / tokens / hidden state bit for bit.
+//   step_bench [--model 8b|70b|tiny] [--layers N] [--steps K] [--warmup W] [--ctx P] [--cap C] [--graph 0|1] [--check N]
+//              [--prefill N [--prefill-reps R]]
+// --check N: runs N steps eagerly and N as the replayed graph from the same state and compares logits / logprobs / tokens / hidden state
+//            bit for bit.  (The persistent one-launch step this tool used to compare against lives under tools/engine/ since round 4.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/step_bench.hip -Iinclude -Lproxy_inference_engine_amd/lib -lpie_hip \
 //        -Wl,-rpath,'$ORIGIN/../proxy_inference_engine_amd/lib' -o tools/step_bench
 #include <dlfcn.h>
@@ -111,10 +111,10 @@ int main(int argc, char **argv) {
         else if (a == "--graph") graph = atoi(next());
         else if (a == "--check") check = atoi(next());
         else if (a == "--kv-splits") kv_splits = atoi(next());
-        else if (a == "--heads") heads = atoi(next());                  // attention plan of the launch sequence: 1 = one workgroup per q-head (the persistent step's), 0 = split-KV, -1 = automatic
+        else if (a == "--heads") heads = atoi(next());                  // accepted and ignored (older scripts): the per-q-head attention plan moved to tools/engine/
         else if (a == "--sync-every") sync_every = atoi(next());       // under rocprofv3: bound the dispatches in flight (thousands of queued
                                                                        // graph nodes overran the profiler: SIGSEGV in its interception)
-        else if (a == "--no-mega") no_mega = 1;                        // never touch the persistent-launch machinery (no allocation, no attribute call)
+        else if (a == "--no-mega") no_mega = 1;                        // accepted and ignored (older scripts)
         else if (a == "--prefill") prefill = atoi(next());            // time pie_decoder_prefill of N tokens instead of decode steps
         else if (a == "--prefill-reps") prefill_reps = atoi(next());
     }
@@ -195,18 +195,14 @@ int main(int argc, char **argv) {
     int32_t *token = (int32_t *)dmalloc(4), *hist = (int32_t *)dmalloc(4 * 65536);
     PK(pie_decoder_bind_outputs(dec, logits, logprobs, token, hidden, hist, 65536));
     CK(hipDeviceSynchronize());
-    const int flags = PIE_STEP_LOGITS | (graph ? PIE_STEP_GRAPH : 0);
-    if (!no_mega) PK(pie_decoder_configure(dec, PIE_OPT_ENGINE, 1));
-    if (!no_mega) printf("persistent launch %s for this configuration (kv_splits %d, capacity %d)\n", pie_debug_buffer(dec, 6) ? "AVAILABLE" : "NOT available: both modes run the launch sequence", kv_splits, cap);
-
+    (void)no_mega, (void)heads, (void)mode;
     struct Snap {
         std::vector<u16> logits, hidden;
         std::vector<float> logprobs;
         int token;
     };
-    auto run = [&](int use_mega, int n, std::vector<Snap> *snaps) -> double {
-        if (!no_mega) PK(pie_decoder_configure(dec, PIE_OPT_ENGINE, use_mega));
-        PK(pie_decoder_configure(dec, PIE_OPT_ATTN_HEADS, snaps ? 1 : (use_mega ? -1 : heads)));  // the check compares like with like
+    auto run = [&](int use_graph, int n, std::vector<Snap> *snaps) -> double {
+        const int flags = PIE_STEP_LOGITS | (use_graph ? PIE_STEP_GRAPH : 0);
         PK(pie_decoder_set_state(dec, ctx, 1, st));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
@@ -239,7 +235,7 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned err = 0;
         PK(pie_decoder_status(dec, &err));
-        if (err) printf("  !! persistent launch gave up at grid barrier %u\n", err);
+        if (err) printf("  !! a bounded wait gave up: %u\n", err);
         return ms / n;
     };
 
@@ -269,27 +265,19 @@ int main(int argc, char **argv) {
         std::vector<Snap> a, b;
         run(0, check, &a);
         run(1, check, &b);
-        unsigned err = 0;
-        PK(pie_decoder_status(dec, &err));
-        if (err) printf("  !! persistent launch gave up at grid barrier %u\n", err), rc = 2;
         for (int i = 0; i < check; ++i) {
             size_t dl = 0, dh = 0, dp = 0;
-            float dpmax = 0.0f;  // the log-sum-exp is summed over each path's own wave partition of the vocabulary: equal to fp32 rounding, not bit for bit
-            for (int j = 0; j < g.V; ++j) dl += a[i].logits[j] != b[i].logits[j], dp += memcmp(&a[i].logprobs[j], &b[i].logprobs[j], 4) != 0, dpmax = std::max(dpmax, std::fabs(a[i].logprobs[j] - b[i].logprobs[j]));
+            for (int j = 0; j < g.V; ++j) dl += a[i].logits[j] != b[i].logits[j], dp += memcmp(&a[i].logprobs[j], &b[i].logprobs[j], 4) != 0;
             for (int j = 0; j < g.H; ++j) dh += a[i].hidden[j] != b[i].hidden[j];
-            printf("check step %d: token %d vs %d, differing logits %zu / %d, hidden %zu / %d; logprobs differing %zu, max |diff| %.3g\n", i, a[i].token, b[i].token, dl, g.V, dh, g.H, dp, dpmax);
-            if (dl || dh || dpmax > 1e-5f || a[i].token != b[i].token) rc = 1;
+            printf("check step %d: token %d vs %d, differing logits %zu / %d, hidden %zu / %d, logprobs %zu\n", i, a[i].token, b[i].token, dl, g.V, dh, g.H, dp);
+            if (dl || dh || dp || a[i].token != b[i].token) rc = 1;
         }
-        printf(rc ? "CHECK FAILED\n" : "check ok: persistent launch == launch sequence (logits, tokens, hidden state bit for bit)\n");
+        printf(rc ? "CHECK FAILED\n" : "check ok: graph replay == eager launches (logits, log-probabilities, tokens, hidden state bit for bit)\n");
     }
     const double bytes = (double)pie_decoder_step_bytes(dec, ctx + steps / 2, 1);
-    if (mode == "launch" || mode == "both") {
-        const double ms = run(0, steps, nullptr);
+    {
+        const double ms = run(graph, steps, nullptr);
         printf("launch sequence : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
-    }
-    if (mode == "mega" || mode == "both") {
-        const double ms = run(1, steps, nullptr);
-        printf("persistent step : %8.3f ms/step  %7.1f tok/s  %6.2f TB/s  (%.1f %% of 8 TB/s)\n", ms, 1e3 / ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0 * 100);
     }
     if (void *ps = pie_debug_buffer(dec, 7)) {  // -DPIE_ATTN_PROF build of the library: stamps of the last attention launch
         unsigned long long t[32] = {};
@@ -350,83 +338,6 @@ int main(int argc, char **argv) {
             printf("attention launch, workgroup (0,0,0), us after its start: position arrived %.2f | first K/V rows %.2f | scoring done %.2f | wave merge %.2f | "
                    "barrier %.2f | partials stored %.2f\n", (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01,
                    (q[6] - q[0]) * 0.01);
-    }
-    if (void *pp = pie_debug_buffer(dec, 5)) {  // -DPIE_ENGINE_PROF build of the library: stamps of one workgroup (consumer wave 0) during the LAST step
-        const int PB = getenv("PIE_ENGINE_PROF_BLOCK") ? atoi(getenv("PIE_ENGINE_PROF_BLOCK")) : 0;
-        std::vector<unsigned long long> all((size_t)n_cus * 132 * 8);
-        CK(hipMemcpy(all.data(), pp, all.size() * 8, hipMemcpyDeviceToHost));
-        const unsigned long long *t = &all[(size_t)PB * 132 * 8];
-        const char *names[5] = {"qkv", "oproj", "gateup", "down", "lmhead"};
-        double sum[5][8] = {}, cnt[5] = {};
-        const int n_ph = 4 * g.L + 1;
-        auto dt = [](unsigned long long b, unsigned long long a2) { return (double)(int)((unsigned)b - (unsigned)a2); };  // 32-bit stamps (100 MHz)
-        for (int ph = 0; ph < n_ph && ph < 132; ++ph) {
-            const unsigned long long *c = &t[ph * 8];
-            if (!c[0]) continue;
-            const int kd = ph == n_ph - 1 ? 4 : ph % 4;
-            const double total = ph + 1 < n_ph && ph + 1 < 132 && t[(ph + 1) * 8] ? dt(t[(ph + 1) * 8], c[0]) : dt(c[3], c[0]);
-            const double v[8] = {dt(c[1], c[0]), dt(c[2], c[1]), dt(c[3], c[2]), c[4] ? dt(c[4], c[3]) : 0.0, total, dt(c[5], c[0]), dt(c[6], c[5]), dt(c[7], c[6])};
-            for (int i = 0; i < 8; ++i) sum[kd][i] += v[i] * 0.01;  // 100 MHz ticks -> us
-            cnt[kd] += 1;
-        }
-        printf("per-phase timeline of workgroup %d, consumer wave 0 (us, mean over layers): input gather | weight stream | epilogue + publish | attention | TOTAL || gather: sweep | rendezvous | norm + image\n", PB);
-        double layer = 0.0;
-        for (int kd = 0; kd < 5; ++kd)
-            if (cnt[kd] > 0) {
-                printf("  %-7s", names[kd]);
-                for (int i = 0; i < 8; ++i) printf(i == 5 ? " || %7.2f" : " %7.2f", sum[kd][i] / cnt[kd]);
-                printf("\n");
-                if (kd < 4) layer += sum[kd][4] / cnt[kd];
-            }
-        printf("  one layer: %.2f us\n", layer);
-        // across ALL workgroups: when does each one publish (epilogue done) relative to the first, per kind of phase -- the skew every gather waits out
-        printf("skew over the %d workgroups (us after the first one, mean over layers): input complete: median / p90 / max | outputs published: median / p90 / max | stream time min / median / max\n", n_cus);
-        for (int kd = 0; kd < 4; ++kd) {
-            double acc[9] = {};
-            int n = 0;
-            for (int ph = kd; ph < 4 * g.L && ph < 132; ph += 4) {
-                std::vector<double> rdy, pub, str;
-                unsigned r0 = 0, p0 = 0;
-                bool first = true;
-                for (int cu2 = 0; cu2 < n_cus; ++cu2) {
-                    const unsigned long long *c = &all[((size_t)cu2 * 132 + ph) * 8];
-                    if (!c[0]) continue;
-                    if (first) r0 = (unsigned)c[1], p0 = (unsigned)c[3], first = false;
-                    rdy.push_back(dt(c[1], r0) * 0.01), pub.push_back(dt(c[3], p0) * 0.01), str.push_back(dt(c[2], c[1]) * 0.01);
-                }
-                if (rdy.size() < 8) continue;
-                std::sort(rdy.begin(), rdy.end()), std::sort(pub.begin(), pub.end()), std::sort(str.begin(), str.end());
-                const size_t m = rdy.size();
-                acc[0] += rdy[m / 2] - rdy[0], acc[1] += rdy[m * 9 / 10] - rdy[0], acc[2] += rdy[m - 1] - rdy[0];
-                acc[3] += pub[m / 2] - pub[0], acc[4] += pub[m * 9 / 10] - pub[0], acc[5] += pub[m - 1] - pub[0];
-                acc[6] += str[0], acc[7] += str[m / 2], acc[8] += str[m - 1];
-                ++n;
-            }
-            if (kd == 2) {  // the longest loader-bound phase: who is slow?  mean stream time by blockIdx % 8 (the XCD under round-robin placement) and the slowest workgroups
-                double xs[8] = {}, xn[8] = {};
-                std::vector<std::pair<double, int>> per(n_cus, {0.0, 0});
-                for (int cu2 = 0; cu2 < n_cus; ++cu2) {
-                    double sm = 0.0;
-                    int k = 0;
-                    for (int ph = kd; ph < 4 * g.L && ph < 132; ph += 4) {
-                        const unsigned long long *c = &all[((size_t)cu2 * 132 + ph) * 8];
-                        if (c[0]) sm += dt(c[2], c[1]) * 0.01, ++k;
-                    }
-                    per[cu2] = {k ? sm / k : 0.0, cu2};
-                    xs[cu2 % 8] += per[cu2].first, xn[cu2 % 8] += 1;
-                }
-                printf("  gateup stream time by blockIdx %% 8:");
-                for (int k = 0; k < 8; ++k) printf(" %.2f", xn[k] ? xs[k] / xn[k] : 0.0);
-                std::sort(per.begin(), per.end());
-                printf("\n  slowest workgroups (mean over layers):");
-                for (int k = n_cus - 10; k < n_cus; ++k) printf(" %d:%.2f", per[k].second, per[k].first);
-                printf("\n  fastest:");
-                for (int k = 0; k < 10; ++k) printf(" %d:%.2f", per[k].second, per[k].first);
-                printf("\n");
-            }
-            if (n) printf("  %-7s %6.2f / %5.2f / %5.2f | %6.2f / %5.2f / %5.2f | %5.2f / %5.2f / %5.2f\n", names[kd], acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n,
-                          acc[6] / n, acc[7] / n, acc[8] / n);
-        }
     }
     PK(pie_decoder_destroy(dec));
     return rc;
