@@ -276,13 +276,14 @@ int pie_add(const void *a, const void *b, size_t n, int dtype, void *y, void *st
 
 // The yardstick of bench.py's roofline.stream_peak: what this chip gives a BARE streaming read shaped like the weight GEMV's -- one 8-wave
 // workgroup per CU, every wave instruction a contiguous KB of non-temporal 16-byte loads, four in flight per lane, nothing computed.
-__global__ void __launch_bounds__(512) k_stream_read(const uint4 *p, size_t n16, unsigned *sink) {
+typedef __attribute__((ext_vector_type(4))) unsigned stream_u32x4;
+__global__ void __launch_bounds__(512) k_stream_read(const stream_u32x4 *p, size_t n16, unsigned *sink) {
     const size_t stride = (size_t)gridDim.x * 512;
     size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
     unsigned acc = 0;
     for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride), c = __builtin_nontemporal_load(p + i + 2 * stride),
-                    d = __builtin_nontemporal_load(p + i + 3 * stride);
+        const stream_u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride), c = __builtin_nontemporal_load(p + i + 2 * stride),
+                           d = __builtin_nontemporal_load(p + i + 3 * stride);
         acc ^= a.x ^ b.y ^ c.z ^ d.w;
     }
     for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i).x;
@@ -293,7 +294,7 @@ int pie_stream_read(const void *p, size_t bytes, void *stream) {
     int dev = 0, n_cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
-    hipLaunchKernelGGL(k_stream_read, dim3(n_cus), dim3(512), 0, (hipStream_t)stream, (const uint4 *)p, bytes / 16, (unsigned *)nullptr);
+    hipLaunchKernelGGL(k_stream_read, dim3(n_cus), dim3(512), 0, (hipStream_t)stream, (const stream_u32x4 *)p, bytes / 16, (unsigned *)nullptr);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
