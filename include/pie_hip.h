@@ -41,6 +41,26 @@ const char *pie_last_error(void);
 /* Fills name (<= name_len bytes, NUL-terminated gcnArchName), CU count, bytes of device memory. */
 int pie_device_info(char *name, int name_len, int *n_cus, size_t *hbm_bytes);
 
+/* Test / tuning switches (no reference counterpart).  One process-wide table; value PIE_KNOB_DEFAULT restores the built-in default.  Every knob is
+ * exercised by a test (tests/test_gpu_decode.py, test_gpu_ops.py, test_gpu_paged.py compare the forms they select); none changes a result beyond
+ * what its comment says.  Nothing in the library reads the environment. */
+enum {
+    PIE_KNOB_PREFILL_MIN = 0,        /* prompts shorter than this run as iterated decode steps (MLX's qmv regime); default 6, min 2 */
+    PIE_KNOB_PREFILL_CHUNK = 1,      /* rows per prompt chunk; default 4096 (16..8192) */
+    PIE_KNOB_PREFILL_RESIDENT = 2,   /* GiB budget for resident dequantised layer matrices; default: half of the free HBM; 0 = none */
+    PIE_KNOB_SMALL_M = 3,            /* rows up to which int4 Linears use the few-row W4M kernel; default 32; 0 = always the many-row path */
+    PIE_KNOB_W4L_SLABS = 4,          /* 0: K-split products of the many-row GEMM reduced by their own launch instead of by their consumers (bit-equal) */
+    PIE_KNOB_W4M_SLABS = 5,          /* 0: the few-row GEMM's two-way atomic K split instead of fp32 slabs (bit-equal) */
+    PIE_KNOB_PREFILL_ATTN_VALU = 6,  /* 1: the VALU prompt attention instead of the MFMA flash kernel (the tests' cross-check) */
+    PIE_KNOB_W4M_MULTI = 7,          /* 0: one strip per workgroup also for the wide matrices (bit-equal) */
+    PIE_KNOB_PREFILL_QT = 8,         /* 1 / 2: one / two 32-row query tiles per prompt-attention workgroup */
+    PIE_KNOB_ATTN_MERGE_MAX_CAP = 9, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
+    PIE_KNOB_COUNT = 10
+};
+#define PIE_KNOB_DEFAULT (-1)
+int pie_set_knob(int knob, int value);
+int pie_get_knob(int knob); /* the value set, or PIE_KNOB_DEFAULT */
+
 /* ---------------------------------------------------------------- mx.quantize / mx.dequantize (K10)
  * Call sites: cache/kv_cache/cache.py:144-147, quantized.py:91-96; defines the checkpoint triplet
  * models/utils.py:96-111 consumes.  w [N,K] T -> codes uint32 [N,K/8], scales/biases T [N,K/64].
@@ -441,15 +461,6 @@ size_t pie_w4m_bytes(int N, int K);
 int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream);
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream);
 
-/* nn.Linear on many rows with 16-bit weights, hand-written (no library GEMM): y [M, N] = x [M, K] . W^T (+ bias [N]: T(T(x W^T) + b)),
- * T x T products on the MFMA units, fp32 accumulation (models/intern/vision.py:97-121,129-133,150-151,192-194; the dense-checkpoint
- * Linears of models/llama/language.py at L > 1 take the same kernel inside pie_decoder_prefill).  The weights live in "W16M" tiles
- * (32 output rows x 64 columns in MFMA operand order, zero-padded to N % 32 == 0 and K % 256 == 0), built once from the row-major
- * [N, K] matrix by pie_repack_w16m -- the row-major copy is not needed afterwards.  K % 8 == 0, N % 4 == 0, x rows 16-byte aligned. */
-size_t pie_w16m_bytes(int N, int K);
-int pie_repack_w16m(const void *weight_rows, int N, int K, void *w16m, void *stream);
-size_t pie_linear_w16m_workspace_bytes(int M, int N, int K);   /* 0 for most shapes; fp32 partial tiles where K is split over workgroups */
-int pie_linear_w16m(const void *x, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,14 @@ _PKG = Path(__file__).resolve().parent
 PIE_BF16, PIE_F16 = 1, 2
 PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
 PIE_OPT_KV_I8 = 2
+# test / tuning switches (include/pie_hip.h: pie_set_knob); -1 restores a default
+KNOBS = {"prefill_min": 0, "prefill_chunk": 1, "prefill_resident": 2, "small_m": 3, "w4l_slabs": 4, "w4m_slabs": 5, "prefill_attn_valu": 6,
+         "w4m_multi": 7, "prefill_qt": 8, "attn_merge_max_cap": 9}
 PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
 
 EXPORTS = [
-    "pie_hello", "pie_version", "pie_last_error", "pie_device_info",
+    "pie_hello", "pie_version", "pie_last_error", "pie_device_info", "pie_set_knob", "pie_get_knob",
     "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_w8s_bytes", "pie_repack_w8g64", "pie_qgemv_w8g64", "pie_quantize_g64", "pie_dequantize_g64", "pie_embedding_g64",
     "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64", "pie_qgemv_w4g64_f32",
     "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode", "pie_sdpa_prefill",
@@ -33,7 +36,7 @@ EXPORTS = [
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_page_i8_bytes", "pie_page_scale_ptrs", "pie_page_i8_set_scales", "pie_paged_kv_append_i8", "pie_paged_attn_decode_i8",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
-    "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m", "pie_w16m_bytes", "pie_repack_w16m", "pie_linear_w16m", "pie_linear_w16m_workspace_bytes",
+    "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
     "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
 ]
 
@@ -56,6 +59,11 @@ class pie_global_weights(C.Structure):
     _fields_ = [("embed_codes", C.c_void_p), ("embed_scales", C.c_void_p), ("embed_biases", C.c_void_p),
                 ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_freqs", C.c_void_p),
                 ("fmt_embed", C.c_int), ("fmt_lm_head", C.c_int)]
+
+
+def set_knob(name: str, value: int | None) -> None:
+    """One of the library's test / tuning switches (KNOBS); None restores its default."""
+    check(load().pie_set_knob(KNOBS[name], -1 if value is None else int(value)))
 
 
 def lib_path() -> Path:
@@ -135,12 +143,6 @@ def load() -> C.CDLL:
     lib.pie_add_bias.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2
     lib.pie_sdpa_segments.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_w4m_bytes.restype = C.c_size_t
-    lib.pie_w16m_bytes.restype = C.c_size_t
-    lib.pie_w16m_bytes.argtypes = [C.c_int, C.c_int]
-    lib.pie_repack_w16m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    lib.pie_linear_w16m.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.pie_linear_w16m_workspace_bytes.restype = C.c_size_t
-    lib.pie_linear_w16m_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.pie_repack_w4s_to_w4m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_qgemm_w4m.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_decoder_step_batch.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]

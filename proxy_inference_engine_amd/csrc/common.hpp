@@ -31,6 +31,9 @@ int fail(int code, const std::string &msg);
         if (!(cond)) return pie::fail((code), (msg)); \
     } while (0)
 
+// Test / tuning switches: ONE process-wide table set through the C ABI (pie_set_knob, include/pie_hip.h); nothing under csrc/ reads the environment.
+int pie_knob(int knob);  // current value; PIE_KNOB_DEFAULT (-1) = the built-in default
+
 static inline bool pie_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // ---------------------------------------------------------------- device side: 16-bit float traits

@@ -20,6 +20,10 @@ int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const voi
 namespace {
 thread_local std::string g_last_error;
 }
+namespace {
+int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+}
+int pie_knob(int knob) { return knob >= 0 && knob < PIE_KNOB_COUNT ? g_knobs[knob] : PIE_KNOB_DEFAULT; }
 namespace pie {
 void set_error(const std::string &msg) { g_last_error = msg; }
 int fail(int code, const std::string &msg) {
@@ -184,6 +188,13 @@ const char *pie_hello(void) { return "pie_core \xe2\x9c\x93"; }
 const char *pie_version(void) { return "pie_hip 0.3.0 (gfx950) " PIE_BUILD_HASH; }  // the hash of the sources: proxy_inference_engine_amd/build.py
 const char *pie_last_error(void) { return g_last_error.c_str(); }
 
+int pie_set_knob(int knob, int value) {
+    PIE_REQUIRE(knob >= 0 && knob < PIE_KNOB_COUNT, PIE_E_ARG, "pie_set_knob: unknown knob");
+    g_knobs[knob] = value < 0 ? PIE_KNOB_DEFAULT : value;
+    return PIE_OK;
+}
+int pie_get_knob(int knob) { return pie_knob(knob); }
+
 int pie_device_info(char *name, int name_len, int *n_cus, size_t *hbm_bytes) {
     int dev = 0;
     PIE_HIP_TRY(hipGetDevice(&dev));
@@ -217,7 +228,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     d->cfg = c;
     d->layers.resize(c.n_layers);
     d->layer_set.assign(c.n_layers, 0);
-    if (const char *e = getenv("PIE_ATTN_MERGE_MAX_CAP")) d->merge_max_cap = atoi(e);  // tuning knob: capacity up to which o_proj merges the splits
+    if (pie_knob(PIE_KNOB_ATTN_MERGE_MAX_CAP) >= 0) d->merge_max_cap = pie_knob(PIE_KNOB_ATTN_MERGE_MAX_CAP);  // capacity up to which o_proj merges the splits
     int rc = PIE_OK;
     d->n_stats = w4s_gemv_waves(c.vocab, c.hidden);
     const int QD = c.n_heads * c.head_dim;

@@ -517,14 +517,14 @@ void prefill_free(pie_decoder *d) {
 }
 
 int prefill_min_rows() {  // read per call (not cached): tests and tools switch regimes inside one process
-    const char *e = getenv("PIE_PREFILL_MIN");  // prompts shorter than this run as iterated decode steps (MLX's qmv regime)
-    const int n = e ? atoi(e) : 6;  // MLX's own qmv limit is 6..32 rows by device and shape; 5 ms batched vs 1.35 ms per iterated row
+    const int k = pie_knob(PIE_KNOB_PREFILL_MIN);  // prompts shorter than this run as iterated decode steps (MLX's qmv regime)
+    const int n = k >= 0 ? k : 6;  // MLX's own qmv limit is 6..32 rows by device and shape; 5 ms batched vs 1.35 ms per iterated row
     return n < 2 ? 2 : n;
 }
 
 static int prefill_chunk_rows() {
-    const char *e = getenv("PIE_PREFILL_CHUNK");  // measured on the 8B model, 4096-token prompt: 512 -> 119 ms, 1024 -> 83, 2048 -> 67, 4096 -> 65
-    const int n = e ? atoi(e) : 4096;
+    const int k = pie_knob(PIE_KNOB_PREFILL_CHUNK);  // measured on the 8B model, 4096-token prompt: 512 -> 119 ms, 1024 -> 83, 2048 -> 67, 4096 -> 65
+    const int n = k >= 0 ? k : 4096;
     return n < 16 ? 16 : (n > 8192 ? 8192 : n);
 }
 
@@ -571,14 +571,14 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
 int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st);
 
 // Byte budget for resident T copies of layer matrices, fixed at the first batched prefill: half of the free device memory
-// (PIE_PREFILL_RESIDENT=0 disables, =<GiB> sets it).  Matrices are admitted in first-use order while the budget lasts
+// (PIE_KNOB_PREFILL_RESIDENT: 0 disables, <GiB> sets it).  Matrices are admitted in first-use order while the budget lasts
 // (8B model: all 15 GB; 70B: ~7/8 of its 140 GB); the rest keep going through the scratch every chunk.
 static size_t resident_budget(pie_decoder *d) {
     PrefillScratch *s = d->prefill;
     if (s->resident_mode < 0) {
         size_t free_b = 0, total_b = 0;
-        const char *e = getenv("PIE_PREFILL_RESIDENT");
-        if (e) s->resident_left = (size_t)atol(e) << 30;
+        const int k = pie_knob(PIE_KNOB_PREFILL_RESIDENT);
+        if (k >= 0) s->resident_left = (size_t)k << 30;
         else s->resident_left = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? free_b / 2 : 0;
         s->resident_mode = 1;
     }
@@ -625,28 +625,16 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
 int w4m_slab_splits(int M, int N, int K);  // few rows, narrow matrix: K split into fp32 slabs (0 = shape not served)
 int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st);
 size_t w4l_workspace_bytes(int M, int N, int K);
-int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
-                     const void *bias, bool *bias_done);  // 16-bit weights in W16M tiles
-size_t w16l_workspace_bytes(int M, int N, int K);
-size_t w16m_bytes(int N, int K);
-int w16m_repack_launch(const void *w16s, const void *rows, int N, int K, void *w16m, hipStream_t st);
 
 // int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
 // copy of the weights, no hipBLASLt (which remains the path of shapes the tile kernels do not take: N not a multiple of 32).
 static bool w4l_enabled() { return true; }
-// dense (16-bit) modules: PIE_W16L=1 takes the hand-written prompt GEMM on W16M tiles (k_w16l_gemm, w4m_gemm.hip) instead of the
-// unpack-to-T + hipBLASLt path.  Off by default on measurement: for 16-bit weights the library GEMM is a plain GEMM done well -- the own
-// kernel ties it up to 128 rows and is 13-20 % slower from 256 rows (8B dense prefill: 8.8 vs 7.8 ms at 256 tokens, 64.9 vs 53.8 at
-// 4096) -- and the tile copy saves no memory over the row-major copy (unlike int4, where the own kernel replaced 15 GB of copies).
-static bool w16l_enabled() {
-    const char *e = getenv("PIE_W16L");
-    return e && e[0] == '1';
-}
-
-// Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_SMALL_M: 0 disables, max 32).
+// Dense (16-bit) modules keep the library GEMM: for 16-bit weights hipBLASLt is a plain GEMM done well.  The hand-written 16-bit kernel of
+// rounds 2-3 (k_w16l_gemm: 0-20 % slower on prompts, 15-38 % on the vision tower's small shapes) was deleted in round 4 (EXPERIMENTS.md).
+// Rows up to which an int4 Linear runs on the W4M kernel instead of the T copy + hipBLASLt (PIE_KNOB_SMALL_M: 0 disables, max 32).
 static int small_rows() {
-    const char *e = getenv("PIE_SMALL_M");
-    const int v = e ? atoi(e) : 32;
+    const int k = pie_knob(PIE_KNOB_SMALL_M);
+    const int v = k >= 0 ? k : 32;
     return v < 0 ? 0 : (v > 32 ? 32 : v);
 }
 
@@ -672,8 +660,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     if (used32) *used32 = false;
     if (used_act) *used_act = false;
     if (slabs) *slabs = W4lSlabs();
-    if (const char *e = getenv("PIE_W4L_SLABS"))  // 0: always reduce in the GEMM's own launch (A/B and the bit-equality test)
-        if (e[0] == '0') slabs = nullptr;
+    if (pie_knob(PIE_KNOB_W4L_SLABS) == 0) slabs = nullptr;  // always reduce in the GEMM's own launch (the bit-equality test)
     // 8B prompt of 64 / 128 / 256 / 512 / 700 tokens, slabs summed by the consumers vs reduce launches: 3.70 / 4.56 / 6.13 / 9.56 / 14.26 ms
     // vs 3.96 / 4.82 / 6.20 / 9.75 / 14.38.  (With ONE workgroup per row the RoPE consumer could not keep enough slab loads in flight
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
@@ -703,8 +690,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             const bool split = y32 && used32 && N / 32 < 256 && K >= split_min_k && (M >= split_min_m || K >= split_long_k) && split_k_enabled();
             // o_proj / down whose consumer can sum fp32 slabs: two strips per workgroup and a deeper, still deterministic K split
             // (k_w4m_gemm_lds4 with part): a quarter of x staged per workgroup for two strips instead of half of it for one
-            const char *s2e = getenv("PIE_W4M_SLABS");  // 0: the one-strip forms with the two-way fp32 atomic split (A/B)
-            const bool slab2_on = !(s2e && s2e[0] == '0');
+            const bool slab2_on = pie_knob(PIE_KNOB_W4M_SLABS) != 0;  // 0: the one-strip forms with the two-way fp32 atomic split (the bit-equality test)
             const int slab_s = slabs && !rope && !act && slab2_on && split_k_enabled() ? w4m_slab_splits(M, N, K) : 0;
             if (slab_s >= 2) {
                 const size_t wb = (size_t)slab_s * M * N * sizeof(float);
@@ -766,34 +752,6 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
-    if (keep && d->mat_fmt(packed) == PIE_W_DENSE && N % 32 == 0 && K % 64 == 0 && w16l_enabled()) {
-        // the layer's matrix as MFMA-ordered 16-bit tiles (same bytes as the row-major copy the library path keeps), built at first use
-        void *wm = nullptr;
-        auto it = s->resident_w4m.find(packed);
-        if (it != s->resident_w4m.end()) wm = it->second;
-        else if (resident_budget(d) >= w16m_bytes(N, K) && hipMalloc(&wm, w16m_bytes(N, K)) == hipSuccess) {
-            s->resident_w4m[packed] = wm, s->resident_left -= w16m_bytes(N, K), ++s->alloc_gen;
-            const int rc = w16m_repack_launch(packed, nullptr, N, K, wm, st);
-            if (rc) return rc;
-        } else {
-            (void)hipGetLastError();
-            wm = nullptr;  // no room for the tile copy: the scratch + library path below
-        }
-        if (wm) {
-            const size_t wb = w16l_workspace_bytes(M, N, K);
-            if (wb > s->w4l_ws_bytes) {
-                if (s->w4l_ws) (void)hipFree(s->w4l_ws);
-                s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
-                PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
-                s->w4l_ws_bytes = wb, ++s->alloc_gen;
-            }
-            bool fused = false, bias_done = false;
-            const int rc = w16l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused, bias, &bias_done);
-            if (fused) *used_act = true;
-            if (rc || !bias || bias_done) return rc;
-            return bias_rows<T>(y, bias, M, N, st);
-        }
-    }
     u16 *wT = s->wT;
     bool ready = false;
     if (keep) {
@@ -825,8 +783,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
     int rc = scratch_reserve(d, chunk, w_elems, d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
-    const char *am = getenv("PIE_PREFILL_ATTN");  // "valu" forces the row-per-launch-slice VALU kernel (tests compare the two)
-    const bool mfma_attn = !(am && am[0] == 'v');
+    const bool mfma_attn = pie_knob(PIE_KNOB_PREFILL_ATTN_VALU) != 1;  // 1 forces the row-per-launch-slice VALU kernel (tests compare the two)
     for (int c0 = 0; c0 < L; c0 += chunk) {
         const int M = L - c0 < chunk ? L - c0 : chunk;
         // h = embed_tokens(inputs)  (language.py:176)

@@ -243,10 +243,10 @@ __global__ void __launch_bounds__(REP * QT * 64) k_prefill_attn(const PrefillAtt
 template <class T, int D>
 static int prefill_attn_launch_d(const PrefillAttnArgs &a, hipStream_t st) {
     const int rep = a.Hq / a.Hkv;
-    const char *e = getenv("PIE_PREFILL_QT");  // tuning / test knob: 1 forces one 32-row query tile per workgroup, 2 forces two wherever they fit
+    const int qt = pie_knob(PIE_KNOB_PREFILL_QT);  // test knob: 1 forces one 32-row query tile per workgroup, 2 forces two wherever they fit
     // 2 tiles need 2*rep <= 8 waves of up to 256 registers, and only pay while the halved grid still fills the 256 CUs
     // (8B model: 4096 tokens 54.9 -> 53.9 ms, 8000 tokens 126.3 -> 125.0 ms; at 1024 tokens it would idle half the chip)
-    const bool two = rep <= 4 && a.M > 32 && (e ? e[0] == '2' : ((a.M + 63) / 64) * a.Hkv >= 256);
+    const bool two = rep <= 4 && a.M > 32 && (qt > 0 ? qt == 2 : ((a.M + 63) / 64) * a.Hkv >= 256);
     const dim3 grid(((a.M + (two ? 63 : 31)) / (two ? 64 : 32)) * a.Hkv);
 #define PA_LAUNCH(R)                                                                                         \
     if (two && R <= 4) hipLaunchKernelGGL((k_prefill_attn<T, D, R, (R <= 4 ? 2 : 1)>), grid, dim3(R * 128), 0, st, a); \

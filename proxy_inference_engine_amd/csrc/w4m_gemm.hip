@@ -923,255 +923,6 @@ __global__ void __launch_bounds__(256) k_w4l_reduce(const float *part, int S, si
     *reinterpret_cast<uint2 *>(y + i) = make_uint2(w4m_pack<T>(a.x, a.y), w4m_pack<T>(a.z, a.w));
 }
 
-// ---------------------------------------------------------------- the same tile for 16-bit weights (dense checkpoints, the vision tower)
-// nn.Linear on many rows (language.py:83,108,127 when the module is not quantised; models/intern/vision.py): y = x . W^T, T x T products,
-// fp32 accumulation, one rounding.  k_w4l2_gemm without the conversion: the weights are kept in "W16M" tiles -- 32 output rows x 64
-// columns in MFMA A-fragment order, piece (k-step k, lane l) at byte k * 1024 + l * 16 holding W[32 nt + (l & 31)][64 g + 16 k + 8 (l >> 5) ..+7]
-// -- so a wave-load is one contiguous KB and lands directly in the operand registers; K is padded with zero tiles to a multiple of 256 (the
-// 4-slot ring is unrolled) and N to 32.  A first version staged the W tile by LDS-DMA straight out of the W16S decode units (no copy): one
-// step of look-ahead could not cover HBM latency (72 ms vs the library's 54 for a 4096-token dense prefill; 7.7 vs 6.0 ms at 64 tokens).
-constexpr int W16M_TILE_BYTES = 4096;
-size_t w16m_bytes(int N, int K) { return (size_t)((N + 31) / 32) * (size_t)((K + 255) / 256 * 4) * W16M_TILE_BYTES; }
-
-// src_w16s != nullptr: from the W16S streaming units (N rows in the packed order, K columns); else from a row-major [N, K] matrix
-__global__ void __launch_bounds__(256) k_to_w16m(const uint4 *src_w16s, const u16 *src_rows, int N, int K, uint4 *w16m) {
-    const int groups = (K + 255) / 256 * 4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece of the output
-    if (i >= (size_t)((N + 31) / 32) * groups * 256) return;
-    const int lane = (int)(i & 63), k = (int)((i >> 6) & 3), g = (int)((i >> 8) % groups), nt = (int)((i >> 8) / groups);
-    const int r = 32 * nt + (lane & 31), k0 = 64 * g + 16 * k + 8 * (lane >> 5);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < N && k0 < K) {
-        if (src_w16s) {
-            const int ns = w16s_slices(K), sl = k0 / W16S_SLICE_K, c = (k0 % W16S_SLICE_K) >> 4, j = (k0 >> 3) & 1;
-            v = src_w16s[(((size_t)(r >> 1) * ns + sl) << 7) + (j << 6) + (r & 1) * 32 + c];
-        } else if (k0 + 8 <= K && (K & 7) == 0) {
-            v = *reinterpret_cast<const uint4 *>(src_rows + (size_t)r * K + k0);
-        } else {  // ragged row end / unaligned rows: element by element
-            u16 e[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) e[t] = k0 + t < K ? src_rows[(size_t)r * K + k0 + t] : (u16)0;
-            v = make_uint4((u32)e[0] | ((u32)e[1] << 16), (u32)e[2] | ((u32)e[3] << 16), (u32)e[4] | ((u32)e[5] << 16), (u32)e[6] | ((u32)e[7] << 16));
-        }
-    }
-    w16m[i] = v;
-}
-int w16m_repack_launch(const void *w16s, const void *rows, int N, int K, void *w16m, hipStream_t st) {
-    PIE_REQUIRE((w16s != nullptr) != (rows != nullptr) && w16m && N > 0 && K > 0, PIE_E_ARG, "W16M repack: one source, a destination");
-    const size_t n = w16m_bytes(N, K) / 16;
-    hipLaunchKernelGGL(k_to_w16m, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)w16s, (const u16 *)rows, N, K, (uint4 *)w16m);
-    PIE_LAUNCH_CHECK();
-    return PIE_OK;
-}
-
-// x [M, K] (row stride K elements, K % 8 == 0), y [M, N] (N % 4 == 0 for the 8-byte stores; columns beyond N are not stored)
-// MB: 32-row blocks of x per workgroup (row tile 32 MB: 64, 128 or 256 rows) -- short prompts do not pay for MFMAs on rows that are not there
-template <class T, int MB, bool SWIGLU = false>
-__global__ void __launch_bounds__(256) k_w16l_gemm(const char *w16m, const u16 *x, int M, int N, int K, u16 *y, float *part, const u16 *bias) {
-    constexpr int MT = 32 * MB;
-    __shared__ __attribute__((aligned(1024))) char s_x[2][MT * 128];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, all_groups = (K + 255) / 256 * 4;
-    const int per_z = all_groups / (int)gridDim.z;  // a multiple of 4 (launcher)
-    const int g_lo = blockIdx.z * per_z, groups = per_z;
-    const int m0 = blockIdx.y * MT;
-    const int rows = M - m0 < MT ? M - m0 : MT;
-    const int nt0 = (blockIdx.x * 4 + wave) * 2;
-    const int n_strips = (N + 31) >> 5;
-    const bool has0 = nt0 < n_strips, has1 = nt0 + 1 < n_strips;
-    const char *strip0 = w16m + ((size_t)(has0 ? nt0 : 0) * all_groups + g_lo) * W16M_TILE_BYTES + lane * 16;
-    const char *strip1 = w16m + ((size_t)(has1 ? nt0 + 1 : 0) * all_groups + g_lo) * W16M_TILE_BYTES + lane * 16;
-
-    // x staging as in k_w4l2_gemm; a column piece beyond K (only zero weight tiles multiply it) re-reads the row's last valid piece
-    constexpr int XJ = MB;  // DMA instructions per wave and tile: MT / 8 row groups over 4 waves
-    const u16 *xrow[XJ];
-    int xc[XJ];
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-        const int r = 8 * MB * wave + 8 * j + (lane >> 3);
-        const int rr = r < rows ? r : rows - 1;
-        xrow[j] = x + (size_t)(m0 + rr) * K;
-        xc[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-    }
-    const int last_piece = K - 8;
-    auto x_issue1 = [&](int g, int buf, int j) {
-        int col = (g_lo + g) * 64 + xc[j];
-        col = col <= last_piece ? col : last_piece;
-        const u16 *src = xrow[j] + col;
-        const unsigned dst = (unsigned)(size_t)(w4l_lds_void *)(s_x[0]) + (unsigned)(buf * (MT * 128) + (8 * MB * wave + 8 * j) * 128);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
-    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
-    uint4 af[4][2][4];  // [ring slot][strip][k-step]: the tiles ARE the A fragments
-    auto w_issue = [&](int slot, int g) {
-        const size_t o = (size_t)(g < groups ? g : groups - 1) * W16M_TILE_BYTES;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const nt_u32x4 a0 = *reinterpret_cast<const nt_u32x4 *>(strip0 + o + k * 1024);
-            const nt_u32x4 a1 = *reinterpret_cast<const nt_u32x4 *>(strip1 + o + k * 1024);
-            af[slot][0][k] = make_uint4(a0.x, a0.y, a0.z, a0.w), af[slot][1][k] = make_uint4(a1.x, a1.y, a1.z, a1.w);
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) x_issue1(0, 0, j);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) w_issue(d, d);
-    asm volatile("" : : "a"(0.0f));  // keeps the accumulators in AGPRs (see k_w4l2_gemm)
-
-    f32x16_t acc[2][MB];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[s2][mi][i] = 0.0f;
-    int xoff[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xoff[k] = n * 128 + (((2 * k + kh) ^ ((n >> 1) & 7)) << 4);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
-    // queue order per step: [x DMA of tile g + 1][weight tile g + 3 (8 loads)]; the closing wait leaves only that weight tile in flight
-    for (int base = 0; base < groups; base += 4) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int g = base + d;
-            const char *xb = s_x[d & 1];
-            constexpr int NS = 4 * MB;  // (k-step, row block) pairs of a step
-            uint4 bq[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const uint4 *>(xb + (t % MB) * 4096 + xoff[t / MB]);
-#pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                const int k = t / MB, mi = t % MB;
-                acc[0][mi] = MfmaT<T>::run(af[d][0][k], bq[t & 3], acc[0][mi]);
-                acc[1][mi] = MfmaT<T>::run(af[d][1][k], bq[t & 3], acc[1][mi]);
-                if (t >= 2 && t < 2 + XJ) x_issue1(g + 1 < groups ? g + 1 : g, (d + 1) & 1, t - 2);
-                if (t == 2 + XJ) w_issue((d + 3) & 3, g + 3);  // slot of tile g - 1, consumed in the previous step
-                if (t + 4 < NS) bq[t & 3] = *reinterpret_cast<const uint4 *>(xb + ((t + 4) % MB) * 4096 + xoff[(t + 4) / MB]);
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70 | 8);  // vmcnt(8): everything but the weight tile just issued -- i.e. the DMA of tile g + 1 -- has landed
-            __syncthreads();
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        if (!(s2 ? has1 : has0)) continue;
-        const int nt = nt0 + s2;
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-            const int m = 32 * mi + n;
-            if (m < rows) {
-                const int col = 32 * nt + 4 * kh;
-                const size_t o = (size_t)(m0 + m) * N + col;
-                if (SWIGLU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u16 out2[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const u32 gu = w4m_pack<T>(acc[s2][mi][4 * q + 2 * e], acc[s2][mi][4 * q + 2 * e + 1]);
-                            const float gt = lo_f32<T>(gu), u = hi_f32<T>(gu);
-                            out2[e] = T::from_f32(round_T<T>(gt / (1.0f + expf(-gt))) * u);
-                        }
-                        if (col + 8 * q < N) *reinterpret_cast<u32 *>(y + (size_t)(m0 + m) * (N >> 1) + ((col + 8 * q) >> 1)) = (u32)out2[0] | ((u32)out2[1] << 16);
-                    }
-                } else if (part) {
-                    float *pr = part + (size_t)blockIdx.z * M * N + o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col + 8 * q < N)
-                            *reinterpret_cast<float4 *>(pr + 8 * q) = make_float4(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1], acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col + 8 * q < N) {
-                            float v[4] = {acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1], acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]};
-                            u32 lo = w4m_pack<T>(v[0], v[1]), hi = w4m_pack<T>(v[2], v[3]);
-                            if (bias) {  // nn.Linear: T(T(x W^T) + b)
-                                const uint2 bb = *reinterpret_cast<const uint2 *>(bias + col + 8 * q);
-                                lo = pack2<T>(lo_f32<T>(lo) + lo_f32<T>(bb.x), hi_f32<T>(lo) + hi_f32<T>(bb.x));
-                                hi = pack2<T>(lo_f32<T>(hi) + lo_f32<T>(bb.y), hi_f32<T>(hi) + hi_f32<T>(bb.y));
-                            }
-                            *reinterpret_cast<uint2 *>(y + o + 8 * q) = make_uint2(lo, hi);
-                        }
-                }
-            }
-        }
-    }
-}
-
-// Decomposition of the dense form: row tile (64 / 128 / 256) and K split (every split a multiple of 4 K groups of the padded K).  Big
-// prompts take 256-row tiles unsplit; small products (the vision tower at a few hundred patches: N = K = 1280) would leave most of the
-// chip idle that way -- 5 workgroups for [256 x 1280 x 1280] -- so smaller row tiles and deeper splits are taken until ~192 workgroups
-// exist, preferring the larger tile (less weight re-reading) and the smaller split (less fp32 reduce traffic).
-static void w16l_plan(int M, int N, int K, int *mt_out, int *s_out) {
-    const int groups = (K + 255) / 256 * 4, col_t = ((N + 31) / 32 + 7) / 8;
-    const int mt_max = M <= 64 ? 64 : (M <= 128 ? 128 : 256);
-    int best_mt = mt_max, best_s = 1, best_wgs = 0;
-    for (int mt = mt_max; mt >= 64; mt >>= 1) {
-        const int row_t = (M + mt - 1) / mt;
-        for (int s = 1; s <= 16 && 4 * s <= groups; ++s) {
-            if (groups % (4 * s)) continue;
-            const int wgs = col_t * row_t * s;
-            if (wgs >= 192) {
-                *mt_out = mt, *s_out = s;
-                return;
-            }
-            if (wgs > best_wgs) best_wgs = wgs, best_mt = mt, best_s = s;
-        }
-    }
-    *mt_out = best_mt, *s_out = best_s;
-}
-size_t w16l_workspace_bytes(int M, int N, int K) {
-    int mt, s;
-    w16l_plan(M, N, K, &mt, &s);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
-}
-// w16m: the tile copy (w16m_repack_launch).  bias (nullable, T [N]): added to the rounded product, rounded again (not with a K split: the
-// caller adds it).  swiglu_act / fused: see w4l_gemm_launch.
-int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
-                     const void *bias, bool *bias_done) {
-    if (fused) *fused = false;
-    if (bias_done) *bias_done = false;
-    PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0, PIE_E_SHAPE, "dense prompt GEMM: N must be a multiple of 4 and K of 8");
-    PIE_REQUIRE(pie_aligned(w16m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8), PIE_E_ALIGN, "dense prompt GEMM: 16-byte alignment required");
-    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "dense prompt GEMM: dtype must be PIE_BF16 or PIE_F16");
-    int mt, S;
-    w16l_plan(M, N, K, &mt, &S);
-    PIE_REQUIRE(S == 1 || workspace, PIE_E_ARG, "dense prompt GEMM: this shape splits K and needs its workspace");
-    const dim3 grid((unsigned)(((N + 31) / 32 + 7) / 8), (unsigned)((M + mt - 1) / mt), (unsigned)S);
-#define W16L_GO(TT, MB_, SW_, Y_, P_, B_) hipLaunchKernelGGL((k_w16l_gemm<TT, MB_, SW_>), grid, dim3(256), 0, st, (const char *)w16m, (const u16 *)x, M, N, K, (u16 *)(Y_), P_, B_)
-#define W16L_MB(TT, SW_, Y_, P_, B_) \
-    if (mt == 64) W16L_GO(TT, 2, SW_, Y_, P_, B_); \
-    else if (mt == 128) W16L_GO(TT, 4, SW_, Y_, P_, B_); \
-    else W16L_GO(TT, 8, SW_, Y_, P_, B_)
-    if (S == 1 && swiglu_act && fused && !bias && N % 64 == 0) {
-        if (dtype == PIE_BF16) { W16L_MB(BF16, true, swiglu_act, nullptr, nullptr); }
-        else { W16L_MB(F16, true, swiglu_act, nullptr, nullptr); }
-        PIE_LAUNCH_CHECK();
-        *fused = true;
-        return PIE_OK;
-    }
-    float *part = S > 1 ? (float *)workspace : nullptr;
-    const u16 *b = S == 1 && bias_done ? (const u16 *)bias : nullptr;
-    if (dtype == PIE_BF16) { W16L_MB(BF16, false, y, part, b); }
-    else { W16L_MB(F16, false, y, part, b); }
-#undef W16L_MB
-#undef W16L_GO
-    PIE_LAUNCH_CHECK();
-    if (b && bias_done) *bias_done = true;
-    if (S > 1) {
-        const size_t MN = (size_t)M * N;
-        const dim3 rg((unsigned)((MN / 4 + 255) / 256));
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l_reduce<BF16>, rg, dim3(256), 0, st, part, S, MN, (u16 *)y);
-        else hipLaunchKernelGGL(k_w4l_reduce<F16>, rg, dim3(256), 0, st, part, S, MN, (u16 *)y);
-        PIE_LAUNCH_CHECK();
-    }
-    return PIE_OK;
-}
 
 // K-split factor the launcher will use for [M, N, K]: enough workgroups for the chip, at least 8 groups (512 columns) per split.
 // Decomposition: row tile (64 / 128 / 256 rows) x K split, and which kernel.  The one-wave-per-SIMD form (k_w4l2_gemm) needs a multiple
@@ -1319,8 +1070,7 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
     constexpr int stage_min = 24;  // rows from which x is staged through LDS; measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
     const int n_strips = N >> 5;
-    const char *ne = getenv("PIE_W4M_MULTI");  // 0: one strip per workgroup also for the wide matrices (A/B, bit-equality test)
-    if (!y32 && n_strips >= 512 && K >= 512 && !(ne && ne[0] == '0')) {  // at every row count: 24.1-25.8 us on gate|up against 32.6-37.2 (persistent form) / 35.0 (staged, one strip)
+    if (!y32 && n_strips >= 512 && K >= 512 && pie_knob(PIE_KNOB_W4M_MULTI) != 0) {  // knob 0: one strip per workgroup also for the wide matrices (bit-equality test)  // at every row count: 24.1-25.8 us on gate|up against 32.6-37.2 (persistent form) / 35.0 (staged, one strip)
         constexpr int NS = 4;  // strips per workgroup (8 measured worse: 256 VGPRs with spills, and gate|up left with 112 workgroups)
         const dim3 mgrid((n_strips + NS - 1) / NS);
         if (dtype == PIE_BF16)
@@ -1382,26 +1132,6 @@ size_t pie_w4m_bytes(int N, int K) { return N > 0 && K > 0 && N % 32 == 0 && K %
 int pie_repack_w4s_to_w4m(const void *w4s, int N, int K, void *w4m, void *stream) {
     PIE_REQUIRE(w4s && w4m, PIE_E_ARG, "pie_repack_w4s_to_w4m: null pointer");
     return w4m_repack_launch(w4s, N, K, w4m, (hipStream_t)stream);
-}
-
-size_t pie_w16m_bytes(int N, int K) { return N > 0 && K > 0 ? w16m_bytes(N, K) : 0; }
-
-int pie_repack_w16m(const void *weight_rows, int N, int K, void *w16m, void *stream) {
-    PIE_REQUIRE(weight_rows && w16m, PIE_E_ARG, "pie_repack_w16m: null pointer");
-    PIE_REQUIRE(pie_aligned(w16m, 16) && pie_aligned(weight_rows, 2), PIE_E_ALIGN, "pie_repack_w16m: misaligned operand");
-    return w16m_repack_launch(nullptr, weight_rows, N, K, w16m, (hipStream_t)stream);
-}
-
-size_t pie_linear_w16m_workspace_bytes(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0 ? w16l_workspace_bytes(M, N, K) : 0; }
-
-int pie_linear_w16m(const void *x, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, void *workspace, void *stream) {
-    PIE_REQUIRE(x && w16m && y, PIE_E_ARG, "pie_linear_w16m: null pointer");
-    PIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 8 == 0, PIE_E_SHAPE, "pie_linear_w16m: M > 0, N a multiple of 4, K a multiple of 8");
-    hipStream_t st = (hipStream_t)stream;
-    bool bias_done = false;
-    const int rc = w16l_gemm_launch(dtype, w16m, x, M, N, K, y, workspace, st, nullptr, nullptr, bias, &bias_done);
-    if (rc || !bias || bias_done) return rc;
-    return bias_any_launch(dtype, y, bias, M, N, st);  // K-split shape: the bias after the fp32 reduce
 }
 
 int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype, void *y, void *stream) {

@@ -425,8 +425,6 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     """nn.Linear on a block of rows: x [M, K] @ weight [N, K].T (+ bias [N]) -> [M, N]; dense 16-bit weights, hipBLASLt GEMM
     with fp32 accumulation (models/intern/vision.py:150-151,192-194,129-133; PatchEmbed's Conv3d with stride = kernel is the
     same product over flattened patches, vision.py:97-121)."""
-    if isinstance(weight, W16MWeight):
-        return linear_rows_w16m(x, weight, bias)
     _dev(x), _dev(weight)
     if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.dtype != weight.dtype:
         raise ValueError("linear_rows: x [M, K], weight [N, K] of one dtype")
@@ -438,55 +436,6 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None
     y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _ffi.check(_ffi.load().pie_linear(_ffi.p(x), _ffi.p(weight), _ffi.p(bias.contiguous() if bias is not None else None), M, N, K,
                                       _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
-    return y
-
-
-class W16MWeight:
-    """A 16-bit nn.Linear weight [N, K] in MFMA-ordered tiles (include/pie_hip.h: pie_repack_w16m) for `linear_rows`: the library's own
-    many-row GEMM reads it directly, so no row-major copy is kept.  K is padded to a multiple of 8 with zero columns (x is padded to
-    match at call time when its width is not)."""
-
-    def __init__(self, weight: torch.Tensor):
-        _dev(weight)
-        if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16):
-            raise ValueError("W16MWeight: a 16-bit [N, K] matrix")
-        self.N, self.K = int(weight.shape[0]), int(weight.shape[1])
-        self.dtype = weight.dtype
-        self.Kp = (self.K + 7) // 8 * 8
-        w = weight.contiguous()
-        if self.Kp != self.K:
-            w = torch.nn.functional.pad(w, (0, self.Kp - self.K))
-        lib = _ffi.load()
-        self.tiles = torch.empty(int(lib.pie_w16m_bytes(self.N, self.Kp)), dtype=torch.uint8, device=weight.device)
-        _ffi.check(lib.pie_repack_w16m(_ffi.p(w), self.N, self.Kp, _ffi.p(self.tiles), _ffi.stream()))
-        torch.cuda.current_stream(weight.device).synchronize()  # `w` may be a temporary
-
-    @property
-    def shape(self):
-        return (self.N, self.K)
-
-    @property
-    def nbytes(self) -> int:
-        return self.tiles.numel()
-
-
-def linear_rows_w16m(x: torch.Tensor, w: W16MWeight, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """nn.Linear on a block of rows through the hand-written dense MFMA GEMM (pie_linear_w16m): x [M, K] -> [M, N]."""
-    _dev(x)
-    if x.dim() != 2 or x.shape[1] != w.K or x.dtype != w.dtype or w.N % 4:
-        raise ValueError("linear_rows_w16m: x [M, K] in the weight's dtype, N % 4 == 0")
-    if bias is not None and (bias.shape != (w.N,) or bias.dtype != x.dtype):
-        raise ValueError("linear_rows_w16m: bias must be [N] in the activation dtype")
-    x = x.contiguous()
-    if w.Kp != w.K:
-        x = torch.nn.functional.pad(x, (0, w.Kp - w.K))  # zero columns against the zero weight columns
-    M = x.shape[0]
-    y = torch.empty((M, w.N), dtype=x.dtype, device=x.device)
-    lib = _ffi.load()
-    wb = int(lib.pie_linear_w16m_workspace_bytes(M, w.N, w.Kp))
-    ws = torch.empty(wb, dtype=torch.uint8, device=x.device) if wb else None  # torch's allocator: safe under graph capture
-    _ffi.check(lib.pie_linear_w16m(_ffi.p(x), _ffi.p(w.tiles), _ffi.p(bias.contiguous() if bias is not None else None), M, w.N, w.Kp,
-                                   _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.p(ws) if ws is not None else None, _ffi.stream()))
     return y
 
 

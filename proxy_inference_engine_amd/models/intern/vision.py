@@ -90,20 +90,8 @@ class VisionModel:
         self._graphs: dict = {}
         self.merger = {"ln_q": get("merger.ln_q.weight"), "w0": get("merger.mlp.0.weight"), "b0": get("merger.mlp.0.bias"),
                        "w2": get("merger.mlp.2.weight"), "b2": get("merger.mlp.2.bias")}
-        # PIE_W16L=1: every Linear's weight in the MFMA-ordered tiles of the library's own dense GEMM (pie_linear_w16m), the row-major
-        # matrices dropped.  Off by default on measurement: the tower's GEMMs are small (N = K = 1280 at a few hundred to a few thousand
-        # rows) and hipBLASLt's tile selection beats the 256-column tile kernel there (7B tower, ms per image at 256 / 1024 / 4096
-        # patches: 2.9 / 4.3 / 11.6 with the library, 3.8 / 6.0 / 13.4 with the own kernel at its best decomposition per size).
-        import os
-        if os.environ.get("PIE_W16L", "0") == "1":
-            def tiles(w):
-                return ops.W16MWeight(w) if w.shape[0] % 4 == 0 else w
-            self.patch_w = tiles(self.patch_w)
-            for b in self.blocks:
-                for k in ("qkv_w", "proj_w", "gateup_w", "down_w"):
-                    b[k] = tiles(b[k])
-            for k in ("w0", "w2"):
-                self.merger[k] = tiles(self.merger[k])
+        # every Linear of the tower is a plain dense GEMM: pie_linear -> hipBLASLt (the hand-written 16-bit kernel of rounds 2-3 was 15-38 % slower on
+        # these small shapes and was deleted in round 4: EXPERIMENTS.md)
 
     # ------------------------------------------------------------------ vision.py:245-279
     def rot_pos_emb(self, grid_thw) -> np.ndarray:

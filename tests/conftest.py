@@ -22,3 +22,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def knobs():
+    """The library's test switches (pie_set_knob; the environment is not read any more): knobs(name, value) sets one, all are back at
+    their defaults after the test."""
+    from proxy_inference_engine_amd import _ffi
+
+    def setter(name, value):
+        _ffi.set_knob(name, value)
+
+    yield setter
+    for name in _ffi.KNOBS:
+        _ffi.set_knob(name, None)

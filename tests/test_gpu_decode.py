@@ -134,15 +134,15 @@ def test_step_equals_its_kernels_launched_by_name(tiny):
         assert np.array_equal(to_bits(model.hidden), hidden_by_name)
 
 
-@pytest.mark.parametrize("merge_cap", [None, "256"])
-def test_cache_growth_across_step_boundary(tiny, merge_cap, monkeypatch):
+@pytest.mark.parametrize("merge_cap", [None, 256])
+def test_cache_growth_across_step_boundary(tiny, merge_cap, knobs):
     """Decode across the 256-position capacity boundary: the cache re-allocates (256 -> 512) and the decoder must
     pick up the new buffers; compare logits right before / after the growth with the oracle.  merge_cap = 256 also
     moves the attention plan at the boundary: 4 splits merged by the o_proj prologue -> 8 splits + k_attn_combine, so the
     captured graph has to be rebuilt mid-stream."""
     g, cfg, w, model = tiny
     if merge_cap:
-        monkeypatch.setenv("PIE_ATTN_MERGE_MAX_CAP", merge_cap)
+        knobs("attn_merge_max_cap", merge_cap)
         model = build(cfg, w)
     rng = np.random.default_rng(21)
     prompt = rng.integers(0, cfg["vocab_size"], 250)
@@ -267,21 +267,21 @@ def test_forced_split_counts_match_oracle(tiny):
     assert ref_bits is not None
 
 
-def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
-    """Prompt processing.  Prompts of >= PIE_PREFILL_MIN (6) tokens run as batched GEMMs on weights
-    dequantised to T (MLX's qmm regime, oracle qmm_min_rows = 6), in chunks of PIE_PREFILL_CHUNK rows; shorter ones as
+def test_batched_prefill_chunks_and_regimes(tiny, knobs):
+    """Prompt processing.  Prompts of >= 6 tokens (knob prefill_min) run as batched GEMMs on weights
+    dequantised to T (MLX's qmm regime, oracle qmm_min_rows = 6), in chunks of `prefill_chunk` rows; shorter ones as
     iterated decode steps (qmv regime: exact fp32 affine sums).  Both against the oracle in the matching regime, every
     position, with a ragged last chunk (100 = 3 x 32 + 4) and a second call that continues at a non-zero offset."""
     g, cfg, w, model = tiny
     rng = np.random.default_rng(31)
     prompt, more = rng.integers(0, cfg["vocab_size"], 100), rng.integers(0, cfg["vocab_size"], 40)
     orc = po.OracleLlama(cfg, w, DT)
-    # PIE_PREFILL_RESIDENT=0: every chunk dequantises into the scratch again (the other prefill tests keep resident copies)
-    for regime, rows, env in (("batched", 6, {"PIE_PREFILL_CHUNK": "32", "PIE_PREFILL_RESIDENT": "0"}), ("iterated", 0, {"PIE_PREFILL_MIN": "100000"})):
-        for k in ("PIE_PREFILL_CHUNK", "PIE_PREFILL_MIN", "PIE_PREFILL_RESIDENT"):
-            monkeypatch.delenv(k, raising=False)
+    # prefill_resident = 0: every chunk dequantises into the scratch again (the other prefill tests keep resident copies)
+    for regime, rows, env in (("batched", 6, {"prefill_chunk": 32, "prefill_resident": 0}), ("iterated", 0, {"prefill_min": 100000})):
+        for k in ("prefill_chunk", "prefill_min", "prefill_resident"):
+            knobs(k, None)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs(k, v)
         po.set_qmm_min_rows(rows)
         try:
             ocache = [po.OracleKVCache() for _ in orc.layers]
@@ -304,9 +304,9 @@ def test_batched_prefill_chunks_and_regimes(tiny, monkeypatch):
 
 
 @pytest.mark.parametrize("L", [6, 9, 16, 24, 32, 33])
-def test_short_prompt_int4_gemm_paths(tiny, monkeypatch, L):
+def test_short_prompt_int4_gemm_paths(tiny, knobs, L):
     """Prompts of 6..32 tokens run the few-row int4 GEMM on W4M tiles (w4m_gemm.hip: direct fragments below 24 rows, x staged
-    through LDS from 24), 33 and PIE_SMALL_M=0 the T copy + hipBLASLt: same qmm contract, every position against the oracle,
+    through LDS from 24), 33 and knob small_m = 0 the T copy + hipBLASLt: same qmm contract, every position against the oracle,
     and the two paths within one rounding of each other."""
     g, cfg, w, _ = tiny
     rng = np.random.default_rng(L)
@@ -314,20 +314,20 @@ def test_short_prompt_int4_gemm_paths(tiny, monkeypatch, L):
     orc = po.OracleLlama(cfg, w, DT)
     want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
     outs = {}
-    for small in ("32", "0"):
-        monkeypatch.setenv("PIE_SMALL_M", small)
+    for small in (32, 0):
+        knobs("small_m", small)
         m = build(cfg, w)
         cache = m.make_cache()
         got = m(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
         for l in range(L):
-            assert_vec_close(got[l], want[l], DT, what=f"PIE_SMALL_M={small} L={L} position {l}")
+            assert_vec_close(got[l], want[l], DT, what=f"small_m={small} L={L} position {l}")
         tok, _, logits = m.step(None, cache)                           # decode continues on the cache the short prompt filled
         outs[small] = (got, logits.float().cpu().numpy())
     assert_vec_close(outs["32"][0][-1], outs["0"][0][-1], DT, what="w4m vs hipBLASLt path")
     assert_vec_close(outs["32"][1], outs["0"][1], DT, what="decode after w4m vs hipBLASLt prompt")
 
 
-def test_batched_prefill_llama8b_shapes(monkeypatch):
+def test_batched_prefill_llama8b_shapes(knobs):
     """The real GEMM shapes (N = 6144 / 4096 / 28672, K = 4096 / 14336) on two Llama-3-8B-shaped layers: 48-token prompt
     through the batched path, then decode steps on the cache it filled."""
     dtype = "bfloat16"
@@ -353,11 +353,11 @@ def test_batched_prefill_llama8b_shapes(monkeypatch):
 
 
 @pytest.mark.parametrize("bias,L", [(False, 200), (True, 200), (False, 70)])
-def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias, L):
+def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(knobs, bias, L):
     """Prompts of a few dozen to a few hundred rows split K in the many-row int4 GEMM; the fp32 partial slabs are summed by the kernels that
     consume the product (RoPE + append for q|k|v, residual add + RMSNorm for o_proj / down) instead of a reduce launch of their own.  Same
     arithmetic in the same order: logits, hidden state and the decode steps that follow are bit-identical to the reduce-launch form
-    (PIE_W4L_SLABS=0), and both follow the oracle.  Two Llama-3-8B-shaped layers, 200- and 70-token prompts; with Linear biases the q|k|v product
+    (knob w4l_slabs = 0), and both follow the oracle.  Two Llama-3-8B-shaped layers, 200- and 70-token prompts; with Linear biases the q|k|v product
     keeps its reduce launch and o_proj / down add the bias after their own rounding."""
     dtype = "bfloat16"
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
@@ -371,7 +371,7 @@ def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias, 
     want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PIE_W4L_SLABS", mode)
+        knobs("w4l_slabs", int(mode))
         model = build(cfg, w, dtype)
         cache = model.make_cache()
         tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
@@ -390,9 +390,9 @@ def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(monkeypatch, bias, 
 
 
 @pytest.mark.parametrize("L", [9, 24, 32])
-def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(monkeypatch, L):
+def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(knobs, L):
     """Prompt suffixes of up to 32 rows on the real layer shapes: gate|up walks K once for four strips per workgroup, o_proj / down run two
-    strips per workgroup with K split into four fp32 slabs that the residual-add + RMSNorm kernel sums (PIE_W4M_SLABS=0: the one-strip forms
+    strips per workgroup with K split into four fp32 slabs that the residual-add + RMSNorm kernel sums (knob w4m_slabs = 0: the one-strip forms
     with the two-way fp32 atomic split).  Both follow the oracle; the two differ only in the order of four fp32 additions."""
     dtype = "bfloat16"
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
@@ -406,22 +406,22 @@ def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(monkeypatch, L):
     want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PIE_W4M_SLABS", mode)
+        knobs("w4m_slabs", int(mode))
         model = build(cfg, w, dtype)
         cache = model.make_cache()
         tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
-        assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what=f"hidden, PIE_W4M_SLABS={mode}")
-        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"logits, PIE_W4M_SLABS={mode}")
+        assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what=f"hidden, w4m_slabs={mode}")
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"logits, w4m_slabs={mode}")
         outs[mode] = logits.float().cpu().numpy()
     assert_vec_close(outs["1"], outs["0"], dtype, what="slab split vs atomic split")   # (a few bf16 roundings flip downstream of the reordered sums)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
+def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, knobs):
     """head_dim 128 prompts use the MFMA causal flash-attention kernel (prefill_attn.hpp).  One Llama-3-8B-shaped layer,
     300-token prompt (ten key blocks, diagonal masking, a ragged last query tile: 300 = 9 x 32 + 12) and a 45-token
     continuation at offset 300 (query rows that start in the middle of a key block): against the oracle and against the
-    VALU kernel run once per query row (PIE_PREFILL_ATTN=valu), on logits, hidden state and the cache rows."""
+    VALU kernel run once per query row (knob prefill_attn_valu = 1), on logits, hidden state and the cache rows."""
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 1, "intermediate_size": 14336,
            "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 2048,
            "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
@@ -436,7 +436,7 @@ def test_prefill_flash_attention_vs_valu_rows_and_oracle(dtype, monkeypatch):
     want2 = orc.forward(p2, ocache)
     got = {}
     for mode in ("mfma", "valu"):
-        monkeypatch.setenv("PIE_PREFILL_ATTN", mode)
+        knobs("prefill_attn_valu", 1 if mode == "valu" else None)
         cache = model.make_cache()
         a = model(torch.from_numpy(p1)[None].cuda(), cache=cache)[0].float().cpu().numpy()
         b = model(torch.from_numpy(p2)[None].cuda(), cache=cache)[0].float().cpu().numpy()
@@ -713,13 +713,13 @@ def test_load_checkpoint_directory(tmp_path, quant):
 
 
 @pytest.mark.parametrize("n_heads,n_kv,D", [(4, 4, 128), (4, 2, 128), (8, 1, 128), (6, 2, 128), (5, 1, 128), (7, 1, 64), (6, 1, 64)])
-def test_attention_head_groupings(n_heads, n_kv, D, monkeypatch):
+def test_attention_head_groupings(n_heads, n_kv, D, knobs):
     """Every GQA ratio from 1 to 8 q-heads per kv-head (Llama-3.2-3B has 3, Qwen2.5-7B 7; the 8B / 70B tests cover 4 and 8
     at full size), head_dim 128 and 64: the MFMA prefill attention (64 .. 512-thread workgroups), then the decode
     attention + merged o_proj on the cache it filled.  75-token prompt + 37-token continuation, every position, 2 steps."""
     # two 32-row query tiles per workgroup wherever they fit (<= 4 q-heads per kv-head); the product only picks that form for
     # prompts long enough to fill the chip, which no parity test can afford
-    monkeypatch.setenv("PIE_PREFILL_QT", "2")
+    knobs("prefill_qt", 2)
     cfg = {"model_type": "llama", "hidden_size": n_heads * D, "num_hidden_layers": 2, "intermediate_size": 768,
            "num_attention_heads": n_heads, "num_key_value_heads": n_kv, "rms_norm_eps": 1e-5, "vocab_size": 512,
            "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": True,
@@ -943,22 +943,3 @@ def test_long_prompt_gate_up_with_fused_swiglu_epilogue():
     got = model(torch.from_numpy(prompt)[None].cuda(), cache=model.make_cache())[0].float().cpu().numpy()
     for l in list(range(0, L, 97)) + [L - 1]:
         assert_vec_close(got[l], want[l], dtype, what=f"long prompt position {l}")
-
-
-def test_dense_checkpoint_on_the_own_prompt_gemm(monkeypatch):
-    """PIE_W16L=1: a dense checkpoint's prompt GEMMs on the hand-written 16-bit MFMA kernel (k_w16l_gemm on W16M tiles, incl. the fused
-    SwiGLU epilogue and K-split shapes) instead of hipBLASLt: every position of a 300-token prompt against the oracle's dense path."""
-    monkeypatch.setenv("PIE_W16L", "1")
-    dtype = "bfloat16"
-    cfg = {"model_type": "llama", "hidden_size": 512, "num_hidden_layers": 2, "intermediate_size": 1408,
-           "num_attention_heads": 8, "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 1024,
-           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": True}
-    w = po.synth_checkpoint(cfg, seed=23, dtype=dtype, lm_head_gain=4.0)
-    model = build(cfg, w, dtype)
-    orc = po.OracleLlama(cfg, w, dtype)
-    for L in (40, 300):
-        prompt = np.random.default_rng(L).integers(0, cfg["vocab_size"], L)
-        want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
-        got = model(torch.from_numpy(prompt)[None].cuda(), cache=model.make_cache())[0].float().cpu().numpy()
-        for l in list(range(0, L, 17)) + [L - 1]:
-            assert_vec_close(got[l], want[l], dtype, what=f"own dense GEMM L={L} position {l}")

@@ -361,10 +361,10 @@ def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 16384 + 96, 1024), (32, 16512, 2048), (19, 16416, 576)])
-def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, monkeypatch, M, N, K):
+def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, knobs, M, N, K):
     """Matrices with 512+ strips of 32 columns (gate|up, lm_head): one workgroup walks K once for four strips (k_w4m_gemm_lds4) -- x is
     staged once per workgroup instead of once per strip.  Same tiles per wave, same accumulation and reduction order: bit-identical to the
-    one-strip-per-workgroup forms (PIE_W4M_MULTI=0), and close to the oracle's qmm.  N not a multiple of 128: the last workgroup owns
+    one-strip-per-workgroup forms (knob w4m_multi = 0), and close to the oracle's qmm.  N not a multiple of 128: the last workgroup owns
     fewer strips; K = 576: fewer groups than two rounds of waves."""
     dt = "bfloat16"
     rng = np.random.default_rng(M + N)
@@ -374,7 +374,7 @@ def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, monkeypatch,
     packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
     xd = to_dev(po.to_bits(x, dt), dt)
     got = ops.quantized_matmul_rows(xd, packed)
-    monkeypatch.setenv("PIE_W4M_MULTI", "0")
+    knobs("w4m_multi", 0)
     ref = ops.quantized_matmul_rows(xd, packed)
     assert torch.equal(got, ref), "four strips per workgroup must not change a bit"
     want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
@@ -410,27 +410,20 @@ def test_many_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 @pytest.mark.parametrize("M,N,K,bias", [(1, 32, 64, False), (33, 1280, 1176, True), (64, 96, 256, False), (130, 3840, 1280, False), (300, 1280, 3420, True),
                                         (513, 6840, 1280, False), (1000, 3584, 5120, True), (257, 100, 72, True)])
-def test_dense_many_row_gemm_vs_oracle_linear(ops, dt, M, N, K, bias):
-    """pie_linear_w16m (k_w16l_gemm on W16M tiles): nn.Linear with 16-bit weights on a block of rows without a library GEMM -- the vision
-    tower's shapes (PatchEmbed K = 1176, qkv 3840 x 1280, the MLP's K = 3420 whose rows are not 16-byte aligned and get padded, gate|up
-    6840 columns, the merger 5120 -> 3584), ragged N / K / M, all three row-tile sizes and K-split shapes, with and without bias --
-    against the oracle's Linear (T x T products, fp32 accumulation, one rounding, then the bias)."""
+def test_linear_rows_at_the_vision_tower_shapes_vs_oracle(ops, dt, M, N, K, bias):
+    """pie_linear (the library GEMM behind every dense many-row Linear): nn.Linear with 16-bit weights on a block of rows at the vision tower's
+    shapes (PatchEmbed K = 1176, qkv 3840 x 1280, the MLP's K = 3420 whose rows are not 16-byte aligned, gate|up 6840 columns, the merger
+    5120 -> 3584) and ragged N / K / M, with and without bias -- against the oracle's Linear (T x T products, fp32 accumulation, one
+    rounding, then the bias)."""
     rng = np.random.default_rng(M + N + K)
     w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
     x = po.round_T(rng.standard_normal((M, K)), dt)
     b = po.round_T(rng.standard_normal(N) * 0.5, dt) if bias else None
-    wt = ops.W16MWeight(to_dev(po.to_bits(w, dt), dt))
-    xd = to_dev(po.to_bits(x, dt), dt)
-    got = ops.linear_rows(xd, wt)
+    wd, xd = to_dev(po.to_bits(w, dt), dt), to_dev(po.to_bits(x, dt), dt)
+    got = ops.linear_rows(xd, wd)
     want = po.linear(x, po.to_bits(w, dt), dtype=dt)
-    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w16l {M}x{N}x{K} {dt}")
-    if bias:  # T(T(x W^T) + b): exactly the rounded sum of the kernel's own product and the bias (in the epilogue, or behind a K split)
-        with_b = ops.linear_rows(xd, wt, to_dev(po.to_bits(b, dt), dt))
-        expect = po.round_T(got.float().cpu().numpy().astype(np.float32) + b.astype(np.float32)[None, :], dt)
-        assert np.array_equal(to_bits(with_b), po.to_bits(expect, dt))
-    if K <= 256 and not bias:  # the identity product recovers the weights bit for bit
-        r = min(M, K)
-        eye = np.zeros((M, K), np.float32)
-        eye[np.arange(r), np.arange(r)] = 1.0
-        cols = ops.linear_rows(to_dev(po.to_bits(eye, dt), dt), wt)
-        assert np.array_equal(to_bits(cols)[:r], po.to_bits(w.T[:r].copy(), dt))
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"linear {M}x{N}x{K} {dt}")
+    if bias:
+        with_b = ops.linear_rows(xd, wd, to_dev(po.to_bits(b, dt), dt))
+        want_b = po.linear(x, po.to_bits(w, dt), dtype=dt, lin_bias=po.to_bits(b, dt))
+        assert_dot_close(with_b.float().cpu().numpy(), want_b, dt, max_frac=0.03, mag=np.abs(want_b).max(), what=f"linear + bias {M}x{N}x{K} {dt}")

@@ -349,20 +349,17 @@ def test_batched_decode_step_matches_each_sequence_alone(golden_dir, B):
     assert pool.size() - pool.get_num_free_pages() == sum((n + steps + 63) // 64 for n in lens)
 
 
-def test_batched_step_equals_single_sequence_batched_path(golden_dir):
-    """A batch of one sequence against a one-token prompt through the batched path on a contiguous cache (PIE_PREFILL_MIN=1):
+def test_batched_step_equals_single_sequence_batched_path(golden_dir, knobs):
+    """A batch of one sequence against a one-token prompt on a contiguous cache (knob prefill_min at its minimum):
     same Linears, different attention kernel (paged split-KV decode vs the MFMA prompt kernel) -- equal within rounding."""
-    import os
     from tests._util import assert_vec_close
     g, cfg, model = _tiny(golden_dir)
     prompt = g["prompt"].astype(np.int32)
     ref_cache = model.make_cache()
     model.step(torch.from_numpy(prompt).cuda(), ref_cache)
-    os.environ["PIE_PREFILL_MIN"] = "1"
-    try:
-        want = model(torch.tensor([[77]]).cuda(), cache=ref_cache)[0, -1]
-    finally:
-        del os.environ["PIE_PREFILL_MIN"]
+    knobs("prefill_min", 1)
+    want = model(torch.tensor([[77]]).cuda(), cache=ref_cache)[0, -1]
+    knobs("prefill_min", None)
     model.enable_paged_kv(num_pages=8)
     c = model.make_cache()
     model.step(torch.from_numpy(prompt).cuda(), c)

@@ -217,7 +217,7 @@ def test_vision_tower_mlx_ordered_conv_weight_and_errors():
     tw2 = dict(tw)
     tw2["vision_tower.patch_embed.proj.weight"] = tw["vision_tower.patch_embed.proj.weight"].permute(0, 2, 3, 4, 1).contiguous()   # MLX order
     b = VisionModel(VisionConfig(**CFG80), tw2)
-    pa, pb = (m.patch_w.tiles if hasattr(m.patch_w, "tiles") else m.patch_w for m in (a, b))   # W16M tiles of the same matrix
+    pa, pb = a.patch_w, b.patch_w
     assert torch.equal(pa, pb)
     with pytest.raises(ValueError, match="grid_thw must be provided"):
         a(torch.zeros(4, 1176, device="cuda"))
@@ -266,21 +266,3 @@ def test_vision_tower_and_few_row_gemm_against_golden_fixture(ops, golden_dir):
     packed = ops.repack_w4s(codes_dev(g["qmm_wq"]), to_dev(g["qmm_scales"], DT), to_dev(g["qmm_biases"], DT))
     y = ops.quantized_matmul_rows(to_dev(g["qmm_x"], DT), packed)
     assert_dot_close(y.float().cpu().numpy(), po.from_bits(g["qmm_y"], DT), DT, max_frac=0.03, what="golden few-row product")
-
-
-def test_vision_tower_on_the_own_dense_gemm(monkeypatch):
-    """PIE_W16L=1: every Linear of the tower on the hand-written dense MFMA GEMM (pie_linear_w16m, W16M tiles; the MLP's K = 3420 rows are
-    padded to 16-byte alignment) instead of hipBLASLt -- same image features within the tower's tolerance, and no row-major weights kept."""
-    from proxy_inference_engine_amd import hip_ops
-    from proxy_inference_engine_amd.models.intern.vision import VisionConfig, VisionModel
-    w = vo.synth_vision_checkpoint(CFG80, 2, DT)
-    tw = {k: to_dev(v, DT) for k, v in w.items()}
-    lib_model = VisionModel(VisionConfig(**CFG80), tw)
-    monkeypatch.setenv("PIE_W16L", "1")
-    own = VisionModel(VisionConfig(**CFG80), tw)
-    assert isinstance(own.patch_w, hip_ops.W16MWeight) and isinstance(own.blocks[0]["down_w"], hip_ops.W16MWeight)
-    grid = [(1, 8, 12)]
-    n = 8 * 12
-    px = dev(po.round_T(np.random.default_rng(4).standard_normal((n, 3 * 2 * 14 * 14)), DT))
-    a, b = lib_model(px, torch.tensor(grid)).float().cpu().numpy(), own(px, torch.tensor(grid)).float().cpu().numpy()
-    assert np.abs(a - b).max() <= 4 * EPS[DT] * np.abs(a).max()
