@@ -344,9 +344,19 @@ int pie_decoder_status(pie_decoder *d, unsigned *error);
  *                                                 enqueue the same sequence of steps.  c must outlive d.
  *   pie_comm_status(c, &err)                      synchronises; err != 0: a bounded wait (2 s) for a peer's data gave up
  *   pie_comm_destroy(c)
- * world == 1 is a valid (self-connected) communicator.  A peer may run at most one collective ahead of the slowest rank. */
+ * world == 1 is a valid (self-connected) communicator.  A peer may run at most one collective ahead of the slowest rank.
+ * Inside the decoder the push half of each all-reduce rides in the row-parallel GEMV's epilogue; the launch behind it pulls, rounds and adds
+ * the residual.
+ * A second backend runs the same collectives through RCCL (north_star: "RCCL all-reduce over xGMI") -- ncclAllReduce / ncclAllGather on the
+ * launch stream, capturable in the step's hipGraph; the comparator and fall-back of the one-shot form on a real node:
+ *   pie_comm_rccl_unique_id(id128)                         on one rank; the host hands the 128 bytes to every rank
+ *   pie_comm_create_rccl(rank, world, max_elems, id128, &c) collective over the world (ncclCommInitRank); the communicator is connected
+ * Its sums are RCCL's (identical on every rank, summed in the ring's order, not in rank order). */
 typedef struct pie_comm pie_comm;
+enum { PIE_COMM_IPC = 0, PIE_COMM_RCCL = 1 };
 int pie_comm_create(int rank, int world, size_t max_elems, pie_comm **out);
+int pie_comm_rccl_unique_id(void *id128);
+int pie_comm_create_rccl(int rank, int world, size_t max_elems, const void *id128, pie_comm **out);
 int pie_comm_export(const pie_comm *c, void *handle64);
 int pie_comm_connect(pie_comm *c, const void *handles);
 int pie_allreduce_f32(pie_comm *c, float *data, size_t n, void *stream);

@@ -37,7 +37,7 @@ EXPORTS = [
     "pie_page_i8_bytes", "pie_page_scale_ptrs", "pie_page_i8_set_scales", "pie_paged_kv_append_i8", "pie_paged_attn_decode_i8",
     "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
     "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
-    "pie_comm_create", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
+    "pie_comm_create", "pie_comm_rccl_unique_id", "pie_comm_create_rccl", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
 ]
 
 
@@ -108,6 +108,8 @@ def load() -> C.CDLL:
     lib.pie_sample_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.pie_sample_workspace_bytes.restype = C.c_size_t
     lib.pie_comm_create.argtypes = [C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.pie_comm_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.pie_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.pie_comm_export.argtypes = [C.c_void_p, C.c_void_p]
     lib.pie_comm_connect.argtypes = [C.c_void_p, C.c_void_p]
     lib.pie_allreduce_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

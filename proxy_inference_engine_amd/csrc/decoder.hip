@@ -121,14 +121,16 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.fmt = gfmt(w.wo), a.w = (const char *)w.wo, a.K = QD, a.N = H, a.resid = d->h, a.lin_bias = (const u16 *)w.bo;
             // tensor-parallel shard (row-parallel Linear over the local heads): un-rounded fp32 partial, summed over the ranks,
             // THEN the Linear's one rounding and the residual add
-            const int epi = d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL;
-            a.y32 = d->tp_part;
+            // the one-shot communicator: the push half of the all-reduce rides in this epilogue (EPI_TP_PUSH); RCCL: fp32 partial in memory
+            const bool push = d->tp() && tp_comm_push_args(d->comm, &a.tp_peers, &a.tp_epoch, &a.tp_stride);
+            const int epi = d->tp() ? (push ? EPI_TP_PUSH : EPI_PARTIAL_F32) : EPI_RESIDUAL;
+            a.y32 = d->tp_part, a.tp_rank = c.tp_rank, a.tp_world = c.tp_world;
             const bool merged_attn = d->combine;  // the attention output is already one T vector
             if (merged_attn) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
             const int rc = w4s_gemv_launch(c.dtype, merged_attn ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
-            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
+            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st, push);
         }
         case PIE_K_GATEUP: {  // silu(gate(post_attention_layernorm(h))) * up(...)  (language.py:127,152)
             GemvArgs a = {};
@@ -140,10 +142,11 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
             GemvArgs a = {};
             a.fmt = gfmt(w.wdown), a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
-            a.y32 = d->tp_part;
+            const bool push = d->tp() && tp_comm_push_args(d->comm, &a.tp_peers, &a.tp_epoch, &a.tp_stride);
+            a.y32 = d->tp_part, a.tp_rank = c.tp_rank, a.tp_world = c.tp_world;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 28;
-            const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? EPI_PARTIAL_F32 : EPI_RESIDUAL, a, 1, st);
-            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st);
+            const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? (push ? EPI_TP_PUSH : EPI_PARTIAL_F32) : EPI_RESIDUAL, a, 1, st);
+            return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st, push);
         }
         case PIE_K_LMHEAD: {  // lm_head(norm(h)) (language.py:187,206-209) with per-tile log-softmax partials
             GemvArgs a = {};
@@ -243,7 +246,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
     PIE_ALLOC(d->pf_sink, 8192);  // the developer builds' stamps (-DPIE_ATTN_PROF: words 2..9; -DPIE_GEMV_PROF: 16 + 4 kind ..)
-    if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));
+    if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));  // RCCL backend: the fp32 partial; [hidden]: the step's log-sum-exp
 #undef PIE_ALLOC
     plan_attention(d);
     *out = d;

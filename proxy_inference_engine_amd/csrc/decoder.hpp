@@ -43,7 +43,7 @@ struct pie_decoder {
     // tensor parallelism (cfg.tp_world > 1): this decoder is one rank's shard; comm is caller-owned (pie_decoder_set_comm)
     pie_comm *comm = nullptr;
     float *tp_part = nullptr;  // [hidden] fp32 partial of the row-parallel Linears, [hidden] = log-sum-exp of the step
-    bool tp() const { return cfg.tp_world > 1; }
+    bool tp() const { return cfg.tp_world >= 1; }  // tp_world = 1: the tensor-parallel code path on one rank (tests; the RCCL backend's only test on one card)
     // per-matrix weight format (PIE_W_*), keyed by the packed matrix pointer; matrices not listed use cfg.weight_format
     std::unordered_map<const void *, int> fmt_map;
     int mat_fmt(const void *packed) const {
@@ -60,7 +60,8 @@ struct pie_decoder {
 };
 
 // tp_comm.hip: sum over the ranks of data[n] (rank order), then h = T(h + T(sum)) when resid != nullptr
-int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st);
+int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st, bool pushed);
+bool tp_comm_push_args(const pie_comm *c, unsigned long long *const **peers, const unsigned **epoch, unsigned *stride);
 int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int vocab_offset, const LogitStat *stats, int n_stats, float *lse, float *logprobs,
                    int *token, DecState *state, int *history, int hist_cap, hipStream_t st);
 int tp_comm_geometry(const pie_comm *c, int *rank, int *world, size_t *max_elems);

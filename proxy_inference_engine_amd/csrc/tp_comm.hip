@@ -13,19 +13,71 @@
 // The epoch lives in device memory and is advanced by the kernels themselves, so a captured hipGraph replays correctly.
 // Every spin is bounded; a give-up sets the communicator's error word.
 //
-// NOT measured on a multi-GPU node (this build pool hands out single-GPU boxes): verified with two processes sharing one card
-// (tests/test_gpu_tp.py), where "peer memory" is the same HBM.
+// Round 4: (1) inside the decoder the PUSH half rides in the row-parallel GEMV's epilogue (EPI_TP_PUSH, w4_gemv.hpp: the lane's two fp32 row
+// sums leave as granules straight from its registers -- no fp32 round trip through memory, and the transfer starts when a wave finishes,
+// not when the launch does); the launch behind it (k_tp_allreduce<T, true>) only pulls, sums in rank order, rounds and adds the residual.
+// (2) A second backend: PIE_COMM_RCCL runs the same collectives through RCCL (ncclAllReduce / ncclAllGather on the launch stream,
+// capturable in the step's hipGraph) -- the comparator and fall-back for the first run on a real multi-GPU node.  RCCL's ring sums in its
+// own order: every rank still gets identical bits, but they differ from the one-shot form's rank-order sum in the last fp32 bit.
+//
+// NOT measured on a multi-GPU node (this build pool hands out single-GPU boxes): the one-shot form is verified with two processes sharing
+// one card (tests/test_gpu_tp.py), where "peer memory" is the same HBM; RCCL refuses two ranks on one device, so its backend is verified
+// with a one-rank communicator (the whole tensor-parallel code path of the decoder, bit for bit against the unsharded decoder).
 #include <cstring>
 #include <new>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include "decoder.hpp"
 
 constexpr int TP_MAX_WORLD = 8;
 constexpr unsigned long long TP_SPIN_LIMIT = 200000000ull;  // s_memrealtime ticks (100 MHz): 2 s
 
+// RCCL, loaded with dlopen at the first RCCL communicator (the copy already in the process -- torch's -- if there is one)
+struct RcclId {
+    char b[128];  // ncclUniqueId, passed by value
+};
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId *id) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, RcclId id, int rank) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t st) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return PIE_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return pie::fail(PIE_E_STATE, std::string("RCCL backend: librccl.so cannot be loaded: ") + dlerror());
+    RcclApi a;
+    a.lib = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather) return pie::fail(PIE_E_STATE, "RCCL backend: librccl.so lacks an entry point");
+    g_rccl = a;
+    return PIE_OK;
+}
+#define PIE_RCCL_TRY(expr)                                                                                                                   \
+    do {                                                                                                                                     \
+        const int r_ = (expr);                                                                                                               \
+        if (r_ != 0) return pie::fail(PIE_E_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error")); \
+    } while (0)
+constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0;  // rccl.h: ncclFloat32, ncclSum
+
 struct pie_comm {
     int rank = 0, world = 1;
+    int backend = PIE_COMM_IPC;
+    void *rccl = nullptr;        // ncclComm_t (PIE_COMM_RCCL)
+    float *gather = nullptr;     // PIE_COMM_RCCL: [4] this rank's (max, sum exp, argmax, -) | [world][4] everybody's
     size_t max_elems = 0;
     unsigned long long *recv = nullptr;       // [2][world][max_elems + 8] granules: slot r of parity p at (p * world + r) * stride
     unsigned long long *peer[TP_MAX_WORLD] = {};  // every rank's recv (own pointer at [rank]); host copies of the mapped pointers
@@ -63,17 +115,20 @@ __device__ __forceinline__ bool tp_pull(const unsigned long long *p, unsigned e,
 //   (language.py:151,153; proxy_inference_engine_amd/tp.py: TPLlama._row_parallel).
 // One thread per PAIR of elements, n / 2048 workgroups (4 for H = 8192): every thread pushes its two values to all peers, then pulls
 // the same two positions of all ranks' slots.  The last workgroup to finish advances the epoch (arrival counter in epoch[2]).
-template <class T>
+// PUSHED: the producer (the row-parallel GEMV's EPI_TP_PUSH epilogue) has already pushed this rank's values; only the pull half runs here.
+template <class T, bool PUSHED>
 __global__ void __launch_bounds__(1024) k_tp_allreduce(unsigned long long *const *peers, unsigned *epoch, int rank, int world, size_t stride, float *data,
                                                        int n, u16 *resid) {
     const unsigned e = epoch[0] + 1;
     const size_t slot = ((size_t)(e & 1) * world + rank) * stride;
     const int i = 2 * (blockIdx.x * 1024 + threadIdx.x);
     if (i < n) {
-        const float v0 = data[i], v1 = i + 1 < n ? data[i + 1] : 0.0f;
-        for (int r = 0; r < world; ++r) {
-            tp_push(peers[r] + slot + i, v0, e);
-            if (i + 1 < n) tp_push(peers[r] + slot + i + 1, v1, e);
+        if (!PUSHED) {
+            const float v0 = data[i], v1 = i + 1 < n ? data[i + 1] : 0.0f;
+            for (int r = 0; r < world; ++r) {
+                tp_push(peers[r] + slot + i, v0, e);
+                if (i + 1 < n) tp_push(peers[r] + slot + i + 1, v1, e);
+            }
         }
         const unsigned long long *mine = peers[rank] + (size_t)(e & 1) * world * stride;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -101,12 +156,37 @@ __global__ void __launch_bounds__(1024) k_tp_allreduce(unsigned long long *const
     }
 }
 
-// Vocabulary-parallel tail, part 1 (one workgroup of 256): merge this rank's per-wave partials of the lm_head GEMV, exchange
-// (max, sum exp, first argmax + vocabulary offset) with the peers, and publish the global log-sum-exp and the greedy token (ties: the
-// lowest vocabulary index, like mx.argmax); advances the device-side decode state exactly as k_logits_finish does.
+// Global log-sum-exp and greedy token from every shard's (max, sum exp, first argmax + vocabulary offset) triple (ties: the lowest vocabulary
+// index, like mx.argmax); advances the device-side decode state exactly as k_logits_finish does.  One thread.
+__device__ __forceinline__ void tp_merge_publish(const float *gm, const float *gs, const float *ga, int world, const unsigned *err_word, float *lse_out, int *token,
+                                                 DecState *state, int *history, int hist_cap) {
+    float GM = -INFINITY;
+    for (int r = 0; r < world; ++r) GM = fmaxf(GM, gm[r]);
+    float S = 0.0f;
+    int gtok = 0x7fffffff;
+    for (int r = 0; r < world; ++r) {
+        S += gs[r] > 0.0f ? gs[r] * expf(gm[r] - GM) : 0.0f;
+        if (gm[r] == GM) gtok = min(gtok, __float_as_int(ga[r]));
+    }
+    *lse_out = GM + logf(S);
+    // a collective of this step gave up (sticky error word): the sums are not sums -- the host sees token -1 instead of a plausible id
+    if (err_word && __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) gtok = -1;
+    *token = gtok;
+    if (state) {
+        const int next_pos = state->pos + 1;
+        if (history && next_pos < hist_cap) history[next_pos] = gtok;
+        state->token = gtok;
+        state->pos = next_pos;
+    }
+}
+
+// Vocabulary-parallel tail, part 1 (one workgroup of 256): merge this rank's per-wave partials of the lm_head GEMV into its triple, then
+//   RCCL == false: exchange the triples with the peers as granules and publish the global log-sum-exp and token;
+//   RCCL == true:  leave the triple in `gather` for ncclAllGather; k_tp_tail_merge publishes.
+template <bool RCCL>
 __global__ void __launch_bounds__(256) k_tp_tail_stats(unsigned long long *const *peers, unsigned *epoch, int rank, int world, size_t stride,
                                                        const LogitStat *stats, int n_stats, int vocab_offset, float *lse_out, int *token, DecState *state,
-                                                       int *history, int hist_cap) {
+                                                       int *history, int hist_cap, float *gather) {
     __shared__ float s_max[4], s_sum[4];
     __shared__ int s_arg[4];
     LogitStat st[16];
@@ -143,6 +223,10 @@ __global__ void __launch_bounds__(256) k_tp_tail_stats(unsigned long long *const
     __syncthreads();
     if (threadIdx.x == 0) {
         const float local_se = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (RCCL) {
+            gather[0] = M, gather[1] = local_se, gather[2] = __int_as_float(tok + vocab_offset), gather[3] = 0.0f;
+            return;
+        }
         const unsigned e = epoch[0] + 1;
         // the three numbers ride in the last 8 granules of this rank's slot (behind the hidden-vector area)
         const size_t slot = ((size_t)(e & 1) * world + rank) * stride + (stride - 8);
@@ -154,31 +238,29 @@ __global__ void __launch_bounds__(256) k_tp_tail_stats(unsigned long long *const
         const unsigned long long *mine = peers[rank] + (size_t)(e & 1) * world * stride + (stride - 8);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         float gm[TP_MAX_WORLD], gs[TP_MAX_WORLD], ga[TP_MAX_WORLD];
-        float GM = -INFINITY;
         for (int r = 0; r < world; ++r) {
             tp_pull(mine + (size_t)r * stride + 0, e, gm[r], t0, epoch + 1);
             tp_pull(mine + (size_t)r * stride + 1, e, gs[r], t0, epoch + 1);
             tp_pull(mine + (size_t)r * stride + 2, e, ga[r], t0, epoch + 1);
-            GM = fmaxf(GM, gm[r]);
         }
-        float S = 0.0f;
-        int gtok = 0x7fffffff;
-        for (int r = 0; r < world; ++r) {
-            S += gs[r] > 0.0f ? gs[r] * expf(gm[r] - GM) : 0.0f;
-            if (gm[r] == GM) gtok = min(gtok, __float_as_int(ga[r]));
-        }
-        *lse_out = GM + logf(S);
-        // a collective of this step gave up (sticky error word): the sums are not sums -- the host sees token -1 instead of a plausible id
-        if (__hip_atomic_load(epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) gtok = -1;
-        *token = gtok;
-        if (state) {
-            const int next_pos = state->pos + 1;
-            if (history && next_pos < hist_cap) history[next_pos] = gtok;
-            state->token = gtok;
-            state->pos = next_pos;
-        }
+        tp_merge_publish(gm, gs, ga, world, epoch + 1, lse_out, token, state, history, hist_cap);
         epoch[0] = e;
     }
+}
+// PIE_COMM_RCCL: the gathered triples [world][4] -> the same publication
+__global__ void k_tp_tail_merge(const float *gathered, int world, float *lse_out, int *token, DecState *state, int *history, int hist_cap) {
+    float gm[TP_MAX_WORLD], gs[TP_MAX_WORLD], ga[TP_MAX_WORLD];
+    for (int r = 0; r < world; ++r) gm[r] = gathered[4 * r], gs[r] = gathered[4 * r + 1], ga[r] = gathered[4 * r + 2];
+    tp_merge_publish(gm, gs, ga, world, nullptr, lse_out, token, state, history, hist_cap);
+}
+// PIE_COMM_RCCL: the row-parallel Linear's tail after ncclAllReduce, h = T(h + T(sum)) (language.py:151,153)
+template <class T>
+__global__ void __launch_bounds__(256) k_tp_round_residual(const float *sum, int n, u16 *resid) {
+    const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    const float2 s2 = *reinterpret_cast<const float2 *>(sum + i);
+    const u32 h2 = *reinterpret_cast<const u32 *>(resid + i);
+    *reinterpret_cast<u32 *>(resid + i) = pack2<T>(lo_f32<T>(h2) + round_T<T>(s2.x), hi_f32<T>(h2) + round_T<T>(s2.y));
 }
 
 // part 2: this rank's slice of the log-probabilities, logits - lse
@@ -194,15 +276,41 @@ __global__ void __launch_bounds__(256) k_tp_tail_logprobs(const u16 *logits, int
 
 }  // namespace
 
-int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st) {
+// pushed: the producing GEMV's EPI_TP_PUSH epilogue already sent this rank's values (one-shot backend only; tp_comm_push_args)
+int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st, bool pushed) {
     PIE_REQUIRE(c && c->connected, PIE_E_STATE, "tensor-parallel communicator is not connected (pie_comm_connect)");
-    PIE_REQUIRE(data && n > 0 && (size_t)n <= c->max_elems && (!resid || n % 2 == 0), PIE_E_SHAPE, "tp all-reduce: vector longer than the communicator's slots");
+    PIE_REQUIRE(n > 0 && (size_t)n <= c->max_elems && (!resid || n % 2 == 0), PIE_E_SHAPE, "tp all-reduce: vector longer than the communicator's slots");
+    PIE_REQUIRE(data || (pushed && resid), PIE_E_ARG, "tp all-reduce: null data");
+    if (c->backend == PIE_COMM_RCCL) {
+        PIE_REQUIRE(!pushed && data, PIE_E_STATE, "tp all-reduce: the RCCL backend reduces the fp32 partial in memory");
+        PIE_RCCL_TRY(g_rccl.AllReduce(data, data, (size_t)n, RCCL_FLOAT32, RCCL_SUM, c->rccl, st));
+        if (!resid) return PIE_OK;
+        const dim3 grid((unsigned)((n / 2 + 255) / 256));
+        if (dtype == PIE_F16) hipLaunchKernelGGL(k_tp_round_residual<F16>, grid, dim3(256), 0, st, data, n, resid);
+        else hipLaunchKernelGGL(k_tp_round_residual<BF16>, grid, dim3(256), 0, st, data, n, resid);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
     const size_t stride = c->max_elems + 8;
     const dim3 grid((unsigned)((n + 2047) / 2048));
-    if (dtype == PIE_F16) hipLaunchKernelGGL(k_tp_allreduce<F16>, grid, dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
-    else hipLaunchKernelGGL(k_tp_allreduce<BF16>, grid, dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid);
+#define TP_AR(TT, P) hipLaunchKernelGGL((k_tp_allreduce<TT, P>), grid, dim3(1024), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, data, n, resid)
+    if (dtype == PIE_F16) {
+        if (pushed) TP_AR(F16, true);
+        else TP_AR(F16, false);
+    } else {
+        if (pushed) TP_AR(BF16, true);
+        else TP_AR(BF16, false);
+    }
+#undef TP_AR
     PIE_LAUNCH_CHECK();
     return PIE_OK;
+}
+
+// What the row-parallel GEMV's EPI_TP_PUSH epilogue needs; false when this communicator's collectives do not run on granules (RCCL)
+bool tp_comm_push_args(const pie_comm *c, unsigned long long *const **peers, const unsigned **epoch, unsigned *stride) {
+    if (!c || c->backend != PIE_COMM_IPC || !c->connected) return false;
+    *peers = c->peer_dev, *epoch = c->epoch, *stride = (unsigned)(c->max_elems + 8);
+    return true;
 }
 
 int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int vocab_offset, const LogitStat *stats, int n_stats, float *lse, float *logprobs,
@@ -210,8 +318,16 @@ int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int v
     PIE_REQUIRE(c && c->connected, PIE_E_STATE, "tensor-parallel communicator is not connected (pie_comm_connect)");
     PIE_REQUIRE(n_stats <= TAIL_MAX_STATS, PIE_E_SHAPE, "tp tail: too many partials");
     const size_t stride = c->max_elems + 8;
-    hipLaunchKernelGGL(k_tp_tail_stats, dim3(1), dim3(256), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, stats, n_stats, vocab_offset, lse, token, state,
-                       history, hist_cap);
+    if (c->backend == PIE_COMM_RCCL) {
+        hipLaunchKernelGGL(k_tp_tail_stats<true>, dim3(1), dim3(256), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, stats, n_stats, vocab_offset, lse, token,
+                           state, history, hist_cap, c->gather);
+        PIE_LAUNCH_CHECK();
+        PIE_RCCL_TRY(g_rccl.AllGather(c->gather, c->gather + 4, 4, RCCL_FLOAT32, c->rccl, st));
+        hipLaunchKernelGGL(k_tp_tail_merge, dim3(1), dim3(1), 0, st, c->gather + 4, c->world, lse, token, state, history, hist_cap);
+    } else {
+        hipLaunchKernelGGL(k_tp_tail_stats<false>, dim3(1), dim3(256), 0, st, c->peer_dev, c->epoch, c->rank, c->world, stride, stats, n_stats, vocab_offset, lse, token,
+                           state, history, hist_cap, (float *)nullptr);
+    }
     PIE_LAUNCH_CHECK();
     const dim3 grid((unsigned)((V_local + 511) / 512 < 64 ? (V_local + 511) / 512 : 64));
     if (dtype == PIE_F16) hipLaunchKernelGGL(k_tp_tail_logprobs<F16>, grid, dim3(256), 0, st, logits, V_local, lse, logprobs);
@@ -262,7 +378,42 @@ int pie_comm_create(int rank, int world, size_t max_elems, pie_comm **out) {
     return PIE_OK;
 }
 
+int pie_comm_rccl_unique_id(void *id128) {
+    PIE_REQUIRE(id128, PIE_E_ARG, "pie_comm_rccl_unique_id: null pointer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    PIE_RCCL_TRY(g_rccl.GetUniqueId((RcclId *)id128));
+    return PIE_OK;
+}
+
+int pie_comm_create_rccl(int rank, int world, size_t max_elems, const void *id128, pie_comm **out) {
+    PIE_REQUIRE(out && id128, PIE_E_ARG, "pie_comm_create_rccl: null pointer");
+    PIE_REQUIRE(world >= 1 && world <= TP_MAX_WORLD && rank >= 0 && rank < world, PIE_E_ARG, "pie_comm_create_rccl: 1 <= world <= 8, 0 <= rank < world");
+    PIE_REQUIRE(max_elems > 0 && max_elems <= (1u << 20), PIE_E_SHAPE, "pie_comm_create_rccl: max_elems out of range");
+    int rc = rccl_load();
+    if (rc) return rc;
+    pie_comm *c = new (std::nothrow) pie_comm();
+    PIE_REQUIRE(c, PIE_E_HIP, "pie_comm_create_rccl: out of host memory");
+    c->rank = rank, c->world = world, c->max_elems = max_elems, c->backend = PIE_COMM_RCCL;
+    if (hipMalloc((void **)&c->epoch, 16) != hipSuccess || hipMemset(c->epoch, 0, 16) != hipSuccess ||
+        hipMalloc((void **)&c->gather, sizeof(float) * 4 * (TP_MAX_WORLD + 1)) != hipSuccess) {
+        (void)pie_comm_destroy(c);
+        return pie::fail(PIE_E_HIP, "pie_comm_create_rccl: device allocation failed");
+    }
+    RcclId id;
+    memcpy(&id, id128, sizeof id);
+    const int r = g_rccl.CommInitRank(&c->rccl, world, id, rank);  // collective: every rank of the world calls it with the same id
+    if (r != 0) {
+        (void)pie_comm_destroy(c);
+        return pie::fail(PIE_E_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+    }
+    c->connected = true;
+    *out = c;
+    return PIE_OK;
+}
+
 int pie_comm_export(const pie_comm *c, void *handle64) {
+    PIE_REQUIRE(c && c->backend == PIE_COMM_IPC, PIE_E_STATE, "pie_comm_export: only the one-shot (IPC) communicator has a receive area to export");
     PIE_REQUIRE(c && handle64, PIE_E_ARG, "pie_comm_export: null pointer");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     hipIpcMemHandle_t h;
@@ -273,6 +424,7 @@ int pie_comm_export(const pie_comm *c, void *handle64) {
 
 int pie_comm_connect(pie_comm *c, const void *handles) {
     PIE_REQUIRE(c && handles, PIE_E_ARG, "pie_comm_connect: null pointer");
+    PIE_REQUIRE(c->backend == PIE_COMM_IPC, PIE_E_STATE, "pie_comm_connect: an RCCL communicator is connected by its creation");
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) continue;
         hipIpcMemHandle_t h;
@@ -290,6 +442,8 @@ int pie_comm_destroy(pie_comm *c) {
     if (!c) return PIE_OK;
     for (int r = 0; r < c->world; ++r)
         if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->rccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->rccl);
+    if (c->gather) (void)hipFree(c->gather);
     if (c->recv) (void)hipFree(c->recv);
     if (c->epoch) (void)hipFree(c->epoch);
     if (c->peer_dev) (void)hipFree(c->peer_dev);
@@ -299,7 +453,7 @@ int pie_comm_destroy(pie_comm *c) {
 
 int pie_allreduce_f32(pie_comm *c, float *data, size_t n, void *stream) {
     PIE_REQUIRE(c && data, PIE_E_ARG, "pie_allreduce_f32: null pointer");
-    return tp_allreduce_launch(c, PIE_BF16, data, (int)n, nullptr, (hipStream_t)stream);
+    return tp_allreduce_launch(c, PIE_BF16, data, (int)n, nullptr, (hipStream_t)stream, false);
 }
 
 int pie_comm_status(pie_comm *c, unsigned *error) {

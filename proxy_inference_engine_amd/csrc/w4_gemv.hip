@@ -220,6 +220,8 @@ static int launch_n(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     else if (pro == PRO_NONE && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_RESIDUAL, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_ATTN && epi == EPI_RESIDUAL) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_RESIDUAL, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_ATTN && epi == EPI_PARTIAL_F32) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_PARTIAL_F32, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_NONE && epi == EPI_TP_PUSH) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_NONE, EPI_TP_PUSH, NPT, 0, FMT>), grid, block, lds, st, a);
+    else if (pro == PRO_ATTN && epi == EPI_TP_PUSH) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_ATTN, EPI_TP_PUSH, (NPT > 2 ? 2 : NPT), 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_RMSNORM && epi == EPI_ROPE_KV) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_RMSNORM, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
     else if (pro == PRO_EMBED && epi == EPI_ROPE_KV) {
         if constexpr (FMT == FMT_W4S) hipLaunchKernelGGL((k_w4s_gemv<T, PRO_EMBED, EPI_ROPE_KV, NPT, 0, FMT>), grid, block, lds, st, a);
@@ -275,6 +277,9 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE((epi != EPI_STORE && epi != EPI_LOGITS && epi != EPI_SWIGLU) || a.y, PIE_E_ARG, "w4s_gemv: null output");
     PIE_REQUIRE(epi != EPI_LOGITS || a.stats, PIE_E_ARG, "w4s_gemv: EPI_LOGITS without a partials buffer");
     PIE_REQUIRE(epi != EPI_PARTIAL_F32 || a.y32, PIE_E_ARG, "w4s_gemv: EPI_PARTIAL_F32 without an fp32 output");
+    PIE_REQUIRE(epi != EPI_TP_PUSH || (a.tp_peers && a.tp_epoch && a.tp_world >= 1 && a.tp_world <= GEMV_TP_MAX_WORLD && a.tp_rank >= 0 && a.tp_rank < a.tp_world &&
+                                       (unsigned)a.N <= a.tp_stride && M == 1),
+                PIE_E_ARG, "w4s_gemv: EPI_TP_PUSH needs the communicator's peer table, epoch word, rank / world and a slot that holds N elements");
     PIE_REQUIRE(epi != EPI_RESIDUAL || a.resid, PIE_E_ARG, "w4s_gemv: EPI_RESIDUAL without a residual stream");
     PIE_REQUIRE(epi != EPI_ROPE_KV || (a.state && a.q_out && a.kv_table && (a.rope_cs || a.freqs)), PIE_E_ARG,
                 "w4s_gemv: EPI_ROPE_KV needs state, q_out, kv_table and rope_cs or freqs");

@@ -36,7 +36,10 @@
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2, PRO_EMBED = 3 };
 constexpr int GEMV_ATTN_SPLITS = 4;  // split-KV factor the PRO_ATTN prologue merges (register budget: 10 floats per split and piece)
 // EPI_PARTIAL_F32: the un-rounded fp32 row sums (row-parallel Linear of a tensor-parallel shard: summed over ranks, THEN rounded)
-enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4, EPI_PARTIAL_F32 = 5 };
+// EPI_TP_PUSH: the same sums PUSHED straight from the lane's registers into this rank's slot of every peer's receive area, as 8-byte
+//              {value, epoch} granules (tp_comm.hip: the one-shot all-reduce's first half; its pull + rounding + residual add is k_tp_pull)
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_ROPE_KV = 2, EPI_SWIGLU = 3, EPI_LOGITS = 4, EPI_PARTIAL_F32 = 5, EPI_TP_PUSH = 6 };
+constexpr int GEMV_TP_MAX_WORLD = 8;
 
 constexpr int GEMV_WAVES = 8;        // waves per workgroup
 #ifndef PIE_GEMV_DEPTH
@@ -87,6 +90,12 @@ struct GemvArgs {
     int emb_vocab;
     u16 *h_out;
     float *rope_cs_out;
+    // EPI_TP_PUSH (tensor-parallel row-parallel Linear): every rank's receive area (device table of world pointers), the communicator's epoch
+    // word (this collective is number *tp_epoch + 1), this rank, the world size and the granules per slot
+    unsigned long long *const *tp_peers;
+    const unsigned *tp_epoch;
+    int tp_rank, tp_world;
+    unsigned tp_stride;
 };
 
 // out[0..8) = T(scale * q + bias) of one code word: separate multiply and add roundings, like the oracle (mx.dequantize)
@@ -186,6 +195,12 @@ __device__ __forceinline__ U *gemv_pin(U *p) {
     return reinterpret_cast<U *>(v);
 }
 
+__device__ __forceinline__ unsigned gemv_pin_u32(unsigned v) {
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-uniform broadcast of one lane (v_readlane)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -277,6 +292,15 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     if (EPI == EPI_PARTIAL_F32) y32_out = gemv_pin(y32_out);
     if (EPI == EPI_LOGITS) stats_out = gemv_pin(stats_out);
     if (EPI == EPI_ROPE_KV) q_dst = gemv_pin(q_dst);
+    // EPI_TP_PUSH: the peers' areas and the collective's number, in SGPRs before the stream (the pushes then leave straight from the epilogue)
+    unsigned long long *tp_dst[EPI == EPI_TP_PUSH ? GEMV_TP_MAX_WORLD : 1];
+    unsigned tp_e = 0;
+    if constexpr (EPI == EPI_TP_PUSH) {
+        tp_e = gemv_pin_u32(*a.tp_epoch + 1u);
+        const size_t slot = ((size_t)(tp_e & 1u) * a.tp_world + a.tp_rank) * a.tp_stride;
+#pragma unroll
+        for (int r = 0; r < GEMV_TP_MAX_WORLD; ++r) tp_dst[r] = gemv_pin(a.tp_peers[r < a.tp_world ? r : 0] + slot);
+    }
     const bool live = lane < run;
     const int pair = lane < kf ? gw + lane * W : last_pair;
     const int R = 2 * pair;  // packed row index; the pair is rows R, R+1
@@ -286,7 +310,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     int pos = 0, cap = 0, kvrow = 0;
     u16 *kdst = nullptr, *vdst = nullptr;
     if (EPI == EPI_RESIDUAL && live) pre_u = *reinterpret_cast<const u32 *>(a.resid + R);
-    const bool has_bias = EPI != EPI_LOGITS && EPI != EPI_PARTIAL_F32 && a.lin_bias != nullptr;  // wave-uniform
+    const bool has_bias = EPI != EPI_LOGITS && EPI != EPI_PARTIAL_F32 && EPI != EPI_TP_PUSH && a.lin_bias != nullptr;  // wave-uniform
     if (has_bias && live) pre_b = *reinterpret_cast<const u32 *>(a.lin_bias + R);
     if (EPI == EPI_ROPE_KV) {
         pos = a.state->pos, cap = a.state->cap;
@@ -537,6 +561,18 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     } else if (EPI == EPI_PARTIAL_F32) {
         if (live) *reinterpret_cast<float2 *>(y32_out + R) = make_float2(va, vb);
+    } else if constexpr (EPI == EPI_TP_PUSH) {
+        // one system-scope 8-byte store per element and peer: the data is its own flag (tp_comm.hip); rows R, R + 1 are adjacent granules
+        if (live) {
+            typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+            const unsigned long long ga = ((unsigned long long)tp_e << 32) | __builtin_bit_cast(unsigned, va), gb = ((unsigned long long)tp_e << 32) | __builtin_bit_cast(unsigned, vb);
+#pragma unroll
+            for (int r = 0; r < GEMV_TP_MAX_WORLD; ++r)
+                if (r < a.tp_world) {
+                    __hip_atomic_store((gu64_t *)(unsigned long long)(tp_dst[r] + R), ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store((gu64_t *)(unsigned long long)(tp_dst[r] + R + 1), gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+        }
     } else if (EPI == EPI_RESIDUAL) {
         // h = x + r (language.py:151,153): Linear output rounded to T, then the add rounded to T
         if (live) *reinterpret_cast<u32 *>(a.resid + R) = pack2<T>(lo_f32<T>(pre_u) + round_T<T>(va), hi_f32<T>(pre_u) + round_T<T>(vb));
