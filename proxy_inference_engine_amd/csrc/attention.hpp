@@ -65,6 +65,15 @@ struct AttnArgs {
     const int *block_table, *ctx_len;
     int bt_stride, n_pages;
     unsigned *prof;   // developer build (-DPIE_ATTN_PROF): stamps of workgroup (0, 0, 0), words 2..9 of the decoder's scratch; nullptr otherwise
+    // Infinity-Cache warm-up riding on the CUs this launch leaves idle (decoder only): workgroups with blockIdx.y >= splits stream o_proj's
+    // weights with plain coalesced loads and discard them, so that launch's 9.4 MB then come from the cache.  Re-decided in round 4
+    // ("x 18.7 attention traffic for 0.3 %"): same box, three alternating repetitions -- with it 1.198-1.201 ms per 8B step,
+    // without it 1.211-1.217 (+1.3 %), with an XCD-matched one-dword-per-line L2 touch instead 1.222-1.245.  The bytes leave HBM once either
+    // way (FETCH_SIZE counts Infinity-Cache hits: o_proj's own fetch is then served on-die); what moves is WHEN they leave it.
+    const char *pf_ptr;
+    unsigned long long pf_bytes;
+    int pf_rows;      // extra blockIdx.y rows doing this (0 = none)
+    unsigned *pf_sink;
 };
 
 constexpr int ATTN_WAVES = 8;  // waves per workgroup (2 per SIMD: one wave's VALU scoring overlaps the other's loads)
@@ -116,6 +125,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
 
     ATTN_STAMP(0);
     const int g = blockIdx.x, split = blockIdx.y;
+    if (split >= a.splits) {  // warm-up role (uniform per workgroup)
+        const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
+        unsigned acc = 0;
+        const unsigned long long n16 = a.pf_bytes >> 4;  // 16-byte pieces
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr);
+        for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
+            const uint4 v = src[i];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+        if (acc == 0x9e3779b9u) a.pf_sink[0] = acc;  // keeps the loads alive; practically never taken
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;

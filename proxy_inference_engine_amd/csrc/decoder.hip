@@ -114,6 +114,14 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
             a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
             a.prof = d->pf_sink;
+            // the CUs this launch leaves idle warm the Infinity Cache with o_proj's weights (attention.hpp: +1.3 % on the step)
+            if (!d->combine) {
+                const int f = d->mat_fmt(w.wo);
+                a.pf_rows = (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;
+                if (a.pf_rows < 0) a.pf_rows = 0;
+                a.pf_ptr = (const char *)w.wo, a.pf_sink = d->pf_sink;
+                a.pf_bytes = f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : pie_w4s_bytes(H, QD));
+            }
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)

@@ -8,7 +8,7 @@
 template <class T, int D, bool PAGED, bool NT, bool SHORT = false>
 static int attn_launch_rep(int rep, const AttnArgs &a, bool combine, hipStream_t st) {
     const int rows = a.rows > 0 ? a.rows : 1;
-    const dim3 grid(a.Hkv, a.splits, rows);
+    const dim3 grid(a.Hkv, a.splits + a.pf_rows, rows);
 #define ATTN_GO(R)                                                                                                                      \
     {                                                                                                                                   \
         constexpr int W_ = SHORT ? attn_short_waves(R) : ATTN_WAVES;                                                                    \

@@ -299,7 +299,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         tp_e = gemv_pin_u32(*a.tp_epoch + 1u);
         const size_t slot = ((size_t)(tp_e & 1u) * a.tp_world + a.tp_rank) * a.tp_stride;
 #pragma unroll
-        for (int r = 0; r < GEMV_TP_MAX_WORLD; ++r) tp_dst[r] = gemv_pin(a.tp_peers[r < a.tp_world ? r : 0] + slot);
+        for (int r = 0; r < GEMV_TP_MAX_WORLD; ++r) {
+            const unsigned long long p = reinterpret_cast<unsigned long long>(a.tp_peers[r < a.tp_world ? r : 0] + slot);  // wave-uniform, but loaded through a pointer: VGPRs to hipcc
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+            tp_dst[r] = gemv_pin(reinterpret_cast<unsigned long long *>(((unsigned long long)hi << 32) | lo));
+        }
     }
     const bool live = lane < run;
     const int pair = lane < kf ? gw + lane * W : last_pair;

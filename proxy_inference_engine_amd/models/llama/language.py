@@ -121,8 +121,8 @@ class Model:
         self.dtype = weights["model.norm.weight"].dtype
         self.device = device
         H, I, V = args.hidden_size, args.intermediate_size, args.vocab_size
-        if tp is not None and tp.world > 1:
-            if args.tie_word_embeddings or V % (2 * tp.world):
+        if tp is not None:
+            if (args.tie_word_embeddings and tp.world > 1) or V % (2 * tp.world):
                 raise ValueError("a tensor-parallel shard carries its own lm_head rows (tie_word_embeddings=False) and needs vocab_size % (2 * world) == 0")
             V //= tp.world  # the rank's slice of the vocabulary: lm_head rows, logits, logprobs
         self.vocab_out = V
@@ -206,7 +206,7 @@ class Model:
                                       tp.rank if tp is not None else 0, tp.world if tp is not None else 0)
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))
-        if tp is not None and tp.world > 1:
+        if tp is not None:  # world == 1: the tensor-parallel code path on one rank (push to self / one-rank RCCL communicator)
             _ffi.check(lib.pie_decoder_set_comm(self._dec, tp.handle))
         for i, blk in enumerate(self.layers):
             lw = _ffi.pie_layer_weights(blk.input_layernorm.data_ptr(), blk.post_attention_layernorm.data_ptr(),

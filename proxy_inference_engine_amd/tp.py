@@ -106,19 +106,34 @@ class TPGroup:
 
 
 class HipComm:
-    """The native communicator of the fused tensor-parallel step (include/pie_hip.h, pie_comm_*): a one-shot all-reduce over
-    IPC-mapped peer buffers, enqueued on HIP streams and capturable in the decoder's hipGraph.  torch.distributed is only the
-    side channel that carries the 64-byte IPC handles at start-up (any backend; gloo in the one-card test)."""
+    """The native communicator of the fused tensor-parallel step (include/pie_hip.h, pie_comm_*), enqueued on HIP streams and capturable
+    in the decoder's hipGraph.  backend "ipc" (default): the one-shot all-reduce over IPC-mapped peer buffers, its push half in the
+    row-parallel GEMV's epilogue; torch.distributed is only the side channel that carries the 64-byte IPC handles at start-up (any
+    backend; gloo in the one-card test).  backend "rccl": the same collectives through RCCL (ncclAllReduce / ncclAllGather on the launch
+    stream) -- the comparator and fall-back on a real multi-GPU node; the side channel carries RCCL's 128-byte unique id."""
 
-    def __init__(self, max_elems: int, group=None):
+    def __init__(self, max_elems: int, group=None, backend: str = "ipc"):
         import ctypes as C
         from . import _ffi
         _ffi.require_gpu()
+        if backend not in ("ipc", "rccl"):
+            raise ValueError("HipComm: backend must be 'ipc' or 'rccl'")
         self._lib = _ffi.load()
         self.group = group
+        self.backend = backend
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handle = C.c_void_p()
+        if backend == "rccl":
+            uid = C.create_string_buffer(128)
+            if self.rank == 0:
+                _ffi.check(self._lib.pie_comm_rccl_unique_id(uid))
+            if self.world > 1:
+                box = [uid.raw]
+                dist.broadcast_object_list(box, src=0, group=group)
+                uid = C.create_string_buffer(box[0], 128)
+            _ffi.check(self._lib.pie_comm_create_rccl(self.rank, self.world, int(max_elems), uid, C.byref(self.handle)))
+            return
         _ffi.check(self._lib.pie_comm_create(self.rank, self.world, int(max_elems), C.byref(self.handle)))
         if self.world > 1:
             mine = C.create_string_buffer(64)

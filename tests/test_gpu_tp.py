@@ -151,3 +151,38 @@ def test_tp2_fused_step_equals_functional_tp():
     assert ret["fused0"] == ret["fused1"] == ret["func0"] == ret["func1"], (ret["fused0"], ret["func0"])
     assert ret["hid_err0"] <= 4 * EPS[DT] and ret["hid_err1"] <= 4 * EPS[DT]
     assert ret["lse_err0"] <= 0.05 and ret["lse_err1"] <= 0.05
+
+
+@pytest.mark.parametrize("backend", ["ipc", "rccl"])
+def test_one_rank_tensor_parallel_step_equals_the_unsharded_decoder(backend):
+    """The decoder's tensor-parallel code path on ONE rank (tp_world = 1), both communicator backends: o_proj / down_proj through the
+    collective (ipc: EPI_TP_PUSH granules to the rank's own area + the pull launch; rccl: fp32 partial + ncclAllReduce + the rounding launch),
+    the vocabulary-parallel tail through its exchange (granules / ncclAllGather).  With one rank every sum has one addend, so logits, greedy
+    tokens and the hidden state must equal the unsharded decoder's BIT FOR BIT, eager and as a captured hipGraph (RCCL captured with it).
+    RCCL refuses two ranks on one device, so this is the only test of its backend a one-GPU box can run; the two-rank tests above run the
+    one-shot backend."""
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    from proxy_inference_engine_amd.tp import HipComm
+    from tests._util import to_bits
+    w = po.synth_checkpoint(CFG, seed=72, dtype=DT, lm_head_gain=4.0)
+    dev_w = {k: (codes_dev(v) if v.dtype == np.uint32 else to_dev(v, DT)) for k, v in w.items()}
+    plain = Model(ModelArgs(**CFG), dev_w)
+    comm = HipComm(CFG["hidden_size"], backend=backend)
+    assert comm.world == 1
+    try:
+        tp = Model(ModelArgs(**CFG), dev_w, tp=comm)
+        prompt = torch.tensor(np.random.default_rng(5).integers(0, CFG["vocab_size"], 5), dtype=torch.int32, device="cuda")  # below 6 rows: both decoders iterate decode steps (one regime)
+        ca, cb = plain.make_cache(), tp.make_cache()
+        ta, la, ga = plain.step(prompt, ca)
+        tb, lb, gb = tp.step(prompt, cb)
+        for i in range(8):
+            assert int(ta.item()) == int(tb.item()), f"step {i}"
+            assert np.array_equal(to_bits(ga), to_bits(gb)), f"step {i}: logits"
+            assert np.array_equal(to_bits(plain.hidden), to_bits(tp.hidden)), f"step {i}: hidden state"
+            assert float((la - lb).abs().max().item()) <= 1e-5, f"step {i}: log-probabilities"   # the log-sum-exp is summed over another partition
+            ta, la, ga = plain.step(None, ca, graph=i >= 2)
+            tb, lb, gb = tp.step(None, cb, graph=i >= 2)
+        assert comm.status() == 0
+        del tp
+    finally:
+        comm.close()
