@@ -97,16 +97,30 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             a.block_table = d->block_table, a.n_pages = d->n_pages;
+            const bool i8 = d->kv_i8 && d->block_table;  // int8 pages: the T rows go to the staging page, then get quantised into the sequence's page
+            if (i8) a.kv_table = d->kv_table_stage, a.block_table = d->zero_table, a.n_pages = 1;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 16;
             if (embed_here) {  // the step's embedding launch folded into this one (embed_in_qkv): x = the token's row, dequantised by every workgroup
                 a.x = nullptr, a.rope_cs = nullptr, a.rope_cs_out = d->rope_cs, a.h_out = d->h, a.token = token_ptr;
                 a.emb_codes = (const u32 *)d->glob.embed_codes, a.emb_scales = (const u16 *)d->glob.embed_scales, a.emb_biases = (const u16 *)d->glob.embed_biases;
                 a.emb_vocab = d->embed_vocab();
-                return w4s_gemv_launch(c.dtype, PRO_EMBED, EPI_ROPE_KV, a, 1, st);
             }
-            return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
+            const int rc = w4s_gemv_launch(c.dtype, embed_here ? PRO_EMBED : PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
+            if (rc || !i8) return rc;
+            const size_t blk = (size_t)c.n_kv_heads * PIE_PAGE_TOKENS * D;
+            return paged_kv_append_i8_staged_launch(c.dtype, d->kv_stage, d->kv_stage + blk, const_cast<void *>(d->slab_host[li]), d->n_pages, d->block_table, d->max_blocks,
+                                                    &d->state->pos, c.n_kv_heads, D, st);
         }
         case PIE_K_ATTN: {  // scaled_dot_product_attention over keys[..., :offset+1, :]  (language.py:98-105, base.py:111-113)
+            if (d->kv_i8 && d->block_table) {  // int8 pages: the batch paths' kernel with one sequence whose length comes from the device-side state
+                AttnArgs a = {};
+                a.q = d->qbuf, a.slab = (const u16 *)d->slab_host[li], a.block_table = d->block_table, a.state = d->state, a.bt_stride = 0, a.n_pages = d->n_pages;
+                a.rows = 1, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.scale = 1.0f / sqrtf((float)D);
+                int splits = d->kv_cap / 128;  // 4-wave workgroups, >= 128 positions each
+                a.splits = splits < 1 ? 1 : (splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : splits);
+                a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
+                return paged_attn_i8_launch(c.dtype, D, a, st);  // merges its splits itself (k_attn_combine): o_proj reads d->attn
+            }
             AttnArgs a = {};
             a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
             a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
@@ -133,7 +147,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             const bool push = d->tp() && tp_comm_push_args(d->comm, &a.tp_peers, &a.tp_epoch, &a.tp_stride);
             const int epi = d->tp() ? (push ? EPI_TP_PUSH : EPI_PARTIAL_F32) : EPI_RESIDUAL;
             a.y32 = d->tp_part, a.tp_rank = c.tp_rank, a.tp_world = c.tp_world;
-            const bool merged_attn = d->combine;  // the attention output is already one T vector
+            const bool merged_attn = d->combine || (d->kv_i8 && d->block_table);  // the attention output is already one T vector
             if (merged_attn) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
             a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
@@ -265,7 +279,8 @@ int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
     prefill_free(d);
-    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part};
+    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part, d->kv_stage, d->kv_table_stage,
+                    d->zero_table};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete d;
@@ -343,18 +358,39 @@ int pie_decoder_set_kv(pie_decoder *d, const void *const *k_ptrs, const void *co
 int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_pages, const int32_t *block_table, int max_blocks,
                              void *stream) {
     PIE_REQUIRE(d && slabs && block_table, PIE_E_ARG, "pie_decoder_set_paged_kv: null pointer");
-    PIE_REQUIRE(!d->kv_i8, PIE_E_STATE, "pie_decoder_set_paged_kv: the single-sequence step reads T pages; int8 pages serve pie_decoder_step_batch / _prefill_batch");
     PIE_REQUIRE(n_pages > 0 && n_pages < 0x7FFFFFFFu && max_blocks > 0 && max_blocks <= (1 << 24), PIE_E_SHAPE,
                 "pie_decoder_set_paged_kv: n_pages and max_blocks must be positive");
     const int L = d->cfg.n_layers;
     const size_t v_off = (size_t)d->cfg.n_kv_heads * PIE_PAGE_TOKENS * d->cfg.head_dim * 2;  // bytes: K block, then V block
     std::vector<unsigned long long> tab(2 * (size_t)L);
+    d->slab_host.assign(L, nullptr);
     for (int i = 0; i < L; ++i) {
         PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_set_paged_kv: null or misaligned slab");
         tab[i] = (unsigned long long)(uintptr_t)slabs[i];
         tab[L + i] = tab[i] + v_off;
+        d->slab_host[i] = slabs[i];
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d->kv_i8) {  // int8 pages (PIE_OPT_KV_I8): the staging page, the table that points every layer at it, and a block table of zeros
+        if (!d->kv_stage) {
+            PIE_HIP_TRY(hipMalloc((void **)&d->kv_stage, 2 * v_off));
+            PIE_HIP_TRY(hipMemset(d->kv_stage, 0, 2 * v_off));
+            PIE_HIP_TRY(hipMalloc((void **)&d->kv_table_stage, sizeof(unsigned long long) * 2 * L));
+            std::vector<unsigned long long> stab(2 * (size_t)L);
+            for (int i = 0; i < L; ++i) stab[i] = (unsigned long long)(uintptr_t)d->kv_stage, stab[L + i] = stab[i] + v_off;
+            PIE_HIP_TRY(hipMemcpy(d->kv_table_stage, stab.data(), stab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
+        if (d->zero_blocks < max_blocks) {
+            if (d->zero_table) (void)hipFree(d->zero_table);
+            d->zero_table = nullptr, d->zero_blocks = 0;
+            PIE_HIP_TRY(hipMalloc((void **)&d->zero_table, sizeof(int) * (size_t)max_blocks));
+            PIE_HIP_TRY(hipMemset(d->zero_table, 0, sizeof(int) * (size_t)max_blocks));
+            d->zero_blocks = max_blocks;
+            drop_graphs(d);  // the table's address is a launch argument
+        }
+    }
+    const bool blocks_changed = d->max_blocks != max_blocks;
+    d->max_blocks = max_blocks;
     const int capacity = max_blocks * PIE_PAGE_TOKENS;
     PIE_HIP_TRY(hipMemcpyAsync(d->kv_table, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_set_state, dim3(1), dim3(1), 0, st, d->state, -1, -1, capacity);
@@ -362,7 +398,7 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
     d->kv_set = true;
     d->kv_cap = capacity;
     // kernel arguments are baked into captured graphs: a new table pointer or pool size invalidates them
-    const bool changed = d->block_table != block_table || d->n_pages != (int)n_pages;
+    const bool changed = d->block_table != block_table || d->n_pages != (int)n_pages || blocks_changed;
     d->block_table = block_table, d->n_pages = (int)n_pages;
     if (plan_attention(d) || changed) drop_graphs(d);
     return PIE_OK;
@@ -451,7 +487,9 @@ int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_
     hipStream_t st = (hipStream_t)stream;
     // a tensor-parallel shard feeds its prompt through the step kernels (2 all-reduces per layer and token); the many-row GEMM
     // path has no collective yet
-    if (L >= prefill_min_rows() && !d->tp()) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime
+    // int8 pages: the batched prompt path of ONE sequence reads and writes T pages; such prompts run as decode steps here (fresh prompts go
+    // through pie_decoder_prefill_batch, which the Python host does)
+    if (L >= prefill_min_rows() && !d->tp() && !(d->kv_i8 && d->block_table)) return prefill_batched(d, ids, nullptr, L, logits_all, st);  // MLX's qmm regime
     for (int l = 0; l < L; ++l) {
         const bool last = l == L - 1;
         u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;
@@ -469,6 +507,7 @@ int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *
     PIE_REQUIRE(embeds && L > 0, PIE_E_ARG, "pie_decoder_prefill_embeds: need at least one row");
     PIE_REQUIRE(pie_aligned(embeds, 16), PIE_E_ALIGN, "pie_decoder_prefill_embeds: 16-byte alignment required");
     PIE_REQUIRE(!d->tp(), PIE_E_STATE, "pie_decoder_prefill_embeds: not available on a tensor-parallel shard");
+    PIE_REQUIRE(!(d->kv_i8 && d->block_table), PIE_E_STATE, "pie_decoder_prefill_embeds: prompts of embeddings run on T pages (int8 pages: pie_decoder_prefill_batch / _step)");
     return prefill_batched(d, nullptr, embeds, L, logits_all, (hipStream_t)stream);
 }
 

@@ -36,7 +36,14 @@ struct pie_decoder {
     // k_attn_combine -- the scoring loop is VALU work, 4 splits leave it on 32 CUs (83 us per layer at T = 8k, measured).
     bool combine = false;
     int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
-    bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs of pie_decoder_step_batch / _prefill_batch hold int8 pages (paged_i8.hip)
+    bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs hold int8 pages (paged_i8.hip)
+    // single-sequence step on int8 pages: the q|k|v GEMV's RoPE + append epilogue writes the new T rows into ONE staging page through a table of
+    // staging pointers and an all-zero block table (the kernel is untouched), k_paged_kv_append_i8 quantises them into the sequence's page
+    u16 *kv_stage = nullptr;                      // [2][n_kv, 64, D] T
+    unsigned long long *kv_table_stage = nullptr;  // [2 * n_layers]: every layer -> the staging K / V block
+    int *zero_table = nullptr;                     // [zero_blocks] zeros
+    int zero_blocks = 0, max_blocks = 0;
+    std::vector<const void *> slab_host;           // the layers' slab bases (host copy of kv_table's first half)
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     int graph_kernels[2] = {-1, -1};                // kernel nodes of each captured graph (hipGraphGetNodes)
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
@@ -66,6 +73,8 @@ int tp_tail_launch(pie_comm *c, int dtype, const u16 *logits, int V_local, int v
                    int *token, DecState *state, int *history, int hist_cap, hipStream_t st);
 int tp_comm_geometry(const pie_comm *c, int *rank, int *world, size_t *max_elems);
 
+int paged_kv_append_i8_staged_launch(int dtype, const void *stage_k, const void *stage_v, void *slab, int n_pages, const int *block_table, int max_blocks,
+                                     const int *position, int Hkv, int D, hipStream_t st);
 // paged_i8.hip: split-KV decode attention over int8 pages (a.slab = the layer's int8 slab, a.ctx_len / a.block_table as for T pages)
 int paged_attn_i8_launch(int dtype, int D, const AttnArgs &a, hipStream_t st);
 

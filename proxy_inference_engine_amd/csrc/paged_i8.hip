@@ -44,14 +44,20 @@ __global__ void __launch_bounds__(256) k_page_i8_set_scales(char *slab, size_t p
 
 // One thread per 8-element piece of the new K and V rows (T [B, Hkv, D]): row (sequence s, kv-head g) is quantised with the scales
 // of page block_table[s][positions[s] / 64] and stored at its slot positions[s] % 64.  positions[s] < 0 = idle slot.
+// staged (the single-sequence decoder step, B = 1): k / v are a STAGING page [Hkv, 64, D] the q|k|v GEMV's RoPE + append epilogue wrote the T rows
+// into (row positions[0] % 64 of every head), not [B, Hkv, D] rows.
 template <class T>
 __global__ void __launch_bounds__(256) k_paged_kv_append_i8(const uint4 *k, const uint4 *v, char *slab, size_t page_bytes, const int *block_table, int bt_stride,
-                                                            const int *positions, int B, int Hkv, int D, int n_pages) {
+                                                            const int *positions, int B, int Hkv, int D, int n_pages, int staged) {
     const int ppr = D >> 3, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * Hkv * ppr) return;
     const int s = i / (Hkv * ppr), g = (i / ppr) % Hkv, pc = i % ppr;
     const int pos = positions[s];
     if (pos < 0 || (pos >> 6) >= bt_stride) return;
+    if (staged) {
+        const size_t src = ((size_t)g * 64 + (pos & 63)) * ppr + pc;
+        k += src - i, v += src - i;  // k[i] / v[i] below then read the staged piece
+    }
     const unsigned pg = min((unsigned)block_table[(size_t)s * bt_stride + (pos >> 6)], (unsigned)n_pages - 1u);
     char *page = slab + (size_t)pg * page_bytes;
     const size_t blk = (size_t)Hkv * 64 * D;
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__((REP > 4 ? 2 : 4) * 64) k_paged_attn_i8(const 
     __shared__ float s_acc[REP][NSTR][D];
     const int g = blockIdx.x, split = blockIdx.y, row = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ts = lane / LPT, dc = lane % LPT;
-    const int Ttot = a.ctx_len[row];
+    const int Ttot = a.ctx_len ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T);  // no ctx_len: the single-sequence decoder step (position in the device-side state)
     const AttnSplit sp = attn_split(Ttot, a.splits);
     if (a.splits == 1 && sp.active == 0) {  // idle slot of a one-split batch: zeros, as k_attn_combine leaves it
         for (int o = threadIdx.x; o < REP * D; o += NT) a.out[((size_t)row * a.Hq + g * REP) * D + o] = 0;
@@ -271,7 +277,7 @@ int attn_i8_launch(int rep, const AttnArgs &a, size_t page_bytes, hipStream_t st
 
 // for the decoder's multi-sequence step on int8 pages (prefill.hip): the AttnArgs of its T-page launch, slab = the layer's int8 slab
 int paged_attn_i8_launch(int dtype, int D, const AttnArgs &a, hipStream_t st) {
-    PIE_REQUIRE(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.slab && a.block_table && a.ctx_len, PIE_E_ARG, "paged_attn_i8: bad arguments");
+    PIE_REQUIRE(a.Hkv > 0 && a.Hq % a.Hkv == 0 && a.slab && a.block_table && (a.ctx_len || a.state), PIE_E_ARG, "paged_attn_i8: bad arguments");
     const size_t pb = pie_page_i8_bytes(a.Hkv, D);
     const int rep = a.Hq / a.Hkv;
     if (dtype == PIE_BF16 && D == 128) return attn_i8_launch<BF16, 128>(rep, a, pb, st);
@@ -279,6 +285,21 @@ int paged_attn_i8_launch(int dtype, int D, const AttnArgs &a, hipStream_t st) {
     if (dtype == PIE_F16 && D == 128) return attn_i8_launch<F16, 128>(rep, a, pb, st);
     if (dtype == PIE_F16 && D == 64) return attn_i8_launch<F16, 64>(rep, a, pb, st);
     return pie::fail(PIE_E_SHAPE, "paged_attn_i8: head_dim must be 64 or 128 and dtype bf16/f16");
+}
+
+// The single-sequence decoder step on int8 pages (decoder.hip): quantise the row the q|k|v GEMV left in the staging page into the sequence's page.
+int paged_kv_append_i8_staged_launch(int dtype, const void *stage_k, const void *stage_v, void *slab, int n_pages, const int *block_table, int max_blocks,
+                                     const int *position, int Hkv, int D, hipStream_t st) {
+    const int n = Hkv * (D >> 3);
+    const size_t pb = pie_page_i8_bytes(Hkv, D);
+    if (dtype == PIE_BF16)
+        hipLaunchKernelGGL(k_paged_kv_append_i8<BF16>, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4 *)stage_k, (const uint4 *)stage_v, (char *)slab, pb, block_table,
+                           max_blocks, position, 1, Hkv, D, n_pages, 1);
+    else
+        hipLaunchKernelGGL(k_paged_kv_append_i8<F16>, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4 *)stage_k, (const uint4 *)stage_v, (char *)slab, pb, block_table,
+                           max_blocks, position, 1, Hkv, D, n_pages, 1);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
 }
 
 extern "C" {
@@ -306,10 +327,10 @@ int pie_paged_kv_append_i8(const void *k, const void *v, void *slab, size_t n_pa
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PIE_BF16)
         hipLaunchKernelGGL(k_paged_kv_append_i8<BF16>, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4 *)k, (const uint4 *)v, (char *)slab, pb, block_table,
-                           max_blocks, positions, B, Hkv, D, (int)n_pages);
+                           max_blocks, positions, B, Hkv, D, (int)n_pages, 0);
     else
         hipLaunchKernelGGL(k_paged_kv_append_i8<F16>, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4 *)k, (const uint4 *)v, (char *)slab, pb, block_table,
-                           max_blocks, positions, B, Hkv, D, (int)n_pages);
+                           max_blocks, positions, B, Hkv, D, (int)n_pages, 0);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }

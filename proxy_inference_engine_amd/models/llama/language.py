@@ -108,12 +108,23 @@ class Model:
         device = _ffi.require_gpu()
         q = args.quantization or {}
         self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
-        if q and (q.get("group_size") != 64 or q.get("bits") not in (4, 8)):
+        if q and (q.get("group_size") not in (64, 128) or q.get("bits") not in (4, 8)):
             # nn.quantize(model, **config["quantization"]) takes any group_size in {32, 64, 128} and bits in {2, 3, 4, 6, 8}
-            # (models/utils.py:96-111); the W4S / W8S streaming units are built around one 64-wide group per lane
-            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size=64 with bits 4 or 8 only "
+            # (models/utils.py:96-111); the W4S / W8S streaming units are built around one 64-wide group per lane.  group_size 128 is
+            # served (below: every group's scale / bias serves both of its 64-wide halves); 32-wide groups and 2/3/6-bit codes are not.
+            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size 64 or 128 with bits 4 or 8 only "
                              f"(got group_size={q.get('group_size')}, bits={q.get('bits')}); re-quantise the checkpoint with "
                              "mlx_lm.convert -q --q-group-size 64 --q-bits 4")
+        self.group_size = int(q.get("group_size", 64)) if q else 0
+        if self.group_size == 128:
+            # mx.quantize(w, group_size=128): one (scale, bias) per 128 weights.  The streaming units keep one per 64-wide lane group, so each
+            # is written twice: w = s q + b holds for both halves unchanged -- the same dequantised matrix (qmm regime: bit for bit), the same
+            # affine sums up to fp32 association (qmv regime) -- for 0.5625 instead of the checkpoint's 0.53125 B per weight in HBM.
+            weights = dict(weights)
+            for k in [k for k in weights if k.endswith(".scales") or k.endswith(".biases")]:
+                if weights[k[:k.rindex(".")] + ".weight"].shape[-1] * (32 // int(q["bits"])) % 128:
+                    raise ValueError(f"{k}: group_size 128 needs a multiple of 128 input features")
+                weights[k] = weights[k].repeat_interleave(2, dim=-1).contiguous()
         self.bits = int(q["bits"]) if q else 16
         self.n_heads = args.num_attention_heads
         self.n_kv_heads = args.num_key_value_heads or self.n_heads
@@ -251,7 +262,8 @@ class Model:
         kv_dtype=torch.int8: the pages are the reference KVPage's own storage (page.hpp:25-32) -- int8 K / V rows with float16 per-head
         scales; kv_scales = (k, v), each float16 [n_layers, n_kv_heads], is written into every page (None: ones, the reference
         constructor's value -- far too coarse for real activations; pass amax / 127 of a calibration prompt).  Such a pool serves
-        prefill_batch / step_batch (the continuous-batching path); the single-sequence step() keeps T pages."""
+        prefill_batch / step_batch (the continuous-batching path) and the single-sequence step() / InferenceEngine (whose prompts then run as
+        decode steps: the batched single-sequence prompt path reads T pages)."""
         kv_dtype = self.dtype if kv_dtype is None else kv_dtype
         if kv_dtype not in (self.dtype, torch.int8):
             raise ValueError(f"kv_dtype must be the model's dtype or torch.int8, got {kv_dtype}")
@@ -296,9 +308,8 @@ class Model:
             raise TypeError("the layers of a paged cache must share one PagedSequence")
         seq.reserve(n_new)
         a = seq.allocator
-        if a.dtype == torch.int8:
-            raise TypeError("int8 pages serve prefill_batch / step_batch; the single-sequence step() reads pages of the model's dtype")
-        key = ("paged", a.slab.data_ptr(), a.size(), seq.table.data_ptr(), seq.max_blocks)
+        self._match_page_format(a)  # int8 pages (round 4): the step's new K / V row is quantised into the sequence's page, attention reads the codes back
+        key = ("paged", a.slab.data_ptr(), a.size(), seq.table.data_ptr(), seq.max_blocks, a.dtype == torch.int8)
         lib = _ffi.load()
         if key != self._kv_key:
             n = len(cache)

@@ -859,6 +859,34 @@ def test_random_model_configs_end_to_end(case):
     assert np.array_equal(to_bits(logits2), dec_bits[0]), f"{what}: paged decode logits differ"
 
 
+def test_group_size_128_checkpoint_vs_oracle():
+    """config["quantization"] = {"group_size": 128, "bits": 4} (nn.quantize forwards it unchanged, models/utils.py:96-111; mx.quantize's other
+    common group size): the triplets carry one (scale, bias) per 128 weights, the streaming units one per 64 -- each is served to both halves.
+    A 40-token prompt (qmm regime: the dequantised matrix is the same, bit for bit) and decode steps (qmv regime: the affine sums associate
+    per 64 instead of per 128) against the oracle, which quantises and multiplies with 128-wide groups."""
+    cfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2, "intermediate_size": 768, "num_attention_heads": 4,
+           "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 512, "rope_theta": 10000.0, "max_position_embeddings": 2048,
+           "tie_word_embeddings": False, "quantization": {"group_size": 128, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=41, dtype=DT, lm_head_gain=4.0)
+    assert w["model.layers.0.mlp.down_proj.scales"].shape == (256, 768 // 128)
+    model = build(cfg, w)
+    assert model.group_size == 128
+    orc = po.OracleLlama(cfg, w, DT)
+    prompt = np.random.default_rng(4).integers(0, cfg["vocab_size"], 40)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache)
+    cache = model.make_cache()
+    got = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+    for l in range(40):
+        assert_vec_close(got[l], want[l], DT, what=f"g=128 prompt position {l}")
+    tok = int(np.argmax(want[-1]))
+    for i in range(4):
+        w1 = orc.forward(np.array([tok]), ocache)[0]
+        _, _, g1 = model.step(torch.tensor([tok], dtype=torch.int32, device="cuda"), cache)
+        assert_vec_close(g1.float().cpu().numpy(), w1, DT, what=f"g=128 decode step {i}")
+        tok = int(np.argmax(w1))
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)

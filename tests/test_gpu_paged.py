@@ -602,10 +602,68 @@ def test_decoder_batch_paths_on_int8_pages(golden_dir):
         assert np.array_equal(k8, po.kv_i8_quantize(new_t[i][0], ksn[0])) and np.array_equal(v8, po.kv_i8_quantize(new_t[i][1], vsn[0]))
         assert_vec_close(la_8.float().cpu().numpy()[i], la_t[i], "bfloat16", c_max=24.0, c_rms=16.0, what=f"int8-page decode step, sequence {i}")
     assert torch.equal(tok_8.cpu(), tok_t.cpu())
-    with pytest.raises(TypeError, match="int8 pages"):
-        model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
-    model.enable_paged_kv(num_pages=8)   # back to T pages: the single-sequence path works again
+    model.enable_paged_kv(num_pages=8)   # back to T pages
     model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
+
+
+def test_single_sequence_step_on_int8_pages(golden_dir):
+    """The single-sequence decoder step (Model.step / InferenceEngine: one replayed hipGraph) on a pool of int8 pages (page.hpp:25-32): the q|k|v
+    launch's RoPE + append epilogue writes the new T row into a staging page, k_paged_kv_append_i8 quantises it into the sequence's page, the
+    int8-page attention reads the codes back.  Against the same sequence on T pages: layer 0's stored codes are exactly the oracle's quantisation
+    of the T-page run's rows (they do not depend on attention), later layers' within one code, logits within the quantisation noise, greedy
+    tokens equal; prompt (iterated steps) + graph-replayed steps across a page boundary; then through InferenceEngine."""
+    from proxy_inference_engine_amd import InferenceEngine
+    from tests._util import assert_vec_close
+    g, cfg, model = _tiny(golden_dir)
+    L, Hkv = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
+    prompt = np.random.default_rng(29).integers(0, cfg["vocab_size"], 58).astype(np.int32)
+    steps = 12                                                              # 58 + 12 positions: crosses the 64-row page boundary
+    model.enable_paged_kv(num_pages=8)
+    ct = model.make_cache()
+    tok, _, lg = model.step(torch.from_numpy(prompt[:5]).cuda(), ct)        # 5 rows: iterated decode steps on both page formats
+    for t in prompt[5:]:
+        tok, _, lg = model.step(torch.tensor([t], dtype=torch.int32).cuda(), ct)
+    ref = [(int(tok.item()), lg.float().cpu().numpy().copy())]
+    for _ in range(steps):
+        tok, _, lg = model.step(None, ct)
+        ref.append((int(tok.item()), lg.float().cpu().numpy().copy()))
+    rows = [tuple(t.float().cpu().numpy()[0].transpose(1, 0, 2) for t in ct[l].state) for l in range(L)]   # [n, Hkv, D]
+    amax = np.stack([np.stack([np.abs(rows[l][w]).max(axis=(0, 2)) for l in range(L)]) for w in range(2)])
+    ks, vs = (torch.from_numpy((amax[w] * 1.25 / 127).astype(np.float16)) for w in range(2))
+    ct[0].page_manager.release()
+
+    model.enable_paged_kv(num_pages=8, kv_dtype=torch.int8, kv_scales=(ks, vs))
+    c8 = model.make_cache()
+    tok, _, lg = model.step(torch.from_numpy(prompt[:5]).cuda(), c8)
+    for t in prompt[5:]:
+        tok, _, lg = model.step(torch.tensor([t], dtype=torch.int32).cuda(), c8)
+    got = [(int(tok.item()), lg.float().cpu().numpy().copy())]
+    for i in range(steps):
+        tok, _, lg = model.step(None, c8, graph=i >= 2)                      # eager, then the captured graph
+        got.append((int(tok.item()), lg.float().cpu().numpy().copy()))
+    n = len(prompt) + steps
+    assert c8[0].offset == n
+    ksn, vsn = ks.numpy(), vs.numpy()
+    k8, v8 = (t.cpu().numpy()[0].transpose(1, 0, 2) for t in c8[0].state)    # layer 0: int8 [n, Hkv, D]
+    assert k8.dtype == np.int8 and k8.shape[0] == n
+    same_tokens = [a[0] == b[0] for a, b in zip(got, ref)]
+    upto = same_tokens.index(False) if False in same_tokens else len(same_tokens)     # rows are comparable while both runs fed the same tokens
+    m = min(len(prompt) + upto, n)
+    assert np.array_equal(k8[:m], po.kv_i8_quantize(rows[0][0][:m], np.broadcast_to(ksn[0], (m, Hkv)))), "layer-0 K codes"
+    assert np.array_equal(v8[:m], po.kv_i8_quantize(rows[0][1][:m], np.broadcast_to(vsn[0], (m, Hkv)))), "layer-0 V codes"
+    k81 = c8[1].state[0].cpu().numpy()[0].transpose(1, 0, 2)[:m].astype(np.int32)
+    assert np.abs(k81 - po.kv_i8_quantize(rows[1][0][:m], np.broadcast_to(ksn[1], (m, Hkv))).astype(np.int32)).max() <= 2, "layer-1 K codes (behind one int8 attention)"
+    for i in range(upto):
+        assert_vec_close(got[i][1], ref[i][1], "bfloat16", c_max=24.0, c_rms=16.0, what=f"int8-page step {i}")
+    assert upto >= 4, f"greedy tokens diverged after {upto} steps: {same_tokens}"
+    c8[0].page_manager.release()
+    # the engine on such a pool: prompt, then greedy steps -- the same tokens as the model-level run above
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(prompt, temp=0)
+    gen = eng.generate_step(torch.from_numpy(prompt.astype(np.int64)))
+    etoks = [int(next(gen)[0].item()) for _ in range(upto)]
+    assert etoks == [t for t, _ in got[:upto]]
+    model.enable_paged_kv(num_pages=8)   # back to T pages
 
 
 def test_continuous_batching_engine_on_int8_pages(golden_dir):
