@@ -141,6 +141,7 @@ int main(int argc, char **argv) {
         const char *name;
         int kind;  // 0 trivial, 1 link plain, 2 link sc1
         int acq, rel, barrier;
+        int wgs = 256, threads = 512;  // launch geometry (trivial kernel only)
     };
     const int NO = HSA_FENCE_SCOPE_NONE, AG = HSA_FENCE_SCOPE_AGENT, SY = HSA_FENCE_SCOPE_SYSTEM;
     const Case cases[] = {
@@ -149,6 +150,12 @@ int main(int argc, char **argv) {
         {"link plain, acquire agent / release agent", 1, AG, AG, 1}, {"link plain, acquire none  / release none ", 1, NO, NO, 1}, {"link plain, acquire agent / release none ", 1, AG, NO, 1},
         {"link plain, acquire none  / release agent", 1, NO, AG, 1}, {"link sc1,   acquire agent / release agent", 2, AG, AG, 1}, {"link sc1,   acquire none  / release none ", 2, NO, NO, 1},
         {"link sc1,   acquire agent / release none ", 2, AG, NO, 1}, {"link sc1,   acquire none  / release agent", 2, NO, AG, 1},
+        // what a dispatch costs by its size (agent fences, barrier bit): is the floor per packet or per wave?
+        {"trivial, 256 wgs x 512 threads (2048 waves)", 0, AG, AG, 1, 256, 512}, {"trivial, 256 wgs x 256 threads (1024 waves)", 0, AG, AG, 1, 256, 256},
+        {"trivial, 256 wgs x 128 threads ( 512 waves)", 0, AG, AG, 1, 256, 128}, {"trivial, 256 wgs x  64 threads ( 256 waves)", 0, AG, AG, 1, 256, 64},
+        {"trivial, 128 wgs x 512 threads (1024 waves)", 0, AG, AG, 1, 128, 512}, {"trivial,  32 wgs x 256 threads ( 128 waves)", 0, AG, AG, 1, 32, 256},
+        {"trivial,   1 wg  x  64 threads (   1 wave )", 0, AG, AG, 1, 1, 64}, {"trivial, 512 wgs x 512 threads (4096 waves)", 0, AG, AG, 1, 512, 512},
+        {"trivial, 1024 wgs x 256 threads (4096 waves)", 0, AG, AG, 1, 1024, 256},
     };
     for (const Case &c : cases) {
         double best = 1e30, sum = 0.0, dev_best = 1e30;
@@ -176,8 +183,9 @@ int main(int argc, char **argv) {
                     memcpy(ka, &in, 8), memcpy(ka + 8, &out, 8), memcpy(ka + 16, &salt, 4);
                 }
                 hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)q->base_address + ((base + (uint64_t)i) & (q->size - 1));
-                p->workgroup_size_x = 512, p->workgroup_size_y = 1, p->workgroup_size_z = 1;
-                p->grid_size_x = 256 * 512, p->grid_size_y = 1, p->grid_size_z = 1;
+                const int wgs = c.kind == 0 ? c.wgs : 256, thr = c.kind == 0 ? c.threads : 512;
+                p->workgroup_size_x = (uint16_t)thr, p->workgroup_size_y = 1, p->workgroup_size_z = 1;
+                p->grid_size_x = (uint32_t)(wgs * thr), p->grid_size_y = 1, p->grid_size_z = 1;
                 p->private_segment_size = k.priv, p->group_segment_size = k.group;
                 p->kernel_object = k.object;
                 p->kernarg_address = ka;
