@@ -323,8 +323,8 @@ def test_short_prompt_int4_gemm_paths(tiny, knobs, L):
             assert_vec_close(got[l], want[l], DT, what=f"small_m={small} L={L} position {l}")
         tok, _, logits = m.step(None, cache)                           # decode continues on the cache the short prompt filled
         outs[small] = (got, logits.float().cpu().numpy())
-    assert_vec_close(outs["32"][0][-1], outs["0"][0][-1], DT, what="w4m vs hipBLASLt path")
-    assert_vec_close(outs["32"][1], outs["0"][1], DT, what="decode after w4m vs hipBLASLt prompt")
+    assert_vec_close(outs[32][0][-1], outs[0][0][-1], DT, what="w4m vs hipBLASLt path")
+    assert_vec_close(outs[32][1], outs[0][1], DT, what="decode after w4m vs hipBLASLt prompt")
 
 
 def test_batched_prefill_llama8b_shapes(knobs):
