@@ -19,6 +19,11 @@ int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const voi
 
 namespace {
 thread_local std::string g_last_error;
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+constexpr int PROF_QKV = 256, PROF_O = 288, PROF_GU = 320, PROF_DOWN = 352;  // 32 words each: the fine prologue stamps sit at +8..13
+#else
+constexpr int PROF_QKV = 16, PROF_O = 20, PROF_GU = 24, PROF_DOWN = 28;
+#endif
 }
 namespace {
 int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -99,7 +104,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.block_table = d->block_table, a.n_pages = d->n_pages;
             const bool i8 = d->kv_i8 && d->block_table;  // int8 pages: the T rows go to the staging page, then get quantised into the sequence's page
             if (i8) a.kv_table = d->kv_table_stage, a.block_table = d->zero_table, a.n_pages = 1;
-            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 16;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + PROF_QKV;
             if (embed_here) {  // the step's embedding launch folded into this one (embed_in_qkv): x = the token's row, dequantised by every workgroup
                 a.x = nullptr, a.rope_cs = nullptr, a.rope_cs_out = d->rope_cs, a.h_out = d->h, a.token = token_ptr;
                 a.emb_codes = (const u32 *)d->glob.embed_codes, a.emb_scales = (const u16 *)d->glob.embed_scales, a.emb_biases = (const u16 *)d->glob.embed_biases;
@@ -150,7 +155,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             const bool merged_attn = d->combine || (d->kv_i8 && d->block_table);  // the attention output is already one T vector
             if (merged_attn) a.x = d->attn;
             else a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.splits = d->splits, a.state = d->state, a.head_dim = D;
-            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 20;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + PROF_O;
             const int rc = w4s_gemv_launch(c.dtype, merged_attn ? PRO_NONE : PRO_ATTN, epi, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st, push);
         }
@@ -158,7 +163,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             GemvArgs a = {};
             a.fmt = gfmt(w.wgateup), a.w = (const char *)w.wgateup, a.K = H, a.N = 2 * c.inter, a.x = d->h, a.norm_w = (const u16 *)w.mlp_norm, a.eps = c.rms_eps;
             a.y = d->act, a.lin_bias = (const u16 *)w.bgateup;
-            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 24;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + PROF_GU;
             return w4s_gemv_launch(c.dtype, PRO_RMSNORM, EPI_SWIGLU, a, 1, st);
         }
         case PIE_K_DOWN: {  // out = h + down_proj(...)  (language.py:127,153)
@@ -166,7 +171,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             a.fmt = gfmt(w.wdown), a.w = (const char *)w.wdown, a.K = c.inter, a.N = H, a.x = d->act, a.resid = d->h, a.lin_bias = (const u16 *)w.bdown;
             const bool push = d->tp() && tp_comm_push_args(d->comm, &a.tp_peers, &a.tp_epoch, &a.tp_stride);
             a.y32 = d->tp_part, a.tp_rank = c.tp_rank, a.tp_world = c.tp_world;
-            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + 28;
+            a.prof = reinterpret_cast<unsigned long long *>(d->pf_sink) + PROF_DOWN;
             const int rc = w4s_gemv_launch(c.dtype, PRO_NONE, d->tp() ? (push ? EPI_TP_PUSH : EPI_PARTIAL_F32) : EPI_RESIDUAL, a, 1, st);
             return rc || !d->tp() ? rc : tp_allreduce_launch(d->comm, c.dtype, d->tp_part, H, d->h, st, push);
         }

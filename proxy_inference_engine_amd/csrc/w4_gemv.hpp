@@ -226,6 +226,17 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 
 template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs a) {
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+    // fine stamps of the prologue (workgroup 0, thread 0; stored at the very end at prof[8..12]): kernel entry | first kernel argument usable |
+    // activations arrived | norm reduced (first barrier) | image staged
+    const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+    {
+        int k_probe = a.K;
+        asm volatile("" ::"s"(k_probe));
+    }
+    const unsigned long long ts_args = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ts_x = 0, ts_b1 = 0, ts_staged = 0;
+#endif
     GEMV_STAMP(0);
     constexpr int D = GEMV_DEPTH;
     constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : W4S_UNIT_BYTES);
@@ -406,6 +417,12 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
 
     // 2. stage x through LDS once per workgroup, with the fused mx.fast.rms_norm
     //    (nn.RMSNorm, language.py:137-141,168): w * T(x * rsqrt(mean(x^2) + eps)), or the split-KV merge.
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+    if (PRO != PRO_ATTN && PRO != PRO_EMBED) {
+        asm volatile("" ::"v"(xv[0].x));
+        ts_x = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (!(ABL & 4)) {
         if (PRO == PRO_ATTN) {
 #pragma unroll
@@ -434,6 +451,9 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             ssq = lane_value(ssq, 31) + lane_value(ssq, 63);
             if (lane == 0) red[wave] = ssq;
             __syncthreads();
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+            ts_b1 = __builtin_amdgcn_s_memrealtime();
+#endif
             const float4 ra = *reinterpret_cast<const float4 *>(red), rb = *reinterpret_cast<const float4 *>(red + 4);
             const float tot = ((ra.x + ra.y) + (ra.z + ra.w)) + ((rb.x + rb.y) + (rb.z + rb.w));
             const float inv = 1.0f / sqrtf(tot / (float)a.K + a.eps);
@@ -465,6 +485,9 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     }
 
     GEMV_STAMP(1);  // x staged
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+    ts_staged = __builtin_amdgcn_s_memrealtime();
+#endif
     // 3. the stream: unit i = (pair p_begin + i / ns, slice i % ns); lanes 0-31 / 32-63 = the pair's two rows.
     //    No global store and no data-dependent branch in here: stores share vmcnt with the loads and would make the
     //    compiler drain the ring.  Row sums are parked in LDS; the epilogue runs after the loop, one lane per pair.
@@ -609,6 +632,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
     GEMV_STAMP(3);
+#if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
+    if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        a.prof[8] = ts_entry, a.prof[9] = ts_args, a.prof[10] = ts_x, a.prof[11] = ts_b1, a.prof[12] = ts_staged, a.prof[13] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------- a few activation rows against ONE pass over the weights

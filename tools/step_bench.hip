@@ -283,6 +283,16 @@ int main(int argc, char **argv) {
         unsigned long long t[32] = {};
         CK(hipMemcpy(t, ps, sizeof t, hipMemcpyDeviceToHost));
         const char *kn[4] = {"qkv", "o_proj", "gate_up", "down"};
+        {  // -DPIE_GEMV_PROF=3 build: fine prologue stamps of workgroup 0 of the last launch of each GEMV (32-word slots from word 256)
+            std::vector<unsigned long long> f(1024);
+            CK(hipMemcpy(f.data(), ps, 8192, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long *q = f.data() + 256 + 32 * k + 8;
+                if (q[0] && q[5] > q[0])
+                    printf("%-8s prologue, workgroup 0, us after kernel entry: kernel arguments %.2f | activations arrived %.2f | norm reduced %.2f | image staged %.2f | end %.2f\n", kn[k],
+                           (q[1] - q[0]) * 0.01, q[2] ? (q[2] - q[0]) * 0.01 : 0.0, q[3] ? (q[3] - q[0]) * 0.01 : 0.0, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01);
+            }
+        }
         for (int k = 0; k < 4; ++k) {  // -DPIE_GEMV_PROF build: workgroup 0 of the last launch of each GEMV
             const unsigned long long *g4 = t + 16 + 4 * k;
             if (g4[0] && g4[3] > g4[0])
