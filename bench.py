@@ -55,6 +55,8 @@ def parse():
                     help="70b: BASELINE.json configs[4]'s model on ONE card (40 GB int4); qv: configs[3]'s Qwen2-VL-7B text tower; 3b: Llama-3.2-3B; not the metric's workload")
     ap.add_argument("--tp", type=int, default=0, help="tensor parallelism over ALL ranks (== --gpus): ONE sequence decoded by the sharded model "
                     "(BASELINE.json configs[4] with --model 70b); strong scaling, value = that sequence's tokens/s")
+    ap.add_argument("--tp-backend", choices=["ipc", "rccl"], default="ipc", help="--tp: the communicator behind the fused step's collectives: the one-shot all-reduce over "
+                    "IPC-mapped peer memory (default) or RCCL (ncclAllReduce on the launch stream): the comparator for the first run on a real node")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
@@ -190,7 +192,7 @@ def main():
                     h = t.cpu()
                     dist.broadcast(h, src=0)
                     t.copy_(h)
-        comm = HipComm(cfg["hidden_size"])
+        comm = HipComm(cfg["hidden_size"], backend=args.tp_backend)
     else:
         # heavy-tailed lm_head rows: the parity gate's id comparison needs steps whose greedy token is decided by more than rounding noise
         # (models/utils.py: synthetic_checkpoint); same shapes and bytes, so the timing is that of any Llama-3-8B int4 checkpoint
@@ -315,7 +317,7 @@ def main():
         "dtype": "bf16", "dtype_detail": ("bf16 weights" if args.dense else f"uint{args.bits} g=64 weights") + " x bf16 activations, fp32 accumulate (v_dot2c_f32_bf16)", "data": "synthetic",
         "config": {"workload": f"{'Qwen2-VL-7B text tower' if args.model == 'qv' else 'Llama-3-' + args.model.upper()}-shaped (H{shape_cfg['hidden_size']} L{n_l} {shape_cfg['num_attention_heads']}/{shape_cfg['num_key_value_heads']} heads I{shape_cfg['intermediate_size']} V{shape_cfg['vocab_size']}) {'dense bf16' if args.dense else f'int{args.bits} g=64'} greedy decode, batch 1, "
                                f"{args.prompt}-token prompt, context {args.prompt + 1 + args.warmup}..{args.prompt + 1 + args.warmup + args.steps}",
-                   "parallelism": f"TP={tp}" if tp else ("replicas" if world > 1 else "single GPU"),
+                   "parallelism": f"TP={tp} ({args.tp_backend} collectives)" if tp else ("replicas" if world > 1 else "single GPU"),
                    "launches_per_step": launches_per_step,  # kernel nodes of the captured hipGraph
                    "hipgraph": True, "kv": "paged (64-token pages)" if args.paged else "contiguous"},
         "roofline": {"bound": "hbm", "kernel": "k_w4s_gemv<bf16, rmsnorm, swiglu> (gate/up)", "achieved": k_gbps, "peak": HBM_PEAK_GBPS,
