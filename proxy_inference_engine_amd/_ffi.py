@@ -28,7 +28,7 @@ EXPORTS = [
     "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode", "pie_sdpa_prefill",
     "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_stream_read", "pie_decoder_graph_launches", "pie_qkv_row_map", "pie_gateup_row_map",
     "pie_decoder_create", "pie_decoder_destroy", "pie_decoder_set_layer", "pie_decoder_set_globals",
-    "pie_decoder_set_kv", "pie_decoder_set_paged_kv", "pie_decoder_step_batch", "pie_decoder_prefill_batch", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill", "pie_decoder_prefill_embeds",
+    "pie_decoder_set_kv", "pie_decoder_set_paged_kv", "pie_decoder_step_batch", "pie_decoder_prefill_batch", "pie_decoder_step_mixed", "pie_decoder_set_state", "pie_decoder_step", "pie_decoder_prefill", "pie_decoder_prefill_embeds",
     "pie_decoder_bind_outputs", "pie_decoder_set_token_from", "pie_decoder_step_bytes",
     "pie_decoder_launch_kernel", "pie_decoder_kernel_bytes", "pie_decoder_configure", "pie_decoder_status",
     "pie_page_pool_slab_bytes", "pie_page_pool_create", "pie_page_pool_destroy", "pie_page_pool_size", "pie_page_pool_num_free",
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
     lib.pie_qgemm_w4m.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_decoder_step_batch.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
     lib.pie_decoder_prefill_batch.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    lib.pie_decoder_step_mixed.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 4
     lib.pie_page_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib

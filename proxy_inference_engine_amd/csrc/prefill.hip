@@ -889,6 +889,23 @@ extern "C" int pie_sdpa_prefill(const void *q, const void *k, const void *v, int
 }
 
 
+// attention splits of a batch of B decode rows over block tables of max_blocks pages
+static int batch_attn_splits(const pie_decoder *d, int B, int max_blocks) {
+    const pie_decoder_config &c = d->cfg;
+    // attention splits: enough workgroups for two per CU across the batch, never more than pages per sequence
+    int splits = ((d->kv_i8 ? 1024 : 512) + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);  // (the int8-page kernel runs 4-wave workgroups: twice as many)
+    splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
+    splits = splits < 1 ? 1 : splits;
+    // short sequences (tables of at most 8 pages) in a batch of 64+ (sequence, kv-head) workgroups: one split, and no combine launch
+    // (threshold 128 -> 64, i.e. from 8 sequences of the 8B model: 8 / 12 sequences 2.46 / 2.57 -> 2.40 / 2.46 ms at ~170 positions,
+    // 2.59 / 2.78 -> 2.57 / 2.61 at ~420; at 48 the 6-sequence step lost 1 % at ~420 positions)
+    if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 64)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
+    // a handful of short sequences: one split as well -- the split kernel + its combine launch cost 10.6 us per layer against 5.5 for the
+    // batch-1 step's attention, and a few hundred positions are a handful of row blocks per wave
+    if (B <= GEMV_ROWS_MAX && max_blocks <= 4 && !d->kv_i8) splits = 1;
+    return splits;
+}
+
 // ---------------------------------------------------------------- one decode step for B sequences (continuous batching)
 // The weights stream once for all B rows (few-row int4 GEMM for B <= 32, the T copy + hipBLASLt beyond); each row is its own
 // sequence: RoPE at its own position, K/V appended to its own page, attention over its own block table (k_attn_decode PAGED,
@@ -902,17 +919,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     size_t w_elems = (size_t)2 * I * H;
     if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
     if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
-    // attention splits: enough workgroups for two per CU across the batch, never more than pages per sequence
-    int splits = ((d->kv_i8 ? 1024 : 512) + B * c.n_kv_heads - 1) / (B * c.n_kv_heads);  // (the int8-page kernel runs 4-wave workgroups: twice as many)
-    splits = splits > ATTN_MAX_SPLITS ? ATTN_MAX_SPLITS : (splits > max_blocks ? max_blocks : splits);
-    splits = splits < 1 ? 1 : splits;
-    // short sequences (tables of at most 8 pages) in a batch of 64+ (sequence, kv-head) workgroups: one split, and no combine launch
-    // (threshold 128 -> 64, i.e. from 8 sequences of the 8B model: 8 / 12 sequences 2.46 / 2.57 -> 2.40 / 2.46 ms at ~170 positions,
-    // 2.59 / 2.78 -> 2.57 / 2.61 at ~420; at 48 the 6-sequence step lost 1 % at ~420 positions)
-    if (max_blocks <= 8 && B * c.n_kv_heads >= (d->kv_i8 ? 512 : 64)) splits = 1;  // (the int8-page kernel's workgroups are half as wide)
-    // a handful of short sequences: one split as well -- the split kernel + its combine launch cost 10.6 us per layer against 5.5 for the
-    // batch-1 step's attention, and a few hundred positions are a handful of row blocks per wave
-    if (B <= GEMV_ROWS_MAX && max_blocks <= 4 && !d->kv_i8) splits = 1;
+    const int splits = batch_attn_splits(d, B, max_blocks);
     int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
@@ -1030,16 +1037,21 @@ __global__ void k_gather_rows(const uint4 *x, const int *rows, int H8, uint4 *y)
 // The rows of S prompts concatenated ([N] ids): one pass of GEMMs over all N rows, RoPE at each row's own position, K / V into
 // each prompt's own pages AND a contiguous copy the attention of this pass reads (causal inside each prompt = the segment
 // kernel with seg_hi[r] = r + 1), lm_head + tail on every prompt's last row.  Fresh prompts only (nothing cached before them).
+// n_decode > 0 (a mixed batch, batch_details.hpp:10-88's prefill- and decode-state sequences in one BatchDetails): rows
+// [0, n_decode) are decode-state sequences -- row r is sequence r (row_seq[r] == r, block-table row r) at position
+// row_ctx[r] - 1 with a trivial segment [r, r + 1) -- whose attention then runs over their pages (the multi-sequence step's
+// paged kernel) and replaces the segment kernel's rows; the prompt rows follow.  One pass over the weights for both kinds.
 template <class T>
 static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *row_ctx, const int32_t *row_seq, const int32_t *seg_lo,
-                            const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, int n_pages,
+                            const int32_t *seg_hi, const int32_t *last_rows, int N, int S, int n_decode, const void *const *slabs, int n_pages,
                             const int32_t *block_tables, int max_blocks, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
     size_t w_elems = (size_t)2 * I * H;
     if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
     if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
-    int rc = scratch_reserve(d, N > S ? N : S, w_elems, d->splits);
+    const int dsplits = n_decode > 0 ? batch_attn_splits(d, n_decode, max_blocks) : 1;
+    int rc = scratch_reserve(d, N > S ? N : S, w_elems, dsplits > d->splits ? dsplits : d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
     if ((rc = tail_stats_reserve(s, (size_t)TAIL_STAT_TILES * (size_t)S))) return rc;
@@ -1065,6 +1077,14 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         pa.q = s->q, pa.k = s->kc, pa.v = s->vc, pa.offset = 0, pa.cap = N, pa.seg_lo = seg_lo, pa.seg_hi = seg_hi;
         pa.M = N, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
         if ((rc = segment_attn_gqa_launch_t<T>(pa, D, st))) return rc;
+        if (n_decode > 0) {  // the decode-state rows attend to their pages (which hold the row just appended)
+            AttnArgs a = {};
+            a.q = s->q, a.slab = (const u16 *)slabs[li], a.block_table = block_tables, a.ctx_len = row_ctx, a.bt_stride = max_blocks, a.n_pages = n_pages;
+            a.rows = n_decode, a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = dsplits, a.scale = pa.scale;
+            a.nt_kv = (size_t)n_decode * max_blocks * 64 >= 2048;
+            a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
+            if ((rc = d->kv_i8 ? paged_attn_i8_launch(c.dtype, D, a, st) : attn_decode_launch(c.dtype, D, a, true, st))) return rc;
+        }
         bool r32 = false;
         W4lSlabs so, sd;  // K-split products handed to their consumers as fp32 slabs (as in the single-prompt path)
         if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
@@ -1094,26 +1114,42 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
 }
 
 static size_t active_page_bytes(const pie_decoder *d);
+static int varlen_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
+                        const int32_t *seg_hi, const int32_t *last_rows, int N, int S, int n_decode, const void *const *slabs, size_t n_pages, size_t slab_bytes,
+                        const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream) {
+    PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
+                PIE_E_ARG, "pie_decoder_prefill_batch / _step_mixed: null pointer");
+    PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch / _step_mixed: set_globals must be called first");
+    for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_prefill_batch / _step_mixed: a layer has no weights (pie_decoder_set_layer)");
+    PIE_REQUIRE(S >= 1 && N >= S && N <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_prefill_batch / _step_mixed: bad batch shape");
+    PIE_REQUIRE(slab_bytes >= n_pages * active_page_bytes(d), PIE_E_SHAPE,
+                "pie_decoder_prefill_batch / _step_mixed: the slabs are smaller than n_pages pages of the active page format (an int8 pool needs PIE_OPT_KV_I8, a T pool must not have it)");
+    PIE_REQUIRE(d->cfg.hidden % 8 == 0 && d->cfg.hidden <= 8192, PIE_E_SHAPE, "pie_decoder_prefill_batch / _step_mixed: hidden must be a multiple of 8, at most 8192");
+    const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
+    PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_prefill_batch / _step_mixed: n_heads / n_kv_heads must be between 1 and 8");
+    for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_prefill_batch / _step_mixed: null or misaligned slab");
+    hipStream_t st = (hipStream_t)stream;
+    return d->cfg.dtype == PIE_BF16 ? prefill_varlen_t<BF16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, n_decode, slabs, (int)n_pages,
+                                                             block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st)
+                                    : prefill_varlen_t<F16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, n_decode, slabs, (int)n_pages,
+                                                            block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st);
+}
+
 extern "C" int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
                                          const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *last_rows, int N, int S,
                                          const void *const *slabs, size_t n_pages, size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits,
                                          float *logprobs, int32_t *next_tokens, void *stream) {
-    PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
-                PIE_E_ARG, "pie_decoder_prefill_batch: null pointer");
-    PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch: set_globals must be called first");
-    for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_prefill_batch: a layer has no weights (pie_decoder_set_layer)");
-    PIE_REQUIRE(S >= 1 && N >= S && N <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_prefill_batch: bad batch shape");
-    PIE_REQUIRE(slab_bytes >= n_pages * active_page_bytes(d), PIE_E_SHAPE,
-                "pie_decoder_prefill_batch: the slabs are smaller than n_pages pages of the active page format (an int8 pool needs PIE_OPT_KV_I8, a T pool must not have it)");
-    PIE_REQUIRE(d->cfg.hidden % 8 == 0 && d->cfg.hidden <= 8192, PIE_E_SHAPE, "pie_decoder_prefill_batch: hidden must be a multiple of 8, at most 8192");
-    const int rep = d->cfg.n_heads / d->cfg.n_kv_heads;
-    PIE_REQUIRE(rep >= 1 && rep <= 8, PIE_E_SHAPE, "pie_decoder_prefill_batch: n_heads / n_kv_heads must be between 1 and 8");
-    for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_prefill_batch: null or misaligned slab");
-    hipStream_t st = (hipStream_t)stream;
-    return d->cfg.dtype == PIE_BF16 ? prefill_varlen_t<BF16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, slabs, (int)n_pages, block_tables,
-                                                             max_blocks, (u16 *)logits, logprobs, next_tokens, st)
-                                    : prefill_varlen_t<F16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, slabs, (int)n_pages, block_tables,
-                                                            max_blocks, (u16 *)logits, logprobs, next_tokens, st);
+    return varlen_batch(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, 0, slabs, n_pages, slab_bytes, block_tables,
+                        max_blocks, logits, logprobs, next_tokens, stream);
+}
+
+extern "C" int pie_decoder_step_mixed(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
+                                      const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *out_rows, int N, int S, int n_decode,
+                                      const void *const *slabs, size_t n_pages, size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits,
+                                      float *logprobs, int32_t *next_tokens, void *stream) {
+    PIE_REQUIRE(n_decode >= 0 && n_decode <= S, PIE_E_SHAPE, "pie_decoder_step_mixed: n_decode must be between 0 and the number of output rows");
+    return varlen_batch(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, out_rows, N, S, n_decode, slabs, n_pages, slab_bytes, block_tables,
+                        max_blocks, logits, logprobs, next_tokens, stream);
 }
 
 static int decode_batch(pie_decoder *d, const int32_t *tokens, const int32_t *ctx_len, const void *const *slabs, int n_pages, const int32_t *block_tables,

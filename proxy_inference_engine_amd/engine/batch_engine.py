@@ -3,9 +3,10 @@
 The reference declares this shape -- a `Scheduler` that forms `BatchDetails` from prefill- and decode-state sequences over the
 paged pool (src/pie_core/include/engine/batch_details.hpp:10-88, scheduler.hpp) -- without a body (`Scheduler::step` is
 empty, the Python engine serves one sequence).  This is the smallest complete loop over the pieces that exist here: requests
-wait in a queue, join the batch when a slot and enough pages are free (their prompt runs through the single-sequence prompt
-path), every step decodes all active sequences with one pass over the weights (`Model.step_batch`), finished sequences leave
-and return their pages.  Greedy by default; `sampler` maps a [B, V] log-probability block to B token ids."""
+wait in a queue, join the batch when a slot and enough pages are free -- their prompt rows ride the decode step of the sequences
+in flight (`Model.step_mixed`: both kinds of sequence in one pass over the weights, as BatchDetails holds both), or run as a
+prompt pass of their own when nothing is decoding -- every step decodes all active sequences with one pass over the weights
+(`Model.step_batch`), finished sequences leave and return their pages.  Greedy by default; `sampler` maps a [B, V] log-probability block to B token ids."""
 from __future__ import annotations
 
 from collections import deque
@@ -28,7 +29,7 @@ class _Active:
 class BatchedEngine:
     def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
                  sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096,
-                 kv_dtype: torch.dtype | None = None, kv_scales=None):
+                 kv_dtype: torch.dtype | None = None, kv_scales=None, mixed: bool = True):
         """kv_dtype=torch.int8 (+ kv_scales = (k, v) float16 [n_layers, n_kv_heads]): the pool holds the reference KVPage's int8 pages with
         per-head scales (page.hpp:25-32) -- half the cache bytes per token, so twice the sequences / context per pool."""
         self.model = model
@@ -39,7 +40,9 @@ class BatchedEngine:
         self.sampler = sampler
         self.batch_prefill = batch_prefill          # admit several waiting prompts with one pass over the weights
         self.max_prefill_rows = max_prefill_rows    # prompt tokens per such pass
+        self.mixed = mixed            # prompts admitted while sequences are decoding join THAT pass (Model.step_mixed) instead of a pass of their own
         self.steps = 0                # batched decode steps taken (for throughput accounting)
+        self.mixed_passes = 0         # ... of which carried prompt rows as well
 
     def _pages_for(self, n_tokens: int) -> int:
         return (n_tokens + TOKEN_CAPACITY_PER_PAGE - 1) // TOKEN_CAPACITY_PER_PAGE
@@ -57,6 +60,19 @@ class BatchedEngine:
         reserved = 0                  # pages promised to the active sequences for their full length
         need = {}
         while pending or active:
+            # every active sequence holds one token not yet recorded (from its prompt or from the last pass): record, retire
+            if active:
+                host = torch.cat([a.token for a in active]).tolist()      # one read-back per pass for the stop / length checks
+                keep = []
+                for a, t in zip(active, host):
+                    a.generated.append(int(t))
+                    if int(t) in self.stop_tokens or len(a.generated) >= max_new_tokens:
+                        out[a.request] = a.generated
+                        a.cache[0].page_manager.release()
+                        reserved -= need.pop(a.request)
+                    else:
+                        keep.append(a)
+                active = keep
             # admit while there is a slot and the pool can hold the request to its end; the admitted prompts run as ONE pass
             batch = []
             rows = 0
@@ -70,46 +86,50 @@ class BatchedEngine:
                 reserved += n_pages
                 rows += len(prompt)
                 batch.append((idx, prompt, self.model.make_cache()))
+            if not active and not batch:
+                if pending:
+                    raise RuntimeError("no request fits the page pool")  # unreachable after the check above
+                break
+            if active and batch and self.mixed:
+                # the admitted prompts ride the decode step of the sequences in flight: one pass over the weights for both
+                nxt, logprobs, _ = self.model.step_mixed(torch.cat([a.token for a in active]), [a.cache for a in active],
+                                                         [p for _, p, _ in batch], [c for _, _, c in batch])
+                self.steps += 1
+                self.mixed_passes += 1
+                if self.sampler is not None:
+                    nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                nb = len(active)
+                for i, a in enumerate(active):
+                    a.token = nxt[i:i + 1]
+                for i, (idx, _, cache) in enumerate(batch):
+                    active.append(_Active(idx, cache, nxt[nb + i:nb + i + 1]))
+                continue
+            joined = []
             if self._i8 and batch and (len(batch) == 1 or not self.batch_prefill):
                 for idx, prompt, cache in batch:
                     toks, logprobs, _ = self.model.prefill_batch([prompt], [cache])
                     if self.sampler is not None:
                         toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
-                    active.append(_Active(idx, cache, toks[:1].clone()))
+                    joined.append(_Active(idx, cache, toks[:1].clone()))
             elif len(batch) == 1 or (batch and not self.batch_prefill):
                 for idx, prompt, cache in batch:
                     ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
                     tok, logprobs, _ = self.model.step(ids.to(self.model.device), cache)
                     if self.sampler is not None:
                         tok = self.sampler(logprobs[None]).reshape(1).to(torch.int32)
-                    active.append(_Active(idx, cache, tok.reshape(1).clone()))
+                    joined.append(_Active(idx, cache, tok.reshape(1).clone()))
             elif batch:
                 toks, logprobs, _ = self.model.prefill_batch([p for _, p, _ in batch], [c for _, _, c in batch])
                 if self.sampler is not None:
                     toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
                 for i, (idx, _, cache) in enumerate(batch):
-                    active.append(_Active(idx, cache, toks[i:i + 1].clone()))
-            if not active:
-                raise RuntimeError("no request fits the page pool")      # unreachable after the check above
-            # every active sequence holds one token not yet recorded (from its prompt or from the last step): record, retire, step
-            tokens = torch.cat([a.token for a in active])
-            host = tokens.tolist()                                        # one read-back per step for the stop / length checks
-            keep = []
-            for a, t in zip(active, host):
-                a.generated.append(int(t))
-                if int(t) in self.stop_tokens or len(a.generated) >= max_new_tokens:
-                    out[a.request] = a.generated
-                    a.cache[0].page_manager.release()
-                    reserved -= need.pop(a.request)
-                else:
-                    keep.append(a)
-            active = keep
-            if not active:
-                continue
-            nxt, logprobs, _ = self.model.step_batch(torch.cat([a.token for a in active]), [a.cache for a in active])
-            self.steps += 1
-            if self.sampler is not None:
-                nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
-            for i, a in enumerate(active):
-                a.token = nxt[i:i + 1]
+                    joined.append(_Active(idx, cache, toks[i:i + 1].clone()))
+            if active:
+                nxt, logprobs, _ = self.model.step_batch(torch.cat([a.token for a in active]), [a.cache for a in active])
+                self.steps += 1
+                if self.sampler is not None:
+                    nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                for i, a in enumerate(active):
+                    a.token = nxt[i:i + 1]
+            active += joined
         return out

@@ -527,46 +527,78 @@ class Model:
         its own position, every prompt its own pages and a causal attention over its own rows only.  caches: empty paged caches
         (make_cache() after enable_paged_kv(), one per prompt).  Returns (next_tokens [S], logprobs [S, V], logits [S, V]) for the
         prompts' last positions; every cache then holds its prompt."""
+        return self._varlen_pass("prefill_batch", None, [], prompts, caches)
+
+    def step_mixed(self, tokens: torch.Tensor | None, decode_caches: list[list[BaseCache]], prompts: list, prompt_caches: list[list[BaseCache]]):
+        """Decode-state sequences AND fresh prompts in one pass over the weights (pie_decoder_step_mixed; the reference's BatchDetails holds
+        both kinds, batch_details.hpp:10-88): tokens [B] = the input token of each decoding sequence (caches as in step_batch), prompts /
+        prompt_caches as in prefill_batch.  Returns (next_tokens [B + S], logprobs [B + S, V], logits [B + S, V]): the decoding sequences
+        first, then every prompt's last position; the decode caches advance by one position, the prompt caches hold their prompts.
+        Every row rides the many-row regime of the Linears (as the rows of a prompt do), also when B alone would take the few-row one."""
+        return self._varlen_pass("step_mixed", tokens, decode_caches, prompts, prompt_caches)
+
+    def _varlen_pass(self, who: str, tokens, decode_caches, prompts, caches):
         import numpy as np
-        seqs = []
-        for c in caches:
+        seqs, dseqs = [], []
+        for c in list(decode_caches) + list(caches):
             if len(c) != len(self.layers) or not isinstance(c[0], PagedKVCache):
-                raise TypeError("prefill_batch runs on paged caches (enable_paged_kv(), then make_cache())")
+                raise TypeError(f"{who} runs on paged caches (enable_paged_kv(), then make_cache())")
+        for c in caches:
             if c[0].offset != 0:
-                raise ValueError("prefill_batch takes fresh caches (nothing cached before the prompt)")
+                raise ValueError(f"{who} takes fresh caches for the prompts (nothing cached before the prompt)")
             seqs.append(c[0].page_manager)
-        a = seqs[0].allocator
-        if len(prompts) != len(seqs) or any(s.allocator is not a for s in seqs) or len({id(s) for s in seqs}) != len(seqs):
-            raise ValueError("prefill_batch: one distinct fresh sequence of one page pool per prompt")
+        dseqs = [c[0].page_manager for c in decode_caches]
+        every = dseqs + seqs
+        if not every:
+            raise ValueError(f"{who}: an empty batch")
+        a = every[0].allocator
+        if len(prompts) != len(seqs) or any(s.allocator is not a for s in every) or len({id(s) for s in every}) != len(every):
+            raise ValueError(f"{who}: one distinct sequence of one page pool per prompt and per decoding row")
+        B = len(dseqs)
+        if B:
+            tokens = torch.as_tensor(tokens).reshape(-1).to(dtype=torch.int32).cpu().numpy()
+            if tokens.size != B:
+                raise ValueError(f"{who}: one token per decoding sequence")
+            if any(s.offset < 1 for s in dseqs):
+                raise ValueError(f"{who}: a decoding sequence holds its prompt already")
+        else:
+            tokens = np.zeros(0, np.int32)
         lens = [len(p) for p in prompts]
-        if min(lens) < 1 or sum(lens) > 65535:
-            raise ValueError("prefill_batch: prompts must be non-empty and hold at most 65535 tokens together")
+        if (lens and min(lens) < 1) or B + sum(lens) > 65535:
+            raise ValueError(f"{who}: prompts must be non-empty and the pass holds at most 65535 rows")
+        for s in dseqs:
+            s.reserve(1)
         for s, n in zip(seqs, lens):
             s.reserve(n)
         S, N = len(seqs), sum(lens)
-        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-        ids = np.concatenate([np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])
-        row_seq = np.repeat(np.arange(S, dtype=np.int32), lens)
-        row_ctx = (np.arange(N, dtype=np.int32) - np.repeat(starts, lens) + 1).astype(np.int32)
-        seg_lo = np.repeat(starts, lens).astype(np.int32)
-        seg_hi = np.arange(1, N + 1, dtype=np.int32)
-        last = (starts + np.asarray(lens, dtype=np.int32) - 1).astype(np.int32)
-        mb = max(len(s.pages) for s in seqs)
-        table = np.zeros((S, mb), np.int32)
-        for i, s in enumerate(seqs):
+        starts = (B + np.concatenate([[0], np.cumsum(lens)[:-1]])).astype(np.int32) if S else np.zeros(0, np.int32)
+        ids = np.concatenate([tokens] + [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])
+        rows_d = np.arange(B, dtype=np.int32)
+        row_seq = np.concatenate([rows_d, B + np.repeat(np.arange(S, dtype=np.int32), lens)]).astype(np.int32)
+        row_ctx = np.concatenate([np.asarray([s.offset + 1 for s in dseqs], dtype=np.int32),
+                                  np.arange(B, B + N, dtype=np.int32) - np.repeat(starts, lens) + 1]).astype(np.int32)
+        seg_lo = np.concatenate([rows_d, np.repeat(starts, lens)]).astype(np.int32)
+        seg_hi = np.arange(1, B + N + 1, dtype=np.int32)
+        last = np.concatenate([rows_d, starts + np.asarray(lens, dtype=np.int32) - 1]).astype(np.int32)
+        mb = max(len(s.pages) for s in every)
+        table = np.zeros((B + S, mb), np.int32)
+        for i, s in enumerate(every):
             table[i, :len(s.pages)] = s.pages
         dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
         t_ids, t_seq, t_ctx, t_lo, t_hi, t_last, t_table = (dev(x) for x in (ids, row_seq, row_ctx, seg_lo, seg_hi, last, table))
         V = self.args.vocab_size
-        logits = torch.empty((S, V), dtype=self.dtype, device=self.device)
-        logprobs = torch.empty((S, V), dtype=torch.float32, device=self.device)
-        nxt = torch.empty(S, dtype=torch.int32, device=self.device)
+        logits = torch.empty((B + S, V), dtype=self.dtype, device=self.device)
+        logprobs = torch.empty((B + S, V), dtype=torch.float32, device=self.device)
+        nxt = torch.empty(B + S, dtype=torch.int32, device=self.device)
         n = len(self.layers)
         slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
         self._match_page_format(a)
-        _ffi.check(_ffi.load().pie_decoder_prefill_batch(self._dec, _ffi.p(t_ids), _ffi.p(t_ctx), _ffi.p(t_seq), _ffi.p(t_lo), _ffi.p(t_hi), _ffi.p(t_last),
-                                                         N, S, slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt),
-                                                         _ffi.stream()))
+        lib = _ffi.load()
+        common = (slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt), _ffi.stream())
+        head = (self._dec, _ffi.p(t_ids), _ffi.p(t_ctx), _ffi.p(t_seq), _ffi.p(t_lo), _ffi.p(t_hi), _ffi.p(t_last), B + N, B + S)
+        _ffi.check(lib.pie_decoder_step_mixed(*head, B, *common) if B else lib.pie_decoder_prefill_batch(*head, *common))
+        for s in dseqs:
+            s.advance(1)
         for s, k in zip(seqs, lens):
             s.advance(k)
         return nxt, logprobs, logits

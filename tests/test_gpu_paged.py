@@ -390,9 +390,18 @@ def test_continuous_batching_engine(golden_dir):
     assert same >= 0.85 * 10 * new, f"{same} of {10 * new} tokens agree"
     # a stop token ends its request (the token is reported, like the reference's loop does before breaking)
     stop = got[3][2]
-    got2 = BatchedEngine(model, num_pages=7, max_batch=4, stop_tokens=[stop]).generate(prompts, new)
+    eng2 = BatchedEngine(model, num_pages=7, max_batch=4, stop_tokens=[stop])
+    got2 = eng2.generate(prompts, new)
     assert got2[3] == got[3][:got[3].index(stop) + 1]
     assert all(len(t) <= new for t in got2)
+    # the request that took the freed slot joined while three others were decoding: its prompt rode their step (Model.step_mixed);
+    # with mixed=False it gets a prompt pass of its own -- same tokens up to low-margin steps (a different GEMM row count)
+    assert eng2.mixed_passes > 0
+    plain = BatchedEngine(model, num_pages=7, max_batch=4, stop_tokens=[stop], mixed=False)
+    got_plain = plain.generate(prompts, new)
+    assert plain.mixed_passes == 0 and [len(t) for t in got_plain] == [len(t) for t in got2]
+    n_tok = sum(len(t) for t in got2)
+    assert sum(a == b for x, y in zip(got2, got_plain) for a, b in zip(x, y)) >= 0.85 * n_tok
     with pytest.raises(ValueError, match="does not fit"):
         BatchedEngine(model, num_pages=2, max_batch=2).generate([list(range(200))], 4)
 
@@ -434,6 +443,121 @@ def test_several_prompts_in_one_pass(golden_dir):
         assert_vec_close(la[i], lb[i], "bfloat16", what=f"decode after batched prefill, prompt {i}")
     with pytest.raises(ValueError, match="fresh"):
         model.prefill_batch([[1, 2]], [caches[0]])
+
+
+def test_mixed_prompt_and_decode_pass_vs_oracle(golden_dir):
+    """pie_decoder_step_mixed (batch_details.hpp:10-88: prefill- and decode-state sequences in one BatchDetails): three decoding sequences
+    (one crossing a page boundary with this very token, one that just did) and fresh prompts of 9 and 70 tokens share ONE pass over the
+    weights; then all five decode while a one-token prompt joins.  Every output row must be what the oracle gives for that sequence alone
+    with its Linears in the many-row regime (the pass multiplies all rows at once); caches, offsets and page accounting as if the
+    sequences had been served separately."""
+    from tests._util import assert_vec_close
+    from tests.test_gpu_decode import margin_bound
+    g, cfg, model = _tiny(golden_dir)
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    rng = np.random.default_rng(5)
+    V = cfg["vocab_size"]
+    dlens, plens = [63, 64, 20], [9, 70]
+    dprompts = [rng.integers(0, V, n).astype(np.int32) for n in dlens]
+    pprompts = [rng.integers(0, V, n).astype(np.int32) for n in plens]
+    late = rng.integers(0, V, 1).astype(np.int32)
+    pool = model.enable_paged_kv(num_pages=16, max_blocks=2)
+    dcaches = []
+    for p in dprompts:
+        c = model.make_cache()
+        model.step(torch.from_numpy(p).cuda(), c)
+        dcaches.append(c)
+    # oracle: each sequence alone; from the mixed pass on every product is in the many-row regime
+    orcs = []
+    for p in dprompts + pprompts + [late]:
+        orc = po.OracleLlama(cfg, w, "bfloat16")
+        orcs.append((orc, [po.OracleKVCache() for _ in orc.layers]))
+    want0 = [orcs[i][0].forward(dprompts[i], orcs[i][1])[-1] for i in range(3)]
+    feed1 = [int(np.argmax(x)) for x in want0]
+    po.set_qmm_min_rows(1)
+    try:
+        want1 = [orcs[i][0].forward(np.array([feed1[i]]), orcs[i][1])[0] for i in range(3)]
+        want1 += [orcs[3 + j][0].forward(pprompts[j], orcs[3 + j][1])[-1] for j in range(2)]
+        feed2 = [int(np.argmax(x)) for x in want1]
+        want2 = [orcs[i][0].forward(np.array([feed2[i]]), orcs[i][1])[0] for i in range(5)]
+        want2.append(orcs[5][0].forward(late, orcs[5][1])[-1])
+    finally:
+        po.set_qmm_min_rows(6)
+
+    def check(got, nxt, want, what):
+        for i, wv in enumerate(want):
+            assert_vec_close(got[i], wv, "bfloat16", what=f"{what} row {i}")
+            top2 = np.sort(wv)[-2:]
+            if top2[1] - top2[0] > margin_bound(wv):
+                assert int(nxt[i].item()) == int(np.argmax(wv)), f"{what} row {i}: greedy token"
+
+    pcaches = [model.make_cache() for _ in pprompts]
+    nxt, logprobs, logits = model.step_mixed(torch.tensor(feed1, dtype=torch.int32), dcaches, [p.tolist() for p in pprompts], pcaches)
+    assert nxt.shape == (5,) and logits.shape == (5, V) and logprobs.shape == (5, V)
+    check(logits.float().cpu().numpy(), nxt, want1, "mixed pass 1")
+    assert np.all(np.abs(logprobs.double().exp().sum(dim=1).cpu().numpy() - 1.0) < 1e-4)
+    assert [c[0].offset for c in dcaches + pcaches] == [64, 65, 21, 9, 70]
+    lcache = model.make_cache()
+    nxt, logprobs, logits = model.step_mixed(torch.tensor(feed2, dtype=torch.int32), dcaches + pcaches, [late.tolist()], [lcache])
+    check(logits.float().cpu().numpy(), nxt, want2, "mixed pass 2")
+    assert [c[0].offset for c in dcaches + pcaches + [lcache]] == [65, 66, 22, 10, 71, 1]
+    assert pool.size() - pool.get_num_free_pages() == sum((n + 63) // 64 for n in [65, 66, 22, 10, 71, 1])
+    # the sequences continue through the plain multi-sequence step, whose rows must agree with the oracle's next step
+    feed3 = [int(np.argmax(x)) for x in want2]
+    po.set_qmm_min_rows(1)
+    try:
+        want3 = [orcs[i][0].forward(np.array([feed3[i]]), orcs[i][1])[0] for i in range(6)]
+    finally:
+        po.set_qmm_min_rows(6)
+    nxt, _, logits = model.step_batch(torch.tensor(feed3, dtype=torch.int32), dcaches + pcaches + [lcache], graph=False)
+    check(logits.float().cpu().numpy(), nxt, want3, "step after the mixed passes")
+    # argument errors
+    with pytest.raises(ValueError, match="fresh"):
+        model.step_mixed(torch.tensor([1], dtype=torch.int32), [dcaches[0]], [[1, 2]], [pcaches[0]])
+    with pytest.raises(ValueError, match="one token per"):
+        model.step_mixed(torch.tensor([1, 2], dtype=torch.int32), [dcaches[0]], [[1, 2]], [model.make_cache()])
+    with pytest.raises(ValueError, match="distinct"):
+        model.step_mixed(torch.tensor([1, 2], dtype=torch.int32), [dcaches[0], dcaches[0]], [], [])
+
+
+def test_mixed_pass_on_int8_pages_matches_the_separate_passes(golden_dir):
+    """step_mixed on a pool of int8 pages: the decode rows read the quantised pages (paged_i8 kernel), the prompt rows this pass's own T rows.
+    Against the same sequences served by a prompt pass + a multi-sequence step of their own on the same pool format: logits within the
+    rounding of two GEMM shapes, the pages' int8 codes of the prompts identical (they do not depend on the other rows), greedy tokens equal."""
+    from tests._util import assert_vec_close
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(29)
+    V = cfg["vocab_size"]
+    dprompts = [rng.integers(0, V, n).astype(np.int32).tolist() for n in (40, 64, 7, 90, 12, 33)]
+    pprompts = [rng.integers(0, V, n).astype(np.int32).tolist() for n in (17, 65)]
+    L, Hkv = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
+    ks = torch.full((L, Hkv), 0.05, dtype=torch.float16)
+    vs = torch.full((L, Hkv), 0.02, dtype=torch.float16)
+    feed = torch.tensor([3, 1, 4, 1, 5, 9], dtype=torch.int32)
+    model.enable_paged_kv(num_pages=32, kv_dtype=torch.int8, kv_scales=(ks, vs))
+    ref_d = [model.make_cache() for _ in dprompts]
+    model.prefill_batch(dprompts, ref_d)
+    ref_p = [model.make_cache() for _ in pprompts]
+    tp, _, lp = model.prefill_batch(pprompts, ref_p)
+    tp, lp = tp.clone(), lp.float().cpu().numpy().copy()
+    td, _, ld = model.step_batch(feed, ref_d, graph=False)          # six rows: the many-row regime, like the mixed pass
+    td, ld = td.clone(), ld.float().cpu().numpy().copy()
+    dc = [model.make_cache() for _ in dprompts]
+    model.prefill_batch(dprompts, dc)
+    pc = [model.make_cache() for _ in pprompts]
+    nxt, _, logits = model.step_mixed(feed, dc, pprompts, pc)
+    got = logits.float().cpu().numpy()
+    for i in range(6):
+        assert_vec_close(got[i], ld[i], "bfloat16", c_max=6.0, c_rms=5.0, what=f"decode row {i}")
+    for j in range(2):
+        assert_vec_close(got[6 + j], lp[j], "bfloat16", c_max=6.0, c_rms=5.0, what=f"prompt {j}")
+        k_ref, v_ref = ref_p[j][0].state
+        k_got, v_got = pc[j][0].state
+        assert k_got.dtype == torch.int8 and torch.equal(k_got, k_ref) and torch.equal(v_got, v_ref)          # layer 0: independent of attention
+    agree = int((nxt.cpu() == torch.cat([td, tp]).cpu()).sum())
+    assert agree >= 7, f"{agree} of 8 greedy tokens agree"
+    model.enable_paged_kv(num_pages=8)   # back to T pages
+    model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
 
 
 def test_prompt_pass_then_few_sequence_step_with_a_large_vocabulary():
