@@ -90,7 +90,11 @@ class BatchedEngine:
                 if pending:
                     raise RuntimeError("no request fits the page pool")  # unreachable after the check above
                 break
-            if active and batch and self.mixed:
+            # Worth it while the decode rows do not push the prompt rows into another 256-row GEMM tile: 8 sequences + a prompt of
+            # 8 / 64 / 192 / 256 / 384 rows on the 8B model take 0.61 / 0.76 / 0.75 / 0.97 / 0.84 of a prompt pass + a step, but
+            # 508 / 2048 rows take 1.08 / 1.06 (516 rows are three 256-row tiles' worth of work for the GEMMs, 508 are two).
+            n_mix = len(active) + rows
+            if active and batch and self.mixed and (n_mix <= 512 or (n_mix + 255) // 256 == (rows + 255) // 256):
                 # the admitted prompts ride the decode step of the sequences in flight: one pass over the weights for both
                 nxt, logprobs, _ = self.model.step_mixed(torch.cat([a.token for a in active]), [a.cache for a in active],
                                                          [p for _, p, _ in batch], [c for _, _, c in batch])

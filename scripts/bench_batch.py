@@ -1,7 +1,7 @@
 """Aggregate decode throughput of the multi-sequence step (pie_decoder_step_batch) on the 8B int4 model: B sequences share one
 pass over the weights.  Prints ms per step and total tokens/s per batch size, next to the single-sequence graph-replayed step.
 
-    python scripts/bench_batch.py [--batches 1,2,4,8,16,32,64] [--prompt 128] [--steps 32]
+    python scripts/bench_batch.py [--batches 1,2,4,8,16,32,64] [--prompt 128] [--steps 32] [--mixed 64,512]
 """
 import argparse
 import json
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--mixed", default="", help="P1,P2,...: per batch size, one fresh prompt of P tokens riding the decode step (step_mixed) vs a prompt pass + a step")
     ap.add_argument("--kv-int8", action="store_true", help="a second pass with the sequences on int8 pages (per-head scales 1/16; prompts through prefill_batch)")
     args = ap.parse_args()
     cfg = dict(LLAMA3_8B)
@@ -30,8 +31,10 @@ def main():
     model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16))
     torch.cuda.empty_cache()
     batches = [int(b) for b in args.batches.split(",")]
-    pages_per_seq = (args.prompt + 8 + 2 * args.steps + 63) // 64 + 1
-    model.enable_paged_kv(num_pages=max(batches) * pages_per_seq + 4, max_blocks=pages_per_seq)
+    n_mixed = len([x for x in args.mixed.split(",") if x])
+    pages_per_seq = (args.prompt + 8 + 2 * args.steps + n_mixed * 2 * (max(4, args.steps // 4) + 2) + 63) // 64 + 1
+    mixed = [int(x) for x in args.mixed.split(",") if x]
+    model.enable_paged_kv(num_pages=max(batches) * pages_per_seq + 4 + (max(mixed) // 64 + 2 if mixed else 0), max_blocks=pages_per_seq)
     # single-sequence baseline: the graph-replayed decode step on a paged cache
     c0 = model.make_cache()
     g = torch.Generator().manual_seed(1)
@@ -65,6 +68,34 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         print(json.dumps({"mode": "step_batch", "sequences": B, "ms_per_step": round(dt * 1e3, 3), "tokens_per_s": round(B / dt, 1),
                           "vs_single": round(B / dt * single, 2)}), flush=True)
+        for P in mixed:  # a prompt of P tokens arrives while B sequences decode: its rows in THEIR pass, or a pass of its own first
+            prompt = torch.randint(0, cfg["vocab_size"], (P,), generator=g).tolist()
+            reps = max(4, args.steps // 4)
+
+            def timed(fn):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+
+            def one_pass():
+                pc = model.make_cache()
+                model.step_mixed(tokens, caches, [prompt], [pc])
+                pc[0].page_manager.release()
+
+            def two_passes():
+                pc = model.make_cache()
+                model.prefill_batch([prompt], [pc])
+                model.step_batch(tokens, caches)
+                pc[0].page_manager.release()
+
+            t_two, t_one = timed(two_passes), timed(one_pass)
+            print(json.dumps({"mode": "mixed pass", "sequences": B, "prompt_rows": P, "ms_step_mixed": round(t_one * 1e3, 3),
+                              "ms_prompt_pass_plus_step": round(t_two * 1e3, 3), "ratio": round(t_one / t_two, 3)}), flush=True)
         for c in caches:
             c[0].page_manager.release()
     if args.kv_int8:  # the same step on the reference page's own storage: int8 rows + per-head fp16 scales (half the cache bytes)
