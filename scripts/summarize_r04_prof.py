@@ -39,7 +39,7 @@ def lin(n, k):
 
 alg = {"k_w4s_gemv<BF16, 1, 2, 1, 0, 0>": ("qkv: rmsnorm + GEMV + RoPE + cache append", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, L - 1),
        "k_w4s_gemv<BF16, 3, 2, 1, 0, 0>": ("layer 0's qkv with the embedding row dequantised in its prologue", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, 1),
-       "k_attn_decode<BF16, 128, 4, false, false, 4>": ("split-KV attention (cache capacity 512: partials merged by o_proj; no warm-up role since round 4)", 2 * KVD * 2 * T, L),
+       "k_attn_decode<BF16, 128, 4, false, false, 4>": ("split-KV attention (cache capacity 512: partials merged by o_proj) + the Infinity-Cache warm-up of o_proj on its idle CUs", 2 * KVD * 2 * T, L),
        "k_w4s_gemv<BF16, 2, 1, 1, 0, 0>": ("o_proj: split merge + GEMV + residual", lin(H, QD), L),
        "k_w4s_gemv<BF16, 1, 3, 1, 0, 0>": ("gate/up: rmsnorm + GEMV + SwiGLU", lin(2 * I, H) + H * 2, L),
        "k_w4s_gemv<BF16, 0, 1, 4, 0, 0>": ("down: GEMV + residual", lin(H, I), L),
