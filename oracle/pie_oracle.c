@@ -119,6 +119,26 @@ int orc_max_threads(void) {
 #endif
 }
 
+/* Code k of a packed row.  MLX packs a row's codes as a little-endian bit stream, code k at bits [k*bits, (k+1)*bits): for bits 2 / 4 / 8
+ * that is word k / (32/bits) at bit bits * (k % (32/bits)) (mlx/backend/common/quantized.cpp); for bits 3 and 6 codes straddle bytes
+ * (8 codes per 3 bytes, 4 codes per 3 bytes: the `bits == 3 || bits == 6` byte-packed layouts of mlx >= 0.21).  A row takes K*bits/32 words. */
+static inline uint32_t orc_code(const uint32_t *row, size_t k, int bits) {
+    const uint8_t *b = (const uint8_t *)row;
+    const size_t bit = k * (size_t)bits, byte = bit >> 3;
+    const unsigned sh = (unsigned)(bit & 7);
+    uint32_t v = b[byte];
+    if (sh + (unsigned)bits > 8) v |= (uint32_t)b[byte + 1] << 8;
+    return (v >> sh) & ((1u << bits) - 1u);
+}
+static inline void orc_put_code(uint32_t *row, size_t k, int bits, uint32_t c) {  /* into a zeroed row */
+    uint8_t *b = (uint8_t *)row;
+    const size_t bit = k * (size_t)bits, byte = bit >> 3;
+    const unsigned sh = (unsigned)(bit & 7);
+    const uint32_t v = c << sh;
+    b[byte] |= (uint8_t)v;
+    if (sh + (unsigned)bits > 8) b[byte + 1] |= (uint8_t)(v >> 8);
+}
+
 /* ------------------------------------------------------------------ A.1 mx.quantize / mx.dequantize
  * Reference call sites: cache/kv_cache/cache.py:144-147, quantized.py:91-96; implicitly the
  * checkpoint format consumed by models/utils.py:96-111 (weight uint32 [N,K/8], scales/biases T [N,K/G]).
@@ -129,9 +149,10 @@ int orc_max_threads(void) {
  */
 void orc_quantize(const float *w, int N, int K, int group_size, int bits, int dtype,
                   uint32_t *wq, void *scales, void *biases) {
-    const int per_word = 32 / bits, G = K / group_size;
+    const int G = K / group_size;
+    const size_t row_words = (size_t)K * bits / 32;
     const float n_bins = (float)((1 << bits) - 1), eps = 1e-7f;
-    memset(wq, 0, (size_t)N * (K / per_word) * sizeof(uint32_t));
+    memset(wq, 0, (size_t)N * row_words * sizeof(uint32_t));
     for (int n = 0; n < N; ++n)
         for (int g = 0; g < G; ++g) {
             const float *wg = w + (size_t)n * K + (size_t)g * group_size;
@@ -155,7 +176,7 @@ void orc_quantize(const float *w, int N, int K, int group_size, int bits, int dt
                 if (c < 0.0f) c = 0.0f;
                 if (c > n_bins) c = n_bins;
                 int k = g * group_size + j;
-                wq[(size_t)n * (K / per_word) + k / per_word] |= ((uint32_t)c) << (bits * (k % per_word));
+                orc_put_code(wq + (size_t)n * row_words, (size_t)k, bits, (uint32_t)c);
             }
         }
 }
@@ -163,12 +184,11 @@ void orc_quantize(const float *w, int N, int K, int group_size, int bits, int dt
 /* w_hat = scale*q + bias, materialised in T (mx.dequantize output dtype = scales dtype). */
 void orc_dequantize(const uint32_t *wq, const void *scales, const void *biases, int N, int K,
                     int group_size, int bits, int dtype, float *out) {
-    const int per_word = 32 / bits, G = K / group_size;
-    const uint32_t mask = (1u << bits) - 1u;
+    const int G = K / group_size;
+    const size_t row_words = (size_t)K * bits / 32;
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
-            uint32_t word = wq[(size_t)n * (K / per_word) + k / per_word];
-            float q = (float)((word >> (bits * (k % per_word))) & mask);
+            float q = (float)orc_code(wq + (size_t)n * row_words, (size_t)k, bits);
             float s = ldT(scales, (size_t)n * G + k / group_size, dtype);
             float b = ldT(biases, (size_t)n * G + k / group_size, dtype);
             out[(size_t)n * K + k] = rnd(s * q + b, dtype);
@@ -184,25 +204,21 @@ void orc_dequantize(const uint32_t *wq, const void *scales, const void *biases, 
 void orc_quantized_matmul_t(const float *x, int M, const uint32_t *wq, const void *scales,
                             const void *biases, int N, int K, int group_size, int bits,
                             int dtype, const void *lin_bias, float *y) {
-    const int per_word = 32 / bits, G = K / group_size, wpg = group_size / per_word;
-    const uint32_t mask = (1u << bits) - 1u;
+    const int G = K / group_size;
+    const size_t row_words = (size_t)K * bits / 32;
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
-        const uint32_t *wrow = wq + (size_t)n * (K / per_word);
+        const uint32_t *wrow = wq + (size_t)n * row_words;
         for (int m = 0; m < M; ++m) {
             const float *xr = x + (size_t)m * K;
             float acc = 0.0f;
             for (int g = 0; g < G; ++g) {
                 const float s = ldT(scales, (size_t)n * G + g, dtype);
                 const float b = ldT(biases, (size_t)n * G + g, dtype);
-                for (int wi = 0; wi < wpg; ++wi) {
-                    uint32_t word = wrow[g * wpg + wi];
-                    const float *xs = xr + g * group_size + wi * per_word;
-                    for (int p = 0; p < per_word; ++p) {
-                        float wv = s * (float)(word & mask) + b;
-                        acc += xs[p] * wv;
-                        word >>= bits;
-                    }
+                const float *xs = xr + g * group_size;
+                for (int p = 0; p < group_size; ++p) {
+                    float wv = s * (float)orc_code(wrow, (size_t)g * group_size + p, bits) + b;
+                    acc += xs[p] * wv;
                 }
             }
             float out = rnd(acc, dtype);
@@ -235,8 +251,8 @@ void orc_embedding(const int32_t *ids, int L, const void *w, const void *scales,
         if (!quantized) {
             for (int k = 0; k < H; ++k) out[(size_t)l * H + k] = ldT(w, row * H + k, dtype);
         } else {
-            const int per_word = 32 / bits, G = H / group_size;
-            const uint32_t *wq = (const uint32_t *)w + row * (H / per_word);
+            const int G = H / group_size;
+            const uint32_t *wq = (const uint32_t *)w + row * ((size_t)H * bits / 32);
             orc_dequantize(wq, (const char *)scales + row * G * (dtype == PIE_F32 ? 4 : 2),
                            (const char *)biases + row * G * (dtype == PIE_F32 ? 4 : 2), 1, H,
                            group_size, bits, dtype, out + (size_t)l * H);
@@ -444,16 +460,15 @@ int orc_get_qmm_min_rows(void) { return g_qmm_min_rows; }
 /* y = T( x @ mx.dequantize(w).T ) with fp32 accumulation: the qmm regime. */
 void orc_quantized_matmul_dequant(const float *x, int M, const uint32_t *wq, const void *scales, const void *biases,
                                   int N, int K, int group_size, int bits, int dtype, const void *lin_bias, float *y) {
-    const int per_word = 32 / bits, G = K / group_size;
-    const uint32_t mask = (1u << bits) - 1u;
+    const int G = K / group_size;
+    const size_t row_words = (size_t)K * bits / 32;
 #pragma omp parallel
     {
         float *wrow = malloc(sizeof(float) * (size_t)K);
 #pragma omp for schedule(static)
         for (int n = 0; n < N; ++n) {
             for (int k = 0; k < K; ++k) {
-                uint32_t word = wq[(size_t)n * (K / per_word) + k / per_word];
-                float q = (float)((word >> (bits * (k % per_word))) & mask);
+                float q = (float)orc_code(wq + (size_t)n * row_words, (size_t)k, bits);
                 float s = ldT(scales, (size_t)n * G + k / group_size, dtype);
                 float b = ldT(biases, (size_t)n * G + k / group_size, dtype);
                 wrow[k] = rnd(s * q + b, dtype);

@@ -25,6 +25,28 @@ LogitsProcessor = Callable[[object, torch.Tensor], torch.Tensor]
 ModelOutput = tuple[int, dict]
 
 
+def check_generate_mask(mask, n_heads: int | None = None) -> None:
+    """generate_step(mask=array).  The reference forwards ONE array to the prompt pass and to every later single-token call
+    (inference_engine.py:246-249), and mx.fast.scaled_dot_product_attention broadcasts it against scores [1, H, L, S] -- L = the prompt
+    length, then 1; S growing by one per step.  The only arrays that broadcast against all of those are constant per head: shape
+    (), (1,)*k or [.., H | 1, 1, 1].  Such a mask cannot change which keys a query sees: a boolean one must be all True (False hides EVERY
+    key of a row: the softmax of an empty row is NaN upstream), an additive one shifts every score of a row by the same finite amount,
+    which the softmax cancels.  Accepted and applied as what they are -- nothing; anything else is refused with the reason the reference
+    itself would fail with (a broadcast error at the first decode step, or NaN logits)."""
+    m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(mask)
+    shape = tuple(m.shape)
+    if len(shape) > 4 or any(d != 1 for d in shape[-2:]) or (len(shape) == 4 and shape[0] != 1) or \
+            (len(shape) >= 3 and shape[-3] != 1 and (n_heads is None or shape[-3] != n_heads)):
+        raise ValueError(f"generate_step(mask=array of shape {shape}): one array is forwarded to the prompt pass and to every single-token step "
+                         "(inference_engine.py:246-249), so it must broadcast against scores [1, H, L, S] for every L and S -- shape [.., H | 1, 1, 1]; "
+                         "a [L, S] causal mask belongs to Model.__call__(inputs, mask=...) for one call")
+    if m.dtype == torch.bool:
+        if not bool(m.all()):
+            raise ValueError("generate_step(mask=boolean array): a False entry hides every key of its rows (softmax of an empty row)")
+    elif not bool(torch.isfinite(m.float()).all()):
+        raise ValueError("generate_step(mask=additive array): a non-finite entry hides every key of its rows (softmax of an empty row)")
+
+
 class InferenceEngine:
     """One model, one PromptCache, not re-entrant -- like the reference (server/app.py:23,35)."""
 
@@ -79,9 +101,7 @@ class InferenceEngine:
         Prefill of the non-cached prompt suffix, then one forward per token; all device work is queued
         asynchronously, the consumer synchronises when it reads a token (generate() does, like `.tolist()` :202)."""
         if mask is not None and not (isinstance(mask, str) and mask == "causal"):
-            # the reference forwards ONE mask array to the prefill and to every later single-token call (inference_engine.py:246-249),
-            # which only type-checks for a mask that broadcasts against both; the causal structure is implicit in the kernels here
-            raise NotImplementedError("generate_step(mask=array) is not supported: pass mask=None (or \"causal\"); Model.__call__ accepts an explicit causal mask")
+            check_generate_mask(mask, getattr(getattr(self.model, "args", None), "num_attention_heads", None))
         if pixel_values is not None and not hasattr(self.model, "get_input_embeddings"):
             raise TypeError("pixel_values need a VLM ensemble (models/intern/ensemble.py: Model) as the engine's model")
         if "root" not in self.samplers:

@@ -3,13 +3,13 @@
 Host-side mirror of models/llama/language.py of the reference (ModelArgs :13-29, Attention :32-108,
 MLP :111-127, TransformerBlock :130-154, LlamaModel :157-187, Model :190-219).  The reference builds a lazy MLX
 graph of ~17 primitives per layer; here `Model` owns a native decoder (csrc/decoder.hip) that runs the same
-graph as 6 fused HIP launches per layer, and this file only (1) repacks the checkpoint's MLX-quantised triplets
-into the W4S streaming layout at load, and (2) keeps the reference's calling convention:
+graph as 5 fused HIP launches per layer, and this file only (1) repacks the checkpoint's MLX-quantised triplets
+into the streaming layouts at load, and (2) keeps the reference's calling convention:
 
     logits[1, L, V] = model(inputs[1, L], mask=None, cache=[ReusableKVCache, ...])
 
-Only int4 group-64 checkpoints (config["quantization"] = {"group_size": 64, "bits": 4}) run on this path;
-see DESIGN.md for the dense 16-bit row.
+Checkpoints: config["quantization"] = {"group_size": 64 | 128, "bits": 2 | 3 | 4 | 6 | 8} (2 / 3-bit codes ride the 4-bit units, 6-bit
+codes the 8-bit units), no entry = dense 16-bit weights, or a per-module mix of both; 32-wide groups are refused by name.
 """
 from __future__ import annotations
 
@@ -87,6 +87,26 @@ def _triplet(weights: dict, prefix: str):
     return w, s, b
 
 
+def _recode_mlx_codes(w: torch.Tensor, bits: int, to_bits: int) -> torch.Tensor:
+    """MLX-packed codes of width `bits` (2, 3 or 6; int32 words [N, K * bits / 32]) re-packed at width `to_bits` (4 or 8).  The VALUES are
+    untouched (q < 2**bits <= 2**to_bits), so w = scale * q + bias is the same number: the streaming formats here hold 4- and 8-bit codes, and
+    a narrower code is a code.  MLX packs a row as a little-endian bit stream (code k at bits [k * bits, (k + 1) * bits)): 2-bit codes sixteen
+    to a word, 3- and 6-bit codes eight / four to three bytes."""
+    N = w.shape[0]
+    by = w.contiguous().view(torch.uint8).reshape(N, -1).to(torch.int32)  # little-endian bytes of the row
+    if bits == 2:
+        q = torch.stack([(by >> (2 * i)) & 3 for i in range(4)], dim=-1).reshape(N, -1)
+    else:
+        t = by.reshape(N, -1, 3)
+        v = t[..., 0] | (t[..., 1] << 8) | (t[..., 2] << 16)                # 24 bits = 8 three-bit or 4 six-bit codes
+        n, m = (8, 7) if bits == 3 else (4, 63)
+        q = torch.stack([(v >> (bits * i)) & m for i in range(n)], dim=-1).reshape(N, -1)
+    q = q.to(torch.uint8)
+    if to_bits == 4:
+        q = q[:, 0::2] | (q[:, 1::2] << 4)
+    return q.contiguous().view(torch.int32)
+
+
 def _dense(weights: dict, prefix: str, dtype: torch.dtype) -> torch.Tensor:
     w = weights.get(f"{prefix}.weight")
     if w is None or w.dtype != dtype or f"{prefix}.scales" in weights:
@@ -108,13 +128,27 @@ class Model:
         device = _ffi.require_gpu()
         q = args.quantization or {}
         self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
-        if q and (q.get("group_size") not in (64, 128) or q.get("bits") not in (4, 8)):
+        if q and (q.get("group_size") not in (64, 128) or q.get("bits") not in (2, 3, 4, 6, 8)):
             # nn.quantize(model, **config["quantization"]) takes any group_size in {32, 64, 128} and bits in {2, 3, 4, 6, 8}
             # (models/utils.py:96-111); the W4S / W8S streaming units are built around one 64-wide group per lane.  group_size 128 is
-            # served (below: every group's scale / bias serves both of its 64-wide halves); 32-wide groups and 2/3/6-bit codes are not.
-            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size 64 or 128 with bits 4 or 8 only "
+            # served (below: every group's scale / bias serves both of its 64-wide halves), 2- / 3-bit codes ride the 4-bit units and 6-bit
+            # codes the 8-bit units (below: a narrower code is a code); 32-wide groups are not.
+            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size 64 or 128 with bits 2, 3, 4, 6 or 8 "
                              f"(got group_size={q.get('group_size')}, bits={q.get('bits')}); re-quantise the checkpoint with "
                              "mlx_lm.convert -q --q-group-size 64 --q-bits 4")
+        self.checkpoint_bits = int(q["bits"]) if q else 16
+        if q and self.checkpoint_bits in (2, 3, 6):
+            # Same weights, wider container: 2- and 3-bit codes are stored as 4-bit codes, 6-bit codes as bytes, scales and biases unchanged --
+            # every product is what the narrow code gives (same q, same affine pair, same fp32 sums); HBM holds 0.5625 / 1.0625 B per weight
+            # instead of the checkpoint's 0.3125 / 0.4375 / 0.8125.
+            to_bits = 8 if self.checkpoint_bits == 6 else 4
+            weights = dict(weights)
+            for k in [k for k in weights if k.endswith(".scales")]:
+                wk = k[:-len(".scales")] + ".weight"
+                if weights[wk].shape[-1] * 32 % self.checkpoint_bits or (weights[wk].shape[-1] * 32 // self.checkpoint_bits) % 64:
+                    raise ValueError(f"{wk}: {self.checkpoint_bits}-bit rows must hold a multiple of 64 codes")
+                weights[wk] = _recode_mlx_codes(weights[wk], self.checkpoint_bits, to_bits)
+            q = dict(q, bits=to_bits)
         self.group_size = int(q.get("group_size", 64)) if q else 0
         if self.group_size == 128:
             # mx.quantize(w, group_size=128): one (scale, bias) per 128 weights.  The streaming units keep one per 64-wide lane group, so each

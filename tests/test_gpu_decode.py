@@ -887,6 +887,35 @@ def test_group_size_128_checkpoint_vs_oracle():
         tok = int(np.argmax(w1))
 
 
+@pytest.mark.parametrize("bits,group", [(2, 64), (3, 64), (6, 64), (3, 128), (6, 128)])
+def test_narrow_code_checkpoints_vs_oracle(bits, group):
+    """config["quantization"]["bits"] in {2, 3, 6} (nn.quantize forwards it unchanged, models/utils.py:96-111): 2-bit codes sixteen to a word,
+    3- and 6-bit codes in MLX's byte-packed bit stream.  The loader re-packs the codes into the 4- / 8-bit streaming units without touching a
+    value, so a 40-token prompt (qmm regime), decode steps (qmv regime) and the quantised embedding must be what the oracle computes from the
+    narrow codes themselves."""
+    cfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2, "intermediate_size": 768, "num_attention_heads": 4,
+           "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 512, "rope_theta": 10000.0, "max_position_embeddings": 2048,
+           "tie_word_embeddings": bits == 3, "quantization": {"group_size": group, "bits": bits}}
+    w = po.synth_checkpoint(cfg, seed=50 + bits, dtype=DT, lm_head_gain=4.0)
+    assert w["model.layers.0.mlp.down_proj.weight"].shape == (256, 768 * bits // 32)
+    model = build(cfg, w)
+    assert model.checkpoint_bits == bits and model.bits == (8 if bits == 6 else 4) and model.group_size == group
+    orc = po.OracleLlama(cfg, w, DT)
+    prompt = np.random.default_rng(bits).integers(0, cfg["vocab_size"], 40)
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache)
+    cache = model.make_cache()
+    got = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
+    for l in range(40):
+        assert_vec_close(got[l], want[l], DT, what=f"{bits}-bit g={group} prompt position {l}")
+    tok = int(np.argmax(want[-1]))
+    for i in range(4):
+        w1 = orc.forward(np.array([tok]), ocache)[0]
+        _, _, g1 = model.step(torch.tensor([tok], dtype=torch.int32, device="cuda"), cache)
+        assert_vec_close(g1.float().cpu().numpy(), w1, DT, what=f"{bits}-bit g={group} decode step {i}")
+        tok = int(np.argmax(w1))
+
+
 def test_tied_embeddings_and_errors(tiny):
     g, cfg, w, _ = tiny
     cfg2 = dict(cfg, tie_word_embeddings=True)
@@ -901,8 +930,8 @@ def test_tied_embeddings_and_errors(tiny):
         build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
     with pytest.raises(ValueError, match="group_size=32"):
         build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other group sizes / bit widths are not on this path
-    with pytest.raises(ValueError, match="bits=6"):
-        build(dict(cfg, quantization={"group_size": 64, "bits": 6}), w)
+    with pytest.raises(ValueError, match="bits=5"):
+        build(dict(cfg, quantization={"group_size": 64, "bits": 5}), w)
     # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109); Linears this build streams as ONE packed
     # matrix (q|k|v, gate|up) must agree -- a dense k_proj next to quantised q / v is refused by name
     bad = {k: v for k, v in w.items() if not k.startswith("model.layers.1.self_attn.k_proj.")}

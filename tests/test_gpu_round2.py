@@ -250,6 +250,31 @@ def test_batched_step_after_trim_and_regrow(tiny):
         assert_vec_close(logits[i].float().cpu().numpy(), want, DT, what=f"sequence {i} after trim + regrow")
 
 
+def test_generate_step_with_a_mask_array(tiny):
+    """generate_step(prompt, mask=array) (inference_engine.py:246-249: the same array goes to the prompt pass and every step): a per-head
+    constant is the only kind that broadcasts against all of them; tokens and logprobs equal the unmasked stream.  A [L, L] mask is refused."""
+    from proxy_inference_engine_amd import InferenceEngine
+    g, cfg, w, model = tiny
+    prompt = torch.from_numpy(g["prompt"])
+
+    def stream(mask):
+        eng = InferenceEngine(model=model)
+        eng.prepare_engine(prompt, temp=0)
+        gen = eng.generate_step(prompt, mask=mask)
+        out = []
+        for _ in range(5):
+            tok, lp = next(gen)
+            out.append((int(tok.item()), lp.clone()))
+        return out
+
+    ref = stream(None)
+    for mk in (torch.zeros(1, 1, 1, 1, device="cuda"), torch.ones(1, cfg["num_attention_heads"], 1, 1, dtype=torch.bool), "causal"):
+        got = stream(mk)
+        assert [t for t, _ in got] == [t for t, _ in ref] and all(torch.equal(a[1], b[1]) for a, b in zip(got, ref))
+    with pytest.raises(ValueError, match="broadcast"):
+        next(InferenceEngine(model=model).generate_step(prompt, mask=torch.zeros(len(prompt), len(prompt))))
+
+
 def test_model_call_accepts_the_causal_mask_it_would_build_itself(tiny):
     """Model.__call__(inputs, mask=...) (language.py:199-204): the reference builds create_attention_mask(h, cache) when mask is None
     and passes a caller's mask through to sdpa; here the causal mask is implicit in the kernels, so that very mask (additive array,

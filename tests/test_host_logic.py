@@ -220,3 +220,17 @@ def test_oracle_forward_from_input_embeddings_equals_forward_from_ids():
     rows = po.dequantize(w["model.embed_tokens.weight"], w["model.embed_tokens.scales"], w["model.embed_tokens.biases"], dtype="bfloat16")[ids]
     b = orc.forward(None, [po.OracleKVCache() for _ in orc.layers], inputs_embeds=rows)
     assert np.array_equal(a, b)
+
+
+def test_generate_step_mask_arrays_that_the_reference_loop_can_carry():
+    """generate_step forwards ONE mask array to the prompt pass and to every single-token step (inference_engine.py:246-249): only arrays that are
+    constant per head broadcast against every [1, H, L, S]; those cannot hide a key, so they are accepted (and change nothing); the rest is
+    refused with the reason."""
+    from proxy_inference_engine_amd.engine.inference_engine import check_generate_mask
+    for ok in (torch.zeros(()), torch.zeros(1, 1), torch.full((1, 1, 1, 1), -3.5), torch.ones(1, 4, 1, 1, dtype=torch.bool), torch.zeros(4, 1, 1), np.zeros((1, 1), np.float32)):
+        check_generate_mask(ok, 4)
+    for bad, why in ((torch.zeros(12, 12), "broadcast"), (torch.zeros(1, 1, 1, 9), "broadcast"), (torch.zeros(2, 1, 1, 1), "broadcast"),
+                     (torch.zeros(1, 3, 1, 1), "broadcast"), (torch.zeros(1, 1, dtype=torch.bool), "hides every key"),
+                     (torch.full((1, 1), float("-inf")), "hides every key")):
+        with pytest.raises(ValueError, match=why):
+            check_generate_mask(bad, 4)

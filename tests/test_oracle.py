@@ -265,3 +265,48 @@ def test_oracle_variants_vs_hf_transformers_fp32():
                      tie_word_embeddings=False, use_sliding_window=False)
     qc._attn_implementation = "eager"
     check(cfg, Qwen2ForCausalLM(qc).eval(), w)
+
+
+def test_byte_packed_3_and_6_bit_codes_known_answers():
+    """MLX packs 3- and 6-bit codes as a little-endian bit stream over bytes (mlx >= 0.21: `bits == 3 || bits == 6`).  Known answers written
+    out from its published unpacking formulas -- 3 bits: w0 & 7, (w0 >> 3) & 7, (w0 >> 6) | ((w1 & 1) << 2), (w1 >> 1) & 7, (w1 >> 4) & 7,
+    (w1 >> 7) | ((w2 & 3) << 1), (w2 >> 2) & 7, w2 >> 5; 6 bits: w0 & 63, (w0 >> 6) | ((w1 & 15) << 2), (w1 >> 4) | ((w2 & 3) << 4), w2 >> 2."""
+    # codes 0..7 (3 bits) -> bytes 136, 198, 250; codes 1, 2, 3, 60 (6 bits) -> bytes 129, 48, 240
+    ones, zeros = po.to_bits(np.ones((1, 1), np.float32), "float32"), po.to_bits(np.zeros((1, 1), np.float32), "float32")
+    row3 = np.zeros((1, 6), np.uint32)                     # 64 codes * 3 bits = 6 words
+    row3.view(np.uint8)[0, :3] = (136, 198, 250)
+    got = po.dequantize(row3, ones, zeros, group_size=64, bits=3, dtype="float32")
+    assert got[0, :8].tolist() == [0, 1, 2, 3, 4, 5, 6, 7] and not got[0, 8:].any()
+    row6 = np.zeros((1, 12), np.uint32)
+    row6.view(np.uint8)[0, :3] = (129, 48, 240)
+    got = po.dequantize(row6, ones, zeros, group_size=64, bits=6, dtype="float32")
+    assert got[0, :4].tolist() == [1, 2, 3, 60] and not got[0, 4:].any()
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 6, 8])
+def test_quantize_round_trip_every_code_width(bits):
+    """mx.quantize / mx.dequantize at every width nn.quantize accepts: |w - w_hat| < one bin per group (the edge that defines the scale is exact, the far
+    end may clip), codes use the full range."""
+    rng = np.random.default_rng(bits)
+    w = rng.standard_normal((8, 256)).astype(np.float32)
+    wq, s, b = po.quantize(w, 64, bits, "float32")
+    assert wq.shape == (8, 256 * bits // 32)
+    back = po.dequantize(wq, s, b, 64, bits, "float32")
+    scale = np.abs(po.from_bits(s, "float32")).repeat(64, axis=1)
+    assert np.all(np.abs(back - w) <= scale * (1 + 1e-5) + 1e-6)
+    codes = np.rint((back - po.from_bits(b, "float32").repeat(64, axis=1)) / po.from_bits(s, "float32").repeat(64, axis=1))
+    assert codes.min() == 0 and codes.max() == (1 << bits) - 1
+
+
+@pytest.mark.parametrize("bits,to_bits", [(2, 4), (3, 4), (6, 8)])
+def test_loader_repacks_narrow_codes_without_touching_a_value(bits, to_bits):
+    """Model.__init__ stores 2- / 3-bit codes as 4-bit codes and 6-bit codes as bytes (models/llama/language.py: _recode_mlx_codes): the re-packed
+    words, read at the wider width, must dequantise to exactly what the checkpoint's own words give."""
+    import torch
+    from proxy_inference_engine_amd.models.llama.language import _recode_mlx_codes
+    rng = np.random.default_rng(10 + bits)
+    w = rng.standard_normal((5, 192)).astype(np.float32)
+    wq, s, b = po.quantize(w, 64, bits, "bfloat16")
+    wide = _recode_mlx_codes(torch.from_numpy(wq.view(np.int32)), bits, to_bits).numpy().view(np.uint32)
+    assert wide.shape == (5, 192 * to_bits // 32)
+    assert np.array_equal(po.dequantize(wide, s, b, 64, to_bits, "bfloat16"), po.dequantize(wq, s, b, 64, bits, "bfloat16"))
