@@ -307,7 +307,8 @@ int pie_decoder_graph_launches(const pie_decoder *d, int flags);
 int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream);
 /* The same with the input embeddings given instead of token ids: embeds T [L, hidden] replaces embed_tokens(ids) --
  * `h = inputs_embeds` of the VLM text tower (models/intern/language.py:155-158), fed by the ensemble's merged text and image
- * features (models/intern/ensemble.py:33-91, :106-108).  Always the batched path, whatever L. */
+ * features (models/intern/ensemble.py:33-91, :106-108).  Always the batched path, whatever L -- except on int8 pages (PIE_OPT_KV_I8 with a
+ * paged cache), where the rows run as decode steps like a prompt of tokens does there. */
 int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *logits_all, void *stream);
 /* Output buffers of the step, allocated by the caller (device): logits T [vocab], logprobs fp32 [vocab],
  * token int32 [1] (the greedy choice), hidden T [hidden] (the residual stream; after a step it holds the

@@ -98,7 +98,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
             GemvArgs a = {};
             a.fmt = gfmt(w.wqkv), a.w = (const char *)w.wqkv, a.K = H, a.N = QD + 2 * KVD;
             a.x = d->h, a.norm_w = (const u16 *)w.attn_norm, a.eps = c.rms_eps;
-            a.freqs = d->glob.rope_freqs, a.rope_cs = dense_embed ? nullptr : d->rope_cs /* filled by the quantised embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
+            a.freqs = d->glob.rope_freqs, a.rope_cs = dense_embed || d->row_is_h ? nullptr : d->rope_cs /* filled by the quantised embedding kernel */, a.state = d->state, a.q_out = d->qbuf, a.kv_table = d->kv_table;
             a.layer = li, a.n_layers = c.n_layers, a.n_heads = c.n_heads, a.n_kv_heads = c.n_kv_heads, a.head_dim = D;
             a.lin_bias = (const u16 *)w.bqkv, a.rope_traditional = c.rope_traditional;
             a.block_table = d->block_table, a.n_pages = d->n_pages;
@@ -194,8 +194,8 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
 static int enqueue_step(pie_decoder *d, const int *token_ptr, bool with_logits, u16 *logits_dst, hipStream_t st) {
     // An int4 embedding table in front of an int4 q|k|v matrix: no embedding launch, layer 0's q|k|v launch dequantises the row itself
     // (4.4 us of kernel + a launch boundary per step; same bits: the same dequantisation, RMSNorm tree and RoPE table).
-    const bool embed_in_qkv = d->mat_fmt(d->glob.embed_codes) == PIE_W_INT4_G64 && d->mat_fmt(d->layers[0].wqkv) == PIE_W_INT4_G64 && !d->tp() && d->cfg.hidden <= 8 * 8 * GEMV_WAVES * 64;
-    int rc = embed_in_qkv ? PIE_OK : enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
+    const bool embed_in_qkv = !d->row_is_h && d->mat_fmt(d->glob.embed_codes) == PIE_W_INT4_G64 && d->mat_fmt(d->layers[0].wqkv) == PIE_W_INT4_G64 && !d->tp() && d->cfg.hidden <= 8 * 8 * GEMV_WAVES * 64;
+    int rc = embed_in_qkv || d->row_is_h ? PIE_OK : enqueue_kernel(d, PIE_K_EMBED, 0, token_ptr, logits_dst, st);
     if (rc) return rc;
     for (int li = 0; li < d->cfg.n_layers; ++li)
         for (int k : {PIE_K_QKV, PIE_K_ATTN, PIE_K_OPROJ, PIE_K_GATEUP, PIE_K_DOWN})
@@ -512,8 +512,23 @@ int pie_decoder_prefill_embeds(pie_decoder *d, const void *embeds, int L, void *
     PIE_REQUIRE(embeds && L > 0, PIE_E_ARG, "pie_decoder_prefill_embeds: need at least one row");
     PIE_REQUIRE(pie_aligned(embeds, 16), PIE_E_ALIGN, "pie_decoder_prefill_embeds: 16-byte alignment required");
     PIE_REQUIRE(!d->tp(), PIE_E_STATE, "pie_decoder_prefill_embeds: not available on a tensor-parallel shard");
-    PIE_REQUIRE(!(d->kv_i8 && d->block_table), PIE_E_STATE, "pie_decoder_prefill_embeds: prompts of embeddings run on T pages (int8 pages: pie_decoder_prefill_batch / _step)");
-    return prefill_batched(d, nullptr, embeds, L, logits_all, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(d->kv_i8 && d->block_table)) return prefill_batched(d, nullptr, embeds, L, logits_all, st);
+    // int8 pages: the batched prompt path of one sequence reads and writes T pages, so -- like a prompt of tokens (pie_decoder_prefill) -- the rows
+    // run as decode steps, each with its row copied into the residual stream instead of an embedding launch (no RoPE table either: the
+    // q|k|v epilogue computes its own angles).  The greedy token the tail leaves in the device-side state is that of the last row.
+    const size_t row_bytes = 2 * (size_t)d->cfg.hidden;
+    d->row_is_h = true;
+    for (int l = 0; l < L && !rc; ++l) {
+        u16 *dst = logits_all ? (u16 *)logits_all + (size_t)l * d->cfg.vocab : d->logits;
+        if (hipMemcpyAsync(d->h, (const char *)embeds + (size_t)l * row_bytes, row_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = pie::fail(PIE_E_HIP, "pie_decoder_prefill_embeds: copying a row failed");
+        else rc = enqueue_step(d, &d->state->token, l == L - 1 || logits_all != nullptr, dst, st);
+    }
+    d->row_is_h = false;
+    if (rc) return rc;
+    if (logits_all)
+        PIE_HIP_TRY(hipMemcpyAsync(d->logits, (u16 *)logits_all + (size_t)(L - 1) * d->cfg.vocab, 2 * (size_t)d->cfg.vocab, hipMemcpyDeviceToDevice, st));
+    return PIE_OK;
 }
 
 int pie_decoder_bind_outputs(pie_decoder *d, void *logits, float *logprobs, int32_t *token, void *hidden, int32_t *history,

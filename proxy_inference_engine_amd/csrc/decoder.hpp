@@ -37,6 +37,7 @@ struct pie_decoder {
     bool combine = false;
     int merge_max_cap = 1024, kv_cap = 0;  // measured: merged wins at capacities 512 and 1024, the combine launch from 2048
     bool kv_i8 = false;  // PIE_OPT_KV_I8: the page slabs hold int8 pages (paged_i8.hip)
+    bool row_is_h = false;  // the step's input row already sits in `h` (a row of caller-made embeddings): no embedding launch, no RoPE table
     // single-sequence step on int8 pages: the q|k|v GEMV's RoPE + append epilogue writes the new T rows into ONE staging page through a table of
     // staging pointers and an all-zero block table (the kernel is untouched), k_paged_kv_append_i8 quantises them into the sequence's page
     u16 *kv_stage = nullptr;                      // [2][n_kv, 64, D] T

@@ -787,6 +787,18 @@ def test_single_sequence_step_on_int8_pages(golden_dir):
     gen = eng.generate_step(torch.from_numpy(prompt.astype(np.int64)))
     etoks = [int(next(gen)[0].item()) for _ in range(upto)]
     assert etoks == [t for t, _ in got[:upto]]
+    eng.prompt_cache.cache[0].page_manager.release()
+    # a prompt of caller-made embeddings (the VLM text tower's entry, intern/ensemble.py:106-108) on int8 pages: its rows run as decode steps,
+    # each copied into the residual stream -- the same rows as the token prompt's, so logits at every position and the pages' codes are equal
+    ca, cb = model.make_cache(), model.make_cache()
+    ids = torch.from_numpy(prompt[:20]).cuda()
+    la = model(ids[None], cache=ca).clone()
+    lb = model(None, cache=cb, inputs_embeds=model.embed(ids)[None])
+    assert ca[0].offset == cb[0].offset == 20 and torch.equal(la, lb)
+    for l in range(L):
+        assert all(torch.equal(x, y) for x, y in zip(ca[l].state, cb[l].state))
+    nb = model.step(torch.tensor([7], dtype=torch.int32).cuda(), cb)[2].clone()
+    assert torch.equal(model.step(torch.tensor([7], dtype=torch.int32).cuda(), ca)[2], nb)
     model.enable_paged_kv(num_pages=8)   # back to T pages
 
 
