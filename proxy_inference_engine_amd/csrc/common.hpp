@@ -183,4 +183,8 @@ static inline __host__ __device__ int w16s_slices(int K) { return (K + W16S_SLIC
 // codes (2, 3) in the two 16-bit halves: a bare byte 0x00qq IS the bf16 number q * 2^-133 for every q <= 255 (denormal below
 // 128, exponent field 1 above: gradual underflow is continuous), so the int4 path's operand trick carries over unchanged.
 constexpr int W8S_UNIT_BYTES = 4352;
-enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2 };
+// W4S32 (MLX int4 group-32 triplets): the W4S unit with TWO {scale | bias << 16} words per lane -- its first code piece (32 codes) is one
+// 32-wide group, its second the next: [2 x 64 lanes x 16 B] codes + [64 x 8 B] = 2560 B.
+constexpr int W4S32_UNIT_BYTES = 2560;
+enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3 };
+constexpr int PIE_EMBED_W4G32 = 36;  // embedding_launch's `bits` for 4-bit codes in 32-wide groups (4 and 8 = the 64-wide group forms)

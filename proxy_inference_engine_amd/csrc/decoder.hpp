@@ -66,6 +66,11 @@ struct pie_decoder {
     }
     int embed_vocab() const { return tp() ? cfg.vocab * cfg.tp_world : cfg.vocab; }
 };
+// embedding_launch's `bits` for the decoder's embedding table: 4 / 8 (64-wide groups) or PIE_EMBED_W4G32
+static inline int embed_bits(const pie_decoder *d) {
+    const int f = d->mat_fmt(d->glob.embed_codes);
+    return f == PIE_W_INT8_G64 ? 8 : (f == PIE_W_INT4_G32 ? PIE_EMBED_W4G32 : 4);
+}
 
 // tp_comm.hip: sum over the ranks of data[n] (rank order), then h = T(h + T(sum)) when resid != nullptr
 int tp_allreduce_launch(pie_comm *c, int dtype, float *data, int n, u16 *resid, hipStream_t st, bool pushed);

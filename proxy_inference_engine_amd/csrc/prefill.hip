@@ -30,15 +30,15 @@ int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const voi
 
 // ---------------------------------------------------------------- kernels
 // W4S -> T row-major [N, K]; one thread per code word (8 weights, 16 B out).  Same arithmetic as k_dequantize_w4g64.
-template <class T>
+template <class T, bool G32 = false>  // G32: W4S32 units (two {scale | bias} words per lane: code piece j is its own 32-wide group)
 __global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int wpr = K >> 3;  // words per row
     if (idx >= (size_t)N * wpr) return;
     const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
     const int g = wk >> 3, lane = (r & 1) * 32 + (g & 31), j = (wk & 7) >> 2, t = wk & 3;
-    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W4S_UNIT_BYTES / 4);
-    const u32 word = unit[j * 256 + lane * 4 + t], sb = unit[512 + lane];
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * ((G32 ? W4S32_UNIT_BYTES : W4S_UNIT_BYTES) / 4);
+    const u32 word = unit[j * 256 + lane * 4 + t], sb = G32 ? unit[512 + 2 * lane + j] : unit[512 + lane];
     const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
     u32 o[4];
 #pragma unroll
@@ -596,7 +596,8 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 
         return PIE_OK;
     }
     const size_t words = (size_t)N * (K >> 3);
-    hipLaunchKernelGGL(k_dequant_w4s<T>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+    if (wf == PIE_W_INT4_G32) hipLaunchKernelGGL((k_dequant_w4s<T, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+    else hipLaunchKernelGGL((k_dequant_w4s<T, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -666,6 +667,11 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
+    if (d->mat_fmt(packed) == PIE_W_INT4_G32 && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 codes, qmv regime: the streaming GEMV, one pass per row
+        GemvArgs a = {};
+        a.fmt = FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
+        return w4s_gemv_launch(d->cfg.dtype, PRO_NONE, EPI_STORE, a, M, st);
+    }
     // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the
     // streaming GEMV with the rows' images side by side -- one pass over the weights, each row with the batch-1 arithmetic.
     if (is_int4 && M <= GEMV_ROWS_MAX && K % 64 == 0 && N % 2 == 0 && gemv_rows_lds_bytes(K, 1) <= 160u * 1024u)
@@ -794,7 +800,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
             rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
                  ? pie_embedding_dense(ids + c0, M, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
                  : embedding_launch(ids + c0, M, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr,
-                                    nullptr, nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
+                                    nullptr, nullptr, 0, st, embed_bits(d));
         if (rc) return rc;
         hipLaunchKernelGGL(k_rope_cs_rows, dim3(M), dim3(64), 0, st, d->glob.rope_freqs, d->state, nullptr, D / 2, s->rope_cs);
         PIE_LAUNCH_CHECK();
@@ -976,7 +982,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
     rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(tokens, B, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
              : embedding_launch(tokens, B, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
-                                nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
+                                nullptr, 0, st, embed_bits(d));
     if (rc) return rc;
     hipLaunchKernelGGL(k_rope_cs_rows, dim3(B), dim3(64), 0, st, d->glob.rope_freqs, nullptr, ctx_len, D / 2, s->rope_cs);
     PIE_LAUNCH_CHECK();
@@ -1058,7 +1064,7 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
     rc = d->mat_fmt(d->glob.embed_codes) == PIE_W_DENSE
              ? pie_embedding_dense(ids, N, d->glob.embed_codes, c.vocab, H, c.dtype, s->x, st)
              : embedding_launch(ids, N, d->glob.embed_codes, d->glob.embed_scales, d->glob.embed_biases, c.vocab, H, c.dtype, s->x, nullptr, nullptr,
-                                nullptr, 0, st, d->mat_fmt(d->glob.embed_codes) == PIE_W_INT8_G64 ? 8 : 4);
+                                nullptr, 0, st, embed_bits(d));
     if (rc) return rc;
     hipLaunchKernelGGL(k_rope_cs_rows, dim3(N), dim3(64), 0, st, d->glob.rope_freqs, nullptr, row_ctx, D / 2, s->rope_cs);
     PIE_LAUNCH_CHECK();

@@ -116,12 +116,12 @@ struct GemvLds {
     int stride;  // 16-byte slots per piece row: groups | 1 (odd -> conflict-free ds_write_b128 across the 8 pieces)
     int off_sx, off_red, off_out, total;
 };
-static inline __host__ __device__ GemvLds gemv_lds(int K) {
+static inline __host__ __device__ GemvLds gemv_lds(int K, bool g32 = false) {  // g32: one activation sum per 32-wide group (FMT_W4S32)
     GemvLds l;
     const int G = K >> 6;
     l.stride = G | 1;
     l.off_sx = 8 * l.stride * 16;
-    l.off_red = l.off_sx + ((G * 4 + 15) & ~15);
+    l.off_red = l.off_sx + (((g32 ? 2 * G : G) * 4 + 15) & ~15);
     l.off_out = l.off_red + 32 * 4;
     l.total = l.off_out + GEMV_WAVES * 2 * GEMV_MAX_RUN * 4;
     return l;
@@ -134,6 +134,19 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
 #pragma unroll
     for (int t = 0; t < 8; ++t) T::dot_word(w[t], xr[4 * t], xr[4 * t + 1], xr[4 * t + 2], xr[4 * t + 3], d);
     return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
+}
+
+// W4S32: the two code pieces of a lane are two 32-wide groups -- the same chains, summed per piece.
+template <class T>
+__device__ __forceinline__ void w4s_unit_dot2(const uint4 &c0, const uint4 &c1, const u32 (&xr)[32], float &da, float &db) {
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const u32 w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) T::dot_word(w[t], xr[4 * t], xr[4 * t + 1], xr[4 * t + 2], xr[4 * t + 3], d);
+#pragma unroll
+    for (int t = 4; t < 8; ++t) T::dot_word(w[t], xr[4 * t], xr[4 * t + 1], xr[4 * t + 2], xr[4 * t + 3], e);
+    da = (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
+    db = (e[0] + e[2]) + (e[1] + e[3]) * T::ODD_SCALE;
 }
 
 // The same dot product in two steps (several activation rows per code word): operands once, four chains per row -- bit-identical to
@@ -239,14 +252,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
 #endif
     GEMV_STAMP(0);
     constexpr int D = GEMV_DEPTH;
-    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : W4S_UNIT_BYTES);
+    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : (FMT == FMT_W4S32 ? W4S32_UNIT_BYTES : W4S_UNIT_BYTES));
     constexpr int NT = GEMV_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ns = a.n_slices;
     const int m = blockIdx.y;
-    const GemvLds L = gemv_lds(a.K);
+    const GemvLds L = gemv_lds(a.K, FMT == FMT_W4S32);
     float *sxs = reinterpret_cast<float *>(smem + L.off_sx);
     float *red = reinterpret_cast<float *>(smem + L.off_red);
     float *outp = reinterpret_cast<float *>(smem + L.off_out) + wave * (2 * GEMV_MAX_RUN);  // this wave's row sums
@@ -345,6 +358,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     uint4 c0[D], c1[D];
     uint4 c2[FMT == FMT_W8S ? D : 1], c3[FMT == FMT_W8S ? D : 1];  // W8S: a lane's 64 codes are four pieces
     u32 sb[D];
+    u32 sb2[FMT == FMT_W4S32 ? D : 1];  // W4S32: the second 32-wide group's {scale | bias << 16}
     // Weight loads go through a buffer descriptor over the whole matrix: a ring slot that has no unit left to fetch is
     // given an out-of-range offset, which the hardware bounds check drops (no memory traffic, no branch around a load).
     // (Clamping to the last unit instead cost up to D redundant loads per wave: 70 % extra at 7-unit runs.)
@@ -378,6 +392,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
             c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
             if (FMT == FMT_W4S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
+            if (FMT == FMT_W4S32) {
+                typedef __attribute__((ext_vector_type(2))) u32 u32x2_t;
+                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrsrc, off + 2048 - lane * 8, 0, AUX);
+                sb[d] = v.x, sb2[d] = v.y;
+            }
             if (FMT == FMT_W8S) {
                 const u32x4_t v2 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 2048, 0, AUX);
                 const u32x4_t v3 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 3072, 0, AUX);
@@ -475,10 +494,13 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             float ps = ok ? sum8<T>(xv[i]) : 0.0f;
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+            if (FMT == FMT_W4S32) {  // one sum per 32-wide group: lanes 4k .. 4k+3 (all hold it after the two quad steps)
+                if (ok && (j & 3) == 0) sxs[j >> 2] = ps;
+            }
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x141, 0xF, 0xF, true);  // row_half_mirror: 8-lane sums
             if (ok) {
                 *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = FMT != FMT_W16S ? scale8<T>(xv[i]) : xv[i];
-                if ((j & 7) == 0) sxs[j >> 3] = ps;
+                if (FMT != FMT_W4S32 && (j & 7) == 0) sxs[j >> 3] = ps;
             }
         }
         __syncthreads();
@@ -530,6 +552,14 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                                               : *reinterpret_cast<const uint4 *>(smem + ((size_t)r * L.stride + gc) * 16);
                     xr[4 * r + 0] = v.x, xr[4 * r + 1] = v.y, xr[4 * r + 2] = v.z, xr[4 * r + 3] = v.w;
                 }
+                if constexpr (FMT == FMT_W4S32) {
+                    float da, db;
+                    w4s_unit_dot2<T>(c0[d], c1[d], xr, da, db);
+                    const float2 sx2 = *reinterpret_cast<const float2 *>(sxs + 2 * gc);
+                    const float pa = fmaf(lo_f32<T>(sb[d]), da * T::DSCALE - T::OFFSET * sx2.x, hi_f32<T>(sb[d]) * sx2.x);
+                    const float pb = fmaf(lo_f32<T>(sb2[d]), db * T::DSCALE - T::OFFSET * sx2.y, hi_f32<T>(sb2[d]) * sx2.y);
+                    acc += gvalid ? pa + pb : 0.0f;
+                } else {
                 const float sx = (ABL & 4) ? 64.0f : sxs[gc];
                 float dd;
                 if (FMT == FMT_W8S) dd = w8s_unit_dot<T>(c0[d], c1[d], c2[d], c3[d], xr);
@@ -538,6 +568,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);
                 const float pr = fmaf(scale, dd * T::DSCALE - T::OFFSET * sx, bias * sx);
                 acc += gvalid ? pr : 0.0f;  // padded groups carry zero codes and zero {scale,bias}; the select keeps a NaN x out
+                }
               }
                 if (++sl == ns) {
                     const float tot = half_wave_sum(acc);

@@ -887,8 +887,8 @@ def test_group_size_128_checkpoint_vs_oracle():
         tok = int(np.argmax(w1))
 
 
-@pytest.mark.parametrize("bits,group", [(2, 64), (3, 64), (6, 64), (3, 128), (6, 128)])
-def test_narrow_code_checkpoints_vs_oracle(bits, group):
+@pytest.mark.parametrize("bits,group", [(2, 64), (3, 64), (6, 64), (3, 128), (6, 128), (4, 32), (3, 32), (2, 32)])
+def test_narrow_code_and_group_32_checkpoints_vs_oracle(bits, group):
     """config["quantization"]["bits"] in {2, 3, 6} (nn.quantize forwards it unchanged, models/utils.py:96-111): 2-bit codes sixteen to a word,
     3- and 6-bit codes in MLX's byte-packed bit stream.  The loader re-packs the codes into the 4- / 8-bit streaming units without touching a
     value, so a 40-token prompt (qmm regime), decode steps (qmv regime) and the quantised embedding must be what the oracle computes from the
@@ -900,6 +900,8 @@ def test_narrow_code_checkpoints_vs_oracle(bits, group):
     assert w["model.layers.0.mlp.down_proj.weight"].shape == (256, 768 * bits // 32)
     model = build(cfg, w)
     assert model.checkpoint_bits == bits and model.bits == (8 if bits == 6 else 4) and model.group_size == group
+    if group == 32:
+        assert w["model.layers.0.mlp.down_proj.scales"].shape == (256, 768 // 32)
     orc = po.OracleLlama(cfg, w, DT)
     prompt = np.random.default_rng(bits).integers(0, cfg["vocab_size"], 40)
     ocache = [po.OracleKVCache() for _ in orc.layers]
@@ -928,8 +930,8 @@ def test_tied_embeddings_and_errors(tiny):
     assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
     with pytest.raises(ValueError):
         build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
-    with pytest.raises(ValueError, match="group_size=32"):
-        build(dict(cfg, quantization={"group_size": 32, "bits": 4}), w)  # other group sizes / bit widths are not on this path
+    with pytest.raises(ValueError, match="group_size=32, bits=8"):
+        build(dict(cfg, quantization={"group_size": 32, "bits": 8}), w)  # 32-wide groups of 6- / 8-bit codes are not on this path
     with pytest.raises(ValueError, match="bits=5"):
         build(dict(cfg, quantization={"group_size": 64, "bits": 5}), w)
     # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109); Linears this build streams as ONE packed
