@@ -104,17 +104,21 @@ int pie_dequantize_g64(const uint32_t *codes, const void *scales, const void *bi
 int pie_embedding_g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
                       int bits, int dtype, void *out, void *stream);
 
-/* ---------------------------------------------------------------- MLX int4 group-32 checkpoints (config "quantization":
- * {"group_size": 32, "bits": 4}; nn.quantize takes any group_size in {32, 64, 128}, models/utils.py:96-111): weight uint32 [N, K/8],
- * scales / biases T [N, K/32].  Same call sites and streaming kernel as the group-64 path on "W4S32" units of 2560 B: the W4S unit with TWO
- * {scale | bias << 16} words per lane (its two 16-byte code pieces are two consecutive 32-wide groups).  Decode steps and prompts below 6
+/* ---------------------------------------------------------------- MLX group-32 checkpoints (config "quantization": {"group_size": 32,
+ * "bits": 4 | 8}; nn.quantize takes any group_size in {32, 64, 128}, models/utils.py:96-111): weight uint32 [N, K*bits/32], scales / biases
+ * T [N, K/32].  Same call sites and streaming kernel as the group-64 paths on "W4S32" units of 2560 B / "W8S32" units of 4608 B: the W4S / W8S
+ * unit with TWO {scale | bias << 16} words per lane (its code pieces are two consecutive 32-wide groups).  Decode steps and prompts below 6
  * rows multiply in the exact-fp32 regime (one pass over the weights per row); longer prompts dequantise to T and call the library GEMM. */
 size_t pie_w4s32_bytes(int N_out, int K);
 int pie_repack_w4g32(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
                      void *packed, void *stream);
 int pie_qgemv_w4g32(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
-int pie_embedding_w4g32(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype, void *out,
-                        void *stream);
+size_t pie_w8s32_bytes(int N_out, int K);
+int pie_repack_w8g32(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream);
+int pie_qgemv_w8g32(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
+int pie_embedding_g32(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int bits, int dtype, void *out,
+                      void *stream);
 
 /* ---------------------------------------------------------------- dense checkpoints (no "quantization" entry in
  * config.json, models/utils.py:96-97): nn.Linear / nn.Embedding with 16-bit weights.  Same streaming kernel as the int4
@@ -220,7 +224,7 @@ typedef struct {
                              pie_decoder_set_comm's communicator adds over the ranks before the one rounding + residual add. */
 } pie_decoder_config;
 enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1, PIE_W_INT8_G64 = 2 /* W8S units, embed_codes uint32 [vocab, hidden/4] */,
-       PIE_W_INT4_G32 = 3 /* W4S32 units, embed scales / biases [vocab, hidden/32] */ };
+       PIE_W_INT4_G32 = 3 /* W4S32 units, embed scales / biases [vocab, hidden/32] */, PIE_W_INT8_G32 = 4 /* W8S32 units */ };
 
 typedef struct {
     const void *attn_norm, *mlp_norm;   /* T [hidden] */

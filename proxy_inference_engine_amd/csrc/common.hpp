@@ -186,5 +186,10 @@ constexpr int W8S_UNIT_BYTES = 4352;
 // W4S32 (MLX int4 group-32 triplets): the W4S unit with TWO {scale | bias << 16} words per lane -- its first code piece (32 codes) is one
 // 32-wide group, its second the next: [2 x 64 lanes x 16 B] codes + [64 x 8 B] = 2560 B.
 constexpr int W4S32_UNIT_BYTES = 2560;
-enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3 };
-constexpr int PIE_EMBED_W4G32 = 36;  // embedding_launch's `bits` for 4-bit codes in 32-wide groups (4 and 8 = the 64-wide group forms)
+// W8S32 (MLX int8 group-32 triplets): likewise the W8S unit with two {scale | bias << 16} words per lane (code pieces 0-1 / 2-3) = 4608 B.
+constexpr int W8S32_UNIT_BYTES = 4608;
+enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3, FMT_W8S32 = 4 };
+static inline __host__ __device__ constexpr int fmt_unit_bytes(int fmt) {
+    return fmt == FMT_W16S ? W16S_UNIT_BYTES : (fmt == FMT_W8S ? W8S_UNIT_BYTES : (fmt == FMT_W4S32 ? W4S32_UNIT_BYTES : (fmt == FMT_W8S32 ? W8S32_UNIT_BYTES : W4S_UNIT_BYTES)));
+}
+constexpr int PIE_EMBED_W4G32 = 36, PIE_EMBED_W8G32 = 40;  // embedding_launch's `bits` for 4- / 8-bit codes in 32-wide groups (4 and 8 = the 64-wide group forms)

@@ -69,7 +69,7 @@ struct pie_decoder {
 // embedding_launch's `bits` for the decoder's embedding table: 4 / 8 (64-wide groups) or PIE_EMBED_W4G32
 static inline int embed_bits(const pie_decoder *d) {
     const int f = d->mat_fmt(d->glob.embed_codes);
-    return f == PIE_W_INT8_G64 ? 8 : (f == PIE_W_INT4_G32 ? PIE_EMBED_W4G32 : 4);
+    return f == PIE_W_INT8_G64 ? 8 : (f == PIE_W_INT4_G32 ? PIE_EMBED_W4G32 : (f == PIE_W_INT8_G32 ? PIE_EMBED_W8G32 : 4));
 }
 
 // tp_comm.hip: sum over the ranks of data[n] (rank order), then h = T(h + T(sum)) when resid != nullptr

@@ -51,15 +51,15 @@ __global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out)
 }
 
 // W8S -> T row-major [N, K]; one thread per code word (4 weights, 8 B out).
-template <class T>
+template <class T, bool G32 = false>  // G32: W8S32 units (code pieces 0-1 / 2-3 are two 32-wide groups)
 __global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int wpr = K >> 2;
     if (idx >= (size_t)N * wpr) return;
     const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
     const int g = wk >> 4, lane = (r & 1) * 32 + (g & 31), j = (wk & 15) >> 2, t = wk & 3;
-    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W8S_UNIT_BYTES / 4);
-    const u32 word = unit[j * 256 + lane * 4 + t], sb = unit[1024 + lane];
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * ((G32 ? W8S32_UNIT_BYTES : W8S_UNIT_BYTES) / 4);
+    const u32 word = unit[j * 256 + lane * 4 + t], sb = G32 ? unit[1024 + 2 * lane + (j >> 1)] : unit[1024 + lane];
     const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
     // stored byte order (c0, c2, c1, c3)
     const float q0 = __fadd_rn(__fmul_rn(s, (float)(word & 0xFFu)), b), q2 = __fadd_rn(__fmul_rn(s, (float)((word >> 8) & 0xFFu)), b);
@@ -589,9 +589,10 @@ template <class T>
 static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 *dst, hipStream_t st) {
     const int wf = d->mat_fmt(packed);  // per-module quantisation: a checkpoint may mix formats (models/utils.py:99-109)
     if (wf == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
-    if (wf == PIE_W_INT8_G64) {
+    if (wf == PIE_W_INT8_G64 || wf == PIE_W_INT8_G32) {
         const size_t w8 = (size_t)N * (K >> 2);
-        hipLaunchKernelGGL(k_dequant_w8s<T>, dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+        if (wf == PIE_W_INT8_G32) hipLaunchKernelGGL((k_dequant_w8s<T, true>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+        else hipLaunchKernelGGL((k_dequant_w8s<T, false>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
         PIE_LAUNCH_CHECK();
         return PIE_OK;
     }
@@ -667,9 +668,9 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
-    if (d->mat_fmt(packed) == PIE_W_INT4_G32 && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 codes, qmv regime: the streaming GEMV, one pass per row
+    if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 codes, qmv regime: the streaming GEMV, one pass per row
         GemvArgs a = {};
-        a.fmt = FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
+        a.fmt = d->mat_fmt(packed) == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
         return w4s_gemv_launch(d->cfg.dtype, PRO_NONE, EPI_STORE, a, M, st);
     }
     // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the

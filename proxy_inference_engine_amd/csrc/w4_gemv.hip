@@ -100,7 +100,7 @@ __global__ void k_embedding_w4g64(const int *ids, const u32 *codes, const u16 *s
     constexpr int WSH = GROUP == 32 ? 2 : 3;  // 4-bit code words per group: 4 or 8
     for (int wd = threadIdx.x; wd < words; wd += blockDim.x) {
         if (BITS == 4) dequant_word<T>(row[wd], T::to_f32(srow[wd >> WSH]), T::to_f32(brow[wd >> WSH]), out + (size_t)l * H + (size_t)wd * 8);
-        else dequant_word8<T>(row[wd], T::to_f32(srow[wd >> 4]), T::to_f32(brow[wd >> 4]), out + (size_t)l * H + (size_t)wd * 4);
+        else dequant_word8<T>(row[wd], T::to_f32(srow[wd >> (WSH + 1)]), T::to_f32(brow[wd >> (WSH + 1)]), out + (size_t)l * H + (size_t)wd * 4);
     }
 }
 
@@ -205,6 +205,33 @@ __global__ void k_repack_w8s(const u32 *codes, const u16 *scales, const u16 *bia
     packed[idx] = out;
 }
 
+// MLX int8 g=32 triplet -> W8S32 (common.hpp): the W8S unit with two {scale | bias << 16} words per lane -- dwords [1024, 1152): lane l ->
+// 1024 + 2l (group 2g: code pieces 0, 1) and 1024 + 2l + 1 (group 2g + 1: pieces 2, 3).
+__global__ void k_repack_w8s32(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs, int ns,
+                               u32 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 1152;
+    if (idx >= total) return;
+    const size_t unit = idx / 1152;
+    const int dw = (int)(idx % 1152);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    const bool is_sb = dw >= 1024;
+    const int lane = is_sb ? (dw - 1024) >> 1 : (dw & 255) >> 2, j = is_sb ? (dw & 1) : dw >> 8, t = dw & 3;
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int g = 32 * s + (lane & 31), G = K >> 6;
+    u32 out = 0;
+    if (g < G && row >= 0 && row < N_src) {
+        if (is_sb) {
+            out = (u32)scales[(size_t)row * 2 * G + 2 * g + j] | ((u32)biases[(size_t)row * 2 * G + 2 * g + j] << 16);
+        } else {
+            const u32 src = codes[(size_t)row * (K >> 2) + 16 * g + 4 * j + t];
+            out = (src & 0xFF0000FFu) | ((src & 0x0000FF00u) << 8) | ((src & 0x00FF0000u) >> 8);
+        }
+    }
+    packed[idx] = out;
+}
+
 // Dense 16-bit weights [N_src, K] (nn.Linear) -> W16S.  One thread per 16-byte piece: unit (pair, slice), piece j, lane l:
 // row = row_map[2*pair + (l>>5)], elements 512*slice + 16*(l&31) + 8*j .. +8 (zero past K or for an unmapped row).
 __global__ void k_repack_w16s(const u16 *w, int N_src, int K, const int *row_map, int n_pairs, int ns, uint4 *packed) {
@@ -279,6 +306,7 @@ static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     if (a.fmt == FMT_W16S) return launch_f<T, FMT_W16S>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W8S) return launch_f<T, FMT_W8S>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W4S32) return launch_f<T, FMT_W4S32>(pro, epi, a, grid, lds, st);
+    if (a.fmt == FMT_W8S32) return launch_f<T, FMT_W8S32>(pro, epi, a, grid, lds, st);
     return launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
 }
 
@@ -296,7 +324,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
     PIE_REQUIRE(a.K <= 32768, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
-    PIE_REQUIRE(a.fmt == FMT_W4S || a.fmt == FMT_W16S || a.fmt == FMT_W8S || a.fmt == FMT_W4S32, PIE_E_ARG, "w4s_gemv: unknown weight format");
+    PIE_REQUIRE(a.fmt >= FMT_W4S && a.fmt <= FMT_W8S32, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
     // Every pointer the chosen prologue / epilogue dereferences, checked HERE so that a null can never reach a kernel (a dense
@@ -319,10 +347,10 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     a.n_slices = a.fmt == FMT_W16S ? w16s_slices(a.K) : w4s_slices(a.K);
     a.n_pairs = a.N / 2;
     a.n_waves = w4s_gemv_waves(a.N, a.K);
-    const size_t unit_bytes = a.fmt == FMT_W16S ? W16S_UNIT_BYTES : (a.fmt == FMT_W8S ? W8S_UNIT_BYTES : (a.fmt == FMT_W4S32 ? W4S32_UNIT_BYTES : W4S_UNIT_BYTES));
+    const size_t unit_bytes = fmt_unit_bytes(a.fmt);
     PIE_REQUIRE((size_t)a.n_pairs * a.n_slices * unit_bytes < ((size_t)1 << 32) - 8192, PIE_E_SHAPE,
                 "w4s_gemv: one matrix must stay below 4 GiB (32-bit buffer offsets)");
-    const unsigned lds = (unsigned)gemv_lds(a.K, a.fmt == FMT_W4S32).total;
+    const unsigned lds = (unsigned)gemv_lds(a.K, a.fmt == FMT_W4S32 || a.fmt == FMT_W8S32).total;
     PIE_REQUIRE(lds <= 65536u, PIE_E_SHAPE, "w4s_gemv: activation vector does not fit the 64 KB LDS image");
     dim3 grid((a.n_waves + GEMV_WAVES - 1) / GEMV_WAVES, M);
     a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs - a.full_rounds * a.n_waves;
@@ -559,9 +587,43 @@ int pie_qgemv_w4g32(const void *x, int M, const void *packed, int N, int K, cons
     return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
 }
 
-int pie_embedding_w4g32(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int dtype, void *out,
-                        void *stream) {
-    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, PIE_EMBED_W4G32);
+int pie_embedding_g32(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H, int bits, int dtype, void *out,
+                      void *stream) {
+    PIE_REQUIRE(bits == 4 || bits == 8, PIE_E_ARG, "pie_embedding_g32: bits must be 4 or 8");
+    return embedding_launch(ids, L, codes, scales, biases, V, H, dtype, out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, bits == 8 ? PIE_EMBED_W8G32 : PIE_EMBED_W4G32);
+}
+
+size_t pie_w8s32_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w4s_slices(K) * W8S32_UNIT_BYTES;
+}
+
+int pie_repack_w8g32(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream) {
+    PIE_REQUIRE(codes && scales && biases && packed, PIE_E_ARG, "pie_repack_w8g32: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_w8g32: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0 && K <= 32768, PIE_E_SHAPE, "pie_repack_w8g32: K must be a multiple of 64, at most 32768");
+    PIE_REQUIRE(pie_aligned(packed, 256), PIE_E_ALIGN, "pie_repack_w8g32: packed must be 256-byte aligned");
+    const int n_pairs = N_out / 2, ns = w4s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 1152;
+    hipLaunchKernelGGL(k_repack_w8s32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes, (const u16 *)scales,
+                       (const u16 *)biases, N_src, K, row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qgemv_w8g32(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w8g32: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w8g32: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w8g32: misaligned pointer");
+    GemvArgs a = {};
+    a.fmt = FMT_W8S32;
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
 }
 
 size_t pie_w16s_bytes(int N_out, int K) {
@@ -640,6 +702,12 @@ int embedding_launch(const int32_t *ids, int L, const uint32_t *codes, const voi
                            rope_cs, half);
     else if (dtype == PIE_F16 && bits == PIE_EMBED_W4G32)
         hipLaunchKernelGGL((k_embedding_w4g64<F16, 4, 32>), dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out, freqs, state,
+                           rope_cs, half);
+    else if (dtype == PIE_BF16 && bits == PIE_EMBED_W8G32)
+        hipLaunchKernelGGL((k_embedding_w4g64<BF16, 8, 32>), dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out, freqs, state,
+                           rope_cs, half);
+    else if (dtype == PIE_F16 && bits == PIE_EMBED_W8G32)
+        hipLaunchKernelGGL((k_embedding_w4g64<F16, 8, 32>), dim3(L), dim3(256), 0, st, ids, codes, (const u16 *)scales, (const u16 *)biases, V, H, (u16 *)out, freqs, state,
                            rope_cs, half);
     else if (dtype == PIE_BF16 && bits == 8) PIE_EMB(BF16, 8);
     else if (dtype == PIE_F16 && bits == 8) PIE_EMB(F16, 8);

@@ -185,6 +185,25 @@ __device__ __forceinline__ float w8s_unit_dot(const uint4 &c0, const uint4 &c1, 
     return (d[0] + d[2]) + (d[1] + d[3]);
 }
 
+// W8S32: code pieces (0, 1) and (2, 3) are two 32-wide groups.
+template <class T>
+__device__ __forceinline__ void w8s_unit_dot2(const uint4 &c0, const uint4 &c1, const uint4 &c2, const uint4 &c3, const u32 (&xr)[32], float &da, float &db) {
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const u32 w[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        d[(2 * i) & 3] = T::dot2(T::bytes2(w[i] & 0x00FF00FFu), xr[2 * i], d[(2 * i) & 3]);
+        d[(2 * i + 1) & 3] = T::dot2(T::bytes2((w[i] >> 8) & 0x00FF00FFu), xr[2 * i + 1], d[(2 * i + 1) & 3]);
+    }
+#pragma unroll
+    for (int i = 8; i < 16; ++i) {
+        e[(2 * i) & 3] = T::dot2(T::bytes2(w[i] & 0x00FF00FFu), xr[2 * i], e[(2 * i) & 3]);
+        e[(2 * i + 1) & 3] = T::dot2(T::bytes2((w[i] >> 8) & 0x00FF00FFu), xr[2 * i + 1], e[(2 * i + 1) & 3]);
+    }
+    da = (d[0] + d[2]) + (d[1] + d[3]);
+    db = (e[0] + e[2]) + (e[1] + e[3]);
+}
+
 // 8 packed activations times the trait's exact power-of-two pre-scale (identity for f16)
 template <class T>
 __device__ __forceinline__ uint4 scale8(const uint4 &v) {
@@ -252,14 +271,16 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
 #endif
     GEMV_STAMP(0);
     constexpr int D = GEMV_DEPTH;
-    constexpr int UB = FMT == FMT_W16S ? W16S_UNIT_BYTES : (FMT == FMT_W8S ? W8S_UNIT_BYTES : (FMT == FMT_W4S32 ? W4S32_UNIT_BYTES : W4S_UNIT_BYTES));
+    constexpr int UB = fmt_unit_bytes(FMT);
+    constexpr bool G32 = FMT == FMT_W4S32 || FMT == FMT_W8S32;  // two 32-wide groups per lane
+    constexpr bool W8 = FMT == FMT_W8S || FMT == FMT_W8S32;      // byte codes: four pieces per lane
     constexpr int NT = GEMV_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ns = a.n_slices;
     const int m = blockIdx.y;
-    const GemvLds L = gemv_lds(a.K, FMT == FMT_W4S32);
+    const GemvLds L = gemv_lds(a.K, FMT == FMT_W4S32 || FMT == FMT_W8S32);
     float *sxs = reinterpret_cast<float *>(smem + L.off_sx);
     float *red = reinterpret_cast<float *>(smem + L.off_red);
     float *outp = reinterpret_cast<float *>(smem + L.off_out) + wave * (2 * GEMV_MAX_RUN);  // this wave's row sums
@@ -356,9 +377,9 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
     uint4 c0[D], c1[D];
-    uint4 c2[FMT == FMT_W8S ? D : 1], c3[FMT == FMT_W8S ? D : 1];  // W8S: a lane's 64 codes are four pieces
+    uint4 c2[W8 ? D : 1], c3[W8 ? D : 1];  // W8S: a lane's 64 codes are four pieces
     u32 sb[D];
-    u32 sb2[FMT == FMT_W4S32 ? D : 1];  // W4S32: the second 32-wide group's {scale | bias << 16}
+    u32 sb2[G32 ? D : 1];  // W4S32 / W8S32: the second 32-wide group's {scale | bias << 16}
     // Weight loads go through a buffer descriptor over the whole matrix: a ring slot that has no unit left to fetch is
     // given an out-of-range offset, which the hardware bounds check drops (no memory traffic, no branch around a load).
     // (Clamping to the last unit instead cost up to D redundant loads per wave: 70 % extra at 7-unit runs.)
@@ -397,12 +418,17 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrsrc, off + 2048 - lane * 8, 0, AUX);
                 sb[d] = v.x, sb2[d] = v.y;
             }
-            if (FMT == FMT_W8S) {
+            if (W8) {
                 const u32x4_t v2 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 2048, 0, AUX);
                 const u32x4_t v3 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 3072, 0, AUX);
                 c2[d] = make_uint4(v2.x, v2.y, v2.z, v2.w);
                 c3[d] = make_uint4(v3.x, v3.y, v3.z, v3.w);
-                sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 4096 - lane * 12, 0, AUX);
+                if (FMT == FMT_W8S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 4096 - lane * 12, 0, AUX);
+                if (FMT == FMT_W8S32) {
+                    typedef __attribute__((ext_vector_type(2))) u32 u32x2_t;
+                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrsrc, off + 4096 - lane * 8, 0, AUX);
+                    sb[d] = v.x, sb2[d] = v.y;
+                }
             }
         }
     };
@@ -494,13 +520,13 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             float ps = ok ? sum8<T>(xv[i]) : 0.0f;
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-            if (FMT == FMT_W4S32) {  // one sum per 32-wide group: lanes 4k .. 4k+3 (all hold it after the two quad steps)
+            if (G32) {  // one sum per 32-wide group: lanes 4k .. 4k+3 (all hold it after the two quad steps)
                 if (ok && (j & 3) == 0) sxs[j >> 2] = ps;
             }
             ps += __builtin_amdgcn_update_dpp(0.0f, ps, 0x141, 0xF, 0xF, true);  // row_half_mirror: 8-lane sums
             if (ok) {
                 *reinterpret_cast<uint4 *>(smem + ((size_t)(j & 7) * L.stride + (j >> 3)) * 16) = FMT != FMT_W16S ? scale8<T>(xv[i]) : xv[i];
-                if (FMT != FMT_W4S32 && (j & 7) == 0) sxs[j >> 3] = ps;
+                if (!G32 && (j & 7) == 0) sxs[j >> 3] = ps;
             }
         }
         __syncthreads();
@@ -552,9 +578,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                                               : *reinterpret_cast<const uint4 *>(smem + ((size_t)r * L.stride + gc) * 16);
                     xr[4 * r + 0] = v.x, xr[4 * r + 1] = v.y, xr[4 * r + 2] = v.z, xr[4 * r + 3] = v.w;
                 }
-                if constexpr (FMT == FMT_W4S32) {
+                if constexpr (G32) {
                     float da, db;
-                    w4s_unit_dot2<T>(c0[d], c1[d], xr, da, db);
+                    if constexpr (FMT == FMT_W8S32) w8s_unit_dot2<T>(c0[d], c1[d], c2[d], c3[d], xr, da, db);
+                    else w4s_unit_dot2<T>(c0[d], c1[d], xr, da, db);
                     const float2 sx2 = *reinterpret_cast<const float2 *>(sxs + 2 * gc);
                     const float pa = fmaf(lo_f32<T>(sb[d]), da * T::DSCALE - T::OFFSET * sx2.x, hi_f32<T>(sb[d]) * sx2.x);
                     const float pb = fmaf(lo_f32<T>(sb2[d]), db * T::DSCALE - T::OFFSET * sx2.y, hi_f32<T>(sb2[d]) * sx2.y);

@@ -97,23 +97,34 @@ class W4S32Weight:
         return self.packed.numel()
 
 
-def repack_w4s32(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W4S32Weight:
-    """Load-time repack of an MLX 4-bit group-32 triplet (weight [N_src, K/8], scales / biases [N_src, K/32]) into W4S32; row_map as for repack_w4s."""
+@dataclass
+class W8S32Weight(W4S32Weight):
+    """One MLX int8 group-32 Linear in the W8S32 streaming layout (include/pie_hip.h)."""
+
+
+def repack_w4s32(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None, bits: int = 4) -> W4S32Weight:
+    """Load-time repack of an MLX 4-bit (bits=8: 8-bit) group-32 triplet (weight [N_src, K*bits/32], scales / biases [N_src, K/32]) into W4S32
+    (W8S32); row_map as for repack_w4s."""
     for t in (codes, scales, biases):
         _dev(t)
-    N_src, K = codes.shape[0], codes.shape[1] * 8
+    N_src, K = codes.shape[0], codes.shape[1] * 32 // bits
     if tuple(scales.shape) != (N_src, K // 32) or tuple(biases.shape) != (N_src, K // 32):
         raise ValueError(f"group-32 scales / biases must be [{N_src}, {K // 32}], got {tuple(scales.shape)} / {tuple(biases.shape)}")
     N_out = N_src if row_map is None else int(row_map.numel())
-    nbytes = _ffi.load().pie_w4s32_bytes(N_out, K)
+    lib = _ffi.load()
+    nbytes = (lib.pie_w8s32_bytes if bits == 8 else lib.pie_w4s32_bytes)(N_out, K)
     if nbytes == 0:
-        raise ValueError(f"unsupported shape for W4S32: N={N_out} (must be even), K={K} (multiple of 64)")
+        raise ValueError(f"unsupported shape for W4S32 / W8S32: N={N_out} (must be even), K={K} (multiple of 64)")
     packed = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
     if row_map is not None:
         row_map = row_map.to(device=codes.device, dtype=torch.int32).contiguous()
-    _ffi.check(_ffi.load().pie_repack_w4g32(_ffi.p(codes.contiguous()), _ffi.p(scales.contiguous()), _ffi.p(biases.contiguous()), N_src, K, _ffi.p(row_map), N_out,
-                                            _ffi.p(packed), _ffi.stream()))
-    return W4S32Weight(packed, N_out, K, scales.dtype, lin_bias)
+    _ffi.check((lib.pie_repack_w8g32 if bits == 8 else lib.pie_repack_w4g32)(_ffi.p(codes.contiguous()), _ffi.p(scales.contiguous()), _ffi.p(biases.contiguous()), N_src, K,
+                                                                            _ffi.p(row_map), N_out, _ffi.p(packed), _ffi.stream()))
+    return (W8S32Weight if bits == 8 else W4S32Weight)(packed, N_out, K, scales.dtype, lin_bias)
+
+
+def repack_w8s32(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8S32Weight:
+    return repack_w4s32(codes, scales, biases, row_map=row_map, lin_bias=lin_bias, bits=8)
 
 
 def repack_w8s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8SWeight:
@@ -212,7 +223,7 @@ def embedding_dense(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", transpose: bool = True, group_size: int | None = None, bits: int | None = None):
     """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64|32, bits=4|8) on a W4S / W8S / W4S32 weight:
     x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""
-    w_bits = 8 if isinstance(w, W8SWeight) else 4
+    w_bits = 8 if isinstance(w, (W8SWeight, W8S32Weight)) else 4
     w_group = 32 if isinstance(w, W4S32Weight) else 64
     if not transpose or (group_size is not None and group_size != w_group) or (bits is not None and bits != w_bits):
         raise ValueError("only transpose=True with the weight's own group size and bit width is implemented (the nn.QuantizedLinear form)")
@@ -222,7 +233,7 @@ def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", 
     M = x.numel() // w.K
     y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
     lib = _ffi.load()
-    fn = lib.pie_qgemv_w4g32 if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
+    fn = (lib.pie_qgemv_w8g32 if w_bits == 8 else lib.pie_qgemv_w4g32) if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
     _ffi.check(fn(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y), _ffi.dtype_code(x.dtype), _ffi.stream()))
     return y
 
@@ -246,10 +257,8 @@ def embedding(ids: torch.Tensor, codes, scales, biases, bits: int = 4, group_siz
     V, H = codes.shape[0], codes.shape[1] * 32 // bits
     out = torch.empty((ids.numel(), H), dtype=scales.dtype, device=codes.device)
     if group_size == 32:
-        if bits != 4:
-            raise ValueError("group_size 32 is implemented for 4-bit codes")
-        _ffi.check(_ffi.load().pie_embedding_w4g32(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H,
-                                                   _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
+        _ffi.check(_ffi.load().pie_embedding_g32(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H, bits,
+                                                 _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))
         return out
     _ffi.check(_ffi.load().pie_embedding_g64(_ffi.p(ids), ids.numel(), _ffi.p(codes), _ffi.p(scales), _ffi.p(biases), V, H, bits,
                                              _ffi.dtype_code(scales.dtype), _ffi.p(out), _ffi.stream()))

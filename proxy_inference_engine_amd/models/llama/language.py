@@ -128,15 +128,13 @@ class Model:
         device = _ffi.require_gpu()
         q = args.quantization or {}
         self.dense = not q  # no "quantization" entry: nn.Linear / nn.Embedding with 16-bit weights (models/utils.py:96-97)
-        if q and (q.get("group_size") not in (32, 64, 128) or q.get("bits") not in (2, 3, 4, 6, 8) or (q.get("group_size") == 32 and q.get("bits") in (6, 8))):
+        if q and (q.get("group_size") not in (32, 64, 128) or q.get("bits") not in (2, 3, 4, 6, 8)):
             # nn.quantize(model, **config["quantization"]) takes any group_size in {32, 64, 128} and bits in {2, 3, 4, 6, 8}
-            # (models/utils.py:96-111).  Served: 64-wide groups (the W4S / W8S streaming units: one group per lane), 128-wide groups (below: every
-            # group's scale / bias serves both of its 64-wide halves), 32-wide groups of 2- / 3- / 4-bit codes (W4S32 units: two scale / bias
-            # pairs per lane); 2- / 3-bit codes ride the 4-bit units and 6-bit codes the 8-bit units (below: a narrower code is a code).
-            # Not served: 32-wide groups of 6- / 8-bit codes.
-            raise ValueError(f"config['quantization'] = {dict(q)}: the MI355X path streams group_size 32 (bits 2, 3, 4), 64 or 128 (bits 2, 3, 4, 6, 8) "
-                             f"(got group_size={q.get('group_size')}, bits={q.get('bits')}); re-quantise the checkpoint with "
-                             "mlx_lm.convert -q --q-group-size 64 --q-bits 4")
+            # (models/utils.py:96-111): all fifteen are served.  64-wide groups are the W4S / W8S streaming units (one group per lane), 128-wide
+            # groups write every scale / bias to both of their 64-wide halves (below), 32-wide groups are the W4S32 / W8S32 units (two scale /
+            # bias pairs per lane); 2- / 3-bit codes ride the 4-bit units and 6-bit codes the 8-bit units (below: a narrower code is a code).
+            raise ValueError(f"config['quantization'] = {dict(q)}: mx.quantize knows group_size 32, 64, 128 and bits 2, 3, 4, 6, 8 "
+                             f"(got group_size={q.get('group_size')}, bits={q.get('bits')})")
         self.checkpoint_bits = int(q["bits"]) if q else 16
         if q and self.checkpoint_bits in (2, 3, 6):
             # Same weights, wider container: 2- and 3-bit codes are stored as 4-bit codes, 6-bit codes as bytes, scales and biases unchanged --
@@ -185,7 +183,8 @@ class Model:
         gu_map = hip_ops.gateup_row_map(I).to(device)
 
         g32 = self.group_size == 32
-        fmt_code = {False: 2, True: (4 if g32 else (3 if self.bits == 8 else 1))}  # pie_layer_weights.fmt_*: PIE_W_* + 1 (dense 1 -> 2, int4 0 -> 1, int8 2 -> 3, int4 g=32 3 -> 4)
+        wfmt = (4 if self.bits == 8 else 3) if g32 else (2 if self.bits == 8 else 0)  # PIE_W_INT8_G32 / INT4_G32 / INT8_G64 / INT4_G64
+        fmt_code = {False: 2, True: wfmt + 1}  # pie_layer_weights.fmt_*: PIE_W_* + 1 (0 = the decoder's default format)
         self.mixed = False  # some module is dense although config["quantization"] is set (per-module predicate, models/utils.py:99-109)
 
         def quantized(names: list[str]) -> bool:
@@ -201,7 +200,9 @@ class Model:
                 ws = [_dense(weights, n, self.dtype) for n in names]
                 return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map), fmt_code[False]
             trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
-            return (hip_ops.repack_w4s32 if g32 else (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s))(*trip, row_map=row_map), fmt_code[True]
+            if g32:
+                return hip_ops.repack_w4s32(*trip, row_map=row_map, bits=self.bits), fmt_code[True]
+            return (hip_ops.repack_w8s if self.bits == 8 else hip_ops.repack_w4s)(*trip, row_map=row_map), fmt_code[True]
 
         def bias(names: list[str], row_map=None):
             """The (concatenated) Linear biases of `names` in the packed row order of the matching matrix; a Linear without a
@@ -249,7 +250,7 @@ class Model:
         lib = _ffi.load()
         cfg = _ffi.pie_decoder_config(_ffi.dtype_code(self.dtype), H, args.num_hidden_layers, self.n_heads, self.n_kv_heads,
                                       self.head_dim, I, V, float(args.rms_norm_eps), int(args.tie_word_embeddings), int(kv_splits),
-                                      1 if self.dense else (3 if g32 else (2 if self.bits == 8 else 0)), int(bool(args.rope_traditional)),
+                                      1 if self.dense else wfmt, int(bool(args.rope_traditional)),
                                       tp.rank if tp is not None else 0, tp.world if tp is not None else 0)
         self._dec = C.c_void_p()
         _ffi.check(lib.pie_decoder_create(C.byref(cfg), C.byref(self._dec)))

@@ -887,7 +887,7 @@ def test_group_size_128_checkpoint_vs_oracle():
         tok = int(np.argmax(w1))
 
 
-@pytest.mark.parametrize("bits,group", [(2, 64), (3, 64), (6, 64), (3, 128), (6, 128), (4, 32), (3, 32), (2, 32)])
+@pytest.mark.parametrize("bits,group", [(2, 64), (3, 64), (6, 64), (3, 128), (6, 128), (4, 32), (3, 32), (2, 32), (8, 32), (6, 32)])
 def test_narrow_code_and_group_32_checkpoints_vs_oracle(bits, group):
     """config["quantization"]["bits"] in {2, 3, 6} (nn.quantize forwards it unchanged, models/utils.py:96-111): 2-bit codes sixteen to a word,
     3- and 6-bit codes in MLX's byte-packed bit stream.  The loader re-packs the codes into the 4- / 8-bit streaming units without touching a
@@ -899,7 +899,7 @@ def test_narrow_code_and_group_32_checkpoints_vs_oracle(bits, group):
     w = po.synth_checkpoint(cfg, seed=50 + bits, dtype=DT, lm_head_gain=4.0)
     assert w["model.layers.0.mlp.down_proj.weight"].shape == (256, 768 * bits // 32)
     model = build(cfg, w)
-    assert model.checkpoint_bits == bits and model.bits == (8 if bits == 6 else 4) and model.group_size == group
+    assert model.checkpoint_bits == bits and model.bits == (8 if bits in (6, 8) else 4) and model.group_size == group
     if group == 32:
         assert w["model.layers.0.mlp.down_proj.scales"].shape == (256, 768 // 32)
     orc = po.OracleLlama(cfg, w, DT)
@@ -930,8 +930,8 @@ def test_tied_embeddings_and_errors(tiny):
     assert_vec_close(logits.float().cpu().numpy(), want, DT, what="tied lm_head")
     with pytest.raises(ValueError):
         build(dict(cfg, quantization=None), w)                          # config says dense, checkpoint holds int4 triplets
-    with pytest.raises(ValueError, match="group_size=32, bits=8"):
-        build(dict(cfg, quantization={"group_size": 32, "bits": 8}), w)  # 32-wide groups of 6- / 8-bit codes are not on this path
+    with pytest.raises(ValueError, match="group_size=16"):
+        build(dict(cfg, quantization={"group_size": 16, "bits": 4}), w)  # not a group size mx.quantize knows
     with pytest.raises(ValueError, match="bits=5"):
         build(dict(cfg, quantization={"group_size": 64, "bits": 5}), w)
     # the reference decides per module ("{path}.scales" in weights, models/utils.py:99-109); Linears this build streams as ONE packed

@@ -246,31 +246,32 @@ def test_int8_g64_quantize_gemv_embedding_vs_oracle(ops, dt):
             assert np.array_equal(to_bits(rows), to_bits(deq[[1, N - 1, 7]]))
 
 
+@pytest.mark.parametrize("bits", [4, 8])
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
-def test_int4_g32_gemv_embedding_vs_oracle(ops, dt):
-    """MLX 4-bit group-32 triplets (config "quantization": {"group_size": 32}): the W4S32 streaming GEMV (two scale / bias pairs per lane, one
-    per 16-byte code piece) against orc_quantized_matmul_t with 32-wide groups -- few and many row pairs, a ragged last K slice (3072), 1-3
-    rows, a Linear bias and a row map; the embedding gather is exact."""
-    rng = np.random.default_rng(132)
+def test_g32_gemv_embedding_vs_oracle(ops, dt, bits):
+    """MLX group-32 triplets (config "quantization": {"group_size": 32}): the W4S32 / W8S32 streaming GEMV (two scale / bias pairs per lane, one
+    per 32-wide half of its codes) against orc_quantized_matmul_t with 32-wide groups -- few and many row pairs, a ragged last K slice (3072),
+    1-3 rows, a Linear bias and a row map; the embedding gather is exact."""
+    rng = np.random.default_rng(132 + bits)
     for N, K, M in ((96, 256, 2), (4096, 4096, 1), (130, 704, 3), (1024, 3072, 1), (64, 14336, 2)):
         w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
         x = po.round_T(rng.standard_normal((M, K)), dt)
-        wq, sc, bi = po.quantize(w, 32, 4, dt)
+        wq, sc, bi = po.quantize(w, 32, bits, dt)
         assert sc.shape == (N, K // 32)
         codes, scales, biases = codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt)
         lin_bias = po.round_T(rng.standard_normal(N) * 0.1, dt) if N == 130 else None
-        want = po.quantized_matmul(x, wq, sc, bi, group_size=32, bits=4, dtype=dt, lin_bias=None if lin_bias is None else po.to_bits(lin_bias, dt))
-        wt = ops.repack_w4s32(codes, scales, biases, lin_bias=None if lin_bias is None else to_dev(po.to_bits(lin_bias, dt), dt))
-        assert wt.nbytes == (N // 2) * ((K + 2047) // 2048) * 2560
-        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt, group_size=32)
-        assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"int4 g=32 gemv {N}x{K} M={M} {dt}")
+        want = po.quantized_matmul(x, wq, sc, bi, group_size=32, bits=bits, dtype=dt, lin_bias=None if lin_bias is None else po.to_bits(lin_bias, dt))
+        wt = ops.repack_w4s32(codes, scales, biases, lin_bias=None if lin_bias is None else to_dev(po.to_bits(lin_bias, dt), dt), bits=bits)
+        assert wt.nbytes == (N // 2) * ((K + 2047) // 2048) * (2560 if bits == 4 else 4608)
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt, group_size=32, bits=bits)
+        assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"int{bits} g=32 gemv {N}x{K} M={M} {dt}")
         if N == 96:
             perm = torch.from_numpy(rng.permutation(N).astype(np.int32))
-            got_p = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), ops.repack_w4s32(codes, scales, biases, row_map=perm))
+            got_p = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), ops.repack_w4s32(codes, scales, biases, row_map=perm, bits=bits))
             assert torch.equal(got_p, got[:, perm.long().cuda()])
             ids = torch.tensor([1, N - 1, 7], dtype=torch.int32, device="cuda")
-            rows = ops.embedding(ids, codes, scales, biases, bits=4, group_size=32)
-            assert np.array_equal(to_bits(rows), po.to_bits(po.dequantize(wq, sc, bi, 32, 4, dt), dt)[[1, N - 1, 7]])
+            rows = ops.embedding(ids, codes, scales, biases, bits=bits, group_size=32)
+            assert np.array_equal(to_bits(rows), po.to_bits(po.dequantize(wq, sc, bi, 32, bits, dt), dt)[[1, N - 1, 7]])
 
 
 def test_gemv_random_shape_sweep_all_formats(ops):
