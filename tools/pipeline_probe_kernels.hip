@@ -1,0 +1,132 @@
+// tools/pipeline_probe_kernels.hip -- device side of tools/pipeline_probe.cpp (developer tool): built to a code object with
+//   hipcc --offload-device-only --no-gpu-bundle-output --offload-arch=gfx950 -O3 tools/pipeline_probe_kernels.hip -o tools/pipeline_probe_kernels.hsaco
+// No blockDim / gridDim (they live in the hidden kernel arguments, which the probe does not fill).
+#include <hip/hip_runtime.h>
+
+struct StageArgs {
+    const uint4 *w;               // this stage's "weights"
+    unsigned long long n16;       // 16-byte pieces of the stream
+    unsigned *counters;           // [n_stages] completion counters, monotonic over the repetitions
+    const unsigned *xin;          // the producer's output vector [4096]
+    unsigned *xout;               // this stage's output vector [4096]
+    unsigned *errors;             // [0] spin timeouts
+    unsigned idx, target;         // stage number; counters[idx - 1] value that means "the producer is complete"
+    unsigned mode;                // bit0: wait on the producer's counter (dispatched WITHOUT the barrier bit); bit1: x moves with agent-scope
+                                  // (sc1) accesses; bit2: the counter increment is a release; bit3: acquire fence after the wait
+    unsigned salt, n_wg, per_wg;  // per_wg = 4096 / n_wg words of xout per workgroup
+    unsigned *flags;              // [n_stages][256] per-workgroup completion flags (mode bit 512: instead of the counter)
+    unsigned prod_wgs, epoch;     // the producer's workgroups; the value its flags take in this repetition
+    const unsigned long long *xin64;  // mode bit 1024: the vector as {epoch << 32 | value} granules -- the data is its own flag, nothing else is polled
+    unsigned long long *xout64;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+extern "C" __global__ void __launch_bounds__(512) k_stage(const StageArgs a) {
+    __shared__ unsigned red[8];
+    const unsigned long long stride = (unsigned long long)a.n_wg * 512ull;
+    unsigned long long i = (unsigned long long)blockIdx.x * 512ull + threadIdx.x;
+    // loads go through a buffer descriptor over the stage's bytes: a slot with nothing left to fetch gets an out-of-range offset, which the
+    // hardware bounds check drops (clamping to the last piece instead made 2048 waves hammer one address: +10 us per stage)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(a.w), 0, (int)(a.n16 * 16ull), 0x00020000);
+    auto ld = [&](unsigned long long j) { return __builtin_amdgcn_raw_buffer_load_b128(rs, j < a.n16 ? (unsigned)(j * 16ull) : 0xFFFFF000u, 0, 2); };
+    // 1. the head of the (input-independent) stream: four pieces per thread in flight before anything else
+    u32x4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = (a.mode & 64u) ? u32x4{0, 0, 0, 0} : ld(i + u * stride);  // (ablation bit 64: no head loads)
+    // 2. wait for the producer (all of its workgroups), bounded
+    if (a.mode & 1024u) {
+    } else if ((a.mode & 513u) == 513u && a.idx > 0u) {
+        // one flag per producer workgroup, one polling thread per flag: no atomic traffic, no serialised increments
+        if (threadIdx.x < a.prod_wgs) {
+            const unsigned *f = a.flags + (a.idx - 1) * 256u + threadIdx.x;
+            int polls = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1 << 13)) {
+                    atomicAdd(a.errors, 1u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    } else if ((a.mode & 1u) && a.idx > 0u) {
+        if (threadIdx.x == 0) {
+            int polls = 0;
+            while (__hip_atomic_load(a.counters + a.idx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1 << 13)) {
+                    atomicAdd(a.errors, 1u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (a.mode & 8u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // 3. the producer's vector: every workgroup reads all of it (a GEMV's activation staging), reduced over the workgroup
+    unsigned v[8] = {1, 2, 3, 4, 5, 6, 7, 8}, acc = 0;
+    if (a.mode & 1024u) {  // every granule carries the epoch of its writer: re-read until all eight of this thread's are current
+        bool all = false;
+        for (int polls = 0; !all; ++polls) {
+            unsigned long long g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = __hip_atomic_load(a.xin64 + threadIdx.x + 512u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            all = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) all = all && (unsigned)(g[k] >> 32) == a.epoch, v[k] = (unsigned)g[k];
+            if (!all) {
+                __builtin_amdgcn_s_sleep(1);
+                if (polls > (1 << 13)) {
+                    atomicAdd(a.errors, 1u);
+                    break;
+                }
+            }
+        }
+    } else
+    if (!(a.mode & 16u))  // (ablation: no read of the vector)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned *q = a.xin + threadIdx.x + 512u * k;
+        v[k] = (a.mode & 2u) ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k] * (2u * (threadIdx.x + 512u * k) + 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = acc;
+    if (!(a.mode & 256u)) __syncthreads();  // (ablation bit 256: no reduction barrier)
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += red[k];
+    // 4. the stream: a ring of four pieces per thread, each slot re-issued as soon as it is consumed (slots past the end fetch nothing)
+    unsigned x = 0;
+    for (unsigned long long cur = i; cur < ((a.mode & 32u) ? 0ull : a.n16); cur += 4 * stride) {  // (ablation bit 32: no stream)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x ^= p[u].x ^ p[u].y ^ p[u].z ^ p[u].w;
+            p[u] = ld(cur + (4 + u) * stride);
+        }
+    }
+    // 5. publish this workgroup's share of the output vector (the stream's checksum keeps the loads alive; it is zero-weighted)
+    if (threadIdx.x < a.per_wg && (a.mode & 1024u)) {
+        const unsigned idx = blockIdx.x * a.per_wg + threadIdx.x;
+        const unsigned own = (unsigned)__hip_atomic_load(a.xin64 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // current: this thread's poll covered the whole vector's epoch only for ITS words, the barrier below the reduction for the rest
+        const unsigned r = tot * 1664525u + own + a.salt + threadIdx.x + (x == 0x9e3779b9u ? 1u : 0u);
+        __hip_atomic_store(a.xout64 + idx, ((unsigned long long)a.target << 32) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x < a.per_wg && !(a.mode & 128u)) {  // (ablation bit 128: no publish)
+        const unsigned idx = blockIdx.x * a.per_wg + threadIdx.x;
+        const unsigned own = (a.mode & 2u) ? __hip_atomic_load(a.xin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.xin[idx];
+        const unsigned r = tot * 1664525u + own + a.salt + threadIdx.x + (x == 0x9e3779b9u ? 1u : 0u);
+        if (a.mode & 2u) __hip_atomic_store(a.xout + idx, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.xout[idx] = r;
+    }
+    if ((a.mode & 1u) && !(a.mode & 1024u)) {
+        __syncthreads();  // s_waitcnt vmcnt(0) in front of the barrier: this workgroup's stores have been acknowledged
+        if (threadIdx.x == 0 && (a.mode & 512u)) __hip_atomic_store(a.flags + a.idx * 256u + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (threadIdx.x == 0) {
+            if (a.mode & 4u) __hip_atomic_fetch_add(a.counters + a.idx, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(a.counters + a.idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
