@@ -53,6 +53,10 @@ def shard_config(config: dict, world: int) -> dict:
 
 def shard_checkpoint(weights: dict, config: dict, rank: int, world: int) -> tuple[dict, dict]:
     """Returns (this rank's checkpoint in the same key layout, the local config)."""
+    q = config.get("quantization") or {}
+    if q.get("group_size", GROUP) != GROUP or q.get("bits", 4) != 4:
+        raise ValueError(f"tensor-parallel sharding is written for int4 group-{GROUP} checkpoints (the K split of o_proj / down_proj slices "
+                         f"code words and groups); got quantization = {dict(q)}")
     local = shard_config(config, world)
     nh = config["num_attention_heads"]
     nkv = config.get("num_key_value_heads") or nh
