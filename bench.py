@@ -57,6 +57,7 @@ def parse():
                     "(BASELINE.json configs[4] with --model 70b); strong scaling, value = that sequence's tokens/s")
     ap.add_argument("--tp-backend", choices=["ipc", "rccl"], default="ipc", help="--tp: the communicator behind the fused step's collectives: the one-shot all-reduce over "
                     "IPC-mapped peer memory (default) or RCCL (ncclAllReduce on the launch stream): the comparator for the first run on a real node")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="developer: one of the library's test / tuning switches (_ffi.KNOBS) for this run")
     ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
@@ -162,6 +163,10 @@ def main():
     from proxy_inference_engine_amd.models.llama import Model, ModelArgs
     from proxy_inference_engine_amd.models.utils import LLAMA3_8B, LLAMA3_70B, LLAMA32_3B, QWEN2VL_7B_TEXT, synthetic_checkpoint
 
+    for kv in args.knob:
+        from proxy_inference_engine_amd import _ffi as _knob_ffi
+        name, _, value = kv.partition("=")
+        _knob_ffi.set_knob(name, int(value))
     cfg = dict({"70b": LLAMA3_70B, "qv": QWEN2VL_7B_TEXT, "3b": LLAMA32_3B}.get(args.model, LLAMA3_8B))
     if args.layers:
         cfg["num_hidden_layers"] = args.layers

@@ -55,7 +55,8 @@ enum {
     PIE_KNOB_W4M_MULTI = 7,          /* 0: one strip per workgroup also for the wide matrices (bit-equal) */
     PIE_KNOB_PREFILL_QT = 8,         /* 1 / 2: one / two 32-row query tiles per prompt-attention workgroup */
     PIE_KNOB_ATTN_MERGE_MAX_CAP = 9, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
-    PIE_KNOB_COUNT = 10
+    PIE_KNOB_ATTN_WARM_MAX_MB = 10,  /* the attention launch's idle CUs warm the Infinity Cache with at most this many MB of o_proj's weights; 0 = off (read per step enqueue / graph capture) */
+    PIE_KNOB_COUNT = 11
 };
 #define PIE_KNOB_DEFAULT (-1)
 int pie_set_knob(int knob, int value);

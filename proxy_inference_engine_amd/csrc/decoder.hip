@@ -26,7 +26,7 @@ constexpr int PROF_QKV = 16, PROF_O = 20, PROF_GU = 24, PROF_DOWN = 28;
 #endif
 }
 namespace {
-int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 }
 int pie_knob(int knob) { return knob >= 0 && knob < PIE_KNOB_COUNT ? g_knobs[knob] : PIE_KNOB_DEFAULT; }
 namespace pie {
@@ -78,6 +78,10 @@ static void drop_graphs(pie_decoder *d) {
         }
 }
 
+// The attention launch's idle CUs warm at most this much of o_proj's stream: 9.4 MB (the 8B int4 matrix, all of it) is what the launch's ~5 us
+// can carry; uncapped, the 33.5 MB of the dense 8B o_proj stretched the launch itself: dense 2.81 -> 3.00 ms per step, int8 (17.8 MB) 1.74 -> 1.81
+// (cap 10: 2.81 / 1.75; off: 2.81 / 1.74; int4: 1.186-1.191 with, 1.190 without)
+constexpr int ATTN_WARM_DEFAULT_MB = 10;
 // One launch of the step's sequence (PIE_K_* of include/pie_hip.h); `li` is the layer for per-layer kernels.
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st, bool embed_here) {
     const pie_decoder_config &c = d->cfg;
@@ -140,6 +144,9 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
                 if (a.pf_rows < 0) a.pf_rows = 0;
                 a.pf_ptr = (const char *)w.wo, a.pf_sink = d->pf_sink;
                 a.pf_bytes = f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : (f == PIE_W_INT4_G32 ? pie_w4s32_bytes(H, QD) : (f == PIE_W_INT8_G32 ? pie_w8s32_bytes(H, QD) : pie_w4s_bytes(H, QD))));
+                const int cap_mb = pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) >= 0 ? pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) : ATTN_WARM_DEFAULT_MB;
+                if (a.pf_bytes > (unsigned long long)cap_mb << 20) a.pf_bytes = (unsigned long long)cap_mb << 20;
+                if (!a.pf_bytes) a.pf_rows = 0;
             }
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
