@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
     // kernel arguments in DEVICE memory (written through a staging copy): from the host kernarg pool every wave's scalar loads cross PCIe
     // and an EMPTY 256-workgroup kernel took 15-24 us
     char *kargs, *kargs_dev;
-    const size_t karg_stride = 256;
+    const size_t karg_stride = 512;
     const bool dev_kargs = !(argc > 3 && atoi(argv[3]) == 0);
     HK(hsa_amd_memory_pool_allocate(g_karg_pool, karg_stride * (size_t)(N + 1), 0, (void **)&kargs));
     HK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, kargs));
@@ -189,6 +189,7 @@ int main(int argc, char **argv) {
         const char *name;
         int barrier, fences;
         unsigned mode;
+        const char *kernel = nullptr;  // another (empty) kernel instead of k_stage
     };
     const Case cases[] = {
         {"serial: barrier bit, agent fences, plain accesses            ", 1, 1, 0u},
@@ -207,9 +208,15 @@ int main(int argc, char **argv) {
         {"serial, ablation: neither, no head loads                     ", 1, 1, 48u | 64u},
         {"serial, ablation: neither, no head loads, no publish         ", 1, 1, 48u | 64u | 128u},
         {"serial, ablation: ... and no barrier (an empty kernel)       ", 1, 1, 48u | 64u | 128u | 256u},
+        {"empty kernel, 8-byte arguments, no LDS                       ", 1, 1, 16u | 128u, "k_empty_ptr"},
+        {"empty kernel, 88-byte arguments, no LDS                      ", 1, 1, 16u | 128u, "k_empty_args88"},
+        {"empty kernel, 88-byte arguments, 32 B of LDS                 ", 1, 1, 16u | 128u, "k_empty_args88_lds"},
+        {"empty kernel, 280-byte arguments, no LDS                     ", 1, 1, 16u | 128u, "k_empty_args280"},
+        {"empty kernel, 280-byte arguments, 40 KB of LDS               ", 1, 1, 16u | 128u, "k_empty_args280_lds40k"},
     };
     unsigned epoch = 0, flag_epoch = 0, tag_epoch = 1;  // completed repetitions with the counters / the flags in use (both are monotonic)
     for (const Case &c : cases) {
+        const Kernel kc = c.kernel ? get_kernel(exe, c.kernel) : k;
         double best = 1e30, sum = 0.0, dev_best = 1e30, dev_sum = 0.0;
         int bad_runs = 0;
         const int REPS = 9;
@@ -242,8 +249,8 @@ int main(int argc, char **argv) {
                 hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)q->base_address + ((base + (uint64_t)i) & (q->size - 1));
                 p->workgroup_size_x = 512, p->workgroup_size_y = 1, p->workgroup_size_z = 1;
                 p->grid_size_x = stages[i].wgs * 512u, p->grid_size_y = 1, p->grid_size_z = 1;
-                p->private_segment_size = k.priv, p->group_segment_size = k.group;
-                p->kernel_object = k.object;
+                p->private_segment_size = kc.priv, p->group_segment_size = kc.group;
+                p->kernel_object = kc.object;
                 p->kernarg_address = (dev_kargs ? kargs_dev : kargs) + karg_stride * (size_t)i;
                 p->reserved2 = 0;
                 p->completion_signal.handle = i == 0 ? first_sig.handle : (i == N - 1 ? last_sig.handle : 0);

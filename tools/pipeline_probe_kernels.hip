@@ -130,3 +130,26 @@ extern "C" __global__ void __launch_bounds__(512) k_stage(const StageArgs a) {
         }
     }
 }
+
+// What an EMPTY dependent dispatch costs by its shape (256 workgroups x 512 threads each): kernel arguments and LDS
+extern "C" __global__ void __launch_bounds__(512) k_empty_args88(const StageArgs a) {
+    if (a.mode == 0xFFFFFFFFu) a.errors[0] = 1u;
+}
+extern "C" __global__ void __launch_bounds__(512) k_empty_args88_lds(const StageArgs a) {
+    __shared__ unsigned red[8];
+    if (a.mode == 0xFFFFFFFFu) red[threadIdx.x & 7] = 1u, a.errors[0] = red[0];
+}
+struct BigArgs {
+    StageArgs s;
+    unsigned long long pad[24];  // 88 + 192 = 280 bytes, like the GEMV's argument block
+};
+extern "C" __global__ void __launch_bounds__(512) k_empty_args280(const BigArgs a) {
+    if (a.s.mode == 0xFFFFFFFFu) a.s.errors[0] = (unsigned)a.pad[23];
+}
+extern "C" __global__ void __launch_bounds__(512) k_empty_args280_lds40k(const BigArgs a) {
+    __shared__ unsigned big[10240];
+    if (a.s.mode == 0xFFFFFFFFu) big[threadIdx.x] = 1u, a.s.errors[0] = big[0] + (unsigned)a.pad[23];
+}
+extern "C" __global__ void __launch_bounds__(512) k_empty_ptr(unsigned *p) {
+    if (p && threadIdx.x == 100000u) p[0] = 1u;
+}
