@@ -593,13 +593,11 @@ class Model:
             raise ValueError(f"{who}: one distinct sequence of one page pool per prompt and per decoding row")
         B = len(dseqs)
         if B:
-            tokens = torch.as_tensor(tokens).reshape(-1).to(dtype=torch.int32).cpu().numpy()
-            if tokens.size != B:
+            tokens = torch.as_tensor(tokens).reshape(-1).to(device=self.device, dtype=torch.int32)   # stays on the device: no host sync per pass
+            if tokens.numel() != B:
                 raise ValueError(f"{who}: one token per decoding sequence")
             if any(s.offset < 1 for s in dseqs):
                 raise ValueError(f"{who}: a decoding sequence holds its prompt already")
-        else:
-            tokens = np.zeros(0, np.int32)
         lens = [len(p) for p in prompts]
         if (lens and min(lens) < 1) or B + sum(lens) > 65535:
             raise ValueError(f"{who}: prompts must be non-empty and the pass holds at most 65535 rows")
@@ -609,7 +607,7 @@ class Model:
             s.reserve(n)
         S, N = len(seqs), sum(lens)
         starts = (B + np.concatenate([[0], np.cumsum(lens)[:-1]])).astype(np.int32) if S else np.zeros(0, np.int32)
-        ids = np.concatenate([tokens] + [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])
+        ids = np.concatenate([np.zeros(B, np.int32)] + [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])   # the decode rows' ids are copied in on the device
         rows_d = np.arange(B, dtype=np.int32)
         row_seq = np.concatenate([rows_d, B + np.repeat(np.arange(S, dtype=np.int32), lens)]).astype(np.int32)
         row_ctx = np.concatenate([np.asarray([s.offset + 1 for s in dseqs], dtype=np.int32),
@@ -623,6 +621,8 @@ class Model:
             table[i, :len(s.pages)] = s.pages
         dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
         t_ids, t_seq, t_ctx, t_lo, t_hi, t_last, t_table = (dev(x) for x in (ids, row_seq, row_ctx, seg_lo, seg_hi, last, table))
+        if B:
+            t_ids[:B] = tokens
         V = self.args.vocab_size
         logits = torch.empty((B + S, V), dtype=self.dtype, device=self.device)
         logprobs = torch.empty((B + S, V), dtype=torch.float32, device=self.device)
