@@ -292,16 +292,20 @@ int pie_decoder_step_batch(pie_decoder *d, const int32_t *tokens, const int32_t 
 int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
                               const int32_t *seg_hi, const int32_t *last_rows, int N, int S, const void *const *slabs, size_t n_pages, size_t slab_bytes,
                               const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream);
-/* A MIXED batch: decode-state sequences and fresh prompts in ONE pass over the weights (batch_details.hpp:10-88 holds both kinds in one
+/* A MIXED batch: decode-state sequences and prompts in ONE pass over the weights (batch_details.hpp:10-88 holds both kinds in one
  * BatchDetails; the scheduler body that would form it is empty upstream).  The layout of pie_decoder_prefill_batch with n_decode decode
  * rows in front: row r < n_decode is sequence r (row_seq[r] == r, block-table row r) with its input token ids[r], row_context_lens[r] =
  * the positions it attends INCLUDING the new one, seg_lo[r] = r, seg_hi[r] = r + 1; the prompts' rows follow with row_seq >= n_decode.
  * out_rows [S]: the rows whose logits are wanted -- the n_decode decode rows first, then every prompt's last row.  The decode rows'
- * attention runs over their pages (pie_decoder_step_batch's kernel), the prompt rows' over this pass's own rows.  n_decode == 0 is
- * pie_decoder_prefill_batch. */
+ * attention runs over their pages (pie_decoder_step_batch's kernel), a fresh prompt's rows' over this pass's own rows.
+ * chunks_host (HOST int32 [n_chunks][4] = {first row, rows, cached positions, sequence}; n_chunks may be 0): prompts that CONTINUE a cached
+ * prefix -- a chunk of a long prompt, or a suffix behind shared prefix pages (KVPage ref counts, page.hpp:55-68).  Their rows carry
+ * row_context_lens = cached + i + 1 and trivial segments (seg_lo = r, seg_hi = r + 1); their attention is the single-prompt causal flash
+ * kernel over the sequence's pages from that offset.  T pages only.  n_decode == 0 and n_chunks == 0 is pie_decoder_prefill_batch. */
 int pie_decoder_step_mixed(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
                            const int32_t *seg_hi, const int32_t *out_rows, int N, int S, int n_decode, const void *const *slabs, size_t n_pages,
-                           size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream);
+                           size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens,
+                           int n_chunks, const int32_t *chunks_host, void *stream);
 /* offset = cache.offset before the step (reusable.py:111); token < 0 keeps the device-side token (the
  * previous step's argmax). */
 int pie_decoder_set_state(pie_decoder *d, int offset, int token, void *stream);

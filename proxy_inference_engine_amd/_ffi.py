@@ -149,7 +149,7 @@ def load() -> C.CDLL:
     lib.pie_qgemm_w4m.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
     lib.pie_decoder_step_batch.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
     lib.pie_decoder_prefill_batch.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 4
-    lib.pie_decoder_step_mixed.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    lib.pie_decoder_step_mixed.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_page_ptrs.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib

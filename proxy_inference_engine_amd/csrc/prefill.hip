@@ -1051,7 +1051,8 @@ __global__ void k_gather_rows(const uint4 *x, const int *rows, int H8, uint4 *y)
 template <class T>
 static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *row_ctx, const int32_t *row_seq, const int32_t *seg_lo,
                             const int32_t *seg_hi, const int32_t *last_rows, int N, int S, int n_decode, const void *const *slabs, int n_pages,
-                            const int32_t *block_tables, int max_blocks, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
+                            const int32_t *block_tables, int max_blocks, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st,
+                            int n_chunks = 0, const int32_t *chunks = nullptr) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
     size_t w_elems = (size_t)2 * I * H;
@@ -1092,6 +1093,15 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
             a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
             if ((rc = d->kv_i8 ? paged_attn_i8_launch(c.dtype, D, a, st) : attn_decode_launch(c.dtype, D, a, true, st))) return rc;
         }
+        for (int ci = 0; ci < n_chunks; ++ci) {  // prompts continuing a cached prefix: causal attention over their pages from the cached length
+            const int32_t *ch = chunks + 4 * ci;
+            PrefillAttnArgs ca = {};
+            ca.q = s->q + (size_t)ch[0] * QD, ca.out = s->attn + (size_t)ch[0] * QD;
+            ca.k = (const u16 *)slabs[li], ca.v = (const u16 *)slabs[li] + (size_t)c.n_kv_heads * PIE_PAGE_TOKENS * D;
+            ca.offset = ch[2], ca.cap = PIE_PAGE_TOKENS, ca.block_table = block_tables + (size_t)ch[3] * max_blocks, ca.n_pages = n_pages;
+            ca.M = ch[1], ca.Hq = c.n_heads, ca.Hkv = c.n_kv_heads, ca.scale = pa.scale;
+            if ((rc = prefill_attn_launch_t<T>(ca, D, st))) return rc;
+        }
         bool r32 = false;
         W4lSlabs so, sd;  // K-split products handed to their consumers as fp32 slabs (as in the single-prompt path)
         if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
@@ -1123,7 +1133,16 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
 static size_t active_page_bytes(const pie_decoder *d);
 static int varlen_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq, const int32_t *seg_lo,
                         const int32_t *seg_hi, const int32_t *last_rows, int N, int S, int n_decode, const void *const *slabs, size_t n_pages, size_t slab_bytes,
-                        const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream) {
+                        const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream, int n_chunks = 0,
+                        const int32_t *chunks = nullptr) {
+    PIE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || chunks), PIE_E_ARG, "pie_decoder_step_mixed: chunks without their descriptor array");
+    PIE_REQUIRE(n_chunks == 0 || !d->kv_i8, PIE_E_STATE, "pie_decoder_step_mixed: a prompt continuing a cached prefix reads T pages (int8 pages: fresh prompts and decode rows only)");
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int32_t *ch = chunks + 4 * ci;
+        PIE_REQUIRE(ch[0] >= n_decode && ch[1] >= 1 && ch[0] + ch[1] <= N && ch[2] >= 1 && ch[3] >= 0 && ch[3] < S &&
+                        (ch[2] + ch[1] + PIE_PAGE_TOKENS - 1) / PIE_PAGE_TOKENS <= max_blocks,
+                    PIE_E_SHAPE, "pie_decoder_step_mixed: a chunk is {first row >= n_decode, rows >= 1, cached positions >= 1, sequence < S} inside the batch and its block table");
+    }
     PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
                 PIE_E_ARG, "pie_decoder_prefill_batch / _step_mixed: null pointer");
     PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch / _step_mixed: set_globals must be called first");
@@ -1137,9 +1156,9 @@ static int varlen_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_c
     for (int i = 0; i < d->cfg.n_layers; ++i) PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_prefill_batch / _step_mixed: null or misaligned slab");
     hipStream_t st = (hipStream_t)stream;
     return d->cfg.dtype == PIE_BF16 ? prefill_varlen_t<BF16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, n_decode, slabs, (int)n_pages,
-                                                             block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st)
+                                                             block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st, n_chunks, chunks)
                                     : prefill_varlen_t<F16>(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, last_rows, N, S, n_decode, slabs, (int)n_pages,
-                                                            block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st);
+                                                            block_tables, max_blocks, (u16 *)logits, logprobs, next_tokens, st, n_chunks, chunks);
 }
 
 extern "C" int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
@@ -1153,10 +1172,10 @@ extern "C" int pie_decoder_prefill_batch(pie_decoder *d, const int32_t *ids, con
 extern "C" int pie_decoder_step_mixed(pie_decoder *d, const int32_t *ids, const int32_t *row_context_lens, const int32_t *row_seq,
                                       const int32_t *seg_lo, const int32_t *seg_hi, const int32_t *out_rows, int N, int S, int n_decode,
                                       const void *const *slabs, size_t n_pages, size_t slab_bytes, const int32_t *block_tables, int max_blocks, void *logits,
-                                      float *logprobs, int32_t *next_tokens, void *stream) {
+                                      float *logprobs, int32_t *next_tokens, int n_chunks, const int32_t *chunks_host, void *stream) {
     PIE_REQUIRE(n_decode >= 0 && n_decode <= S, PIE_E_SHAPE, "pie_decoder_step_mixed: n_decode must be between 0 and the number of output rows");
     return varlen_batch(d, ids, row_context_lens, row_seq, seg_lo, seg_hi, out_rows, N, S, n_decode, slabs, n_pages, slab_bytes, block_tables,
-                        max_blocks, logits, logprobs, next_tokens, stream);
+                        max_blocks, logits, logprobs, next_tokens, stream, n_chunks, chunks_host);
 }
 
 static int decode_batch(pie_decoder *d, const int32_t *tokens, const int32_t *ctx_len, const void *const *slabs, int n_pages, const int32_t *block_tables,

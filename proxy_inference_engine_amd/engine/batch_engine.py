@@ -29,7 +29,7 @@ class _Active:
 class BatchedEngine:
     def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
                  sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096,
-                 kv_dtype: torch.dtype | None = None, kv_scales=None, mixed: bool = True):
+                 kv_dtype: torch.dtype | None = None, kv_scales=None, mixed: bool = True, prefill_chunk: int | None = None):
         """kv_dtype=torch.int8 (+ kv_scales = (k, v) float16 [n_layers, n_kv_heads]): the pool holds the reference KVPage's int8 pages with
         per-head scales (page.hpp:25-32) -- half the cache bytes per token, so twice the sequences / context per pool."""
         self.model = model
@@ -41,6 +41,9 @@ class BatchedEngine:
         self.batch_prefill = batch_prefill          # admit several waiting prompts with one pass over the weights
         self.max_prefill_rows = max_prefill_rows    # prompt tokens per such pass
         self.mixed = mixed            # prompts admitted while sequences are decoding join THAT pass (Model.step_mixed) instead of a pass of their own
+        # chunked prefill: an admitted prompt is fed at most this many rows per pass (all filling prompts together), every pass also decoding the
+        # sequences in flight -- a long prompt no longer stalls them for its whole length.  T pages only (a continuing prompt reads T pages).
+        self.prefill_chunk = None if (prefill_chunk is None or self._i8) else max(1, int(prefill_chunk))
         self.steps = 0                # batched decode steps taken (for throughput accounting)
         self.mixed_passes = 0         # ... of which carried prompt rows as well
 
@@ -59,7 +62,8 @@ class BatchedEngine:
         out: list[list[int]] = [[] for _ in prompts]
         reserved = 0                  # pages promised to the active sequences for their full length
         need = {}
-        while pending or active:
+        filling: list = []            # chunked prefill: [request, prompt, cache, rows done] of admitted prompts not yet fully in their pages
+        while pending or active or filling:
             # every active sequence holds one token not yet recorded (from its prompt or from the last pass): record, retire
             if active:
                 host = torch.cat([a.token for a in active]).tolist()      # one read-back per pass for the stop / length checks
@@ -76,7 +80,7 @@ class BatchedEngine:
             # admit while there is a slot and the pool can hold the request to its end; the admitted prompts run as ONE pass
             batch = []
             rows = 0
-            while pending and len(active) + len(batch) < self.max_batch:
+            while pending and len(active) + len(batch) + len(filling) < self.max_batch:
                 idx, prompt = pending[0]
                 n_pages = self._pages_for(len(prompt) + max_new_tokens)
                 if reserved + n_pages > self.pool.size() or (rows > 0 and rows + len(prompt) > self.max_prefill_rows):
@@ -86,10 +90,36 @@ class BatchedEngine:
                 reserved += n_pages
                 rows += len(prompt)
                 batch.append((idx, prompt, self.model.make_cache()))
-            if not active and not batch:
+            if self.prefill_chunk:
+                filling += [[idx, prompt, cache, 0] for idx, prompt, cache in batch]
+                batch = []
+            if not active and not batch and not filling:
                 if pending:
                     raise RuntimeError("no request fits the page pool")  # unreachable after the check above
                 break
+            if filling:
+                # one pass: every decoding sequence's step + the next rows of the filling prompts, oldest first, prefill_chunk rows in all
+                take, budget = [], self.prefill_chunk
+                for f in filling:
+                    n = min(len(f[1]) - f[3], budget)
+                    if n > 0:
+                        take.append((f, n))
+                        budget -= n
+                nxt, logprobs, _ = self.model.step_mixed(torch.cat([a.token for a in active]) if active else None, [a.cache for a in active],
+                                                         [f[1][f[3]:f[3] + n] for f, n in take], [f[2] for f, _ in take])
+                self.steps += 1
+                self.mixed_passes += bool(active)
+                if self.sampler is not None:
+                    nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                nb = len(active)
+                for i, a in enumerate(active):
+                    a.token = nxt[i:i + 1]
+                for i, (f, n) in enumerate(take):
+                    f[3] += n
+                    if f[3] == len(f[1]):                                 # its last chunk: the row's token is the request's first
+                        active.append(_Active(f[0], f[2], nxt[nb + i:nb + i + 1]))
+                filling = [f for f in filling if f[3] < len(f[1])]
+                continue
             # Worth it while the decode rows do not push the prompt rows into another 256-row GEMM tile: 8 sequences + a prompt of
             # 8 / 64 / 192 / 256 / 384 rows on the 8B model take 0.61 / 0.76 / 0.75 / 0.97 / 0.84 of a prompt pass + a step, but
             # 508 / 2048 rows take 1.08 / 1.06 (516 rows are three 256-row tiles' worth of work for the GEMMs, 508 are two).

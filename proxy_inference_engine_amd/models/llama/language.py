@@ -569,7 +569,8 @@ class Model:
     def step_mixed(self, tokens: torch.Tensor | None, decode_caches: list[list[BaseCache]], prompts: list, prompt_caches: list[list[BaseCache]]):
         """Decode-state sequences AND fresh prompts in one pass over the weights (pie_decoder_step_mixed; the reference's BatchDetails holds
         both kinds, batch_details.hpp:10-88): tokens [B] = the input token of each decoding sequence (caches as in step_batch), prompts /
-        prompt_caches as in prefill_batch.  Returns (next_tokens [B + S], logprobs [B + S, V], logits [B + S, V]): the decoding sequences
+        prompt_caches as in prefill_batch -- or caches that already hold a PREFIX (offset > 0: the next chunk of a long prompt, or a suffix
+        behind shared prefix pages of a forked sequence): such rows attend to the sequence's pages from that offset.  Returns (next_tokens [B + S], logprobs [B + S, V], logits [B + S, V]): the decoding sequences
         first, then every prompt's last position; the decode caches advance by one position, the prompt caches hold their prompts.
         Every row rides the many-row regime of the Linears (as the rows of a prompt do), also when B alone would take the few-row one."""
         return self._varlen_pass("step_mixed", tokens, decode_caches, prompts, prompt_caches)
@@ -581,7 +582,7 @@ class Model:
             if len(c) != len(self.layers) or not isinstance(c[0], PagedKVCache):
                 raise TypeError(f"{who} runs on paged caches (enable_paged_kv(), then make_cache())")
         for c in caches:
-            if c[0].offset != 0:
+            if c[0].offset != 0 and who == "prefill_batch":
                 raise ValueError(f"{who} takes fresh caches for the prompts (nothing cached before the prompt)")
             seqs.append(c[0].page_manager)
         dseqs = [c[0].page_manager for c in decode_caches]
@@ -601,6 +602,9 @@ class Model:
         lens = [len(p) for p in prompts]
         if (lens and min(lens) < 1) or B + sum(lens) > 65535:
             raise ValueError(f"{who}: prompts must be non-empty and the pass holds at most 65535 rows")
+        cached = [int(s.offset) for s in seqs]      # > 0: the prompt continues a cached prefix (a chunk of a long prompt, a suffix behind shared pages)
+        if any(cached) and a.dtype == torch.int8:
+            raise ValueError(f"{who}: a prompt that continues a cached prefix reads T pages (int8 pools: fresh prompts and decoding rows)")
         for s in dseqs:
             s.reserve(1)
         for s, n in zip(seqs, lens):
@@ -609,12 +613,15 @@ class Model:
         starts = (B + np.concatenate([[0], np.cumsum(lens)[:-1]])).astype(np.int32) if S else np.zeros(0, np.int32)
         ids = np.concatenate([np.zeros(B, np.int32)] + [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts])   # the decode rows' ids are copied in on the device
         rows_d = np.arange(B, dtype=np.int32)
+        rows_p = np.arange(B, B + N, dtype=np.int32)
+        cont = np.repeat(np.asarray(cached, dtype=np.int32) > 0, lens) if S else np.zeros(0, bool)   # rows of continuing prompts: trivial segments
         row_seq = np.concatenate([rows_d, B + np.repeat(np.arange(S, dtype=np.int32), lens)]).astype(np.int32)
         row_ctx = np.concatenate([np.asarray([s.offset + 1 for s in dseqs], dtype=np.int32),
-                                  np.arange(B, B + N, dtype=np.int32) - np.repeat(starts, lens) + 1]).astype(np.int32)
-        seg_lo = np.concatenate([rows_d, np.repeat(starts, lens)]).astype(np.int32)
+                                  rows_p - np.repeat(starts, lens) + np.repeat(np.asarray(cached, dtype=np.int32), lens) + 1]).astype(np.int32)
+        seg_lo = np.concatenate([rows_d, np.where(cont, rows_p, np.repeat(starts, lens))]).astype(np.int32)
         seg_hi = np.arange(1, B + N + 1, dtype=np.int32)
         last = np.concatenate([rows_d, starts + np.asarray(lens, dtype=np.int32) - 1]).astype(np.int32)
+        chunks = np.asarray([[starts[i], lens[i], cached[i], B + i] for i in range(S) if cached[i] > 0], dtype=np.int32).reshape(-1, 4)
         mb = max(len(s.pages) for s in every)
         table = np.zeros((B + S, mb), np.int32)
         for i, s in enumerate(every):
@@ -631,9 +638,12 @@ class Model:
         slabs = (C.c_void_p * n)(*[a.slab[i].data_ptr() for i in range(n)])
         self._match_page_format(a)
         lib = _ffi.load()
-        common = (slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt), _ffi.stream())
         head = (self._dec, _ffi.p(t_ids), _ffi.p(t_ctx), _ffi.p(t_seq), _ffi.p(t_lo), _ffi.p(t_hi), _ffi.p(t_last), B + N, B + S)
-        _ffi.check(lib.pie_decoder_step_mixed(*head, B, *common) if B else lib.pie_decoder_prefill_batch(*head, *common))
+        tail = (slabs, a.size(), a.slab[0].numel() * a.slab.element_size(), _ffi.p(t_table), mb, _ffi.p(logits), _ffi.p(logprobs), _ffi.p(nxt))
+        if B or len(chunks):
+            _ffi.check(lib.pie_decoder_step_mixed(*head, B, *tail, len(chunks), chunks.ctypes.data if len(chunks) else None, _ffi.stream()))
+        else:
+            _ffi.check(lib.pie_decoder_prefill_batch(*head, *tail, _ffi.stream()))
         for s in dseqs:
             s.advance(1)
         for s, k in zip(seqs, lens):

@@ -402,6 +402,13 @@ def test_continuous_batching_engine(golden_dir):
     assert plain.mixed_passes == 0 and [len(t) for t in got_plain] == [len(t) for t in got2]
     n_tok = sum(len(t) for t in got2)
     assert sum(a == b for x, y in zip(got2, got_plain) for a, b in zip(x, y)) >= 0.85 * n_tok
+    # chunked prefill: admitted prompts are fed 24 rows per pass while the sequences in flight keep decoding (prompts continuing their own
+    # cached prefix: pie_decoder_step_mixed's chunks) -- every request completes with (up to low-margin steps) the same tokens, pages drain
+    chunked = BatchedEngine(model, num_pages=7, max_batch=4, stop_tokens=[stop], prefill_chunk=24)
+    got_c = chunked.generate(prompts, new)
+    assert [len(t) for t in got_c] == [len(t) for t in got2] and chunked.pool.get_num_free_pages() == chunked.pool.size()
+    assert chunked.steps > eng2.steps                      # the prompts took several passes each
+    assert sum(a == b for x, y in zip(got2, got_c) for a, b in zip(x, y)) >= 0.85 * n_tok
     with pytest.raises(ValueError, match="does not fit"):
         BatchedEngine(model, num_pages=2, max_batch=2).generate([list(range(200))], 4)
 
@@ -512,12 +519,73 @@ def test_mixed_prompt_and_decode_pass_vs_oracle(golden_dir):
     nxt, _, logits = model.step_batch(torch.tensor(feed3, dtype=torch.int32), dcaches + pcaches + [lcache], graph=False)
     check(logits.float().cpu().numpy(), nxt, want3, "step after the mixed passes")
     # argument errors
-    with pytest.raises(ValueError, match="fresh"):
-        model.step_mixed(torch.tensor([1], dtype=torch.int32), [dcaches[0]], [[1, 2]], [pcaches[0]])
     with pytest.raises(ValueError, match="one token per"):
         model.step_mixed(torch.tensor([1, 2], dtype=torch.int32), [dcaches[0]], [[1, 2]], [model.make_cache()])
     with pytest.raises(ValueError, match="distinct"):
         model.step_mixed(torch.tensor([1, 2], dtype=torch.int32), [dcaches[0], dcaches[0]], [], [])
+
+
+def test_prompt_chunks_and_shared_prefix_suffixes_in_a_mixed_pass(golden_dir):
+    """step_mixed with prompts that CONTINUE a cached prefix (pie_decoder_step_mixed's chunks): a 150-token prompt fed as chunks of 64 + 50 + 36
+    rows, each riding the step of two decoding sequences -- the chunk's last-position logits must be the oracle's logits of the WHOLE prompt
+    at that position (causal attention over the cached pages + the chunk's own rows, across a page boundary), the cache afterwards the
+    single-pass cache.  Then the sequence is forked (two shared prefix pages, KVPage ref counts page.hpp:55-68) and both branches take
+    different suffixes in ONE pass; each must match the oracle's continuation.  int8 pools refuse such prompts by name."""
+    from proxy_inference_engine_amd.cache.kv_cache.paged import PagedKVCache
+    from tests._util import assert_vec_close
+    g, cfg, model = _tiny(golden_dir)
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    rng = np.random.default_rng(77)
+    V = cfg["vocab_size"]
+    prompt = rng.integers(0, V, 150).astype(np.int32)
+    orc = po.OracleLlama(cfg, w, "bfloat16")
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache)                                    # logits at all 150 positions (many-row regime)
+    pool = model.enable_paged_kv(num_pages=24, max_blocks=4)
+    dcaches = []
+    for n in (20, 63):
+        c = model.make_cache()
+        model.step(torch.from_numpy(rng.integers(0, V, n).astype(np.int32)).cuda(), c)
+        dcaches.append(c)
+    feed = torch.tensor([5, 9], dtype=torch.int32)
+    c = model.make_cache()
+    for lo, hi in ((0, 64), (64, 114), (114, 150)):
+        nxt, _, logits = model.step_mixed(feed, dcaches, [prompt[lo:hi].tolist()], [c])
+        assert c[0].offset == hi and logits.shape == (3, V)
+        assert_vec_close(logits[2].float().cpu().numpy(), want[hi - 1], "bfloat16", what=f"chunk [{lo}, {hi}): logits of its last position")
+    ref = model.make_cache()
+    model.step(torch.from_numpy(prompt).cuda(), ref)                      # the whole prompt in one pass
+    for l in range(len(ref)):
+        for got_t, ref_t in zip(c[l].state, ref[l].state):
+            assert_vec_close(got_t.float().cpu().numpy().ravel(), ref_t.float().cpu().numpy().ravel(), "bfloat16", what=f"layer {l} cache after the chunks")
+    # fork: two full pages shared, the partly filled third copied; both branches continue with their own suffix in one pass
+    seq_b = c[0].page_manager.fork()
+    b = [PagedKVCache(seq_b, i) for i in range(len(c))]
+    assert seq_b.pages[:2] == c[0].page_manager.pages[:2] and all(pool.get_page(p).get_ref_count() == 2 for p in seq_b.pages[:2])
+    suf_a, suf_b = rng.integers(0, V, 7).astype(np.int32), rng.integers(0, V, 70).astype(np.int32)
+    ocache_b = [po.OracleKVCache() for _ in orc.layers]
+    orc.forward(prompt, ocache_b)
+    po.set_qmm_min_rows(1)                                                # every row of the pass multiplies in the many-row regime
+    try:
+        want_a = orc.forward(suf_a, ocache)[-1]
+        want_b = orc.forward(suf_b, ocache_b)[-1]
+    finally:
+        po.set_qmm_min_rows(6)
+    _, _, logits = model.step_mixed(None, [], [suf_a.tolist(), suf_b.tolist()], [c, b])
+    assert c[0].offset == 157 and b[0].offset == 220
+    assert_vec_close(logits[0].float().cpu().numpy(), want_a, "bfloat16", what="7-token suffix behind the shared prefix")
+    assert_vec_close(logits[1].float().cpu().numpy(), want_b, "bfloat16", what="70-token suffix behind the shared prefix")
+    assert all(pool.get_page(p).get_ref_count() == 2 for p in seq_b.pages[:2])
+    with pytest.raises(ValueError, match="fresh"):
+        model.prefill_batch([[1, 2]], [c])
+    seq_b.release()
+    model.enable_paged_kv(num_pages=8, kv_dtype=torch.int8)
+    c8 = model.make_cache()
+    model.prefill_batch([[1, 2, 3, 4, 5, 6, 7]], [c8])
+    with pytest.raises(ValueError, match="T pages"):
+        model.step_mixed(None, [], [[8, 9]], [c8])
+    model.enable_paged_kv(num_pages=8)   # back to T pages
+    model.step(torch.tensor([1, 2, 3], dtype=torch.int32).cuda(), model.make_cache())
 
 
 def test_mixed_pass_on_int8_pages_matches_the_separate_passes(golden_dir):
