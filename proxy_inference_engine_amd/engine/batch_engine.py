@@ -29,7 +29,7 @@ class _Active:
 class BatchedEngine:
     def __init__(self, model, num_pages: int = 1024, max_batch: int = 32, stop_tokens: Iterable[int] = (),
                  sampler: Callable[[torch.Tensor], torch.Tensor] | None = None, batch_prefill: bool = True, max_prefill_rows: int = 4096,
-                 kv_dtype: torch.dtype | None = None, kv_scales=None, mixed: bool = True, prefill_chunk: int | None = None):
+                 kv_dtype: torch.dtype | None = None, kv_scales=None, mixed: bool = True, prefill_chunk: int | None = None, share_prefix: bool = False):
         """kv_dtype=torch.int8 (+ kv_scales = (k, v) float16 [n_layers, n_kv_heads]): the pool holds the reference KVPage's int8 pages with
         per-head scales (page.hpp:25-32) -- half the cache bytes per token, so twice the sequences / context per pool."""
         self.model = model
@@ -44,6 +44,11 @@ class BatchedEngine:
         # chunked prefill: an admitted prompt is fed at most this many rows per pass (all filling prompts together), every pass also decoding the
         # sequences in flight -- a long prompt no longer stalls them for its whole length.  T pages only (a continuing prompt reads T pages).
         self.prefill_chunk = None if (prefill_chunk is None or self._i8) else max(1, int(prefill_chunk))
+        # shared prompt prefix (a system prompt): the whole pages of the requests' longest common prefix are computed ONCE and shared by
+        # reference count (KVPage::add_ref, page.hpp:55-68 -- PagedSequence.fork); every request then feeds only its own suffix, as a prompt
+        # continuing a cached prefix.  T pages only.
+        self.share_prefix = bool(share_prefix) and not self._i8
+        self.shared_pages = 0         # pages of the last generate()'s shared prefix
         self.steps = 0                # batched decode steps taken (for throughput accounting)
         self.mixed_passes = 0         # ... of which carried prompt rows as well
 
@@ -62,6 +67,29 @@ class BatchedEngine:
         out: list[list[int]] = [[] for _ in prompts]
         reserved = 0                  # pages promised to the active sequences for their full length
         need = {}
+        root, P = None, 0             # the sequence holding the shared prefix, its length (whole pages)
+        self.shared_pages = 0
+        if self.share_prefix and len(prompts) > 1:
+            lcp = min(len(p) for p in prompts) - 1                         # every request keeps at least one token of its own
+            first = prompts[0]
+            for p in prompts[1:]:
+                n = 0
+                while n < lcp and p[n] == first[n]:
+                    n += 1
+                lcp = n
+            P = lcp // TOKEN_CAPACITY_PER_PAGE * TOKEN_CAPACITY_PER_PAGE
+            if P and self._pages_for(P) + self._pages_for(max(len(p) for p in prompts) - P + max_new_tokens) <= self.pool.size():
+                root = self.model.make_cache()
+                self.model.step_mixed(None, [], [list(first[:P])], [root])    # one pass over the prefix; its pages are shared from here on
+                reserved = self.shared_pages = P // TOKEN_CAPACITY_PER_PAGE
+            else:
+                P = 0
+
+        def new_cache():
+            if root is None:
+                return self.model.make_cache()
+            seq = root[0].page_manager.fork()                               # whole pages: add_ref only, nothing is copied
+            return [type(root[0])(seq, i) for i in range(len(root))]
         filling: list = []            # chunked prefill: [request, prompt, cache, rows done] of admitted prompts not yet fully in their pages
         while pending or active or filling:
             # every active sequence holds one token not yet recorded (from its prompt or from the last pass): record, retire
@@ -82,14 +110,14 @@ class BatchedEngine:
             rows = 0
             while pending and len(active) + len(batch) + len(filling) < self.max_batch:
                 idx, prompt = pending[0]
-                n_pages = self._pages_for(len(prompt) + max_new_tokens)
-                if reserved + n_pages > self.pool.size() or (rows > 0 and rows + len(prompt) > self.max_prefill_rows):
+                n_pages = self._pages_for(len(prompt) + max_new_tokens) - P // TOKEN_CAPACITY_PER_PAGE
+                if reserved + n_pages > self.pool.size() or (rows > 0 and rows + len(prompt) - P > self.max_prefill_rows):
                     break
                 pending.popleft()
                 need[idx] = n_pages
                 reserved += n_pages
-                rows += len(prompt)
-                batch.append((idx, prompt, self.model.make_cache()))
+                rows += len(prompt) - P
+                batch.append((idx, prompt[P:] if P else prompt, new_cache()))
             if self.prefill_chunk:
                 filling += [[idx, prompt, cache, 0] for idx, prompt, cache in batch]
                 batch = []
@@ -145,6 +173,12 @@ class BatchedEngine:
                     if self.sampler is not None:
                         toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
                     joined.append(_Active(idx, cache, toks[:1].clone()))
+            elif P and batch:                                            # suffixes behind the shared prefix: prompts continuing a cached prefix
+                toks, logprobs, _ = self.model.step_mixed(None, [], [p for _, p, _ in batch], [c for _, _, c in batch])
+                if self.sampler is not None:
+                    toks = self.sampler(logprobs).reshape(-1).to(torch.int32)
+                for i, (idx, _, cache) in enumerate(batch):
+                    joined.append(_Active(idx, cache, toks[i:i + 1].clone()))
             elif len(batch) == 1 or (batch and not self.batch_prefill):
                 for idx, prompt, cache in batch:
                     ids = torch.as_tensor(prompt, dtype=torch.int32).reshape(-1)
@@ -166,4 +200,6 @@ class BatchedEngine:
                 for i, a in enumerate(active):
                     a.token = nxt[i:i + 1]
             active += joined
+        if root is not None:
+            root[0].page_manager.release()
         return out

@@ -413,6 +413,38 @@ def test_continuous_batching_engine(golden_dir):
         BatchedEngine(model, num_pages=2, max_batch=2).generate([list(range(200))], 4)
 
 
+def test_engine_shares_the_pages_of_a_common_prompt_prefix(golden_dir):
+    """BatchedEngine(share_prefix=True): eight requests start with the same 140 tokens (a system prompt).  The two whole pages of that prefix are
+    computed once and shared by reference count (KVPage::add_ref, page.hpp:55-68); every request feeds only its suffix, as a prompt continuing a
+    cached prefix.  Same tokens as the engine that prefills every prompt whole (up to low-margin steps), fewer pages in use, the pool drains;
+    also together with chunked prefill."""
+    from proxy_inference_engine_amd.engine import BatchedEngine
+    g, cfg, model = _tiny(golden_dir)
+    rng = np.random.default_rng(91)
+    V = cfg["vocab_size"]
+    system = rng.integers(0, V, 140).tolist()
+    prompts = [system + rng.integers(0, V, int(n)).tolist() for n in rng.integers(1, 40, 8)]
+    new = 5
+    plain = BatchedEngine(model, num_pages=16, max_batch=4)
+    want = plain.generate(prompts, new)
+    assert plain.shared_pages == 0
+    eng = BatchedEngine(model, num_pages=16, max_batch=4, share_prefix=True)
+    got = eng.generate(prompts, new)
+    assert eng.shared_pages == 2 and eng.pool.get_num_free_pages() == eng.pool.size()
+    assert [len(t) for t in got] == [new] * 8
+    assert sum(a == b for x, y in zip(got, want) for a, b in zip(x, y)) >= 0.85 * 8 * new
+    # a pool too small for four whole prompts (3 pages each) serves four requests at once when they share the prefix: 2 + 4 * 1 pages
+    tight = BatchedEngine(model, num_pages=7, max_batch=4, share_prefix=True)
+    got_t = tight.generate(prompts, new)
+    assert sum(a == b for x, y in zip(got_t, want) for a, b in zip(x, y)) >= 0.85 * 8 * new and tight.pool.get_num_free_pages() == 7
+    narrow = BatchedEngine(model, num_pages=7, max_batch=4)             # without sharing only two whole prompts fit at a time: more steps
+    narrow.generate(prompts, new)
+    assert tight.steps < narrow.steps
+    both = BatchedEngine(model, num_pages=16, max_batch=4, share_prefix=True, prefill_chunk=16)
+    got_b = both.generate(prompts, new)
+    assert sum(a == b for x, y in zip(got_b, want) for a, b in zip(x, y)) >= 0.85 * 8 * new and both.pool.get_num_free_pages() == 16
+
+
 def test_several_prompts_in_one_pass(golden_dir):
     """pie_decoder_prefill_batch: prompts of 1..150 tokens concatenated into one pass.  Every prompt's last-position logits, its
     cache rows and the decode steps that follow must be what the single-prompt path gives for it alone (same GEMM contract;
