@@ -133,15 +133,20 @@ def engine_mode():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--new", type=int, default=64)
     ap.add_argument("--slots", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=0, help="BatchedEngine(prefill_chunk=N): chunked prefill")
+    ap.add_argument("--shared", type=int, default=0, help="the first N tokens of every prompt are the same (a system prompt); with --share-prefix its pages are computed once")
+    ap.add_argument("--share-prefix", action="store_true")
+    ap.add_argument("--no-mixed", action="store_true")
     args = ap.parse_args()
     from proxy_inference_engine_amd.engine import BatchedEngine
     cfg = dict(LLAMA3_8B)
     model = Model(ModelArgs(**cfg), synthetic_checkpoint(cfg, seed=0, dtype=torch.bfloat16))
     torch.cuda.empty_cache()
     pages = args.slots * ((args.prompt + args.new + 63) // 64 + 1) + 4
-    eng = BatchedEngine(model, num_pages=pages, max_batch=args.slots)
+    eng = BatchedEngine(model, num_pages=pages, max_batch=args.slots, prefill_chunk=args.chunk or None, share_prefix=args.share_prefix, mixed=not args.no_mixed)
     g = torch.Generator().manual_seed(3)
-    prompts = [torch.randint(0, cfg["vocab_size"], (args.prompt + (i % 5),), generator=g).tolist() for i in range(args.requests)]
+    system = torch.randint(0, cfg["vocab_size"], (args.shared,), generator=g).tolist()
+    prompts = [system + torch.randint(0, cfg["vocab_size"], (args.prompt - args.shared + (i % 5),), generator=g).tolist() for i in range(args.requests)]
     eng.generate(prompts[:args.slots], 4)                       # warm-up: scratch, tile copies, hipBLASLt plans
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -151,7 +156,8 @@ def engine_mode():
     n_new = sum(len(o) for o in out)
     print(json.dumps({"mode": "BatchedEngine", "requests": args.requests, "slots": args.slots, "prompt": args.prompt, "new_tokens": n_new,
                       "seconds": round(dt, 3), "generated_tokens_per_s": round(n_new / dt, 1),
-                      "prompt_plus_generated_tokens_per_s": round((n_new + sum(len(p) for p in prompts)) / dt, 1), "batched_steps": eng.steps}))
+                      "prompt_plus_generated_tokens_per_s": round((n_new + sum(len(p) for p in prompts)) / dt, 1), "batched_steps": eng.steps,
+                      "mixed_passes": eng.mixed_passes, "shared_pages": eng.shared_pages, "prefill_chunk": args.chunk, "mixed": not args.no_mixed}))
 
 
 if __name__ == "__main__" and "--engine" in sys.argv:
