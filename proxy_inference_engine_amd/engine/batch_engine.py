@@ -126,8 +126,8 @@ class BatchedEngine:
                     raise RuntimeError("no request fits the page pool")  # unreachable after the check above
                 break
             if filling:
-                # one pass: every decoding sequence's step + the next rows of the filling prompts, oldest first, prefill_chunk rows in all
-                take, budget = [], self.prefill_chunk
+                # one pass: every decoding sequence's step + the next rows of the filling prompts, oldest first, prefill_chunk rows in all (decode rows included)
+                take, budget = [], max(1, self.prefill_chunk - len(active))   # the pass's rows INCLUDING the decode rows: a chunk of 256 + 8 decode rows would cost the GEMMs a second 256-row tile
                 for f in filling:
                     n = min(len(f[1]) - f[3], budget)
                     if n > 0:
