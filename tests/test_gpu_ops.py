@@ -275,13 +275,13 @@ def test_g32_gemv_embedding_vs_oracle(ops, dt, bits):
 
 
 def test_gemv_random_shape_sweep_all_formats(ops):
-    """Seeded sweep over irregular shapes for the three weight formats of the streaming GEMV: N any even number (incl. fewer
-    row pairs than waves and non-multiples of the wave geometry), K any multiple of 64 up to 9 slices (ragged last slice:
-    the zero-padded lanes are not fetched), M 1..3, both dtypes.  Against the oracle's exact qmv / dense forms."""
+    """Seeded sweep over irregular shapes for the five weight formats of the streaming GEMV (int4 / int8 in 64- and 32-wide groups, dense): N any
+    even number (incl. fewer row pairs than waves and non-multiples of the wave geometry), K any multiple of 64 up to 9 slices (ragged last
+    slice: the zero-padded lanes are not fetched), M 1..3, both dtypes.  Against the oracle's exact qmv / dense forms."""
     rng = np.random.default_rng(2024)
-    for case in range(24):
+    for case in range(40):
         dt = ("bfloat16", "float16")[case % 2]
-        fmt = ("int4", "int8", "dense")[case % 3]
+        fmt = ("int4", "int8", "dense", "int4g32", "int8g32")[case % 5]
         N = 2 * int(rng.integers(1, 700))
         K = 64 * int(rng.integers(1, 150))
         M = int(rng.integers(1, 4))
@@ -292,11 +292,14 @@ def test_gemv_random_shape_sweep_all_formats(ops):
             got = ops.linear(xd, ops.repack_dense(to_dev(po.to_bits(w, dt), dt)))
             want = po.linear(x, po.to_bits(w, dt), dt)
         else:
-            bits = 4 if fmt == "int4" else 8
-            wq, sc, bi = po.quantize(w, 64, bits, dt)
-            repack = ops.repack_w4s if bits == 4 else ops.repack_w8s
-            got = ops.quantized_matmul(xd, repack(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt)))
-            want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=bits, dtype=dt)
+            bits, group = (4 if fmt.startswith("int4") else 8), (32 if fmt.endswith("g32") else 64)
+            wq, sc, bi = po.quantize(w, group, bits, dt)
+            if group == 32:
+                packed = ops.repack_w4s32(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt), bits=bits)
+            else:
+                packed = (ops.repack_w4s if bits == 4 else ops.repack_w8s)(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+            got = ops.quantized_matmul(xd, packed)
+            want = po.quantized_matmul(x, wq, sc, bi, group_size=group, bits=bits, dtype=dt)
         assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"case {case}: {fmt} N={N} K={K} M={M} {dt}")
 
 

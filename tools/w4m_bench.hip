@@ -8,6 +8,7 @@
 #include "../proxy_inference_engine_amd/csrc/w4m_gemm.hip"
 
 int bias_any_launch(int, void *, const void *, int, int, hipStream_t) { return 0; }  // vision.hip's; not reached from here
+int pie_knob(int) { return -1; }  // decoder.hip's knob table: every knob at its default
 namespace pie {
 int fail(int code, const std::string &msg) {
     std::fprintf(stderr, "error %d: %s\n", code, msg.c_str());
