@@ -82,6 +82,24 @@ def test_engine_generate_step_matches_golden_tokens(tiny):
     assert eng.prompt_cache.cache[0].offset == len(g["prompt"])
 
 
+def test_attention_warmup_cap_knob_changes_no_result(tiny, knobs):
+    """PIE_KNOB_ATTN_WARM_MAX_MB: the attention launch's idle CUs read (and discard) at most that many MB of o_proj's weights to warm the
+    Infinity Cache; 0 turns the role off.  A pure prefetch: the steps' logits are bit-identical with it off, capped to 1 MB and at the default."""
+    g, cfg, w, model = tiny
+    outs = []
+    for mb in (0, 1, None):
+        knobs("attn_warm_max_mb", mb)
+        cache = model.make_cache()
+        model.step(torch.from_numpy(g["prompt"]).cuda(), cache)
+        bits = []
+        for t in g["tokens"][:6]:
+            _, _, logits = model.step(torch.tensor([int(t)], dtype=torch.int32, device="cuda"), cache, graph=False)
+            bits.append(to_bits(logits).copy())
+        outs.append(bits)
+    for other in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))
+
+
 def test_teacher_forced_steps_and_graph_replay_identical(tiny):
     g, cfg, w, model = tiny
     orc = po.OracleLlama(cfg, w, DT)
