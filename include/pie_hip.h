@@ -56,7 +56,8 @@ enum {
     PIE_KNOB_PREFILL_QT = 8,         /* 1 / 2: one / two 32-row query tiles per prompt-attention workgroup */
     PIE_KNOB_ATTN_MERGE_MAX_CAP = 9, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
     PIE_KNOB_ATTN_WARM_MAX_MB = 10,  /* the attention launch's idle CUs warm the Infinity Cache with at most this many MB of o_proj's weights; 0 = off (read per step enqueue / graph capture) */
-    PIE_KNOB_COUNT = 11
+    PIE_KNOB_W4R = 11,               /* 0: int4 Linears of 6..256 rows on the round-2 kernels (k_w4m_gemm*, k_w4l2_gemm) instead of the weight-streaming k_w4r_gemm (the tests' cross-check) */
+    PIE_KNOB_COUNT = 12
 };
 #define PIE_KNOB_DEFAULT (-1)
 int pie_set_knob(int knob, int value);

@@ -627,6 +627,13 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
 int w4m_slab_splits(int M, int N, int K);  // few rows, narrow matrix: K split into fp32 slabs (0 = shape not served)
 int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st);
 size_t w4l_workspace_bytes(int M, int N, int K);
+// 6 .. 256 rows: the weight-streaming form (w4r_gemm.hpp); epi 0 store (+ bias), 1 SwiGLU (+ bias), 2 RoPE + append
+bool w4r_serves(int M, int N, int K);
+int w4r_splits(int M, int N, int K);
+size_t w4r_workspace_bytes(int M, int N, int K);
+bool w4m_wide_scales(const void *w4m);
+int w4r_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, int epi, const void *bias,
+                    const W4mRope *rope, int *slabs, bool *bias_done, bool wide_scales);
 
 // int4 checkpoints: prompts beyond small_rows() rows run the hand-written many-row W4 MFMA GEMM on the same W4M tiles -- no 16-bit
 // copy of the weights, no hipBLASLt (which remains the path of shapes the tile kernels do not take: N not a multiple of 32).
@@ -677,6 +684,62 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // streaming GEMV with the rows' images side by side -- one pass over the weights, each row with the batch-1 arithmetic.
     if (is_int4 && M <= GEMV_ROWS_MAX && K % 64 == 0 && N % 2 == 0 && gemv_rows_lds_bytes(K, 1) <= 160u * 1024u)
         return w4s_gemv_rows_launch(d->cfg.dtype, packed, N, K, x, M, y, (const u16 *)bias, st);
+    // resident W4M tile copy of an int4 matrix (0.5625 B per weight, built on first use within the residency budget); nullptr: no room
+    auto w4m_tiles = [&](void **out) -> int {
+        *out = nullptr;
+        auto it = s->resident_w4m.find(packed);
+        if (it != s->resident_w4m.end()) {
+            *out = it->second;
+            return PIE_OK;
+        }
+        void *wm = nullptr;
+        if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
+            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K), ++s->alloc_gen;
+            *out = wm;
+            return w4m_repack_launch(packed, N, K, wm, st);
+        }
+        (void)hipGetLastError();
+        return PIE_OK;
+    };
+    auto w4l_reserve = [&](size_t wb) -> int {  // fp32 slabs of a K-split product
+        if (wb > s->w4l_ws_bytes) {
+            if (s->w4l_ws) (void)hipFree(s->w4l_ws);
+            s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
+            PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
+            s->w4l_ws_bytes = wb, ++s->alloc_gen;
+        }
+        return PIE_OK;
+    };
+    // 6 .. 256 rows (a chat turn behind a cached prefix, a prompt chunk, a multi-sequence step): the weight-streaming MFMA GEMM, every CU
+    // streaming its slab of W4M tiles once (w4r_gemm.hpp).  q|k|v, o_proj and down split K over workgroups and hand fp32 slabs to their
+    // consumers (RoPE + append, add + RMSNorm); gate|up carries the SwiGLU in its epilogue.
+    if (is_int4 && w4r_serves(M, N, K)) {
+        void *wm = nullptr;
+        int rc = w4m_tiles(&wm);
+        if (rc) return rc;
+        if (wm) {
+            const bool wide = w4m_wide_scales(wm);
+            if (act && used_act) {  // gate|up: SwiGLU (and the Linear's bias) in the epilogue
+                *used_act = true;
+                return w4r_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, nullptr, st, 1, bias, nullptr, nullptr, nullptr, wide);
+            }
+            if (rope && used_act && w4r_splits(M, N, K) == 1) {  // q|k|v wide enough to fill the chip without a K split: RoPE + append in the epilogue
+                *used_act = true;
+                rope->bias = (const u16 *)bias;
+                return w4r_gemm_launch(d->cfg.dtype, wm, x, M, N, K, nullptr, nullptr, st, 2, nullptr, rope, nullptr, nullptr, wide);
+            }
+            if ((rc = w4l_reserve(w4r_workspace_bytes(M, N, K)))) return rc;
+            int n_slabs = 0;
+            bool bias_done = false;
+            rc = w4r_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, 0, bias, nullptr, slabs ? &n_slabs : nullptr, &bias_done, wide);
+            if (!rc && n_slabs > 1) {  // y was NOT written: the consumer sums the slabs, rounds and adds the bias
+                slabs->part = (const float *)s->w4l_ws, slabs->S = n_slabs, slabs->MN = (size_t)M * N;
+                return PIE_OK;
+            }
+            if (rc || !bias || bias_done) return rc;
+            return bias_rows<T>(y, bias, M, N, st);
+        }
+    }
     if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
         auto it = s->resident_w4m.find(packed);
@@ -994,13 +1057,16 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         W4mRope re = {s->rope_cs, nullptr, ctx_len, nullptr, (u16 *)slabs[li], block_tables, max_blocks, n_pages, li, c.n_layers, c.n_heads, c.n_kv_heads,
                       D, c.rope_traditional, s->q, nullptr, i8pb};
         bool roped = false;
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re))) return rc;
+        W4lSlabs sq;  // q|k|v as the fp32 slabs of a K-split product (no Linear bias: RoPE takes T(x W^T + b))
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
+            return rc;
         if (!roped) {
             decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
-            if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
-            hipLaunchKernelGGL(rope_k, dim3(B), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+            if (sq.S > 1) rope_k = d->kv_i8 ? &k_rope_append_rows<T, true, true> : &k_rope_append_rows<T, true, false>;
+            else if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
+            hipLaunchKernelGGL(rope_k, dim3(B, sq.S > 1 ? 4u : 1u), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                                c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, ctx_len, max_blocks, (u16 *)slabs[li],
-                               (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, (const float *)nullptr, 0, (size_t)0, i8pb);
+                               (const int *)nullptr, (u16 *)nullptr, (u16 *)nullptr, sq.part, sq.S, sq.MN, i8pb);
             PIE_LAUNCH_CHECK();
         }
         AttnArgs a = {};
@@ -1073,12 +1139,15 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
     for (int li = 0; li < c.n_layers; ++li) {
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, N, H, c.dtype, s->xn, st))) return rc;
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv))) return rc;
+        W4lSlabs sq;  // q|k|v as the fp32 slabs of a K-split product (no Linear bias: RoPE takes T(x W^T + b))
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, nullptr, nullptr, w.bqkv ? nullptr : &sq)))
+            return rc;
         decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
-        if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
-        hipLaunchKernelGGL(rope_k, dim3(N), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
+        if (sq.S > 1) rope_k = d->kv_i8 ? &k_rope_append_rows<T, true, true> : &k_rope_append_rows<T, true, false>;
+        else if (d->kv_i8) rope_k = &k_rope_append_rows<T, false, true>;
+        hipLaunchKernelGGL(rope_k, dim3(N, sq.S > 1 && N < 512 ? 4u : 1u), dim3(256), 0, st, s->qkv, NQKV, d->glob.rope_freqs, nullptr, nullptr, li, c.n_layers,
                            c.n_heads, c.n_kv_heads, D, c.rope_traditional, s->q, block_tables, n_pages, s->rope_cs, row_ctx, max_blocks, (u16 *)slabs[li],
-                           row_seq, s->kc, s->vc, (const float *)nullptr, 0, (size_t)0,
+                           row_seq, s->kc, s->vc, sq.part, sq.S, sq.MN,
                            d->kv_i8 ? pie_page_i8_bytes(c.n_kv_heads, D) : (size_t)0);  // int8 pages: quantised on the way in; this pass's own attention reads the T copies
         PIE_LAUNCH_CHECK();
         PrefillAttnArgs pa = {};

@@ -24,6 +24,8 @@
 // One workgroup per 32-row tile strip, 8 waves splitting the K/64 groups round-robin (consecutive groups are consecutive
 // 1152-byte blocks: the 8 waves stream one contiguous range), fp32 partial tiles summed through LDS in fixed order.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "prefill_attn.hpp"  // MfmaT, f32x16_t, DecState
 
@@ -38,7 +40,7 @@ constexpr int W4M_WDEPTH = 8;  // direct kernel: weight tiles (16 B codes + 4 B 
 constexpr int W4M_XDEPTH = 2;  //                x fragment sets (4 x 16 B per lane) in flight per wave
 
 // W4S unit stream -> W4M tiles.  One thread per (tile, lane): pure word shuffle, no nibble work.
-__global__ void __launch_bounds__(256) k_w4s_to_w4m(const u32 *w4s, int N, int K, int ns, u32 *w4m) {
+__global__ void __launch_bounds__(256) k_w4s_to_w4m(const u32 *w4s, int N, int K, int ns, u32 *w4m, int *wide) {
     const int groups = K >> 6;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)(N >> 5) * groups * 64) return;
@@ -54,7 +56,12 @@ __global__ void __launch_bounds__(256) k_w4s_to_w4m(const u32 *w4s, int N, int K
         o[s] = unit[(wk >> 2) * 256 + src_lane * 4 + (wk & 3)];
     }
     *reinterpret_cast<uint4 *>(tile + lane * 4) = make_uint4(o[0], o[1], o[2], o[3]);
-    if (kh == 0) tile[256 + n] = unit[512 + src_lane];
+    if (kh == 0) {
+        const u32 sbw = unit[512 + src_lane];
+        tile[256 + n] = sbw;
+        // |scale| >= 2^100 read as bf16 (an f16 scale can only trip this falsely): outside w4r_dequant's domain (w4r_gemm.hpp)
+        if (wide && ((sbw >> 7) & 0xFFu) >= 127u + 100u) atomicOr(wide, 1);
+    }
 }
 
 // two fp32 -> one packed pair of T in a single v_cvt_pk_* (pack2<T> converts each half separately and ORs them: 3 instructions)
@@ -123,14 +130,9 @@ struct W4mRope {
     size_t i8_page_bytes;               // != 0 (with slab): the pages are int8 with per-head fp16 scales (paged_i8.hip): K / V are quantised on the way in
 };
 
+// one packed column pair (R, R + 1) of x-row m: the fp32 sums a, b -> T, (+ bias), then RoPE + store / cache append
 template <class T>
-__device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt, int M, const W4mRope &r) {
-    const int i = 2 * (threadIdx.x >> 6), l = threadIdx.x & 63;
-    float a = 0.0f, b = 0.0f;
-#pragma unroll
-    for (int w = 0; w < W4M_WAVES; ++w) a += s_red[w][i][l], b += s_red[w][i + 1][l];
-    const int m = l & 31, R = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // packed columns (R, R + 1)
-    if (m >= M) return;
+__device__ __forceinline__ void w4m_rope_pair(float a, float b, int m, int R, const W4mRope &r) {
     a = round_T<T>(a), b = round_T<T>(b);
     if (r.bias) a = round_T<T>(a + T::to_f32(r.bias[R])), b = round_T<T>(b + T::to_f32(r.bias[R + 1]));
     const int pos = r.ctx_len ? r.ctx_len[m] - 1 : r.state->pos + m, HD = r.HD, half = HD >> 1;
@@ -175,6 +177,17 @@ __device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt
             vb[0] = q8(a, sv), vb[1] = q8(b, sv);
         } else *reinterpret_cast<u32 *>(vdst + ((size_t)(rr / HD) * cap + kvrow) * HD + rr % HD) = pack2<T>(a, b);
     }
+}
+
+template <class T>
+__device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt, int M, const W4mRope &r) {
+    const int i = 2 * (threadIdx.x >> 6), l = threadIdx.x & 63;
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int w = 0; w < W4M_WAVES; ++w) a += s_red[w][i][l], b += s_red[w][i + 1][l];
+    const int m = l & 31, R = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // packed columns (R, R + 1)
+    if (m >= M) return;
+    w4m_rope_pair<T>(a, b, m, R, r);
 }
 
 // ... or (swiglu) the MLP activation: the packed gate|up matrix interleaves its rows (2i, 2i + 1) = (gate_i, up_i), so a strip holds
@@ -1043,13 +1056,140 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     return PIE_OK;
 }
 
+// ---------------------------------------------------------------- 6 .. 256 rows: the weight-streaming form (w4r_gemm.hpp)
+#include "w4r_gemm.hpp"
+
+// Decomposition: 4 strips (128 columns) per workgroup, all rows; K split over blockIdx.y into runs of whole steps where the column
+// workgroups alone cannot fill the chip (q|k|v: 48, o_proj / down: 32 on the 8B model) -- the splits' fp32 slabs are summed by the consumer.
+// Geometry per row count (tools/w4r_bench on the 8B shapes; EXPERIMENTS.md): <= 64 rows two strips per wave, four K-phases, four x buffers;
+// 65..128 rows one strip per wave, two K-phases, four (half-size) x buffers -- the x chunk of 128 rows is 64 KB per 256 columns and has to be
+// in flight two steps ahead; 129..256 rows the same with two buffers (LDS).
+struct W4rPlan {
+    int mb, kw, S, steps;  // row blocks, K-phases, K splits, steps per split; mb == 0: shape not served
+};
+static W4rPlan w4r_plan(int M, int N, int K, bool may_split) {
+    W4rPlan pl = {0, 0, 1, 0};
+    if (M < 1 || M > 256 || N < 32 || N % 32 || K < 64 || K % 64) return pl;
+    const int mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 8)), kw = mb >= 4 ? 2 : 4;
+    const int groups = K >> 6;
+    if (groups < kw) return pl;
+    const int total = (groups + kw - 1) / kw, col_wgs = (N / 32 + 3) / 4;
+    int S = 1;
+    if (may_split && col_wgs < 192) {
+        S = 256 / col_wgs;
+        const int min_steps = 16 / kw;  // at least 1024 columns per split (measured: o_proj at 32 rows 7.9 us with four splits, 9.3 with eight)
+        const int max_s = total / min_steps > 0 ? total / min_steps : 1;
+        S = S > max_s ? max_s : S;
+        S = S > 16 ? 16 : (S < 1 ? 1 : S);
+    }
+    const int per = (total + S - 1) / S;
+    S = (total + per - 1) / per;
+    pl.mb = mb, pl.kw = kw, pl.S = S, pl.steps = per;
+    return pl;
+}
+bool w4r_serves(int M, int N, int K) { return pie_knob(PIE_KNOB_W4R) != 0 && w4r_plan(M, N, K, false).mb != 0; }
+int w4r_splits(int M, int N, int K) { return w4r_plan(M, N, K, true).S; }
+size_t w4r_workspace_bytes(int M, int N, int K) {
+    const int s = w4r_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+template <class T, int EPI>
+static void w4r_go(const W4rPlan &pl, int N, bool plain, hipStream_t st, const W4rArgs &a, const W4mRope &r) {
+    const dim3 grid((unsigned)((N / 32 + 3) / 4), (unsigned)pl.S), block(512);
+    if (pl.mb == 1) {
+        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 1, 2, 4, 4, EPI, true>), grid, block, 0, st, a, r);
+        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 1, 2, 4, 4, EPI, false>), grid, block, 0, st, a, r);
+    } else if (pl.mb == 2) {
+        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 2, 2, 4, 4, EPI, true>), grid, block, 0, st, a, r);
+        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 2, 2, 4, 4, EPI, false>), grid, block, 0, st, a, r);
+    } else if (pl.mb == 4) {
+        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 4, 1, 2, 4, EPI, true>), grid, block, 0, st, a, r);
+        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 4, 1, 2, 4, EPI, false>), grid, block, 0, st, a, r);
+    } else {
+        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 8, 1, 2, 2, EPI, true>), grid, block, 0, st, a, r);
+        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 8, 1, 2, 2, EPI, false>), grid, block, 0, st, a, r);
+    }
+}
+
+// epi: W4R_STORE (y [M, N], + bias), W4R_SWIGLU (y = activation [M, N / 2], + bias), W4R_ROPE (rope != nullptr; q -> rope->q_out, k / v -> cache).
+// slabs (nullable, STORE only): the caller's consumer sums the fp32 slabs of a K-split shape itself -> *slabs = S and workspace holds
+// [S][M][N]; otherwise a K-split shape is reduced here (k_w4l_reduce) and the bias, if any, is left to the caller (returns *slabs = 0).
+// wide_scales: some |scale| of the matrix is >= 2^100 (w4m_repack_launch reports it): outside w4r_dequant's domain, the plain conversion everywhere.
+int w4r_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, int epi, const void *bias,
+                    const W4mRope *rope, int *slabs, bool *bias_done, bool wide_scales) {
+    if (slabs) *slabs = 0;
+    if (bias_done) *bias_done = false;
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4R GEMM: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE((epi == W4R_ROPE) == (rope != nullptr), PIE_E_ARG, "W4R GEMM: the q|k|v epilogue needs its arguments");
+    const bool may_split = epi == W4R_STORE && workspace != nullptr;
+    const W4rPlan pl = w4r_plan(M, N, K, may_split);
+    PIE_REQUIRE(pl.mb != 0, PIE_E_SHAPE, "W4R GEMM: 1..256 rows, N a multiple of 32, K a multiple of 64 and at least 256 (128 beyond 64 rows)");
+    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 16) && pie_aligned(bias, 16), PIE_E_ALIGN, "W4R GEMM: 16-byte alignment required");
+    PIE_REQUIRE(epi != W4R_SWIGLU || N % 64 == 0, PIE_E_SHAPE, "W4R GEMM: the SwiGLU epilogue needs whole column octets of pairs");
+    W4rArgs a = {(const char *)w4m, (const u16 *)x, M, N, K, pl.steps, (u16 *)y, nullptr, (const u16 *)bias};
+#ifdef W4R_PROF
+    extern unsigned long long *g_w4r_prof;
+    a.prof = g_w4r_prof;
+#endif
+    const W4mRope r = rope ? *rope : W4mRope{};
+    const int e = pl.S > 1 ? W4R_SLAB : epi;
+    if (pl.S > 1) a.part = (float *)workspace, a.bias = nullptr;
+#define W4R_EPI(TT)                                                   \
+    if (e == W4R_STORE) w4r_go<TT, W4R_STORE>(pl, N, wide_scales, st, a, r);    \
+    else if (e == W4R_SWIGLU) w4r_go<TT, W4R_SWIGLU>(pl, N, wide_scales, st, a, r); \
+    else if (e == W4R_ROPE) w4r_go<TT, W4R_ROPE>(pl, N, wide_scales, st, a, r); \
+    else w4r_go<TT, W4R_SLAB>(pl, N, wide_scales, st, a, r)
+    if (dtype == PIE_BF16) { W4R_EPI(BF16); }
+    else { W4R_EPI(F16); }
+#undef W4R_EPI
+    PIE_LAUNCH_CHECK();
+    if (pl.S > 1) {
+        if (slabs) {
+            *slabs = pl.S;
+            return PIE_OK;
+        }
+        const size_t MN = (size_t)M * N;
+        const dim3 rg((unsigned)((MN / 4 + 255) / 256));
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l_reduce<BF16>, rg, dim3(256), 0, st, (const float *)workspace, pl.S, MN, (u16 *)y);
+        else hipLaunchKernelGGL(k_w4l_reduce<F16>, rg, dim3(256), 0, st, (const float *)workspace, pl.S, MN, (u16 *)y);
+        PIE_LAUNCH_CHECK();
+        return PIE_OK;
+    }
+    if (bias_done) *bias_done = true;
+    return PIE_OK;
+}
+
 size_t w4m_bytes(int N, int K) { return (size_t)(N >> 5) * (K >> 6) * W4M_TILE_BYTES; }
+
+// Which W4M buffers hold a scale of magnitude >= 2^100 (k_w4r_gemm then converts with plain instructions): recorded per buffer when it is
+// built -- one 4-byte read-back and a stream synchronisation per matrix, at load / first use -- and looked up by every launcher.
+static std::mutex g_w4m_wide_mutex;
+static std::map<const void *, bool> g_w4m_wide;
+static int *g_w4m_wide_dev = nullptr;
+bool w4m_wide_scales(const void *w4m) {
+    std::lock_guard<std::mutex> lock(g_w4m_wide_mutex);
+    auto it = g_w4m_wide.find(w4m);
+    return it == g_w4m_wide.end() ? true : it->second;  // a buffer nobody checked: the conversion without a domain
+}
 
 int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) {
     PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M repack: N must be a multiple of 32 and K of 64");
     const size_t n = (size_t)(N >> 5) * (K >> 6) * 64;
-    hipLaunchKernelGGL(k_w4s_to_w4m, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K), (u32 *)w4m);
+    std::lock_guard<std::mutex> lock(g_w4m_wide_mutex);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool check = cap == hipStreamCaptureStatusNone;  // no read-back inside a stream capture: the buffer then counts as wide
+    if (check && !g_w4m_wide_dev) PIE_HIP_TRY(hipMalloc((void **)&g_w4m_wide_dev, sizeof(int)));
+    if (check) PIE_HIP_TRY(hipMemsetAsync(g_w4m_wide_dev, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_w4s_to_w4m, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32 *)w4s, N, K, w4s_slices(K), (u32 *)w4m, check ? g_w4m_wide_dev : (int *)nullptr);
     PIE_LAUNCH_CHECK();
+    int wide = 1;
+    if (check) {
+        PIE_HIP_TRY(hipMemcpyAsync(&wide, g_w4m_wide_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        PIE_HIP_TRY(hipStreamSynchronize(st));
+    }
+    g_w4m_wide[w4m] = wide != 0;
     return PIE_OK;
 }
 
@@ -1138,6 +1278,15 @@ int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype
     PIE_REQUIRE(x && w4m && y, PIE_E_ARG, "pie_qgemm_w4m: null pointer");
     // before any plan or workspace arithmetic: with N < 32 a plan has no column tiles and divides by zero on the host
     PIE_REQUIRE(M > 0 && N >= 32 && N % 32 == 0 && K >= 64 && K % 64 == 0, PIE_E_SHAPE, "pie_qgemm_w4m: M > 0, N a multiple of 32, K a multiple of 64");
+    if (w4r_serves(M, N, K)) {  // 6 .. 256 rows (and fewer, when asked at this level): the weight-streaming form
+        hipStream_t st = (hipStream_t)stream;
+        void *ws = nullptr;
+        const size_t wb = w4r_workspace_bytes(M, N, K);
+        if (wb && hipMallocAsync(&ws, wb, st) != hipSuccess) return pie::fail(PIE_E_HIP, "pie_qgemm_w4m: hipMallocAsync failed");
+        const int rc = w4r_gemm_launch(dtype, w4m, x, M, N, K, y, ws, st, W4R_STORE, nullptr, nullptr, nullptr, nullptr, w4m_wide_scales(w4m));
+        if (ws) (void)hipFreeAsync(ws, st);
+        return rc;
+    }
     if (M > 32) {  // the prompt GEMM; a K-split shape takes stream-ordered scratch for its fp32 partial tiles
         hipStream_t st = (hipStream_t)stream;
         void *ws = nullptr;
