@@ -1061,16 +1061,18 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
 
 // Decomposition: 4 strips (128 columns) per workgroup, all rows; K split over blockIdx.y into runs of whole steps where the column
 // workgroups alone cannot fill the chip (q|k|v: 48, o_proj / down: 32 on the 8B model) -- the splits' fp32 slabs are summed by the consumer.
-// Geometry per row count (tools/w4r_bench on the 8B shapes; EXPERIMENTS.md): <= 64 rows two strips per wave, four K-phases, four x buffers;
-// 65..128 rows one strip per wave, two K-phases, four (half-size) x buffers -- the x chunk of 128 rows is 64 KB per 256 columns and has to be
-// in flight two steps ahead; 129..256 rows the same with two buffers (LDS).
+// Geometry per row count (tools/w4r_bench on the 8B shapes; EXPERIMENTS.md): <= 64 rows two strips per wave, four K-phases, four x buffers
+// of 16 / 32 KB; from 65 rows one strip per wave, two K-phases and as many x buffers of 24 .. 64 KB as LDS holds (4 / 3 / 2 up to 128 / 192 /
+// 256 rows): the x chunk has to be in flight two steps ahead, and a 256-column chunk of 128 rows alone is 64 KB.
 struct W4rPlan {
     int mb, kw, S, steps;  // row blocks, K-phases, K splits, steps per split; mb == 0: shape not served
 };
 static W4rPlan w4r_plan(int M, int N, int K, bool may_split) {
     W4rPlan pl = {0, 0, 1, 0};
     if (M < 1 || M > 256 || N < 32 || N % 32 || K < 64 || K % 64) return pl;
-    const int mb = M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : 8)), kw = mb >= 4 ? 2 : 4;
+    int mb = (M + 31) / 32;
+    if (mb == 7) mb = 8;
+    const int kw = mb >= 3 ? 2 : 4;
     const int groups = K >> 6;
     if (groups < kw) return pl;
     const int total = (groups + kw - 1) / kw, col_wgs = (N / 32 + 3) / 4;
@@ -1094,21 +1096,17 @@ size_t w4r_workspace_bytes(int M, int N, int K) {
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-template <class T, int EPI>
-static void w4r_go(const W4rPlan &pl, int N, bool plain, hipStream_t st, const W4rArgs &a, const W4mRope &r) {
+template <class T, bool PLAIN>
+static void w4r_go(const W4rPlan &pl, int N, hipStream_t st, const W4rArgs &a, const W4mRope &r) {
     const dim3 grid((unsigned)((N / 32 + 3) / 4), (unsigned)pl.S), block(512);
-    if (pl.mb == 1) {
-        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 1, 2, 4, 4, EPI, true>), grid, block, 0, st, a, r);
-        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 1, 2, 4, 4, EPI, false>), grid, block, 0, st, a, r);
-    } else if (pl.mb == 2) {
-        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 2, 2, 4, 4, EPI, true>), grid, block, 0, st, a, r);
-        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 2, 2, 4, 4, EPI, false>), grid, block, 0, st, a, r);
-    } else if (pl.mb == 4) {
-        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 4, 1, 2, 4, EPI, true>), grid, block, 0, st, a, r);
-        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 4, 1, 2, 4, EPI, false>), grid, block, 0, st, a, r);
-    } else {
-        if (plain) hipLaunchKernelGGL((k_w4r_gemm<T, 8, 8, 1, 2, 2, EPI, true>), grid, block, 0, st, a, r);
-        else hipLaunchKernelGGL((k_w4r_gemm<T, 8, 8, 1, 2, 2, EPI, false>), grid, block, 0, st, a, r);
+    switch (pl.mb) {
+    case 1: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 1, 2, 4, 4, PLAIN>), grid, block, 0, st, a, r); break;
+    case 2: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 2, 2, 4, 4, PLAIN>), grid, block, 0, st, a, r); break;
+    case 3: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 3, 1, 2, 4, PLAIN>), grid, block, 0, st, a, r); break;
+    case 4: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 4, 1, 2, 4, PLAIN>), grid, block, 0, st, a, r); break;
+    case 5: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 5, 1, 2, 3, PLAIN>), grid, block, 0, st, a, r); break;
+    case 6: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 6, 1, 2, 3, PLAIN>), grid, block, 0, st, a, r); break;
+    default: hipLaunchKernelGGL((k_w4r_gemm<T, 8, 8, 1, 2, 2, PLAIN>), grid, block, 0, st, a, r); break;
     }
 }
 
@@ -1127,7 +1125,7 @@ int w4r_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     PIE_REQUIRE(pl.mb != 0, PIE_E_SHAPE, "W4R GEMM: 1..256 rows, N a multiple of 32, K a multiple of 64 and at least 256 (128 beyond 64 rows)");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(y, 16) && pie_aligned(bias, 16), PIE_E_ALIGN, "W4R GEMM: 16-byte alignment required");
     PIE_REQUIRE(epi != W4R_SWIGLU || N % 64 == 0, PIE_E_SHAPE, "W4R GEMM: the SwiGLU epilogue needs whole column octets of pairs");
-    W4rArgs a = {(const char *)w4m, (const u16 *)x, M, N, K, pl.steps, (u16 *)y, nullptr, (const u16 *)bias};
+    W4rArgs a = {(const char *)w4m, (const u16 *)x, M, N, K, pl.steps, (u16 *)y, nullptr, (const u16 *)bias, epi};
 #ifdef W4R_PROF
     extern unsigned long long *g_w4r_prof;
     a.prof = g_w4r_prof;
@@ -1135,14 +1133,10 @@ int w4r_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     const W4mRope r = rope ? *rope : W4mRope{};
     const int e = pl.S > 1 ? W4R_SLAB : epi;
     if (pl.S > 1) a.part = (float *)workspace, a.bias = nullptr;
-#define W4R_EPI(TT)                                                   \
-    if (e == W4R_STORE) w4r_go<TT, W4R_STORE>(pl, N, wide_scales, st, a, r);    \
-    else if (e == W4R_SWIGLU) w4r_go<TT, W4R_SWIGLU>(pl, N, wide_scales, st, a, r); \
-    else if (e == W4R_ROPE) w4r_go<TT, W4R_ROPE>(pl, N, wide_scales, st, a, r); \
-    else w4r_go<TT, W4R_SLAB>(pl, N, wide_scales, st, a, r)
-    if (dtype == PIE_BF16) { W4R_EPI(BF16); }
-    else { W4R_EPI(F16); }
-#undef W4R_EPI
+    a.epi = e;
+    if (dtype == PIE_F16) w4r_go<F16, false>(pl, N, st, a, r);  // f16 scales cannot leave w4r_dequant's domain
+    else if (wide_scales) w4r_go<BF16, true>(pl, N, st, a, r);
+    else w4r_go<BF16, false>(pl, N, st, a, r);
     PIE_LAUNCH_CHECK();
     if (pl.S > 1) {
         if (slabs) {

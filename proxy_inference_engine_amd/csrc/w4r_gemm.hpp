@@ -38,6 +38,7 @@ struct W4rArgs {
     u16 *y;            // STORE: [M, N]; SWIGLU: the activation [M, N / 2]
     float *part;       // SLAB: [gridDim.y][M][N] un-rounded fp32 sums
     const u16 *bias;   // the Linear's bias (nullable; STORE / SWIGLU; ROPE takes W4mRope::bias)
+    int epi;           // W4R_STORE / W4R_SWIGLU / W4R_ROPE / W4R_SLAB (run-time: the epilogues are outside the loop, one kernel per geometry)
 #ifdef W4R_PROF
     unsigned long long *prof;  // developer build: [workgroup][wave][step][4] s_memtime stamps (tools/w4r_bench)
 #endif
@@ -90,16 +91,19 @@ __device__ __forceinline__ uint4 w4r_dequant_plain(u32 word, float s, float b) {
 // ---------------- epilogue (both kernel forms): per 32-row block, all phases' partial tiles -> LDS, summed in phase order by all threads
 // block (phase, strip ts) at ((phase NS + ts) RED_BLK): lane l's 16 accumulators at l 80 (+ 16 q): conflict-free b128 writes and reads
 constexpr int W4R_RED_BLK = 64 * 80;  // one (phase, strip) block: 64 lanes x (16 floats + pad)
-template <class T, int WAVES, int MB, int SPW, int KW, int EPI>
+template <class T, int WAVES, int MB, int SPW, int KW>
 __device__ __forceinline__ void w4r_epilogue(const f32x16_t (&acc)[SPW][MB], char *smem, const W4rArgs &a, const W4mRope &rp, int p, int sg, int lane) {
     constexpr int NS = (WAVES / KW) * SPW, RED_BLK = W4R_RED_BLK;
+    const int EPI = a.epi;  // uniform
     static_assert(WAVES * 64 >= 128 * NS, "at most one output octet per reducer thread");
     const int n_strips = a.N >> 5;
     const int t = threadIdx.x, em = t / (4 * NS), ej = t % (4 * NS), ets = ej >> 2, ec = ej & 3;  // reducer thread: row em, strip ets, columns 8 ec .. + 8
     const int ent = blockIdx.x * NS + ets;
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-        if (mi * 32 >= a.M) break;  // uniform
+    // a compile-time loop: with a run-time `break` in a body of this size the compiler stops unrolling at 8 row blocks, indexes the
+    // accumulators dynamically and moves ALL of them to scratch (measured: the 256-row kernel 9 x slower)
+    pa_static_for<0, MB>([&](auto mi_c) {
+        constexpr int mi = decltype(mi_c)::value;
+        if (mi * 32 >= a.M) return;  // uniform: this row block is past the end (so are the later ones)
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
             char *blk = smem + (p * NS + sg * SPW + s) * RED_BLK + lane * 80;
@@ -153,14 +157,14 @@ __device__ __forceinline__ void w4r_epilogue(const f32x16_t (&acc)[SPW][MB], cha
             }
         }
         __syncthreads();  // the next row block reuses the blocks
-    }
+    });
 }
 
 // WAVES: waves per workgroup (8: two per SIMD, one workgroup per CU)
 // MB: 32-row blocks of x (all M <= 32 MB rows in ONE workgroup: a weight tile is converted once)
 // SPW: strips per wave; KW: K-phases (groups per step); XB: x buffers = weight ring slots
 // PLAIN: convert with w4r_dequant_plain (matrices whose scales exceed w4r_dequant's domain; rows from which it is no slower)
-template <class T, int WAVES, int MB, int SPW, int KW, int XB, int EPI, bool PLAIN>
+template <class T, int WAVES, int MB, int SPW, int KW, int XB, bool PLAIN>
 __global__ void __launch_bounds__(WAVES * 64) k_w4r_gemm(const W4rArgs a, const W4mRope rp) {
     constexpr int NSW = WAVES / KW, NS = NSW * SPW;       // strip groups; strips per workgroup
     constexpr int ROWB = KW * 128, MT = 32 * MB;              // bytes per staged x row; rows
@@ -363,6 +367,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_w4r_gemm(const W4rArgs a, const 
             a.prof[(size_t)(blockIdx.x / 50) * WAVES * 32 * 4 + i] = *reinterpret_cast<unsigned long long *>(smem + XB * CHUNK + i * 8);
     __syncthreads();
 #endif
-    w4r_epilogue<T, WAVES, MB, SPW, KW, EPI>(acc, smem, a, rp, p, sg, lane);
+    w4r_epilogue<T, WAVES, MB, SPW, KW>(acc, smem, a, rp, p, sg, lane);
 }
 

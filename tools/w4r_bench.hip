@@ -139,11 +139,12 @@ static int check_shape(int M, int N, int K, int epi, bool with_bias, bool no_sla
     } else {
         for (size_t i = 0; i < out_elems; ++i) {
             float want = bf2f(f2bf(ref[i]));
+            const float mag = fabs(want);  // the rounding slack is one bf16 ulp of the Linear's output, whatever the bias then cancels
             if (with_bias && bias_done) want = bf2f(f2bf(want + bf2f(hb[i % N])));
             const float have = bf2f(hy[i]);
             const double e = fabs((double)have - want);
             max_err = e > max_err ? e : max_err, max_ref = fabs(want) > max_ref ? fabs(want) : max_ref;
-            if (e > 0.0079 * (0.01 + fabs(want))) ++bad;  // one bf16 ulp of slack: fp32 summation order differs from the double reference
+            if (e > 0.0079 * (0.01 + (mag > fabs(want) ? mag : fabs(want)))) ++bad;  // one bf16 ulp of slack: fp32 summation order differs from the double reference
             else if (have != want) ++off1;
         }
     }
@@ -180,7 +181,7 @@ int main(int argc, char **argv) {
     if (getenv("W4R_PLAIN")) g_plain = atoi(getenv("W4R_PLAIN")) != 0;
     if (mode == "check") {
         int fails = 0;
-        const int Ms[] = {6, 17, 32, 33, 64, 100, 128, 129, 200, 256};
+        const int Ms[] = {6, 17, 32, 33, 64, 65, 96, 100, 128, 129, 160, 161, 192, 200, 256};
         for (int M : Ms) {
             fails += check_shape(M, 256, 512, W4R_STORE, false, false);          // tiny: 2 column workgroups, K split
             fails += check_shape(M, 6144, 4096, W4R_STORE, M % 2 == 0, false);   // q|k|v shape, slabs
@@ -192,7 +193,7 @@ int main(int argc, char **argv) {
         fails += check_shape(128, 28672, 4096, W4R_SWIGLU, false, false);  // gate|up
         fails += check_shape(48, 4128, 2048, W4R_STORE, true, false);      // 129 strips: a ragged last column workgroup
         fails += check_shape(9, 128256, 4096, W4R_STORE, false, false);    // lm_head
-        for (int M : {7, 40, 100, 200}) {
+        for (int M : {7, 40, 100, 150, 200}) {
             fails += check_shape(M, 256, 704, W4R_STORE, false, false);   // 11 groups: a partial last step
             fails += check_shape(M, 1408, 1408, W4R_SWIGLU, false, false);  // 22 groups, 44 strips
             fails += check_shape(M, 512, 320, W4R_STORE, true, true);     // 5 groups
