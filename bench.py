@@ -135,8 +135,8 @@ def cpu_baseline(cfg, weights_host, n_tokens, model=None, prompt=None, what="Lla
               "vs_float32_oracle": {"hip_max_eps": hip_exact[0], "hip_rms_eps": hip_exact[1], "bf16_oracle_max_eps": orc_exact[0], "bf16_oracle_rms_eps": orc_exact[1]},
               "tolerance_eps": tol, "tolerance_rule": "HIP vs float32 oracle <= max(1.5 x (bf16 oracle vs float32 oracle), 8) ulps of the largest logit",
               "reference": "oracle/pie_oracle.c (parity unpinned: the reference holds no fixture for this path)",
-              "min_ids_checked": min(16, n_tokens // 3),
-              "ok": bool(equal == checked and checked >= min(16, n_tokens // 3) and hip_exact[0] <= tol)}
+              "min_ids_checked": min(16, n_tokens // 2),
+              "ok": bool(equal == checked and checked >= min(16, n_tokens // 2) and hip_exact[0] <= tol)}
     return base, parity
 
 

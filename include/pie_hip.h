@@ -320,11 +320,11 @@ int pie_decoder_step(pie_decoder *d, int flags, void *stream);
  * been captured.  bench.py reports it as config.launches_per_step. */
 int pie_decoder_graph_launches(const pie_decoder *d, int flags);
 /* Prompt processing: Model.__call__(inputs[1, L]) from the current device-side offset, ids[0..L) device int32, all
- * launches queued back to back with no host round trip.  L >= 6 (env PIE_PREFILL_MIN): batched, in chunks of
- * PIE_PREFILL_CHUNK (4096) rows -- per layer the W4S weights are dequantised to T and multiplied by hipBLASLt (MLX's
- * qmm regime: nn.QuantizedLinear at L > 1 dequantises to T before a T x T -> fp32 MMA), with HIP kernels for RMSNorm,
- * RoPE + cache append, causal attention, SwiGLU and residuals; needs libhipblaslt.so at run time (PIE_E_STATE if it
- * cannot be loaded).  Shorter prompts: iterated decode steps (the qmv regime).  logits_all == NULL: lm_head + tail only for the last token (the engine only
+ * launches queued back to back with no host round trip.  L >= 6 (pie_set_knob(PIE_KNOB_PREFILL_MIN, n)): batched, in chunks of
+ * 4096 rows (PIE_KNOB_PREFILL_CHUNK) -- MLX's qmm regime: nn.QuantizedLinear at L > 1 dequantises to T before a T x T -> fp32 MMA.
+ * int4 group-64 matrices run hand-written MFMA GEMMs straight from their 4-bit tiles (k_w4r_gemm up to 256 rows, k_w4l2_gemm beyond);
+ * dense, int8 and group-32 matrices are unpacked / dequantised to T and multiplied by hipBLASLt (dlopen'ed: PIE_E_STATE if it cannot be
+ * loaded), with HIP kernels for RMSNorm, RoPE + cache append, causal attention, SwiGLU and residuals.  Shorter prompts: iterated decode steps (the qmv regime).  logits_all == NULL: lm_head + tail only for the last token (the engine only
  * reads logits[:, -1, :], engine/inference_engine.py:254).  logits_all != NULL: T [L, vocab], lm_head on every
  * position like the reference's Model.__call__ (language.py:205-209). */
 int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream);

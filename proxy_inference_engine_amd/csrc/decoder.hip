@@ -375,13 +375,16 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
     const int L = d->cfg.n_layers;
     const size_t v_off = (size_t)d->cfg.n_kv_heads * PIE_PAGE_TOKENS * d->cfg.head_dim * 2;  // bytes: K block, then V block
     std::vector<unsigned long long> tab(2 * (size_t)L);
-    d->slab_host.assign(L, nullptr);
+    // int8 pages: the single-sequence step passes the slab bases as launch arguments (baked into a captured graph), so new slabs under an
+    // unchanged table, pool size and width must drop the graphs too (T pages are reached through the device-side kv_table)
+    bool slabs_changed = (int)d->slab_host.size() != L;
     for (int i = 0; i < L; ++i) {
         PIE_REQUIRE(slabs[i] && pie_aligned(slabs[i], 16), PIE_E_ALIGN, "pie_decoder_set_paged_kv: null or misaligned slab");
         tab[i] = (unsigned long long)(uintptr_t)slabs[i];
         tab[L + i] = tab[i] + v_off;
-        d->slab_host[i] = slabs[i];
+        slabs_changed = slabs_changed || d->slab_host[i] != slabs[i];
     }
+    d->slab_host.assign(slabs, slabs + L);
     hipStream_t st = (hipStream_t)stream;
     if (d->kv_i8) {  // int8 pages (PIE_OPT_KV_I8): the staging page, the table that points every layer at it, and a block table of zeros
         if (!d->kv_stage) {
@@ -410,7 +413,7 @@ int pie_decoder_set_paged_kv(pie_decoder *d, const void *const *slabs, size_t n_
     d->kv_set = true;
     d->kv_cap = capacity;
     // kernel arguments are baked into captured graphs: a new table pointer or pool size invalidates them
-    const bool changed = d->block_table != block_table || d->n_pages != (int)n_pages || blocks_changed;
+    const bool changed = d->block_table != block_table || d->n_pages != (int)n_pages || blocks_changed || (d->kv_i8 && slabs_changed);
     d->block_table = block_table, d->n_pages = (int)n_pages;
     if (plan_attention(d) || changed) drop_graphs(d);
     return PIE_OK;

@@ -13,7 +13,7 @@
 //   * hand-written HIP for everything around it: RMSNorm rows, RoPE + cache append from the packed q|k|v rows, causal
 //     attention (the decode kernel with one query row per blockIdx.z: row r attends offset + r + 1 positions), the
 //     split merge, SwiGLU on the interleaved gate/up rows, residual adds.
-// The chunk is bounded (PIE_PREFILL_CHUNK, default 4096 rows: ~0.6 GB of activation scratch on the 8B model).
+// The chunk is bounded (PIE_KNOB_PREFILL_CHUNK, default 4096 rows: ~0.6 GB of activation scratch on the 8B model).
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 
@@ -362,7 +362,7 @@ int lt_init() {
     const char *dl_msg = g_lt.lib ? nullptr : dlerror();  // dlerror() clears itself: read it once
     PIE_REQUIRE(g_lt.lib, PIE_E_STATE,
                 std::string("prefill: cannot load hipBLASLt (") + (dl_msg ? dl_msg : "not found") +
-                    "); put libhipblaslt.so on the loader path, or set PIE_PREFILL_MIN=1000000 to process prompts as iterated decode steps");
+                    "); put libhipblaslt.so on the loader path, or pie_set_knob(PIE_KNOB_PREFILL_MIN, 1000000) to process prompts as iterated decode steps");
 #define LT_SYM(field, name)                                                        \
     g_lt.field = reinterpret_cast<decltype(g_lt.field)>(dlsym(g_lt.lib, #name)); \
     PIE_REQUIRE(g_lt.field, PIE_E_STATE, "prefill: hipBLASLt lacks " #name)
@@ -455,7 +455,7 @@ struct PrefillScratch {
     int part_splits = 0;
     // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
-    // that is a small share of the free memory (PIE_PREFILL_RESIDENT=0/1 overrides), built on first use.
+    // that is a small share of the free memory (PIE_KNOB_PREFILL_RESIDENT overrides), built on first use.
     std::map<const void *, u16 *> resident;
     // W4M tile copies (w4m_gemm.hip) of int4 layer matrices for prompts of at most small_rows() rows: 0.5625 B per weight each
     std::map<const void *, void *> resident_w4m;
@@ -672,7 +672,7 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     if (pie_knob(PIE_KNOB_W4L_SLABS) == 0) slabs = nullptr;  // always reduce in the GEMM's own launch (the bit-equality test)
     // 8B prompt of 64 / 128 / 256 / 512 / 700 tokens, slabs summed by the consumers vs reduce launches: 3.70 / 4.56 / 6.13 / 9.56 / 14.26 ms
     // vs 3.96 / 4.82 / 6.20 / 9.75 / 14.38.  (With ONE workgroup per row the RoPE consumer could not keep enough slab loads in flight
-    // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; PIE_W4L_SLABS_MIN_ROWS restricts the
+    // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; that split applies to the RoPE consumer, not to the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
     if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 codes, qmv regime: the streaming GEMV, one pass per row
@@ -894,7 +894,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                 pa.block_table = d->block_table, pa.n_pages = d->n_pages;
                 pa.M = M, pa.Hq = c.n_heads, pa.Hkv = c.n_kv_heads, pa.scale = 1.0f / sqrtf((float)D), pa.out = s->attn;
                 if ((rc = prefill_attn_launch_t<T>(pa, D, st))) return rc;
-            } else {  // PIE_PREFILL_ATTN=valu: the VALU decode kernel, one query row per blockIdx.z (cross-check for the tests)
+            } else {  // PIE_KNOB_PREFILL_ATTN_VALU = 1: the VALU decode kernel, one query row per blockIdx.z (cross-check for the tests)
                 AttnArgs a = {};
                 a.q = s->q, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
                 a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;  // every row reads the one sequence's table
@@ -1204,6 +1204,8 @@ static int varlen_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_c
                         const int32_t *seg_hi, const int32_t *last_rows, int N, int S, int n_decode, const void *const *slabs, size_t n_pages, size_t slab_bytes,
                         const int32_t *block_tables, int max_blocks, void *logits, float *logprobs, int32_t *next_tokens, void *stream, int n_chunks = 0,
                         const int32_t *chunks = nullptr) {
+    PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
+                PIE_E_ARG, "pie_decoder_prefill_batch / _step_mixed: null pointer");
     PIE_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || chunks), PIE_E_ARG, "pie_decoder_step_mixed: chunks without their descriptor array");
     PIE_REQUIRE(n_chunks == 0 || !d->kv_i8, PIE_E_STATE, "pie_decoder_step_mixed: a prompt continuing a cached prefix reads T pages (int8 pages: fresh prompts and decode rows only)");
     for (int ci = 0; ci < n_chunks; ++ci) {
@@ -1212,8 +1214,6 @@ static int varlen_batch(pie_decoder *d, const int32_t *ids, const int32_t *row_c
                         (ch[2] + ch[1] + PIE_PAGE_TOKENS - 1) / PIE_PAGE_TOKENS <= max_blocks,
                     PIE_E_SHAPE, "pie_decoder_step_mixed: a chunk is {first row >= n_decode, rows >= 1, cached positions >= 1, sequence < S} inside the batch and its block table");
     }
-    PIE_REQUIRE(d && ids && row_context_lens && row_seq && seg_lo && seg_hi && last_rows && slabs && block_tables && logits && logprobs && next_tokens,
-                PIE_E_ARG, "pie_decoder_prefill_batch / _step_mixed: null pointer");
     PIE_REQUIRE(d->glob_set, PIE_E_STATE, "pie_decoder_prefill_batch / _step_mixed: set_globals must be called first");
     for (char s : d->layer_set) PIE_REQUIRE(s, PIE_E_STATE, "pie_decoder_prefill_batch / _step_mixed: a layer has no weights (pie_decoder_set_layer)");
     PIE_REQUIRE(S >= 1 && N >= S && N <= 65535 && max_blocks > 0 && n_pages > 0 && n_pages < 0x7FFFFFFFu, PIE_E_SHAPE, "pie_decoder_prefill_batch / _step_mixed: bad batch shape");

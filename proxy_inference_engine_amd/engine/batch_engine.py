@@ -137,9 +137,16 @@ class BatchedEngine:
                                                          [f[1][f[3]:f[3] + n] for f, n in take], [f[2] for f, _ in take])
                 self.steps += 1
                 self.mixed_passes += bool(active)
-                if self.sampler is not None:
-                    nxt = self.sampler(logprobs).reshape(-1).to(torch.int32)
                 nb = len(active)
+                if self.sampler is not None:
+                    # the sampler sees generation steps only: the decode rows and the rows of prompts whose LAST chunk is in this pass; the row
+                    # of a prompt that is still filling is discarded (its greedy id stands in), so a seeded sampler's stream and a stateful
+                    # sampler's history do not depend on the chunk size
+                    live = list(range(nb)) + [nb + i for i, (f, n) in enumerate(take) if f[3] + n == len(f[1])]
+                    if live:
+                        idx = torch.tensor(live, dtype=torch.long, device=logprobs.device)
+                        nxt = nxt.clone()
+                        nxt[idx] = self.sampler(logprobs[idx]).reshape(-1).to(torch.int32)
                 for i, a in enumerate(active):
                     a.token = nxt[i:i + 1]
                 for i, (f, n) in enumerate(take):

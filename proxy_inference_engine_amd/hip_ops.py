@@ -633,7 +633,7 @@ def sample(logprobs: torch.Tensor, mode: str, temp: float, p: float = 0.0, k: in
     from .samplers import _rng
     x = logprobs
     if not x.is_cuda:
-        raise ValueError("hip_ops.sample needs the log-probabilities on the GPU")
+        raise ValueError("the samplers take device tensors (ROCm): there is no host path; got a CPU tensor")
     if x.dim() == 1:
         x = x[None]
     if x.dtype != torch.float32:

@@ -299,8 +299,9 @@ class Model:
         kv_dtype=torch.int8: the pages are the reference KVPage's own storage (page.hpp:25-32) -- int8 K / V rows with float16 per-head
         scales; kv_scales = (k, v), each float16 [n_layers, n_kv_heads], is written into every page (None: ones, the reference
         constructor's value -- far too coarse for real activations; pass amax / 127 of a calibration prompt).  Such a pool serves
-        prefill_batch / step_batch (the continuous-batching path) and the single-sequence step() / InferenceEngine (whose prompts then run as
-        decode steps: the batched single-sequence prompt path reads T pages)."""
+        prefill_batch / step_batch (the continuous-batching path) and the single-sequence step() / InferenceEngine: a fresh token prompt goes through
+        the several-prompts pass as a batch of one (quantised into its pages on the way); a suffix behind a cached prefix, and a prompt of
+        embeddings, run as decode steps (the batched single-sequence pass reads T pages)."""
         kv_dtype = self.dtype if kv_dtype is None else kv_dtype
         if kv_dtype not in (self.dtype, torch.int8):
             raise ValueError(f"kv_dtype must be the model's dtype or torch.int8, got {kv_dtype}")
@@ -462,8 +463,14 @@ class Model:
         return hip_ops.embedding(ids, *self.embed_tokens, bits=self.bits, group_size=32 if self.group_size == 32 else 64)
 
     def step_embeds(self, inputs_embeds: torch.Tensor, cache: list[BaseCache]):
-        """`step` for a prompt given as embeddings: forwards the rows, lm_head + tail on the last one only."""
+        """`step` for a prompt given as embeddings: forwards the rows, lm_head + tail on the last one only.
+        On an int8 page pool such a prompt runs as L decode steps (~1.2 ms per row on the 8B model: the batched single-sequence pass reads
+        T pages and the several-prompts pass takes token ids only); warned about once."""
         emb = self._check_embeds(inputs_embeds)
+        if emb.shape[0] >= 6 and isinstance(cache[0], PagedKVCache) and cache[0].page_manager.allocator.dtype == torch.int8 and not getattr(self, "_warned_i8_embeds", False):
+            import warnings
+            warnings.warn("a prompt of embeddings on int8 KV pages is processed one row per decode step; use T pages for VLM prompts, or token prompts", stacklevel=2)
+            self._warned_i8_embeds = True
         L = emb.shape[0]
         self._sync_cache(cache, L)
         _ffi.check(_ffi.load().pie_decoder_prefill_embeds(self._dec, _ffi.p(emb), L, None, _ffi.stream()))
@@ -486,6 +493,18 @@ class Model:
         else:
             ids = ids.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
             L = ids.numel()
+            if L >= 6 and isinstance(cache[0], PagedKVCache) and cache[0].page_manager.allocator.dtype == torch.int8 and cache[0].offset == 0:
+                # A fresh prompt on int8 pages: the single-sequence prompt pass reads T pages (it would run the prompt as L decode steps,
+                # ~1.2 ms per token), the several-prompts pass quantises into int8 pages -- one prompt is a batch of one.
+                nxt, logprobs, logits = self.prefill_batch([ids.cpu().numpy()], [cache])  # (a prompt arrives once: the host copy is the pass's own row bookkeeping)
+                pos = cache[0].offset  # position the chosen token will occupy
+                self._kv_key = None     # the pass bound its own table: the next step re-binds the sequence and sets the device-side offset
+                self._dev_offset = None
+                _ffi.check(lib.pie_decoder_set_token_from(self._dec, _ffi.p(nxt), _ffi.stream()))  # device to device: step(None) feeds it back
+                if pos < self.history.numel():
+                    self.history[pos:pos + 1].copy_(nxt[:1])
+                    return self.history[pos:pos + 1], logprobs[0], logits[0]
+                return nxt[:1].clone(), logprobs[0], logits[0]
             self._sync_cache(cache, L)
             if L == 1:
                 _ffi.check(lib.pie_decoder_set_token_from(self._dec, _ffi.p(ids), _ffi.stream()))

@@ -3,9 +3,10 @@
 `make_sampler(temp=0)` -- the greedy branch (samplers/__init__.py:37-38) -- is the parity target of the decode
 path and runs in the fused HIP tail (argmax of the fp32 log-probabilities, first maximal index).
 The stochastic branches (top-p, min-p, top-k, categorical: samplers/{top_p,min_p,top_k,categorical}.py, SURVEY.md
-8f-4) restate the reference's filters op for op on the device that holds the log-probabilities (no host sync: the
-drawn token stays a device tensor and feeds the next step); their random stream is torch's, not MLX's, so parity is
-the kept-token set (exact) and the distribution, not the individual draw.  `seed(n)` = mx.random.seed(n).
+8f-4) are sort-free HIP kernels (csrc/sampler.hip) on the device that holds the log-probabilities (no host sync: the
+drawn token stays a device tensor and feeds the next step; host tensors are refused -- the reference's definitions restated
+with torch ops live in tests/sampler_reference.py as the comparator); their random stream is Philox, not MLX's, so parity
+is the kept-token set (exact) and the distribution, not the individual draw.  `seed(n)` = mx.random.seed(n).
 """
 from __future__ import annotations
 

@@ -539,6 +539,47 @@ def test_dense_checkpoint_prefill_and_decode(dtype):
     assert model.step_bytes(100) > 2 * sum(v.size for k, v in w.items() if k.endswith("proj.weight"))  # 2 B per parameter
 
 
+def test_tinyllama_dense_fp16_128_plus_64_greedy_vs_oracle():
+    """BASELINE.json configs[0] AS WRITTEN: TinyLlama-1.1B geometry (H=2048, I=5632, 32/4 heads, D=64, V=32000, theta 1e4), UNQUANTISED
+    fp16 (nn.Linear / nn.Embedding: no "quantization" entry, models/utils.py:96-97), greedy, a 128-token prompt + 64 generated tokens through
+    InferenceEngine.generate_step (engine/inference_engine.py:228-297); 2 of the 22 layers (the oracle runs on the host).  The oracle decodes
+    the same 64 steps teacher-forced with ITS greedy tokens; logits at every step within the end-to-end tolerance, greedy ids identical
+    wherever the oracle's top-2 margin exceeds the bound, and once an id differs inside the bound the comparison stops (the runs diverge)."""
+    from proxy_inference_engine_amd import InferenceEngine
+    dtype = "float16"
+    cfg = {"model_type": "llama", "hidden_size": 2048, "num_hidden_layers": 2, "intermediate_size": 5632,
+           "num_attention_heads": 32, "num_key_value_heads": 4, "rms_norm_eps": 1e-5, "vocab_size": 32000,
+           "rope_theta": 10000.0, "max_position_embeddings": 2048, "tie_word_embeddings": False}
+    w = po.synth_checkpoint(cfg, seed=17, dtype=dtype, lm_head_gain=4.0)
+    assert "model.layers.0.mlp.down_proj.scales" not in w and "model.embed_tokens.scales" not in w
+    model = build(cfg, w, dtype)
+    assert model.dense
+    orc = po.OracleLlama(cfg, w, dtype)
+    prompt = np.random.default_rng(128).integers(0, cfg["vocab_size"], 128)
+    eng = InferenceEngine(model=model)
+    eng.prepare_engine(prompt, temp=0)
+    gen = eng.generate_step(torch.from_numpy(prompt))
+    ocache = [po.OracleKVCache() for _ in orc.layers]
+    want = orc.forward(prompt, ocache, last_only=True).reshape(-1)       # the batched prompt pass (128 rows: MLX's GEMM regime)
+    checked = compared = 0
+    for i in range(64):
+        tok, lp = next(gen)
+        otok, olp = po.logprobs_argmax(want)
+        got_lp = lp.float().cpu().numpy().reshape(-1)
+        err = float(np.abs(got_lp - olp).max())
+        assert err <= 4 * 2.0 ** -11 * float(np.abs(want).max()) + 1e-3, f"token {i}: log-probabilities off by {err}"
+        compared += 1
+        top2 = np.sort(olp)[-2:]
+        if top2[1] - top2[0] > margin_bound(want, dtype):
+            assert int(tok.item()) == otok, f"token {i}: {int(tok.item())} vs oracle {otok} at margin {top2[1] - top2[0]:.4f}"
+            checked += 1
+        elif int(tok.item()) != otok:
+            break                                                        # a near-tie decided differently: the sequences diverge from here
+        want = orc.forward(np.array([otok]), ocache, last_only=True).reshape(-1)
+    assert compared >= 16 and checked >= compared // 2, (compared, checked)
+    assert model.make_cache and eng.prompt_cache.cache[0].offset >= 128 + compared - 1
+
+
 def test_llama8b_dense_bf16_layers_vs_oracle():
     """BASELINE.json configs[2] at ITS geometry: two Llama-3-8B-shaped UNQUANTISED bf16 layers (H=4096, I=14336, 32/8 heads, D=128:
     W16S units of 512-wide K slices -> 8 and 28 slices per row; a config without a "quantization" entry keeps nn.Linear,

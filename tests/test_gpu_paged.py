@@ -888,6 +888,22 @@ def test_single_sequence_step_on_int8_pages(golden_dir):
     etoks = [int(next(gen)[0].item()) for _ in range(upto)]
     assert etoks == [t for t, _ in got[:upto]]
     eng.prompt_cache.cache[0].page_manager.release()
+    # a FRESH multi-token prompt on int8 pages goes through the several-prompts pass as a batch of one (not L decode steps): its pages hold the
+    # codes of the batched pass's rows (MLX's qmm regime: within one code of the row-by-row run's), the first token and the following
+    # graph-replayed steps continue from them
+    cf = model.make_cache()
+    tok, _, lg = model.step(torch.from_numpy(prompt).cuda(), cf)
+    assert cf[0].offset == len(prompt)
+    kf = cf[0].state[0].cpu().numpy()[0].transpose(1, 0, 2).astype(np.int32)
+    assert np.abs(kf - k8[:len(prompt)].astype(np.int32)).max() <= 1, "layer-0 K codes of the batched prompt pass"
+    assert_vec_close(lg.float().cpu().numpy(), got[0][1], "bfloat16", c_max=24.0, c_rms=16.0, what="int8-page batched prompt")
+    ftoks = [int(tok.item())]
+    for i in range(upto - 1):
+        tok, _, lg = model.step(None, cf)
+        ftoks.append(int(tok.item()))
+    assert cf[0].offset == len(prompt) + upto - 1
+    assert ftoks[:2] == [t for t, _ in got[:2]], (ftoks, [t for t, _ in got[:upto]])
+    cf[0].page_manager.release()
     # a prompt of caller-made embeddings (the VLM text tower's entry, intern/ensemble.py:106-108) on int8 pages: its rows run as decode steps,
     # each copied into the residual stream -- the same rows as the token prompt's, so logits at every position and the pages' codes are equal
     ca, cb = model.make_cache(), model.make_cache()

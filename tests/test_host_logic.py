@@ -128,17 +128,17 @@ def _ref_sets(logprobs, temp, top_p=0.0, min_p=0.0, keep=1, top_k=-1):
 
 @pytest.mark.parametrize("kw", [dict(top_p=0.6), dict(top_p=0.95), dict(min_p=0.1), dict(min_p=0.3, min_tokens_to_keep=4),
                                 dict(top_k=5), dict()])
-def test_stochastic_samplers_keep_sets_and_distribution(kw):
-    """samplers/*.py restated with torch ops: every draw lies in the set the reference's filter keeps (numpy restatement
-    above), every kept token with non-negligible mass is drawn, and the empirical frequencies follow the renormalised
-    probabilities (total variation < 0.05 over 4000 draws).  The random stream itself is torch's, not MLX's."""
-    from proxy_inference_engine_amd import samplers
+def test_sampler_reference_keep_sets_and_distribution(kw):
+    """tests/sampler_reference.py (the reference's samplers/*.py restated with torch ops, the comparator of the HIP kernels): every draw lies
+    in the set the reference's filter keeps (numpy restatement above), every kept token with non-negligible mass is drawn, and the empirical
+    frequencies follow the renormalised probabilities (total variation < 0.05 over 4000 draws)."""
+    from tests import sampler_reference as sr
     rng = np.random.default_rng(11)
     V, temp = 64, 0.8
     logits = rng.standard_normal(V).astype(np.float32) * 2.0
     logprobs = logits - np.log(np.exp(logits.astype(np.float64)).sum()).astype(np.float32)
-    sampler = make_sampler(temp=temp, **kw)
-    samplers.seed(1234)
+    sampler = sr.make_sampler(temp=temp, **kw)
+    sr.seed(1234)
     x = torch.from_numpy(logprobs)[None].repeat(4000, 1)                # 4000 independent rows, one call
     draws = sampler(x).numpy()
     assert draws.shape == (4000,) and draws.dtype == np.int32
@@ -150,11 +150,11 @@ def test_stochastic_samplers_keep_sets_and_distribution(kw):
     freq = np.bincount(draws, minlength=V) / 4000.0
     assert 0.5 * np.abs(freq - p).sum() < 0.05
     assert all(freq[i] > 0 for i in allowed if p[i] > 0.01)
-    samplers.seed(1234)
+    sr.seed(1234)
     assert np.array_equal(sampler(x).numpy(), draws)                   # seed() restarts the stream
 
 
-def test_stochastic_sampler_argument_errors():
+def test_stochastic_sampler_argument_errors_and_no_host_path():
     x = torch.zeros((1, 16))
     with pytest.raises(ValueError):
         make_sampler(temp=1.0, top_k=16)(x)                             # top_k must be < vocab (top_k.py:20-24)
@@ -162,6 +162,10 @@ def test_stochastic_sampler_argument_errors():
         make_sampler(temp=1.0, min_p=1.5)(x)                            # min_p.py:33-36
     with pytest.raises(ValueError):
         make_sampler(temp=1.0, min_p=0.1, min_tokens_to_keep=0)(x)      # min_p.py:37-40
+    # the product has no CPU path: a host tensor is refused by every stochastic branch, not sampled by torch
+    for kw in (dict(top_p=0.6), dict(min_p=0.1), dict(top_k=5), dict()):
+        with pytest.raises(ValueError, match="device tensors"):
+            make_sampler(temp=1.0, **kw)(x)
 
 
 def test_prompt_cache_persistence_round_trip(tmp_path):
