@@ -15,6 +15,13 @@ Prints ONE JSON line on rank 0 with the driver's contract plus:
                   measured here with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
                   `step` = the same fraction for the whole decode step (the north-star figure).
                   `stream_peak` / `frac_of_stream`: the same against a bare streaming read measured in this run (pie_stream_read).
+                  `step.floor`: what the launch structure itself costs -- per dependent launch 1.59 us of command-processor time, 0.56 us of
+                  workgroup start-up, 0.63 us to publish its output, 1.15 us until the consumer has touched it (the barrier-bit chain of
+                  tools/pipeline_probe, profiles/r04_pipeline_probe.txt) -- plus the step's bytes at the stream rate measured in this run;
+                  `ms_per_step / floor` says how far the step is from ITS floor, `frac` how far from 8 TB/s.
+  tp70b        -- only with --gpus N > 1 on the default workload: after the replicas' timing the same ranks decode ONE Llama-3-70B int4
+                  sequence tensor-parallel (BASELINE.json configs[4]), once per communicator backend (IPC one-shot, RCCL); `value` stays
+                  the replicas figure.
   repetitions  -- 5 repetitions of the K timed steps (the first is `value`): median and min ms per step.
   cpu_baseline -- the CPU oracle (oracle/pie_oracle.c, OpenMP) timed on this box's host cores on a bounded sample, at the GPU run's
                   context (the same 128-token prompt).
@@ -140,6 +147,77 @@ def cpu_baseline(cfg, weights_host, n_tokens, model=None, prompt=None, what="Lla
     return base, parity
 
 
+def tp_shard(full_cfg, tp, rank, dist, backend):
+    """This rank's shard of a synthetic tensor-parallel checkpoint, generated directly in the local shapes (the full 70B checkpoint never
+    exists anywhere); the replicated tensors (embedding table, norm weights) are rank 0's, broadcast once.  Returns (local config, weights, HipComm)."""
+    from proxy_inference_engine_amd.models.utils import synthetic_checkpoint
+    from proxy_inference_engine_amd.tp import HipComm, shard_config
+    cfg = {k: v for k, v in shard_config(full_cfg, tp).items() if k not in ("tp_world", "tp_vocab_shard")}
+    cfg["tie_word_embeddings"] = False
+    weights = synthetic_checkpoint(cfg, seed=100 + rank, dtype=torch.bfloat16)
+    v_loc = full_cfg["vocab_size"] // tp
+    for k in ("weight", "scales", "biases"):
+        weights[f"lm_head.{k}"] = weights[f"lm_head.{k}"][:v_loc].contiguous()
+    for k, t in weights.items():
+        if k.startswith("model.embed_tokens.") or k.endswith("layernorm.weight") or k == "model.norm.weight":
+            if dist.get_backend() == "nccl":
+                dist.broadcast(t, src=0)
+            else:
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
+    return cfg, weights, HipComm(cfg["hidden_size"], backend=backend)
+
+
+def tp70b_leg(args, rank, world, dist):
+    """--gpus N > 1 on the default workload: the first contact with a multi-GPU node should also measure BASELINE.json configs[4] -- ONE
+    Llama-3-70B int4 sequence decoded tensor-parallel over all N ranks, once per communicator backend.  Strong scaling: tokens/s of that one
+    sequence.  Every failure is recorded, never raised: the replicas line above must survive it."""
+    from proxy_inference_engine_amd import InferenceEngine
+    from proxy_inference_engine_amd.models.llama import Model, ModelArgs
+    from proxy_inference_engine_amd.models.utils import LLAMA3_70B
+    out = {"model": "Llama-3-70B-shaped int4 g=64, batch 1", "tp": world, "steps": args.steps, "warmup": args.warmup}
+    for backend in ("ipc", "rccl"):
+        comm = model = eng = gen = None
+        try:
+            cfg, weights, comm = tp_shard(dict(LLAMA3_70B), world, rank, dist, backend)
+            model = Model(ModelArgs(**cfg), weights, tp=comm)
+            del weights
+            torch.cuda.empty_cache()
+            eng = InferenceEngine(model=model)
+            prompt = torch.randint(0, LLAMA3_70B["vocab_size"], (args.prompt,), generator=torch.Generator().manual_seed(1))
+            eng.prepare_engine(prompt, temp=0)
+            gen = eng.generate_step(prompt)
+            for _ in range(1 + args.warmup):
+                next(gen)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                next(gen)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            elapsed = float(t.item())
+            T_mid = args.prompt + 1 + args.warmup + args.steps // 2
+            err = comm.status()
+            out[backend] = {"tokens_per_s": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "launches_per_step": model.graph_launches(True),
+                            "hbm_gbps_per_gpu": model.step_bytes(T_mid, True) * (args.steps / elapsed) / 1e9, "comm_gave_up_at_epoch": err or None}
+        except Exception as e:  # noqa: BLE001 -- recorded in the line
+            out[backend] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            del eng, gen, model
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -179,25 +257,8 @@ def main():
         raise SystemExit("--tp N needs N ranks (--gpus N under torch.distributed.run), int4 weights and contiguous caches")
     comm = None
     if tp:
-        # every rank generates ITS shard directly in the local shapes (the full 70B checkpoint never exists anywhere); the replicated
-        # tensors (embedding table, norm weights) are rank 0's, broadcast once
-        from proxy_inference_engine_amd.tp import HipComm, shard_config
         full_cfg = cfg
-        cfg = {k: v for k, v in shard_config(full_cfg, tp).items() if k not in ("tp_world", "tp_vocab_shard")}
-        cfg["tie_word_embeddings"] = False
-        weights = synthetic_checkpoint(cfg, seed=100 + rank, dtype=torch.bfloat16)
-        v_loc = full_cfg["vocab_size"] // tp
-        for k in ("weight", "scales", "biases"):
-            weights[f"lm_head.{k}"] = weights[f"lm_head.{k}"][:v_loc].contiguous()
-        for k, t in weights.items():
-            if k.startswith("model.embed_tokens.") or k.endswith("layernorm.weight") or k == "model.norm.weight":
-                if dist.get_backend() == "nccl":
-                    dist.broadcast(t, src=0)
-                else:
-                    h = t.cpu()
-                    dist.broadcast(h, src=0)
-                    t.copy_(h)
-        comm = HipComm(cfg["hidden_size"], backend=args.tp_backend)
+        cfg, weights, comm = tp_shard(full_cfg, tp, rank, dist, args.tp_backend)
     else:
         # heavy-tailed lm_head rows: the parity gate's id comparison needs steps whose greedy token is decided by more than rounding noise
         # (models/utils.py: synthetic_checkpoint); same shapes and bytes, so the timing is that of any Llama-3-8B int4 checkpoint
@@ -305,11 +366,26 @@ def main():
     # scripts/profile_r03.sh, profiles/README.md).  The file names the library build it was measured on; any other build gets null
     # rather than last round's kernels' traffic.
     traffic = None
-    tf = ROOT / "profiles" / "r04_traffic.json"
+    tf = ROOT / "profiles" / "r05_traffic.json"
     if tf.exists() and not args.layers and not args.dense and args.model == "8b" and args.bits == 4:
         rec = json.loads(tf.read_text())
         if rec.get("library") == _ffi.load().pie_version().decode():
             traffic = rec.get("hbm_bytes_per_launch")
+
+    # The floor of the launch structure: a synthetic chain of the step's 161 dependent launches, written as raw AQL packets with
+    # the barrier bit and agent fences HIP emits, costs per launch 1.59 us (empty dispatch) + 0.56 (8-wave workgroups, LDS, one barrier) + 0.63
+    # (publish the output) + 1.15 (the consumer's first touch of it) = 3.93 us before any weight is streamed, and 1.150 ms with the 8B model's
+    # 4.24 GB behind it (tools/pipeline_probe.cpp; profiles/r04_pipeline_probe.txt, "serial: barrier bit, agent fences").  The serial sum below
+    # assumes no overlap between those per-launch costs and the stream; the probe's chain overlaps the stream's head with the staging.
+    per_launch_us = {"dispatch": 1.59, "workgroup_start": 0.56, "publish": 0.63, "first_touch": 1.15}
+    n_launch = launches_per_step if launches_per_step and launches_per_step > 0 else 5 * n_l + 2
+    stream_ms = step_bytes / (stream_gbps * 1e9) * 1e3
+    launch_ms = n_launch * sum(per_launch_us.values()) * 1e-3
+    floor = {"launches": n_launch, "per_launch_us": per_launch_us, "launch_ms": launch_ms, "stream_ms": stream_ms, "serial_sum_ms": launch_ms + stream_ms,
+             "probe_chain_ms_8b": 1.150, "source": "tools/pipeline_probe.cpp, profiles/r04_pipeline_probe.txt (raw-AQL chain of the step's shape); stream term = step bytes / stream_peak of this run",
+             "ms_per_step_over_serial_sum": (1e3 * elapsed / args.steps) / (launch_ms + stream_ms)}
+    if args.model == "8b" and args.bits == 4 and not args.dense and not args.layers:
+        floor["ms_per_step_over_probe_chain"] = (1e3 * elapsed / args.steps) / 1.150
 
     shape_cfg = full_cfg if tp else cfg
     out = {
@@ -329,9 +405,16 @@ def main():
                      "unit": "GB/s", "frac": k_gbps / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": k_bytes,
                      "ms_per_launch": k_ms,
                      "stream_peak": stream_gbps, "frac_of_stream": k_gbps / stream_gbps,  # measured in this run: pie_stream_read over 1 GiB
-                     "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "frac_of_stream": step_gbps / stream_gbps, "bytes_per_step": step_bytes}},
+                     "step": {"achieved": step_gbps, "frac": step_gbps / HBM_PEAK_GBPS, "frac_of_stream": step_gbps / stream_gbps, "bytes_per_step": step_bytes,
+                              "floor": floor}},
         "repetitions": {"ms_per_step": rep_ms, "median_ms_per_step": float(np.median(rep_ms)), "min_ms_per_step": float(np.min(rep_ms))},
     }
+    if world > 1 and not tp and args.model == "8b" and args.bits == 4 and not args.dense and not args.layers and not args.paged \
+            and os.environ.get("PIE_BENCH_TP70B", "1") != "0":
+        del eng, gen, model
+        eng = gen = model = None
+        torch.cuda.empty_cache()
+        out["tp70b"] = tp70b_leg(args, rank, world, dist)
     if rank == 0:
         if want_cpu:
             del eng, gen

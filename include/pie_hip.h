@@ -48,16 +48,14 @@ enum {
     PIE_KNOB_PREFILL_MIN = 0,        /* prompts shorter than this run as iterated decode steps (MLX's qmv regime); default 6, min 2 */
     PIE_KNOB_PREFILL_CHUNK = 1,      /* rows per prompt chunk; default 4096 (16..8192) */
     PIE_KNOB_PREFILL_RESIDENT = 2,   /* GiB budget for resident dequantised layer matrices; default: half of the free HBM; 0 = none */
-    PIE_KNOB_SMALL_M = 3,            /* rows up to which int4 Linears use the few-row W4M kernel; default 32; 0 = always the many-row path */
-    PIE_KNOB_W4L_SLABS = 4,          /* 0: K-split products of the many-row GEMM reduced by their own launch instead of by their consumers (bit-equal) */
-    PIE_KNOB_W4M_SLABS = 5,          /* 0: the few-row GEMM's two-way atomic K split instead of fp32 slabs (bit-equal) */
-    PIE_KNOB_PREFILL_ATTN_VALU = 6,  /* 1: the VALU prompt attention instead of the MFMA flash kernel (the tests' cross-check) */
-    PIE_KNOB_W4M_MULTI = 7,          /* 0: one strip per workgroup also for the wide matrices (bit-equal) */
-    PIE_KNOB_PREFILL_QT = 8,         /* 1 / 2: one / two 32-row query tiles per prompt-attention workgroup */
-    PIE_KNOB_ATTN_MERGE_MAX_CAP = 9, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
-    PIE_KNOB_ATTN_WARM_MAX_MB = 10,  /* the attention launch's idle CUs warm the Infinity Cache with at most this many MB of o_proj's weights; 0 = off (read per step enqueue / graph capture) */
-    PIE_KNOB_W4R = 11,               /* 0: int4 Linears of 6..256 rows on the round-2 kernels (k_w4m_gemm*, k_w4l2_gemm) instead of the weight-streaming k_w4r_gemm (the tests' cross-check) */
-    PIE_KNOB_COUNT = 12
+    PIE_KNOB_SMALL_M = 3,            /* rows up to which int4 Linears that k_w4r_gemm does not take use the few-row kernel; default 32; 0 = the T copy + library GEMM */
+    PIE_KNOB_W4L_SLABS = 4,          /* 0: K-split products of the int4 GEMMs reduced by their own launch instead of by their consumers (bit-equal) */
+    PIE_KNOB_PREFILL_ATTN_VALU = 5,  /* 1: the VALU prompt attention instead of the MFMA flash kernel (the tests' cross-check) */
+    PIE_KNOB_PREFILL_QT = 6,         /* 1 / 2: one / two 32-row query tiles per prompt-attention workgroup */
+    PIE_KNOB_ATTN_MERGE_MAX_CAP = 7, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
+    PIE_KNOB_ATTN_WARM_MAX_MB = 8,   /* the attention launch's idle CUs warm the Infinity Cache with at most this many MB of o_proj's weights; 0 = off (read per step enqueue / graph capture) */
+    PIE_KNOB_W4R = 9,                /* 0: int4 Linears of 6..256 rows on the round-2 kernels (k_w4m_gemm, k_w4l2_gemm) instead of the weight-streaming k_w4r_gemm (the tests' cross-check) */
+    PIE_KNOB_COUNT = 10
 };
 #define PIE_KNOB_DEFAULT (-1)
 int pie_set_knob(int knob, int value);

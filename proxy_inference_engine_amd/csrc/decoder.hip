@@ -26,7 +26,7 @@ constexpr int PROF_QKV = 16, PROF_O = 20, PROF_GU = 24, PROF_DOWN = 28;
 #endif
 }
 namespace {
-int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 }
 int pie_knob(int knob) { return knob >= 0 && knob < PIE_KNOB_COUNT ? g_knobs[knob] : PIE_KNOB_DEFAULT; }
 namespace pie {

@@ -232,16 +232,13 @@ __global__ void k_bias_rows(u16 *y, const u16 *b, size_t n8, int N8) {
 
 // h = x + r (language.py:151,153) fused with the RMSNorm that follows it (language.py:137-141): x <- T(x + r) in place,
 // xn <- w * T(h * rsqrt(mean(h^2) + eps)).  One workgroup per row; the row stays in registers between the two passes.
-// r32 != nullptr: the Linear's output arrives as fp32 sums of a K-split few-row GEMM (w4m_gemm.hip): r = T(T(r32) + bias) is formed
-// here (the Linear's own roundings) and the buffer is handed back zeroed for the next GEMM.
 template <class T>
-__global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn, float *r32 = nullptr,
-                                                          const u16 *bias = nullptr, const float *part = nullptr, int S = 0, size_t MN = 0) {
+__global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r, const u16 *w, float eps, int H, u16 *xn, const u16 *bias = nullptr,
+                                                          const float *part = nullptr, int S = 0, size_t MN = 0) {
     // part != nullptr: the Linear's output arrives as the fp32 slabs of a K-split many-row GEMM (W4lSlabs): r = T(T(sum of the slabs) + bias)
     __shared__ float red[4];
     u16 *xr = x + (size_t)blockIdx.x * H;
     const u16 *rr = r + (size_t)blockIdx.x * H;
-    float *r32r = r32 ? r32 + (size_t)blockIdx.x * H : nullptr;
     u16 *yr = xn + (size_t)blockIdx.x * H;
     constexpr int MAXP = 4;  // 8-element pieces per thread: H <= 8192
     uint4 hv[MAXP];
@@ -252,16 +249,13 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
         if (i < H) {
             const uint4 a = *reinterpret_cast<const uint4 *>(xr + i);
             uint4 b;
-            if (r32r || part) {
+            if (part) {
                 float4 f0, f1;
-                if (part) {
+                {
                     const size_t o[2] = {(size_t)blockIdx.x * H + i, (size_t)blockIdx.x * H + i + 4};
                     float4 f[2];
                     slab_sum<float4, 2, SLAB_BATCH>(part, S, MN, o, f);
                     f0 = f[0], f1 = f[1];
-                } else {
-                    f0 = *reinterpret_cast<const float4 *>(r32r + i), f1 = *reinterpret_cast<const float4 *>(r32r + i + 4);
-                    *reinterpret_cast<float4 *>(r32r + i) = make_float4(0, 0, 0, 0), *reinterpret_cast<float4 *>(r32r + i + 4) = make_float4(0, 0, 0, 0);
                 }
                 float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
                 if (bias) {
@@ -308,9 +302,9 @@ __global__ void __launch_bounds__(256) k_add_rms_norm_rows(u16 *x, const u16 *r,
 
 template <class T>
 static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int M, int H, int dtype, u16 *xn, hipStream_t st,
-                             float *r32 = nullptr, const void *bias = nullptr, const W4lSlabs *sl = nullptr) {
+                             const void *bias = nullptr, const W4lSlabs *sl = nullptr) {
     if (sl && sl->S > 1) {  // (linear_rows only hands out slabs for H <= 8192)
-        hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, (float *)nullptr, (const u16 *)bias, sl->part, sl->S,
+        hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, (const u16 *)bias, sl->part, sl->S,
                            sl->MN);
         PIE_LAUNCH_CHECK();
         return PIE_OK;
@@ -319,7 +313,7 @@ static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int
         const int rc = pie_add(x, r, (size_t)M * H, dtype, x, st);
         return rc ? rc : pie_rms_norm(x, w, eps, M, H, dtype, xn, st);
     }
-    hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, r32, (const u16 *)bias);
+    hipLaunchKernelGGL(k_add_rms_norm_rows<T>, dim3(M), dim3(256), 0, st, x, r, (const u16 *)w, eps, H, xn, (const u16 *)bias);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -451,7 +445,6 @@ struct PrefillScratch {
     u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     u16 *kc = nullptr, *vc = nullptr;  // [n_kv_heads, rows, head_dim]: this pass's K / V rows, contiguous (several prompts in one pass)
-    float *y32 = nullptr;  // [rows, hidden] fp32, zero between uses: K-split few-row GEMM sums (o_proj, down), consumed by k_add_rms_norm_rows
     int part_splits = 0;
     // Resident T copies of the layer matrices, keyed by the packed-weight pointer: the per-chunk dequantisation moves
     // 4.6 B per parameter (7 ms of a 10.8 ms 128-token prefill on the 8B model) for 2 B per parameter of HBM; kept when
@@ -485,7 +478,7 @@ static int tail_stats_reserve(PrefillScratch *s, size_t entries) {
 }
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
-    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->y32, s->kc, s->vc};
+    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->kc, s->vc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
@@ -549,11 +542,8 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         PF_ALLOC(s->part_acc, 4 * R * c.n_heads * splits * c.head_dim);
         PF_ALLOC(s->part_ml, 4 * R * c.n_heads * splits * 2);
         PF_ALLOC(s->rope_cs, 4 * R * c.head_dim);
-        PF_ALLOC(s->y32, 4 * R * c.hidden);
         PF_ALLOC(s->kc, 2 * R * c.n_kv_heads * c.head_dim);
         PF_ALLOC(s->vc, 2 * R * c.n_kv_heads * c.head_dim);
-        PIE_HIP_TRY(hipMemset(s->y32, 0, 4 * R * c.hidden));
-        PIE_HIP_TRY(hipDeviceSynchronize());  // (re)allocation only: the zeros must be in place whatever stream the GEMMs run on
         PF_ALLOC(s->wT, 2 * we);
         s->rows = rows, s->part_splits = splits, s->w_elems = we;
     }
@@ -620,12 +610,9 @@ struct W4mRope {  // q|k|v epilogue arguments (defined identically in w4m_gemm.h
     const u16 *bias;
     size_t i8_page_bytes;  // != 0 (with slab): int8 pages with per-head scales (paged_i8.hip)
 };
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
-                    const void *bias, const W4mRope *rope);
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, int swiglu, const void *bias, const W4mRope *rope);
 int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, void *swiglu_act, bool *fused,
                     int *slabs);  // many rows (MFMA-bound)
-int w4m_slab_splits(int M, int N, int K);  // few rows, narrow matrix: K split into fp32 slabs (0 = shape not served)
-int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st);
 size_t w4l_workspace_bytes(int M, int N, int K);
 // 6 .. 256 rows: the weight-streaming form (w4r_gemm.hpp); epi 0 store (+ bias), 1 SwiGLU (+ bias), 2 RoPE + append
 bool w4r_serves(int M, int N, int K);
@@ -647,8 +634,6 @@ static int small_rows() {
     return v < 0 ? 0 : (v > 32 ? 32 : v);
 }
 
-static bool split_k_enabled() { return true; }
-
 template <class T>
 static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
     const size_t n8 = (size_t)M * N / 8;
@@ -659,14 +644,12 @@ static int bias_rows(u16 *y, const void *bias, int M, int N, hipStream_t st) {
 
 template <class T>
 static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u16 *x, int M, u16 *y, hipStream_t st, bool keep = true,
-                       const void *bias = nullptr, bool keep_w4m = false, float *y32 = nullptr, bool *used32 = nullptr, u16 *act = nullptr,
-                       bool *used_act = nullptr, W4mRope *rope = nullptr, W4lSlabs *slabs = nullptr) {
+                       const void *bias = nullptr, bool keep_w4m = false, u16 *act = nullptr, bool *used_act = nullptr, W4mRope *rope = nullptr,
+                       W4lSlabs *slabs = nullptr) {
     // slabs: the caller's consumer takes the fp32 slabs of a K-split many-row GEMM (and the bias) instead of y; slabs->S > 1 tells whether it must
     // rope / used_act: for the packed q|k|v matrix the few-row kernel can rotate q / k and append k / v itself
     // act / used_act: for the packed gate|up matrix the few-row kernel can apply the SwiGLU itself and write act [M, N / 2]
-    // y32 / used32: the caller's consumer can take fp32 K-split sums (+ the bias) instead of y; *used32 tells whether it must
     PrefillScratch *s = d->prefill;
-    if (used32) *used32 = false;
     if (used_act) *used_act = false;
     if (slabs) *slabs = W4lSlabs();
     if (pie_knob(PIE_KNOB_W4L_SLABS) == 0) slabs = nullptr;  // always reduce in the GEMM's own launch (the bit-equality test)
@@ -740,79 +723,36 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
+    // Up to 32 rows of a shape k_w4r_gemm does not take (K < 256) -- or all of them with knob PIE_KNOB_W4R = 0, the tests' comparator: round 2's
+    // first few-row kernel, one workgroup per 32-column strip
     if ((keep || keep_w4m) && is_int4 && M <= small_rows() && N % 32 == 0 && K % 64 == 0) {
         void *wm = nullptr;
-        auto it = s->resident_w4m.find(packed);
-        if (it != s->resident_w4m.end()) wm = it->second;
-        else if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
-            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K), ++s->alloc_gen;
-            const int rc = w4m_repack_launch(packed, N, K, wm, st);
-            if (rc) return rc;
-        } else {
-            (void)hipGetLastError();
-            wm = nullptr;  // no room for the tile copy: the T-copy path below
-        }
+        int rc = w4m_tiles(&wm);
+        if (rc) return rc;
         if (wm) {
-            // K split over two workgroups per strip where the strips alone cannot fill the chip (N / 32 < 256) and K is long enough
-            // (measured on the 8B shapes: down, K = 14336, gains at every row count -- 8 rows 3.05 -> 2.85 ms per prompt, half the
-            // chip is VALU-bound on its dequantisation; o_proj, K = 4096, only from ~24 rows, below that its halves are too short)
-            constexpr int split_min_k = 2048, split_min_m = 24, split_long_k = 8192;  // split_long_k: K from which any M splits
-            const bool split = y32 && used32 && N / 32 < 256 && K >= split_min_k && (M >= split_min_m || K >= split_long_k) && split_k_enabled();
-            // o_proj / down whose consumer can sum fp32 slabs: two strips per workgroup and a deeper, still deterministic K split
-            // (k_w4m_gemm_lds4 with part): a quarter of x staged per workgroup for two strips instead of half of it for one
-            const bool slab2_on = pie_knob(PIE_KNOB_W4M_SLABS) != 0;  // 0: the one-strip forms with the two-way fp32 atomic split (the bit-equality test)
-            const int slab_s = slabs && !rope && !act && slab2_on && split_k_enabled() ? w4m_slab_splits(M, N, K) : 0;
-            if (slab_s >= 2) {
-                const size_t wb = (size_t)slab_s * M * N * sizeof(float);
-                if (wb > s->w4l_ws_bytes) {
-                    if (s->w4l_ws) (void)hipFree(s->w4l_ws);
-                    s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
-                    PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
-                    s->w4l_ws_bytes = wb, ++s->alloc_gen;
-                }
-                const int rc = w4m_slab_gemm_launch(d->cfg.dtype, wm, x, M, N, K, (float *)s->w4l_ws, st);
-                if (rc) return rc;
-                slabs->part = (const float *)s->w4l_ws, slabs->S = slab_s, slabs->MN = (size_t)M * N;  // the consumer also adds the bias
-                return PIE_OK;
-            }
             if (rope && used_act) {
                 *used_act = true;
                 rope->bias = (const u16 *)bias;
-                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, nullptr, st, nullptr, 2, nullptr, rope);
+                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, nullptr, st, 2, nullptr, rope);
             }
             if (act && used_act) {
                 *used_act = true;
-                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, st, nullptr, 1, bias, nullptr);
+                return w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, act, st, 1, bias, nullptr);
             }
-            const int rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, split ? y32 : nullptr, 0, nullptr, nullptr);
-            if (split) *used32 = rc == PIE_OK;
-            if (rc || !bias || split) return rc;
+            rc = w4m_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, st, 0, nullptr, nullptr);
+            if (rc || !bias) return rc;
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
-    if (is_int4 && N % 32 == 0 && K % 64 == 0 && w4l_enabled()) {
+    if (is_int4 && N % 32 == 0 && K % 64 == 0 && w4l_enabled()) {  // beyond 256 rows: the many-row tile kernels
         void *wm = nullptr;
-        auto it = s->resident_w4m.find(packed);
-        if (it != s->resident_w4m.end()) wm = it->second;
-        else if (resident_budget(d) >= w4m_bytes(N, K) && hipMalloc(&wm, w4m_bytes(N, K)) == hipSuccess) {
-            s->resident_w4m[packed] = wm, s->resident_left -= w4m_bytes(N, K), ++s->alloc_gen;
-            const int rc = w4m_repack_launch(packed, N, K, wm, st);
-            if (rc) return rc;
-        } else {
-            (void)hipGetLastError();
-            wm = nullptr;
-        }
+        int rc = w4m_tiles(&wm);
+        if (rc) return rc;
         if (wm) {
-            const size_t wb = w4l_workspace_bytes(M, N, K);  // fp32 partial tiles of a K-split shape (medium prompts)
-            if (wb > s->w4l_ws_bytes) {
-                if (s->w4l_ws) (void)hipFree(s->w4l_ws);
-                s->w4l_ws = nullptr, s->w4l_ws_bytes = 0;
-                PIE_HIP_TRY(hipMalloc(&s->w4l_ws, wb));
-                s->w4l_ws_bytes = wb, ++s->alloc_gen;
-            }
+            if ((rc = w4l_reserve(w4l_workspace_bytes(M, N, K)))) return rc;  // fp32 partial tiles of a K-split shape (medium prompts)
             bool fused = false;  // gate|up without a Linear bias: the SwiGLU rides in the GEMM's epilogue where the shape allows
             int n_slabs = 0;
-            const int rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused, slabs ? &n_slabs : nullptr);
+            rc = w4l_gemm_launch(d->cfg.dtype, wm, x, M, N, K, y, s->w4l_ws, st, (act && used_act && !bias) ? act : nullptr, &fused, slabs ? &n_slabs : nullptr);
             if (fused) *used_act = true;
             if (!rc && n_slabs > 1) {  // y was NOT written: the consumer sums the slabs, rounds and adds the bias
                 slabs->part = (const float *)s->w4l_ws, slabs->S = n_slabs, slabs->MN = (size_t)M * N;
@@ -877,7 +817,7 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                           c.rope_traditional, s->q, nullptr, 0};
             bool roped = false;
             W4lSlabs sq, so, sd;  // K-split products handed over as fp32 slabs (q|k|v only without a bias: RoPE takes T(x W^T + b))
-            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
+            if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, M, s->qkv, st, true, w.bqkv, false, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
                 return rc;
             if (!roped) {
                 const unsigned row_wgs = sq.S > 1 ? (M < 512 ? 4u : 1u) : 1u;  // few rows of slabs: four workgroups per row (256 tokens: 6.03 vs 6.20 ms; from 512 rows no difference)
@@ -902,28 +842,26 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
                 a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
                 if ((rc = attn_decode_launch(c.dtype, D, a, true, st))) return rc;
             }
-            bool r32 = false;
-            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+            if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, M, s->r, st, true, w.bo, false, nullptr, nullptr, nullptr,
                                      H <= 8192 ? &so : nullptr)))
                 return rc;
             // h = x + r (language.py:151) + post_attention_layernorm(h) for MLP.__call__ (language.py:126-127)
-            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+            if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, M, H, c.dtype, s->xn, st, so.S > 1 ? w.bo : nullptr, &so)))
                 return rc;
             bool fused_act = false;
-            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+            if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, M, s->gu, st, true, w.bgateup, false, s->act, &fused_act))) return rc;
             if (!fused_act) {
                 const size_t n_act = (size_t)M * I;
                 hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
                 PIE_LAUNCH_CHECK();
             }
             const bool fused_next = li + 1 < c.n_layers;
-            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, fused_next && H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+            if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, M, s->r, st, true, w.bdown, false, nullptr, nullptr, nullptr,
                                      fused_next && H <= 8192 ? &sd : nullptr)))
                 return rc;
             // out = h + r (language.py:153), fused with the next block's input_layernorm when there is one
             if (fused_next)
-                rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr,
-                                          r32 || sd.S > 1 ? w.bdown : nullptr, &sd);
+                rc = add_rms_norm_rows<T>(s->x, s->r, d->layers[li + 1].attn_norm, c.rms_eps, M, H, c.dtype, s->xn, st, sd.S > 1 ? w.bdown : nullptr, &sd);
             else rc = pie_add(s->x, s->r, (size_t)M * H, c.dtype, s->x, st);
             if (rc) return rc;
         }
@@ -1058,7 +996,7 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
                       D, c.rope_traditional, s->q, nullptr, i8pb};
         bool roped = false;
         W4lSlabs sq;  // q|k|v as the fp32 slabs of a K-split product (no Linear bias: RoPE takes T(x W^T + b))
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, B, s->qkv, st, true, w.bqkv, false, nullptr, &roped, &re, w.bqkv ? nullptr : &sq)))
             return rc;
         if (!roped) {
             decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
@@ -1075,25 +1013,24 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
         a.nt_kv = (size_t)B * max_blocks * 64 >= 2048;
         a.part_acc = s->part_acc, a.part_ml = s->part_ml, a.out = s->attn;
         if ((rc = d->kv_i8 ? paged_attn_i8_launch(c.dtype, D, a, st) : attn_decode_launch(c.dtype, D, a, true, st))) return rc;
-        bool r32 = false;
         W4lSlabs so, sd;  // o_proj / down handed over as K-split fp32 slabs where the shape qualifies
-        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, B, s->r, st, true, w.bo, false, nullptr, nullptr, nullptr,
                                  H <= 8192 ? &so : nullptr)))
             return rc;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, B, H, c.dtype, s->xn, st, so.S > 1 ? w.bo : nullptr, &so)))
             return rc;
         bool fused_act = false;
-        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, B, s->gu, st, true, w.bgateup, false, s->act, &fused_act))) return rc;
         if (!fused_act) {
             const size_t n_act = (size_t)B * I;
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
         }
-        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, B, s->r, st, true, w.bdown, false, nullptr, nullptr, nullptr,
                                  H <= 8192 ? &sd : nullptr)))
             return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;  // final norm: language.py:187
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || sd.S > 1 ? w.bdown : nullptr, &sd)))
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, B, H, c.dtype, s->xn, st, sd.S > 1 ? w.bdown : nullptr, &sd)))
             return rc;
     }
     if ((rc = linear_rows<T>(d, d->glob.lm_head, c.vocab, H, s->xn, B, logits, st, false, nullptr, true))) return rc;
@@ -1140,7 +1077,7 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
         const pie_layer_weights &w = d->layers[li];
         if (li == 0 && (rc = pie_rms_norm(s->x, w.attn_norm, c.rms_eps, N, H, c.dtype, s->xn, st))) return rc;
         W4lSlabs sq;  // q|k|v as the fp32 slabs of a K-split product (no Linear bias: RoPE takes T(x W^T + b))
-        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, nullptr, nullptr, w.bqkv ? nullptr : &sq)))
+        if ((rc = linear_rows<T>(d, w.wqkv, NQKV, H, s->xn, N, s->qkv, st, true, w.bqkv, false, nullptr, nullptr, nullptr, w.bqkv ? nullptr : &sq)))
             return rc;
         decltype(&k_rope_append_rows<T, false, false>) rope_k = &k_rope_append_rows<T, false, false>;
         if (sq.S > 1) rope_k = d->kv_i8 ? &k_rope_append_rows<T, true, true> : &k_rope_append_rows<T, true, false>;
@@ -1171,25 +1108,24 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
             ca.M = ch[1], ca.Hq = c.n_heads, ca.Hkv = c.n_kv_heads, ca.scale = pa.scale;
             if ((rc = prefill_attn_launch_t<T>(ca, D, st))) return rc;
         }
-        bool r32 = false;
         W4lSlabs so, sd;  // K-split products handed to their consumers as fp32 slabs (as in the single-prompt path)
-        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+        if ((rc = linear_rows<T>(d, w.wo, H, QD, s->attn, N, s->r, st, true, w.bo, false, nullptr, nullptr, nullptr,
                                  H <= 8192 ? &so : nullptr)))
             return rc;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || so.S > 1 ? w.bo : nullptr, &so)))
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, w.mlp_norm, c.rms_eps, N, H, c.dtype, s->xn, st, so.S > 1 ? w.bo : nullptr, &so)))
             return rc;
         bool fused_act = false;
-        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, N, s->gu, st, true, w.bgateup, false, nullptr, nullptr, s->act, &fused_act))) return rc;
+        if ((rc = linear_rows<T>(d, w.wgateup, 2 * I, H, s->xn, N, s->gu, st, true, w.bgateup, false, s->act, &fused_act))) return rc;
         if (!fused_act) {
             const size_t n_act = (size_t)N * I;
             hipLaunchKernelGGL(k_swiglu_rows<T>, dim3((unsigned)((n_act / 4 + 255) / 256)), dim3(256), 0, st, s->gu, n_act, s->act);
             PIE_LAUNCH_CHECK();
         }
-        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, N, s->r, st, true, w.bdown, false, H <= 8192 ? s->y32 : nullptr, &r32, nullptr, nullptr, nullptr,
+        if ((rc = linear_rows<T>(d, w.wdown, H, I, s->act, N, s->r, st, true, w.bdown, false, nullptr, nullptr, nullptr,
                                  H <= 8192 ? &sd : nullptr)))
             return rc;
         const void *next_norm = li + 1 < c.n_layers ? d->layers[li + 1].attn_norm : d->glob.final_norm;
-        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, N, H, c.dtype, s->xn, st, r32 ? s->y32 : nullptr, r32 || sd.S > 1 ? w.bdown : nullptr, &sd)))
+        if ((rc = add_rms_norm_rows<T>(s->x, s->r, next_norm, c.rms_eps, N, H, c.dtype, s->xn, st, sd.S > 1 ? w.bdown : nullptr, &sd)))
             return rc;
     }
     // the normalised last row of every prompt -> lm_head -> tail

@@ -1,19 +1,13 @@
-// w4m_gemm.hip -- int4 g=64 x T GEMM for a FEW rows (2..32 prompt tokens) on the MFMA units, weights read once in 4-bit form.
+// w4m_gemm.hip -- int4 g=64 x T GEMMs on the MFMA units, weights read once in 4-bit form (MLX's qmm contract: weights dequantised to T,
+// T x T products, fp32 accumulation, one rounding: mx.quantized_matmul for many rows, models/llama/language.py:83,108,127).
 //
-// Measured (8B model, whole prompt incl. lm_head and tail): 6..8 tokens 5.1 -> 2.8 ms, 16 tokens 5.2 -> 3.2, 32 tokens 5.1 -> 3.8; the
-// 32-sequence decode step built on it: 3.7 ms.  Three kernel forms, one arithmetic: k_w4m_gemm (fragments of x
-// straight from L2; optionally K split over two workgroups with a commutative fp32 atomic pair), k_w4m_gemm_p (persistent: several
-// strips per workgroup behind one load ring, for gate|up and lm_head), k_w4m_gemm_lds (x staged through LDS, from 24 rows); three
-// epilogues: store, SwiGLU on the interleaved gate|up rows, RoPE + cache append on the packed q|k|v rows.
-// tools/w4m_bench ablations of the first form at 8 rows (us: qkv / o_proj / gate|up / down): full 8.4 / 8.2 / 26.8 / 20.5; without x
-// loads 7.9 / 7.9 / 22.1 / 17.5; without dequantisation 8.1 / 8.1 / 26.3 / 19.7; stream + reduction only 5.3 / 5.1 / 16.7 / 9.6 -- the
-// arithmetic is nearly free; what costs is the grid shape (N / 32 workgroups of ~74 KB each) and the x fragments.
-//
-// Why: a short prompt (a chat turn appended to a cached prefix) sits between the two existing paths -- the GEMV reads the
-// 0.5625 B/weight stream once PER TOKEN, the hipBLASLt path reads a 2 B/weight T copy (and its skinny-GEMM kernels reach
-// ~3 TB/s): 6..32 tokens cost a flat 5.1 ms on the 8B model.  This kernel keeps MLX's qmm contract (weights dequantised to T,
-// T x T products, fp32 accumulation: mx.quantized_matmul for many rows, models/llama/language.py:83,108,127) but dequantises
-// in registers straight into MFMA operand fragments, so a pass over the model moves 4.2 GB instead of 15 GB.
+// Three kernels, one arithmetic, by row count:
+//   6 .. 256 rows   k_w4r_gemm  (w4r_gemm.hpp, round 5): every CU streams its slab of tiles once and multiplies it into all the rows
+//   > 256 rows      k_w4l2_gemm (one wave per SIMD, 256 accumulators in AGPRs, x by LDS-DMA) / k_w4l_gemm (8 waves, shapes the former does not take)
+//   <= 32 rows      k_w4m_gemm  (round 2's first form: one workgroup per 32-column strip, x fragments straight from L2): what remains for
+//                   K < 256 columns and as the tests' comparator (knob PIE_KNOB_W4R = 0); its persistent, LDS-staged and multi-strip
+//                   siblings were replaced by k_w4r_gemm (19 us against 26 us on gate|up at 32 rows: EXPERIMENTS.md)
+// Epilogues: store, SwiGLU on the interleaved gate|up rows, RoPE + cache append on the packed q|k|v rows, fp32 slabs of a K split.
 //
 // W4M layout (derived on the device from the W4S stream, cached next to it; same 0.5625 B/weight): tiles of 32 output rows x
 // 64 columns (one quantisation group per row), 1152 B each, tile (nt, g) at ((nt * K/64) + g) * 1152:
@@ -21,8 +15,6 @@
 //                    64 g + 16 s + 8 kh .. + 8, in the W4S word format (codes 2i, 2i+1 at nibble i of the low / high half)
 //                    -- after dequantisation exactly the A fragment of v_mfma_f32_32x32x16 k-step s (row n, k-half kh);
 //   bytes [1024, 1152): row n's (scale, bias) as one 32-bit word.
-// One workgroup per 32-row tile strip, 8 waves splitting the K/64 groups round-robin (consecutive groups are consecutive
-// 1152-byte blocks: the 8 waves stream one contiguous range), fp32 partial tiles summed through LDS in fixed order.
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -35,8 +27,7 @@
 
 constexpr int W4M_TILE_BYTES = 1152;
 constexpr int W4M_WAVES = 8;
-constexpr int W4M_DEPTH = 3;   // staged kernel: weight tiles in flight per wave
-constexpr int W4M_WDEPTH = 8;  // direct kernel: weight tiles (16 B codes + 4 B scale/bias per lane) in flight per wave
+constexpr int W4M_WDEPTH = 8;  // weight tiles (16 B codes + 4 B scale/bias per lane) in flight per wave
 constexpr int W4M_XDEPTH = 2;  //                x fragment sets (4 x 16 B per lane) in flight per wave
 
 // W4S unit stream -> W4M tiles.  One thread per (tile, lane): pure word shuffle, no nibble work.
@@ -113,9 +104,7 @@ __device__ __forceinline__ uint4 w4m_dequant_pk(u32 word, w4m_f32x2 s2, w4m_f32x
     return make_uint4(w4m_pack<T>(r01.x, r01.y), w4m_pack<T>(r23.x, r23.y), w4m_pack<T>(r45.x, r45.y), w4m_pack<T>(r67.x, r67.y));
 }
 
-// Sum of the 8 waves' partial tiles (fixed order), then either the T result or -- K split over two workgroups (gridDim.y = 2:
-// the N = 4096 matrices have only 128 strips, half the chip) -- an fp32 atomic add into a zeroed [M, N] buffer that the consumer
-// kernel rounds and re-zeroes.  Two addends commute exactly, so the sum does not depend on which workgroup arrives first.
+// Sum of the 8 waves' partial tiles (fixed order), rounded once, stored for the live rows.
 // Arguments of the q|k|v epilogue (rope = 2): RoPE on the q and k pairs and the cache append, exactly k_rope_append_rows (prefill.hip).
 struct W4mRope {
     const float *rope_cs;               // [M, HD / 2, 2] (cos, sin) of every row's position (k_rope_cs_rows)
@@ -194,7 +183,7 @@ __device__ __forceinline__ void w4m_epilogue_rope(float (*s_red)[16][64], int nt
 // 16 complete pairs and act[m][16 nt + j] = T(T(silu(g)) * u) with g, u the T-rounded (and biased) Linear outputs -- exactly what
 // the GEMM followed by the bias and SwiGLU row kernels produce, without writing and re-reading the [M, 2I] block.
 template <class T>
-__device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int M, int N, u16 *y, float *y32, bool swiglu, const u16 *bias) {
+__device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int M, int N, u16 *y, bool swiglu, const u16 *bias) {
     if (swiglu) {  // one (gate, up) pair per thread: accumulator registers (2p, 2p + 1) of lane l
         const int i = 2 * (threadIdx.x >> 6), l = threadIdx.x & 63;
         float g = 0.0f, u = 0.0f;
@@ -212,26 +201,20 @@ __device__ __forceinline__ void w4m_epilogue(float (*s_red)[16][64], int nt, int
 #pragma unroll
         for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
         const int mm = l & 31, nn = 32 * nt + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);  // accumulator register i <-> A row (i & 3) + 8 (i >> 2) + 4 kh
-        if (mm < M) {
-            if (y32) atomicAdd(y32 + (size_t)mm * N + nn, v);
-            else y[(size_t)mm * N + nn] = T::from_f32(v);
-        }
+        if (mm < M) y[(size_t)mm * N + nn] = T::from_f32(v);
     }
 }
 
-// y[M, N] = x[M, K] . dequant(W)[N, K]^T, M <= 32.  grid = N / 32 workgroups of 8 waves (x 2 K-halves with y32).
-// Two rings per wave: the weight tiles come from HBM (~2 us away) and cost 5 registers per slot -> W4M_WDEPTH = 8 slots in
-// flight (with depth 3 the 128-workgroup matrices, o_proj and down, had 27 KB in flight per CU on half the chip: 1.7 TB/s);
+// y[M, N] = x[M, K] . dequant(W)[N, K]^T, M <= 32.  grid = N / 32 workgroups of 8 waves.
+// Two rings per wave: the weight tiles come from HBM (~2 us away) and cost 5 registers per slot -> W4M_WDEPTH = 8 slots in flight;
 // the x fragments come from L2 and cost 16 registers per slot -> 2 slots.
 template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias, const W4mRope rope) {
+__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias, const W4mRope rope) {
     __shared__ float s_red[W4M_WAVES][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
     const int nt = blockIdx.x;
-    // this workgroup's share of the K groups: everything, or one half (gridDim.y == 2)
-    const int g_lo = gridDim.y == 2 ? (blockIdx.y ? (all_groups >> 1) : 0) : 0;
-    const int groups = gridDim.y == 2 ? (blockIdx.y ? all_groups - (all_groups >> 1) : (all_groups >> 1)) : all_groups;
+    const int g_lo = 0, groups = all_groups;
     const char *strip = w4m + ((size_t)nt * all_groups + g_lo) * W4M_TILE_BYTES;
     const int m = n < M ? n : M - 1;                          // B-operand column = x row (columns >= M are never stored)
     const u16 *xrow = x + (size_t)m * K + 8 * kh + (size_t)g_lo * 64;
@@ -292,297 +275,7 @@ __global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm(const char *w4m, co
     for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
     __syncthreads();
     if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt, M, rope);
-    else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
-}
-
-// Persistent form for matrices with more strips than workgroup slots (gate|up: 896, lm_head: 4008): every workgroup walks
-// several strips (blockIdx.x, + gridDim.x, ...) with ONE load ring running across the strip boundaries, so the next strip's
-// tiles are in flight while this one is reduced.  (One strip per workgroup, every wave issues all its loads up front, waits
-// ~2 us, computes with the other waves of its SIMD all in the same phase, and leaves: SQ counters on gate|up showed waves 45 %
-// of their life in s_waitcnt and the VALU 46 % busy.)  Same arithmetic and summation order as k_w4m_gemm.
-template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_p(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias,
-                                                              const W4mRope rope) {
-    __shared__ float s_red[2][W4M_WAVES][16][64];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, groups = K >> 6, n_strips = N >> 5;
-    const int m = n < M ? n : M - 1;
-    const u16 *xrow = x + (size_t)m * K + 8 * kh;
-    const int my_groups = (groups - wave + W4M_WAVES - 1) / W4M_WAVES;                       // >= 1: the launcher requires K >= 512
-    const int my_strips = ((n_strips - (int)blockIdx.x) + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: gridDim.x <= n_strips
-    const int total = my_strips * my_groups;
-
-    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
-    uint4 cw[W4M_WDEPTH], xf[W4M_XDEPTH][4];
-    u32 sb[W4M_WDEPTH];
-    f32x16_t acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    // issue-side cursors: (strip, group-iteration) of the next weight tile / x fragment set to fetch; they stop at the last valid one
-    int wj = 0, wit = 0, xit = 0;
-#define W4M_WISSUE(d)                                                                                              \
-    {                                                                                                              \
-        const int nt_ = (int)blockIdx.x + wj * (int)gridDim.x;                                                      \
-        const char *tile_ = w4m + ((size_t)nt_ * groups + wave + wit * W4M_WAVES) * W4M_TILE_BYTES;                  \
-        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);           \
-        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                                \
-        sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);                        \
-        if (!(wj == my_strips - 1 && wit == my_groups - 1)) {                                                       \
-            if (++wit == my_groups) wit = 0, ++wj;                                                                  \
-        }                                                                                                          \
-    }
-#define W4M_XISSUE(d)                                                                                              \
-    {                                                                                                              \
-        const u16 *xp_ = xrow + (size_t)(wave + xit * W4M_WAVES) * 64;                                              \
-        xf[d][0] = *reinterpret_cast<const uint4 *>(xp_), xf[d][1] = *reinterpret_cast<const uint4 *>(xp_ + 16);    \
-        xf[d][2] = *reinterpret_cast<const uint4 *>(xp_ + 32), xf[d][3] = *reinterpret_cast<const uint4 *>(xp_ + 48); \
-        if (++xit == my_groups) xit = 0;                                                                            \
-    }
-#pragma unroll
-    for (int d = 0; d < W4M_WDEPTH; ++d) W4M_WISSUE(d)
-#pragma unroll
-    for (int d = 0; d < W4M_XDEPTH; ++d) W4M_XISSUE(d)
-    int cj = 0, cit = 0;  // compute-side cursor
-    for (int base = 0; base < total; base += W4M_WDEPTH) {
-#pragma unroll
-        for (int d = 0; d < W4M_WDEPTH; ++d) {
-            constexpr int XD = W4M_XDEPTH;
-            if (base + d < total) {  // wave-uniform
-                const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
-                const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint4 af = (W4M_ABL & 1) ? make_uint4(words[k], words[k] ^ sb[d], words[k] + 1, sb[d]) : w4m_dequant<T>(words[k], s, b);
-                    if (W4M_ABL & 4) acc[k] += __builtin_bit_cast(float, af.x ^ af.y ^ af.z ^ af.w ^ xf[d % XD][k].x);
-                    else acc = MfmaT<T>::run(af, xf[d % XD][k], acc);
-                }
-                W4M_WISSUE(d)
-                if (!(W4M_ABL & 2)) W4M_XISSUE(d % XD)
-                if (++cit == my_groups) {  // strip done for this wave: all eight waves meet here once per strip
-                    const int buf = cj & 1, nt = (int)blockIdx.x + cj * (int)gridDim.x;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s_red[buf][wave][i][lane] = acc[i], acc[i] = 0.0f;
-                    __syncthreads();  // also orders this buffer's previous use (two strips ago) before these writes: one barrier per strip
-                    if (swiglu == 2) w4m_epilogue_rope<T>(s_red[buf], nt, M, rope);
-                    else w4m_epilogue<T>(s_red[buf], nt, M, N, y, nullptr, swiglu != 0, bias);
-                    cit = 0, ++cj;
-                }
-            }
-        }
-    }
-#undef W4M_WISSUE
-#undef W4M_XISSUE
-}
-
-// The same product with the x rows staged through LDS.  Without staging every B fragment is a 16-byte piece of a different x
-// row per lane (32 cache lines per load instruction): at 32 rows the address unit, not HBM, sets the pace (5.0 ms per 8B-model
-// prompt, no better than the T-copy path).  Here each round of 8 groups (512 columns) first lands in LDS with row-contiguous
-// 16-byte loads (one x row segment per wave instruction), double-buffered against the MFMA work of the previous round; the
-// fragments are then ds_read_b128 with rows 1040 bytes apart (16 lanes of a quarter-wave hit 16 distinct bank quads).
-constexpr int W4M_XROW = 1024 + 16;  // bytes per staged x row: 512 columns + pad
-template <class T>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *y32, int swiglu, const u16 *bias, const W4mRope rope) {
-    __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
-    const int nt = blockIdx.x;
-    // K halves for gridDim.y == 2, cut at a multiple of 8 groups (512 columns) so a staging round never straddles the cut
-    const int half_lo = ((all_groups >> 1) + 7) & ~7;
-    const int g_lo = gridDim.y == 2 && blockIdx.y ? (half_lo < all_groups ? half_lo : all_groups) : 0;
-    const int groups = gridDim.y == 2 ? (blockIdx.y ? all_groups - g_lo : (half_lo < all_groups ? half_lo : all_groups)) : all_groups;
-    const char *strip = w4m + ((size_t)nt * all_groups + g_lo) * W4M_TILE_BYTES;
-    x += (size_t)g_lo * 64;                // this half's first column
-    const int Kx = K - g_lo * 64;          // columns of x from there on (row stride stays K)
-    const int rounds = groups > 0 ? (groups + W4M_WAVES - 1) / W4M_WAVES : 1;  // an empty half still walks one (idle) round
-    const int m_read = n < M ? n : M - 1;  // fragment row (columns >= M of the product are never stored)
-
-    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
-    uint4 cw[W4M_DEPTH];
-    u32 sb[W4M_DEPTH];
-#define W4M_WLOAD(d, r)                                                                                   \
-    {                                                                                                     \
-        int g_ = wave + ((r) < rounds ? (r) : rounds - 1) * W4M_WAVES;                                    \
-        g_ = g_ < groups ? g_ : groups - 1;                                                               \
-        const char *tile_ = strip + (size_t)g_ * W4M_TILE_BYTES;                                          \
-        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);  \
-        cw[d] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                       \
-        sb[d] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);               \
-    }
-    // x rows of round r: wave w owns rows w, w + 8, w + 16, w + 24; lane l their columns 512 r + 8 l .. + 8
-    uint4 xs[4];
-    auto x_fetch = [&](int r) {
-        const int col = 512 * r + 8 * lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = wave + 8 * j;
-            xs[j] = (m < M && col < Kx) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto x_store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = wave + 8 * j;
-            if (m < M) *reinterpret_cast<uint4 *>(s_x[buf] + m * W4M_XROW + lane * 16) = xs[j];
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < W4M_DEPTH; ++d) W4M_WLOAD(d, d)
-    x_fetch(0);
-    x_store(0);
-    __syncthreads();
-
-    f32x16_t acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int base = 0; base < rounds; base += W4M_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < W4M_DEPTH; ++d) {
-            const int r = base + d;
-            if (r < rounds) {  // uniform for the workgroup
-                if (r + 1 < rounds) x_fetch(r + 1);
-                if (wave + r * W4M_WAVES < groups) {  // wave-uniform: the last round may be short
-                    const float s = lo_f32<T>(sb[d]), b = hi_f32<T>(sb[d]);
-                    const u32 words[4] = {cw[d].x, cw[d].y, cw[d].z, cw[d].w};
-                    const char *xr = s_x[r & 1] + m_read * W4M_XROW + wave * 128 + kh * 16;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        acc = MfmaT<T>::run(w4m_dequant<T>(words[k], s, b), *reinterpret_cast<const uint4 *>(xr + 32 * k), acc);
-                }
-                W4M_WLOAD(d, r + W4M_DEPTH)
-                if (r + 1 < rounds) x_store((r + 1) & 1);
-                __syncthreads();
-            }
-        }
-    }
-#undef W4M_WLOAD
-    float(*s_red)[16][64] = reinterpret_cast<float(*)[16][64]>(&s_x[0][0]);  // every wave is past its last fragment read (barrier above)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[i];
-    __syncthreads();
-    if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt, M, rope);
-    else w4m_epilogue<T>(s_red, nt, M, N, y, y32, swiglu != 0, bias);
-}
-
-// The staged form for matrices with many strips (gate|up: 896, lm_head: 4008): one workgroup owns W4M_NS (= 4) consecutive strips and walks K
-// ONCE for all of them -- a round's x tile is staged once and its fragments are read once per wave, then multiplied into W4M_NS
-// accumulators.  With one strip per workgroup every strip re-reads the whole of x from L2: at 32 rows that is 256 KB per strip, 229 MB
-// per gate|up launch against 66 MB of weights (the 32-sequence step's gate|up: 35 us for what the decode GEMV streams in 12).
-// Same tiles per wave (groups wave, wave + 8, ...), same accumulation order per strip, same reduction: bit-identical results.
-// Used at every row count 2..32: gate|up 24.1-25.8 us against 32.6-37.2 (the persistent gather form below 24 rows) / 35.0 (staged, one strip);
-// 8B prompt suffix of 8 / 16 / 32 tokens 2.20 / 2.49 / 3.01 ms against 2.56 / 2.81 / 3.27, multi-sequence step at 8 / 16 / 32 sequences
-// 2.48 / 2.77 / 3.42 ms against 2.81 / 3.18 / 3.73.
-// part != nullptr (the narrow matrices -- o_proj, down: 128 strips -- with W4M_NS = 2): K is split over gridDim.y workgroups at multiples of
-// 512 columns and every split stores its un-rounded fp32 tile sums to its own slab part[blockIdx.y][M][N]; the consumer adds the slabs in
-// slab order and rounds once (W4lSlabs, prefill.hip) -- deterministic at any split depth, where the two-way fp32 atomics of the one-strip
-// forms stop at two addends.  Four splits x two strips: 256 workgroups that each stage a quarter of x for two strips.
-template <class T, int W4M_NS>
-__global__ void __launch_bounds__(W4M_WAVES * 64) k_w4m_gemm_lds4(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, int swiglu, const u16 *bias,
-                                                                 const W4mRope rope, float *part) {
-    __shared__ __attribute__((aligned(16))) char s_x[2][32 * W4M_XROW];  // 65 KB; the reduction buffer (32 KB) aliases it afterwards
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6, n_strips = N >> 5;
-    const int nt0 = blockIdx.x * W4M_NS;
-    // this workgroup's K groups: all of them, or (part != nullptr) the blockIdx.y-th run of per_z groups (a multiple of 8: whole rounds)
-    const int per_z = part ? ((all_groups + (int)gridDim.y - 1) / (int)gridDim.y + 7) & ~7 : all_groups;
-    const int g_lo = part ? (int)blockIdx.y * per_z : 0;
-    const int groups = all_groups - g_lo < per_z ? all_groups - g_lo : per_z;  // >= 1 (launcher)
-    w4m += (size_t)g_lo * W4M_TILE_BYTES;  // tile (strip, group) lives at (strip * all_groups + group): only the group offset moves
-    x += (size_t)g_lo * 64;
-    const int Kx = K - g_lo * 64;  // columns of x from there on (row stride stays K)
-    const int rounds = (groups + W4M_WAVES - 1) / W4M_WAVES;
-    const int m_read = n < M ? n : M - 1;
-
-    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
-    uint4 cw[2][W4M_NS];  // ring: two rounds ahead, one slot per strip
-    u32 sb[2][W4M_NS];
-#define W4M_WLOAD4(p, st, r)                                                                              \
-    {                                                                                                     \
-        int g_ = wave + ((r) < rounds ? (r) : rounds - 1) * W4M_WAVES;                                    \
-        g_ = g_ < groups ? g_ : groups - 1;                                                               \
-        const int nt_ = nt0 + (st) < n_strips ? nt0 + (st) : n_strips - 1;                                \
-        const char *tile_ = w4m + ((size_t)nt_ * all_groups + g_) * W4M_TILE_BYTES;                       \
-        const nt_u32x4 c_ = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(tile_) + lane);  \
-        cw[p][st] = make_uint4(c_.x, c_.y, c_.z, c_.w);                                                   \
-        sb[p][st] = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(tile_ + 1024) + n);           \
-    }
-    uint4 xs[4];
-    auto x_fetch = [&](int r) {
-        const int col = 512 * r + 8 * lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = wave + 8 * j;
-            xs[j] = (m < M && col < Kx) ? *reinterpret_cast<const uint4 *>(x + (size_t)m * K + col) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto x_store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = wave + 8 * j;
-            if (m < M) *reinterpret_cast<uint4 *>(s_x[buf] + m * W4M_XROW + lane * 16) = xs[j];
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int st = 0; st < W4M_NS; ++st) W4M_WLOAD4(p, st, p)
-    x_fetch(0);
-    x_store(0);
-    __syncthreads();
-
-    f32x16_t acc[W4M_NS];
-#pragma unroll
-    for (int st = 0; st < W4M_NS; ++st)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[st][i] = 0.0f;
-    for (int base = 0; base < rounds; base += 2) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = base + p;
-            if (r < rounds) {  // uniform for the workgroup
-                if (r + 1 < rounds) x_fetch(r + 1);
-                const bool live = wave + r * W4M_WAVES < groups;  // wave-uniform: the last round may be short
-                uint4 xf[4];
-                const char *xr = s_x[r & 1] + m_read * W4M_XROW + wave * 128 + kh * 16;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) xf[k] = *reinterpret_cast<const uint4 *>(xr + 32 * k);
-#pragma unroll
-                for (int st = 0; st < W4M_NS; ++st) {
-                    if (live) {
-                        const float sc = lo_f32<T>(sb[p][st]), bi = hi_f32<T>(sb[p][st]);
-                        const u32 words[4] = {cw[p][st].x, cw[p][st].y, cw[p][st].z, cw[p][st].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[st] = MfmaT<T>::run(w4m_dequant<T>(words[k], sc, bi), xf[k], acc[st]);
-                    }
-                    W4M_WLOAD4(p, st, r + 2)
-                }
-                if (r + 1 < rounds) x_store((r + 1) & 1);
-                __syncthreads();
-            }
-        }
-    }
-#undef W4M_WLOAD4
-    float(*s_red)[16][64] = reinterpret_cast<float(*)[16][64]>(&s_x[0][0]);  // every wave is past its last fragment read (barrier above)
-#pragma unroll
-    for (int st = 0; st < W4M_NS; ++st) {
-        if (nt0 + st < n_strips) {  // uniform
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s_red[wave][i][lane] = acc[st][i];
-            __syncthreads();
-            if (part) {  // this split's fp32 sums (waves added in wave order), un-rounded
-                float *slab = part + (size_t)blockIdx.y * M * N;
-                for (int o = threadIdx.x; o < 16 * 64; o += W4M_WAVES * 64) {
-                    const int i = o >> 6, l = o & 63;
-                    float v = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < W4M_WAVES; ++w) v += s_red[w][i][l];
-                    const int mm = l & 31, nn = 32 * (nt0 + st) + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-                    if (mm < M) slab[(size_t)mm * N + nn] = v;
-                }
-            } else if (swiglu == 2) w4m_epilogue_rope<T>(s_red, nt0 + st, M, rope);
-            else w4m_epilogue<T>(s_red, nt0 + st, M, N, y, nullptr, swiglu != 0, bias);
-            __syncthreads();  // the next strip reuses the buffer
-        }
-    }
+    else w4m_epilogue<T>(s_red, nt, M, N, y, swiglu != 0, bias);
 }
 
 // ---------------------------------------------------------------- MANY rows (33 .. thousands): the prompt GEMM
@@ -1079,10 +772,13 @@ static W4rPlan w4r_plan(int M, int N, int K, bool may_split) {
     int S = 1;
     if (may_split && col_wgs < 192) {
         S = 256 / col_wgs;
-        const int min_steps = 16 / kw;  // at least 1024 columns per split (measured: o_proj at 32 rows 7.9 us with four splits, 9.3 with eight)
+        // at least 1024 columns per split up to 64 rows (measured: o_proj at 32 rows 7.9 us with four splits, 9.3 with eight), 512 beyond (there the
+        // matrix cores bound the launch and half a chip of workgroups costs more than short splits do)
+        const int min_steps = mb <= 2 ? 16 / kw : 8 / kw;
         const int max_s = total / min_steps > 0 ? total / min_steps : 1;
         S = S > max_s ? max_s : S;
         S = S > 16 ? 16 : (S < 1 ? 1 : S);
+        while (S > 1 && total % S) --S;  // equal splits: five uneven splits of q|k|v (7, 7, 7, 7, 4 steps) lose to four even ones (16.3 vs 15.0 us at 128 rows)
     }
     const int per = (total + S - 1) / S;
     S = (total + per - 1) / per;
@@ -1187,72 +883,18 @@ int w4m_repack_launch(const void *w4s, int N, int K, void *w4m, hipStream_t st) 
     return PIE_OK;
 }
 
-// y32 != nullptr: K split over two workgroups per strip, fp32 sums added into y32 [M, N] (zero on entry; the consumer rounds and
-// re-zeroes it); y is then unused.
 // swiglu: N = 2 * inter interleaved gate|up rows -> y is the activation [M, N / 2] (bias: the Linear's, applied before it).
 // swiglu == 2 (rope != nullptr): N = packed q|k|v rows; the epilogue rotates q / k and appends k / v to the cache (y unused).
-int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, float *y32, int swiglu,
-                    const void *bias, const W4mRope *rope) {
+int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, void *y, hipStream_t st, int swiglu, const void *bias, const W4mRope *rope) {
     const W4mRope rope_args = rope ? *rope : W4mRope{};
     PIE_REQUIRE((swiglu == 2) == (rope != nullptr), PIE_E_ARG, "W4M GEMM: the q|k|v epilogue needs its arguments");
     PIE_REQUIRE(M >= 1 && M <= 32, PIE_E_SHAPE, "W4M GEMM: 1 to 32 rows");
     PIE_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 64 == 0, PIE_E_SHAPE, "W4M GEMM: N must be a multiple of 32 and K of 64");
     PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16), PIE_E_ALIGN, "W4M GEMM: 16-byte alignment required");
-    PIE_REQUIRE(!(swiglu && y32), PIE_E_ARG, "W4M GEMM: the SwiGLU epilogue needs the whole K in one workgroup");
-    PIE_REQUIRE(!y32 || K >= 1024, PIE_E_SHAPE, "W4M GEMM: the K-split form needs K >= 1024 (both halves non-empty)");
-    const dim3 grid(N >> 5, y32 ? 2 : 1), block(W4M_WAVES * 64);
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "W4M GEMM: dtype must be PIE_BF16 or PIE_F16");
-    constexpr int stage_min = 24;  // rows from which x is staged through LDS; measured on the 8B shapes: staging wins from ~24 rows (4.3 vs 4.5 ms per prompt), loses below
-    const int n_strips = N >> 5;
-    if (!y32 && n_strips >= 512 && K >= 512 && pie_knob(PIE_KNOB_W4M_MULTI) != 0) {  // knob 0: one strip per workgroup also for the wide matrices (bit-equality test)  // at every row count: 24.1-25.8 us on gate|up against 32.6-37.2 (persistent form) / 35.0 (staged, one strip)
-        constexpr int NS = 4;  // strips per workgroup (8 measured worse: 256 VGPRs with spills, and gate|up left with 112 workgroups)
-        const dim3 mgrid((n_strips + NS - 1) / NS);
-        if (dtype == PIE_BF16)
-            hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args, (float *)nullptr);
-        else
-            hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, NS>), mgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args, (float *)nullptr);
-        PIE_LAUNCH_CHECK();
-        return PIE_OK;
-    }
-    if (M < stage_min && !y32 && n_strips > 512 && K >= 512) {
-        const int per = (n_strips + 511) / 512;                 // strips per workgroup, balanced: 896 -> 448 x 2, 4008 -> 501 x 8
-        const dim3 pgrid((n_strips + per - 1) / per);
-        if (dtype == PIE_BF16)
-            hipLaunchKernelGGL(k_w4m_gemm_p<BF16>, pgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
-        else
-            hipLaunchKernelGGL(k_w4m_gemm_p<F16>, pgrid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
-        PIE_LAUNCH_CHECK();
-        return PIE_OK;
-    }
-    if (M >= stage_min) {
-        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm_lds<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
-        else hipLaunchKernelGGL(k_w4m_gemm_lds<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
-    } else if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
-    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, y32, swiglu, (const u16 *)bias, rope_args);
-    PIE_LAUNCH_CHECK();
-    return PIE_OK;
-}
-
-// Few rows, narrow matrix (128-255 strips), long K: two strips per workgroup, K split into fp32 slabs part[S][M][N] that the consumer sums
-// (see k_w4m_gemm_lds4).  Returns the split count S (>= 2), or 0 when the shape does not qualify; workspace: S * M * N floats.
-int w4m_slab_splits(int M, int N, int K) {
-    const int n_strips = N >> 5, groups = K >> 6;
-    if (M < 1 || M > 32 || n_strips < 64 || n_strips >= 512 || (n_strips & 1) || groups < 32) return 0;
-    int S = 512 / n_strips;  // workgroups = n_strips / 2 * S ~ 256
-    S = S < 2 ? 2 : (S > 8 ? 8 : S);
-    while (S > 2 && (S - 1) * ((((groups + S - 1) / S) + 7) & ~7) >= groups) --S;  // every split must own at least one group
-    return (S - 1) * ((((groups + S - 1) / S) + 7) & ~7) < groups ? S : 0;
-}
-int w4m_slab_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int K, float *part, hipStream_t st) {
-    const int S = w4m_slab_splits(M, N, K);
-    PIE_REQUIRE(S >= 2 && part, PIE_E_ARG, "W4M slab GEMM: shape not served");
-    PIE_REQUIRE(pie_aligned(w4m, 16) && pie_aligned(x, 16) && pie_aligned(part, 16), PIE_E_ALIGN, "W4M slab GEMM: 16-byte alignment required");
-    const dim3 grid((unsigned)((N >> 5) / 2), (unsigned)S), block(W4M_WAVES * 64);
-    if (dtype == PIE_BF16)
-        hipLaunchKernelGGL((k_w4m_gemm_lds4<BF16, 2>), grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)nullptr, 0, (const u16 *)nullptr, W4mRope{}, part);
-    else if (dtype == PIE_F16)
-        hipLaunchKernelGGL((k_w4m_gemm_lds4<F16, 2>), grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)nullptr, 0, (const u16 *)nullptr, W4mRope{}, part);
-    else return pie::fail(PIE_E_ARG, "W4M slab GEMM: dtype must be PIE_BF16 or PIE_F16");
+    const dim3 grid(N >> 5), block(W4M_WAVES * 64);
+    if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4m_gemm<BF16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
+    else hipLaunchKernelGGL(k_w4m_gemm<F16>, grid, block, 0, st, (const char *)w4m, (const u16 *)x, M, N, K, (u16 *)y, swiglu, (const u16 *)bias, rope_args);
     PIE_LAUNCH_CHECK();
     return PIE_OK;
 }
@@ -1290,7 +932,7 @@ int pie_qgemm_w4m(const void *x, const void *w4m, int M, int N, int K, int dtype
         if (ws) (void)hipFreeAsync(ws, st);
         return rc;
     }
-    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, nullptr, 0, nullptr, nullptr);
+    return w4m_gemm_launch(dtype, w4m, x, M, N, K, y, (hipStream_t)stream, 0, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -323,26 +323,28 @@ def test_batched_prefill_chunks_and_regimes(tiny, knobs):
 
 @pytest.mark.parametrize("L", [6, 9, 16, 24, 32, 33])
 def test_short_prompt_int4_gemm_paths(tiny, knobs, L):
-    """Prompts of 6..32 tokens run the few-row int4 GEMM on W4M tiles (w4m_gemm.hip: direct fragments below 24 rows, x staged
-    through LDS from 24), 33 and knob small_m = 0 the T copy + hipBLASLt: same qmm contract, every position against the oracle,
-    and the two paths within one rounding of each other."""
+    """Prompts of 6..33 tokens on the three int4 GEMM paths: the weight-streaming k_w4r_gemm (default), round 2's kernels (knob w4r = 0: the
+    one-strip few-row kernel up to 32 rows, the many-row tile kernel at 33) and, with small_m = 0 as well, the T copy + hipBLASLt below 33
+    rows: same qmm contract, every position against the oracle, and the paths within one rounding of each other."""
     g, cfg, w, _ = tiny
     rng = np.random.default_rng(L)
     prompt = rng.integers(0, cfg["vocab_size"], L)
     orc = po.OracleLlama(cfg, w, DT)
     want = orc.forward(prompt, [po.OracleKVCache() for _ in orc.layers])
     outs = {}
-    for small in (32, 0):
+    for name, w4r, small in (("w4r", None, None), ("round-2 kernels", 0, 32), ("library GEMM", 0, 0)):
+        knobs("w4r", w4r)
         knobs("small_m", small)
         m = build(cfg, w)
         cache = m.make_cache()
         got = m(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
         for l in range(L):
-            assert_vec_close(got[l], want[l], DT, what=f"small_m={small} L={L} position {l}")
+            assert_vec_close(got[l], want[l], DT, what=f"{name} L={L} position {l}")
         tok, _, logits = m.step(None, cache)                           # decode continues on the cache the short prompt filled
-        outs[small] = (got, logits.float().cpu().numpy())
-    assert_vec_close(outs[32][0][-1], outs[0][0][-1], DT, what="w4m vs hipBLASLt path")
-    assert_vec_close(outs[32][1], outs[0][1], DT, what="decode after w4m vs hipBLASLt prompt")
+        outs[name] = (got, logits.float().cpu().numpy())
+    for name in ("round-2 kernels", "library GEMM"):
+        assert_vec_close(outs["w4r"][0][-1], outs[name][0][-1], DT, what=f"w4r vs {name}")
+        assert_vec_close(outs["w4r"][1], outs[name][1], DT, what=f"decode after w4r vs {name} prompt")
 
 
 def test_batched_prefill_llama8b_shapes(knobs):
@@ -407,11 +409,11 @@ def test_k_split_prompt_gemm_slabs_summed_by_their_consumers(knobs, bias, L):
             assert torch.equal(a, b), "slab-consuming kernels differ from the reduce launch"
 
 
-@pytest.mark.parametrize("L", [9, 24, 32])
-def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(knobs, L):
-    """Prompt suffixes of up to 32 rows on the real layer shapes: gate|up walks K once for four strips per workgroup, o_proj / down run two
-    strips per workgroup with K split into four fp32 slabs that the residual-add + RMSNorm kernel sums (knob w4m_slabs = 0: the one-strip forms
-    with the two-way fp32 atomic split).  Both follow the oracle; the two differ only in the order of four fp32 additions."""
+@pytest.mark.parametrize("L", [9, 24, 32, 64, 100, 130, 200, 256])
+def test_prompt_rows_on_8b_shapes_weight_streaming_gemm_vs_round2_kernels(knobs, L):
+    """Prompts / suffixes of 9..256 rows on the real layer shapes: k_w4r_gemm in each of its row-block geometries (1, 2, 4, 5, 7 -> 8, 8 blocks) --
+    gate|up with the SwiGLU epilogue, q|k|v / o_proj / down as K-split fp32 slabs summed by their consumers -- against the oracle and against
+    round 2's kernels (knob w4r = 0); the two differ only in the order of fp32 additions."""
     dtype = "bfloat16"
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 2, "intermediate_size": 14336,
            "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
@@ -423,15 +425,15 @@ def test_few_row_prompt_on_8b_shapes_slab_and_atomic_k_splits(knobs, L):
     ocache = [po.OracleKVCache() for _ in orc.layers]
     want, hid = orc.forward(prompt, ocache, last_only=True, want_hidden=True)
     outs = {}
-    for mode in ("1", "0"):
-        knobs("w4m_slabs", int(mode))
+    for mode in (None, 0):
+        knobs("w4r", mode)
         model = build(cfg, w, dtype)
         cache = model.make_cache()
         tok, lp, logits = model.step(torch.from_numpy(prompt).cuda(), cache)
-        assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what=f"hidden, w4m_slabs={mode}")
-        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"logits, w4m_slabs={mode}")
+        assert_vec_close(model.hidden.float().cpu().numpy(), hid[-1], dtype, what=f"hidden, w4r={mode}")
+        assert_vec_close(logits.float().cpu().numpy(), want, dtype, what=f"logits, w4r={mode}")
         outs[mode] = logits.float().cpu().numpy()
-    assert_vec_close(outs["1"], outs["0"], dtype, what="slab split vs atomic split")   # (a few bf16 roundings flip downstream of the reordered sums)
+    assert_vec_close(outs[None], outs[0], dtype, what="k_w4r_gemm vs round-2 kernels")   # (a few bf16 roundings flip downstream of the reordered sums)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])

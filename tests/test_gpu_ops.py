@@ -391,13 +391,14 @@ def test_few_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
         assert np.array_equal(to_bits(cols), po.to_bits(deq[:, :min(32, K)].T.copy(), dt))
 
 
-@pytest.mark.parametrize("M,N,K", [(5, 16384 + 96, 1024), (32, 16512, 2048), (19, 16416, 576)])
-def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, knobs, M, N, K):
-    """Matrices with 512+ strips of 32 columns (gate|up, lm_head): one workgroup walks K once for four strips (k_w4m_gemm_lds4) -- x is
-    staged once per workgroup instead of once per strip.  Same tiles per wave, same accumulation and reduction order: bit-identical to the
-    one-strip-per-workgroup forms (knob w4m_multi = 0), and close to the oracle's qmm.  N not a multiple of 128: the last workgroup owns
-    fewer strips; K = 576: fewer groups than two rounds of waves."""
-    dt = "bfloat16"
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K", [(5, 16384 + 96, 1024), (32, 16512, 2048), (19, 16416, 576), (6, 96, 256), (31, 4128, 704), (64, 6144, 4096), (65, 1408, 1408),
+                                   (128, 4096, 14336), (150, 512, 320), (160, 28672, 512), (192, 288, 4096), (255, 160, 128), (256, 4096, 4096)])
+def test_weight_streaming_int4_gemm_vs_oracle_qmm_and_round2_kernels(ops, knobs, dt, M, N, K):
+    """pie_qgemm_w4m up to 256 rows = k_w4r_gemm (w4r_gemm.hpp): every row-block geometry, column counts that are not a multiple of the 128-column
+    workgroup tile (a ragged last workgroup), K / 64 that is not a multiple of the K-phases (704 = 11 groups, 320 = 5: the partial last step),
+    K-split shapes reduced inside the call -- against the oracle's many-row regime of mx.quantized_matmul (weights dequantised to T first) and
+    against round 2's kernels (knob w4r = 0), which differ only in the order of fp32 additions."""
     rng = np.random.default_rng(M + N)
     w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
     wq, sc, bi = po.quantize(w, 64, 4, dt)
@@ -405,11 +406,31 @@ def test_few_row_int4_gemm_wide_matrices_share_x_across_strips(ops, knobs, M, N,
     packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
     xd = to_dev(po.to_bits(x, dt), dt)
     got = ops.quantized_matmul_rows(xd, packed)
-    knobs("w4m_multi", 0)
-    ref = ops.quantized_matmul_rows(xd, packed)
-    assert torch.equal(got, ref), "four strips per workgroup must not change a bit"
     want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
-    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w4m wide {M}x{N}x{K}")
+    assert_dot_close(got.float().cpu().numpy(), want, dt, max_frac=0.03, what=f"w4r {M}x{N}x{K}")
+    knobs("w4r", 0)
+    ref = ops.quantized_matmul_rows(xd, packed)
+    assert_dot_close(got.float().cpu().numpy(), ref.float().cpu().numpy().astype(np.float64), dt, max_frac=0.03, what=f"w4r vs round-2 kernels {M}x{N}x{K}")
+
+
+def test_weight_streaming_int4_gemm_scales_beyond_the_fast_conversions_domain(ops):
+    """k_w4r_gemm converts codes with v_fma_mix_f32 on f16-denormal operands, exact while |scale| * 2^24 is finite; a matrix with a scale of
+    2^101 is flagged when its tiles are built and converted with plain instructions instead: same results as the oracle either way."""
+    dt = "bfloat16"
+    rng = np.random.default_rng(7)
+    N, K, M = 256, 512, 40
+    w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+    wq, sc, bi = po.quantize(w, 64, 4, dt)
+    sc = sc.copy()
+    bi = bi.copy()
+    sc[3, 2] = 0x7200                          # bf16 bits of 2^101: one absurd group -- its row's outputs are huge but finite, every other row is untouched
+    bi[3, 2] = 0xF300                          # -2^103
+    x = po.round_T(rng.standard_normal((M, K)) * 2.0 ** -20, dt)
+    packed = ops.repack_w4s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+    got = ops.quantized_matmul_rows(to_dev(po.to_bits(x, dt), dt), packed).float().cpu().numpy()
+    want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=4, dtype=dt, regime="qmm")
+    assert np.isfinite(got).all()
+    assert_dot_close(got, want, dt, max_frac=0.03, what="wide-scale matrix")
 
 
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])

@@ -30,12 +30,12 @@ int main(int argc, char **argv) {
         char *w;
         hipMalloc(&w, bytes * copies);
         hipMemset(w, 0x21, bytes * copies);
-        for (int i = 0; i < copies; ++i) w4m_gemm_launch(PIE_BF16, w + bytes * i, x, M, s.N, s.K, y, nullptr, nullptr, 0, nullptr, nullptr);
+        for (int i = 0; i < copies; ++i) w4m_gemm_launch(PIE_BF16, w + bytes * i, x, M, s.N, s.K, y, nullptr, 0, nullptr, nullptr);
         hipDeviceSynchronize();
         hipEventRecord(e0);
         const int reps = 4;
         for (int r = 0; r < reps; ++r)
-            for (int i = 0; i < copies; ++i) w4m_gemm_launch(PIE_BF16, w + bytes * i, x, M, s.N, s.K, y, nullptr, nullptr, 0, nullptr, nullptr);
+            for (int i = 0; i < copies; ++i) w4m_gemm_launch(PIE_BF16, w + bytes * i, x, M, s.N, s.K, y, nullptr, 0, nullptr, nullptr);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;

@@ -1,5 +1,5 @@
 // tools/w4r_bench.hip -- the weight-streaming int4 GEMM (k_w4r_gemm, w4r_gemm.hpp) alone: parity against a plain reference kernel and
-// against the kernels it replaces, and timing on the 8B model's layer shapes with cold weights (developer tool, not part of the product).
+// against round 2's kernels (k_w4m_gemm up to 32 rows -- its multi-strip siblings, which this kernel replaced, are in git history -- and k_w4l2_gemm), and timing on the 8B model's layer shapes with cold weights (developer tool, not part of the product).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DW4R_ABL=<mask>] tools/w4r_bench.hip -o tools/w4r_bench[_<mask>]
 //   tools/w4r_bench check            parity over a grid of (M, N, K) incl. ragged M, K splits and every epilogue
 //   tools/w4r_bench time [M ...]     us per launch per shape, new vs old kernels
@@ -179,6 +179,7 @@ static double time_it(int iters, const std::function<void(int)> &f) {
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     if (getenv("W4R_PLAIN")) g_plain = atoi(getenv("W4R_PLAIN")) != 0;
+    if (getenv("W4R_KNOB")) g_knob_w4r = atoi(getenv("W4R_KNOB"));  // developer: plan variants behind PIE_KNOB_W4R values > 1
     if (mode == "check") {
         int fails = 0;
         const int Ms[] = {6, 17, 32, 33, 64, 65, 96, 100, 128, 129, 160, 161, 192, 200, 256};
@@ -261,9 +262,7 @@ int main(int argc, char **argv) {
             const double us_new = time_it(2 * copies, [&](int i) { w4r_gemm_launch(PIE_BF16, w + bytes * (i % copies), x, M, s.N, s.K, y, ws, 0, s.epi, nullptr, nullptr, &slabs, nullptr, g_plain); });
             double us_old;
             if (M <= 32) {
-                const int ss = s.epi == W4R_STORE ? w4m_slab_splits(M, s.N, s.K) : 0;
-                if (ss >= 2) us_old = time_it(2 * copies, [&](int i) { w4m_slab_gemm_launch(PIE_BF16, w + bytes * (i % copies), x, M, s.N, s.K, ws, 0); });
-                else us_old = time_it(2 * copies, [&](int i) { w4m_gemm_launch(PIE_BF16, w + bytes * (i % copies), x, M, s.N, s.K, y, 0, nullptr, s.epi == W4R_SWIGLU ? 1 : 0, nullptr, nullptr); });
+                us_old = time_it(2 * copies, [&](int i) { w4m_gemm_launch(PIE_BF16, w + bytes * (i % copies), x, M, s.N, s.K, y, 0, s.epi == W4R_SWIGLU ? 1 : 0, nullptr, nullptr); });
             } else {
                 bool fused = false;
                 int sl = 0;
