@@ -1,0 +1,80 @@
+"""Turns gpurun_out/r5/prof_step (scripts/profile_r05.sh on the MI355X box) into the committed summaries under profiles/; every CSV it copies gets
+a first line naming the library build (pie_version()) it was measured on."""
+import glob
+import json
+import re  # noqa: F401
+import shutil
+from pathlib import Path
+
+import pandas as pd
+
+ROOT = Path(__file__).resolve().parent.parent
+P = ROOT / "gpurun_out" / "r5" / "prof_step"
+OUT = ROOT / "profiles"
+
+
+def counters(d):
+    df = pd.read_csv(glob.glob(str(P / d / "*" / "*_counter_collection.csv"))[0])
+    return df.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].agg(["mean", "count"]).reset_index()
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
+version = (P / "pie_version.txt").read_text().strip()
+for src, dst in (("step_stats", "r05_step_kernel_stats.csv"), ("bench_stats", "r05_bench_kernel_stats.csv")):
+    hit = glob.glob(str(P / src / "*" / "*_kernel_stats.csv"))
+    if hit:
+        (OUT / dst).write_text(f"# library: {version}; rocprofv3 --kernel-trace --stats, scripts/profile_r05.sh ({src})\n" + Path(hit[0]).read_text())
+
+H, I, QD, KVD, V, L = 4096, 14336, 4096, 1024, 128256, 32
+T = 133
+
+
+def lin(n, k):
+    return n * k // 2 + 2 * (n * k // 64) * 2
+
+
+alg = {"k_w4s_gemv<BF16, 1, 2, 1, 0, 0>": ("qkv: rmsnorm + GEMV + RoPE + cache append", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, L - 1),
+       "k_w4s_gemv<BF16, 3, 2, 1, 0, 0>": ("layer 0's qkv with the embedding row dequantised in its prologue", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, 1),
+       "k_attn_decode<BF16, 128, 4, false, false, 4>": ("split-KV attention (cache capacity 512: partials merged by o_proj) + the Infinity-Cache warm-up of o_proj on its idle CUs", 2 * KVD * 2 * T, L),
+       "k_w4s_gemv<BF16, 2, 1, 1, 0, 0>": ("o_proj: split merge + GEMV + residual", lin(H, QD), L),
+       "k_w4s_gemv<BF16, 1, 3, 1, 0, 0>": ("gate/up: rmsnorm + GEMV + SwiGLU", lin(2 * I, H) + H * 2, L),
+       "k_w4s_gemv<BF16, 0, 1, 4, 0, 0>": ("down: GEMV + residual", lin(H, I), L),
+       "k_w4s_gemv<BF16, 1, 4, 1, 0, 0>": ("lm_head: rmsnorm + GEMV + log-softmax partials", lin(V, H) + H * 2, 1),
+       "k_logits_finish<BF16>": ("tail: log-softmax + argmax", V * 4, 1)}
+f, w = counters("step_fetch"), counters("step_write")
+
+
+def pick(df, key):
+    names = df.Kernel_Name.map(short)
+    hit = df[names == key]
+    return hit if len(hit) else df[names.str.startswith(key.rsplit(",", 1)[0])]
+
+
+rows, step_meas, step_alg = {}, 0.0, 0.0
+for key, (what, a, per_step) in alg.items():
+    pf, pw = pick(f, key), pick(w, key)
+    if not len(pf) or not len(pw):
+        print("not in the capture:", key)
+        continue
+    fk = pf["mean"].iloc[0] * 1024 * 2  # KB; gfx950: wide streaming reads are tallied at half their size (MI355X_MICROARCH.md, HBM)
+    wk = pw["mean"].iloc[0] * 1024
+    rows[key] = {"what": what, "launches_per_step": per_step, "algorithmic_bytes": a, "hbm_bytes_per_launch": int(fk + wk),
+                 "FETCH_SIZE_KB": round(fk / 2048, 2), "WRITE_SIZE_KB": round(wk / 1024, 2), "ratio": round((fk + wk) / a, 4)}
+    step_meas += (fk + wk) * per_step
+    step_alg += a * per_step
+gu = rows["k_w4s_gemv<BF16, 1, 3, 1, 0, 0>"]
+out = {"library": version, "kernel": "k_w4s_gemv<BF16, rmsnorm, swiglu> (gate/up, N=28672 K=4096)", "hbm_bytes_per_launch": gu["hbm_bytes_per_launch"],
+       "algorithmic_bytes_per_launch": gu["algorithmic_bytes"], "FETCH_SIZE_KB": gu["FETCH_SIZE_KB"], "WRITE_SIZE_KB": gu["WRITE_SIZE_KB"],
+       "step": {"hbm_bytes": int(step_meas), "algorithmic_bytes": int(step_alg), "ratio": round(step_meas / step_alg, 4), "context": T},
+       "per_kernel": rows,
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the PRODUCT decode step driven through the C ABI by "
+               "tools/step_bench (--graph 0: the launch sequence of pie_decoder_step, the kernels and arguments the hipGraph replays; "
+               "8 steps after 2 warm-up, means over all dispatches).  FETCH_SIZE doubled (gfx950 tallies the 128-B requests of wide coalesced "
+               "streams at 64 B: MI355X_MICROARCH.md, HBM section; calibrated in round 1 against a pure stream kernel).  `library` is the "
+               "pie_version() of the build that was measured: bench.py reports traffic only for exactly that build."}
+json.dump(out, open(OUT / "r05_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1)[:1500])
