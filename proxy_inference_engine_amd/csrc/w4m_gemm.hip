@@ -749,6 +749,139 @@ int w4l_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     return PIE_OK;
 }
 
+// ---------------------------------------------------------------- 16-bit weights, many rows (w16_gemm.hpp)
+#include "w16_gemm.hpp"
+int bias_any_launch(int dtype, void *y, const void *bias, int M, int N, hipStream_t st);  // vision.hip
+
+static char *g_w16_zero = nullptr;  // 4 KiB of zeros: the weight tile of the ring's dummy steps
+static std::mutex g_w16_mutex;
+static int w16_zero_block(const char **out) {
+    std::lock_guard<std::mutex> lock(g_w16_mutex);
+    if (!g_w16_zero) {
+        PIE_HIP_TRY(hipMalloc((void **)&g_w16_zero, W16M_TILE_BYTES));
+        PIE_HIP_TRY(hipMemset(g_w16_zero, 0, W16M_TILE_BYTES));
+    }
+    *out = g_w16_zero;
+    return PIE_OK;
+}
+
+size_t w16m_size(int N, int K) { return w16m_bytes(N, K); }
+// row-major [N][K] (any N, K) -> W16M
+int w16m_from_rows_launch(const void *w, int N, int K, void *w16m, hipStream_t st) {
+    const char *zero;
+    if (const int rc = w16_zero_block(&zero)) return rc;  // (first use of the format: never under stream capture)
+    const int groups = (K + 63) / 64;
+    const size_t pieces = w16m_bytes(N, K) / 16;
+    hipLaunchKernelGGL(k_rows_to_w16m, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const u16 *)w, N, K, groups, pieces, (uint4 *)w16m);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+// W16S units (the dense decode stream) -> W16M, packed row order
+int w16m_from_w16s_launch(const void *w16s, int N, int K, void *w16m, hipStream_t st) {
+    const char *zero;
+    if (const int rc = w16_zero_block(&zero)) return rc;
+    const int groups = (K + 63) / 64;
+    const size_t pieces = w16m_bytes(N, K) / 16;
+    hipLaunchKernelGGL(k_w16s_to_w16m, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const uint4 *)w16s, N, K, (K + 511) / 512, groups, pieces,
+                       (uint4 *)w16m);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+// Decomposition: row tile (64 / 128 / 256 rows), strips per wave (workgroup = 128 or 256 columns) and K split, by a small cost model:
+// a step is 4 MB SW MFMAs per wave (24.6 ns each at the ~1.3 GHz the chip holds under matrix load) at the tile's measured efficiency,
+// workgroups run in rounds of 256, a K split pays the fp32 slabs' write + read and the reduce launch.
+struct W16Plan {
+    int mb, sw, S;
+};
+static int g_w16_plan_override[3] = {0, 0, 0};  // developer override (tools/w16_bench)
+static int g_w16_block[2] = {4, 8};              // XCD-local traversal block (row tiles x column tiles)
+#ifdef W16L_PROF
+static unsigned long long *g_w16_prof = nullptr;
+#endif
+static int w16_even_splits(int groups, int S) {  // the largest split count <= S whose ceil-sized runs are all non-empty
+    for (;;) {
+        const int per = (groups + S - 1) / S, s2 = (groups + per - 1) / per;
+        if (s2 == S) return S;
+        S = s2;
+    }
+}
+static W16Plan w16_plan(int M, int N, int K) {
+    const int groups = (K + 63) / 64;
+    if (g_w16_plan_override[0]) return {g_w16_plan_override[0], g_w16_plan_override[1], w16_even_splits(groups, g_w16_plan_override[2])};
+    const int mb_max = M <= 64 ? 2 : (M <= 128 ? 4 : 8);
+    W16Plan best = {mb_max, 2, 1};
+    double best_us = 1e30;
+    for (int S = 1; S <= 16 && (S == 1 || 8 * S <= groups); ++S)
+        for (int mb = mb_max; mb >= 2; mb >>= 1)
+            for (int sw = 2; sw >= 1; --sw) {
+                const double eff = (sw == 2 ? 0.85 : 0.70) * (mb == 8 ? 1.0 : (mb == 4 ? 0.92 : 0.80));
+                const int wgs = ((N + 128 * sw - 1) / (128 * sw)) * ((M + 32 * mb - 1) / (32 * mb)) * S;
+                const int steps = ((groups + S - 1) / S + 3) & ~3;
+                double us = (double)((wgs + 255) / 256) * steps * (4 * mb * sw * 0.0246 / eff) + 4.0;
+                if (S > 1) us += (double)M * N * 4.0 * (S + 1) / 2.0e6 + 4.0;
+                if (us < best_us) best_us = us, best = {mb, sw, S};
+            }
+    best.S = w16_even_splits(groups, best.S);
+    return best;
+}
+int w16l_splits(int M, int N, int K) { return w16_plan(M, N, K).S; }
+size_t w16l_workspace_bytes(int M, int N, int K) {
+    const int s = w16l_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+// y [M, N] = x [M, Kx] . W^T (+ bias), W in W16M tiles of an [N, K] Linear; Kx = 64 ceil(K / 64) is x's row length (zero columns past K).
+// swiglu_act (nullable): the packed gate|up matrix and the caller wants the MLP activation [M, N / 2] there; *fused says whether it got it.
+// workspace: w16l_workspace_bytes() of device scratch (may be null when that is 0).
+int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, const void *bias,
+                     void *swiglu_act, bool *fused) {
+    if (fused) *fused = false;
+    PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 4 == 0, PIE_E_SHAPE, "16-bit GEMM: N must be a multiple of 4");
+    PIE_REQUIRE(pie_aligned(w16m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8) && (!bias || pie_aligned(bias, 8)), PIE_E_ALIGN, "16-bit GEMM: 16-byte alignment required");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "16-bit GEMM: dtype must be PIE_BF16 or PIE_F16");
+    W16Plan plan = w16_plan(M, N, K);
+    const bool sg = swiglu_act && fused && plan.S == 1;
+    if (sg) plan.sw = 2;  // (the fused activation is built for two strips per wave)
+    PIE_REQUIRE(plan.S == 1 || workspace, PIE_E_ARG, "16-bit GEMM: this shape splits K and needs its workspace");
+    W16Args a = {};
+    int rc = w16_zero_block(&a.zero);
+    if (rc) return rc;
+    a.w16m = (const char *)w16m, a.x = (const u16 *)x, a.M = M, a.N = N, a.K = 64 * ((K + 63) / 64);
+    a.y = (u16 *)(sg ? swiglu_act : y), a.part = plan.S > 1 ? (float *)workspace : nullptr;
+    a.bias = plan.S > 1 ? nullptr : (const u16 *)bias;
+    a.tm = (M + 32 * plan.mb - 1) / (32 * plan.mb), a.tn = (N + 128 * plan.sw - 1) / (128 * plan.sw);
+    a.bm = g_w16_block[0] < a.tm ? g_w16_block[0] : a.tm, a.bc = g_w16_block[1];
+#ifdef W16L_PROF
+    a.prof = g_w16_prof;
+#endif
+    const dim3 grid((unsigned)(8 * ((a.tn + 7) / 8) * a.tm), (unsigned)plan.S);
+#define W16_GO(TT, MB_, SW_, SG_) hipLaunchKernelGGL((k_w16l_gemm<TT, MB_, SW_, SG_>), grid, dim3(256), 0, st, a)
+#define W16_SW(TT, MB_) \
+    if (sg) W16_GO(TT, MB_, 2, true); \
+    else if (plan.sw == 2) W16_GO(TT, MB_, 2, false); \
+    else W16_GO(TT, MB_, 1, false)
+#define W16_MB(TT) \
+    if (plan.mb == 2) { W16_SW(TT, 2); } \
+    else if (plan.mb == 4) { W16_SW(TT, 4); } \
+    else { W16_SW(TT, 8); }
+    if (dtype == PIE_BF16) { W16_MB(BF16) } else { W16_MB(F16) }
+#undef W16_MB
+#undef W16_SW
+#undef W16_GO
+    PIE_LAUNCH_CHECK();
+    if (sg) *fused = true;
+    if (plan.S > 1) {
+        const size_t MN = (size_t)M * N;
+        const dim3 rg((unsigned)((MN / 4 + 255) / 256));
+        if (dtype == PIE_BF16) hipLaunchKernelGGL(k_w4l_reduce<BF16>, rg, dim3(256), 0, st, a.part, plan.S, MN, (u16 *)y);
+        else hipLaunchKernelGGL(k_w4l_reduce<F16>, rg, dim3(256), 0, st, a.part, plan.S, MN, (u16 *)y);
+        PIE_LAUNCH_CHECK();
+        if (bias) return bias_any_launch(dtype, y, bias, M, N, st);
+    }
+    return PIE_OK;
+}
+
 // ---------------------------------------------------------------- 6 .. 256 rows: the weight-streaming form (w4r_gemm.hpp)
 #include "w4r_gemm.hpp"
 
@@ -899,7 +1032,6 @@ int w4m_gemm_launch(int dtype, const void *w4m, const void *x, int M, int N, int
     return PIE_OK;
 }
 
-int bias_any_launch(int dtype, void *y, const void *bias, int M, int N, hipStream_t st);  // vision.hip
 
 extern "C" {
 
