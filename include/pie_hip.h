@@ -321,8 +321,8 @@ int pie_decoder_graph_launches(const pie_decoder *d, int flags);
  * launches queued back to back with no host round trip.  L >= 6 (pie_set_knob(PIE_KNOB_PREFILL_MIN, n)): batched, in chunks of
  * 4096 rows (PIE_KNOB_PREFILL_CHUNK) -- MLX's qmm regime: nn.QuantizedLinear at L > 1 dequantises to T before a T x T -> fp32 MMA.
  * int4 group-64 matrices run hand-written MFMA GEMMs straight from their 4-bit tiles (k_w4r_gemm up to 256 rows, k_w4l2_gemm beyond);
- * dense, int8 and group-32 matrices are unpacked / dequantised to T and multiplied by hipBLASLt (dlopen'ed: PIE_E_STATE if it cannot be
- * loaded), with HIP kernels for RMSNorm, RoPE + cache append, causal attention, SwiGLU and residuals.  Shorter prompts: iterated decode steps (the qmv regime).  logits_all == NULL: lm_head + tail only for the last token (the engine only
+ * dense, int8 and group-32 matrices multiply a 16-bit copy in MFMA-ordered tiles (W16M; k_w16l_gemm -- no library GEMM since round 5;
+ * in_features % 64 == 0), with HIP kernels for RMSNorm, RoPE + cache append, causal attention, SwiGLU and residuals.  Shorter prompts: iterated decode steps (the qmv regime).  logits_all == NULL: lm_head + tail only for the last token (the engine only
  * reads logits[:, -1, :], engine/inference_engine.py:254).  logits_all != NULL: T [L, vocab], lm_head on every
  * position like the reference's Model.__call__ (language.py:205-209). */
 int pie_decoder_prefill(pie_decoder *d, const int32_t *ids, int L, void *logits_all, void *stream);
@@ -468,19 +468,31 @@ int pie_paged_attn_decode_i8(const void *q, const void *slab, size_t n_pages, co
 /* ---------------------------------------------------------------- vision tower ops
  * Call sites: models/intern/vision.py (Qwen2.5-VL vision tower: PatchEmbed :87-121, Attention :143-186, MLP :189-197,
  * PatchMerger :124-140).  RMSNorm, SiLU * up and the residual adds are pie_rms_norm / pie_silu_mul / pie_add.
- * pie_linear: nn.Linear on M rows -- y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]), T in, fp32 accumulate, T out (rounded
- *   before the bias is added, like the text tower's Linear); hipBLASLt (PIE_E_STATE if it cannot be loaded).
+ * pie_linear_w16m: nn.Linear on M rows -- y [M, N] = x [M, K] . w [N, K]^T (+ bias [N]), T in, fp32 accumulate, T out (rounded
+ *   before the bias is added, like the text tower's Linear) on the hand-written 16-bit MFMA GEMM (csrc/w16_gemm.hpp; rounds 1-4
+ *   called hipBLASLt here).  The weight is given as W16M tiles -- 32 output rows x 64 columns in MFMA operand order, zero-padded --
+ *   built once per matrix: pie_w16m_bytes(N, K) bytes (256-byte aligned), filled by pie_repack_w16m from the row-major [N, K] weight.
+ *   x: M rows of ldx elements (0 = packed) holding 64 * ceil(K / 64) used columns, ZEROS past K (the tower's two odd widths, 1176
+ *   and 3420, are padded by the host); y: rows of ldy elements (0 = packed).  swiglu != 0: the weight's rows interleave (gate_i, up_i),
+ *   bias likewise, and y [M, N / 2] = T(T(silu(g)) * u) with g, u the rounded, biased Linear outputs (MLP, vision.py:196-197: the values
+ *   of the GEMM followed by pie_bias_silu_mul).  workspace: pie_linear_w16m_workspace(M, N, K) bytes of device scratch for the
+ *   shapes that split K (few rows, narrow matrices; 0 for most and for swiglu).  Any N (16-byte stores when N and ldy are multiples
+ *   of 8); swiglu needs N % 8 == 0.
  * pie_gelu: nn.GELU() exact form, fp32 inside, one rounding.
  * pie_vision_qkv_rope: qkv T [N, 3, H, D] (+ optional bias T [3 * H * D], the qkv Linear's) -> q T [N, H, DP], k, v T [H, N, DP] with rotate-half rotary on q and k
  *   (apply_rotary_pos_emb_vision, vision.py:55-70; cos / sin fp32 [N, D/2] = the row's angles) and head dims D..DP-1 zeroed
  *   (DP = 64 or 128, the attention kernel's head sizes).
  * pie_sdpa_segments: block-diagonal non-causal attention, the mask of vision.py:160-167: query row r attends keys
  *   [seg_lo[r], seg_hi[r]) (device int32 [N], non-decreasing, lo <= r < hi).  q, out T [N, H, D]; k, v T [H, N, D]. */
-int pie_linear(const void *x, const void *w, const void *bias, int M, int N, int K, int dtype, void *y, void *stream);
+size_t pie_w16m_bytes(int N, int K);
+int pie_repack_w16m(const void *w, int N, int K, int dtype, void *w16m, void *stream);
+size_t pie_linear_w16m_workspace(int M, int N, int K);
+int pie_linear_w16m(const void *x, int ldx, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, int ldy, int swiglu,
+                    void *workspace, size_t workspace_bytes, void *stream);
 int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream);
 int pie_vision_qkv_rope(const void *qkv, const void *bias, const float *cos_t, const float *sin_t, int N, int H, int D, int DP, int dtype,
                         void *q, void *k, void *v, void *stream);
-/* Bias adds folded into the op that consumes the GEMM output (same values as pie_linear with a bias followed by the op):
+/* Bias adds folded into the op that consumes the GEMM output (same values as pie_linear_w16m with a bias followed by the op):
  * pie_bias_silu_mul: y = silu(gate + bias_gate) * (up + bias_up), T [M, N] (MLP, vision.py:196-197); gate / up rows are `ld`
  *   elements apart (0 = N), so both may be column halves of one [M, 2N] GEMM output;
  * pie_add_bias: y = x + (r + bias), T [M, N] (the residual adds of vision.py:212-218). */

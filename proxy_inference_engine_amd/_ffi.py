@@ -35,7 +35,7 @@ EXPORTS = [
     "pie_page_alloc", "pie_page_free", "pie_page_add_ref", "pie_page_ref_count", "pie_page_num_tokens", "pie_page_set_num_tokens",
     "pie_page_ptrs", "pie_paged_attn_workspace_bytes", "pie_paged_attn_decode", "pie_paged_kv_append",
     "pie_page_i8_bytes", "pie_page_scale_ptrs", "pie_page_i8_set_scales", "pie_paged_kv_append_i8", "pie_paged_attn_decode_i8",
-    "pie_linear", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
+    "pie_w16m_bytes", "pie_repack_w16m", "pie_linear_w16m_workspace", "pie_linear_w16m", "pie_gelu", "pie_vision_qkv_rope", "pie_sdpa_segments", "pie_bias_silu_mul", "pie_add_bias", "pie_add_bias_rms_norm",
     "pie_w4m_bytes", "pie_repack_w4s_to_w4m", "pie_qgemm_w4m",
     "pie_comm_create", "pie_comm_rccl_unique_id", "pie_comm_create_rccl", "pie_comm_export", "pie_comm_connect", "pie_allreduce_f32", "pie_comm_status", "pie_comm_destroy", "pie_decoder_set_comm", "pie_sample", "pie_sample_workspace_bytes",
 ]
@@ -137,7 +137,12 @@ def load() -> C.CDLL:
     lib.pie_paged_attn_decode_i8.argtypes = lib.pie_paged_attn_decode.argtypes
     lib.pie_paged_kv_append_i8.argtypes = lib.pie_paged_kv_append.argtypes
     lib.pie_decoder_set_paged_kv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
-    lib.pie_linear.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+    lib.pie_w16m_bytes.restype = C.c_size_t
+    lib.pie_w16m_bytes.argtypes = [C.c_int, C.c_int]
+    lib.pie_repack_w16m.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pie_linear_w16m_workspace.restype = C.c_size_t
+    lib.pie_linear_w16m_workspace.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.pie_linear_w16m.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.pie_gelu.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     lib.pie_vision_qkv_rope.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p] * 4
     lib.pie_bias_silu_mul.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2

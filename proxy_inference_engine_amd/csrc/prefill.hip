@@ -5,22 +5,17 @@
 // and feed a T x T -> fp32 MMA; the vector kernels (qmv, exact fp32 affine math) serve only the few-row case.  This file
 // follows that split: prompts of prefill_min_rows() tokens or more run here, shorter ones as iterated decode steps.
 //
-// MI355X design: 288 GB of HBM make a transient T copy of one layer's weights cheap, and a T x T GEMM is a plain library
-// GEMM, so per layer and chunk
-//   * k_dequant_w4s   W4S units -> T [N, K]  (the mx.dequantize arithmetic: T(fp32(s*q) + b)), into one reused scratch;
-//   * hipBLASLt       y[M, N] = x[M, K] . W_T[N, K]^T, fp32 accumulate, one rounding  (dlopen'ed: the process may
-//                     already hold torch's copy of the library, and a second copy must not be loaded next to it);
+// MI355X design, per weight format (no library GEMM anywhere: the hipBLASLt path of rounds 1-4 was removed in round 5):
+//   * int4 g=64 modules multiply their 4-bit W4M tiles directly (w4m_gemm.hip: k_w4r_gemm up to 256 rows, k_w4l2_gemm beyond);
+//   * dense modules, and int8 / group-32 modules, multiply a 16-bit copy in W16M tiles (w16_gemm.hpp: k_w16l_gemm, the weights
+//     straight into MFMA fragment registers, x through LDS-DMA) -- dense ones tiled from their W16S units, quantised ones from
+//     k_dequant_w4s / k_dequant_w8s (the mx.dequantize arithmetic: T(fp32(s*q) + b)); 288 GB of HBM keep the copies resident;
 //   * hand-written HIP for everything around it: RMSNorm rows, RoPE + cache append from the packed q|k|v rows, causal
-//     attention (the decode kernel with one query row per blockIdx.z: row r attends offset + r + 1 positions), the
-//     split merge, SwiGLU on the interleaved gate/up rows, residual adds.
+//     attention (MFMA flash kernel), the split merge, SwiGLU on the interleaved gate/up rows, residual adds.
 // The chunk is bounded (PIE_KNOB_PREFILL_CHUNK, default 4096 rows: ~0.6 GB of activation scratch on the 8B model).
-#include <dlfcn.h>
-#include <hipblaslt/hipblaslt.h>
-
 #include <cstdlib>
 #include <map>
 #include <mutex>
-#include <tuple>
 
 #include "decoder.hpp"
 #include "prefill_attn.hpp"
@@ -320,129 +315,11 @@ static int add_rms_norm_rows(u16 *x, const u16 *r, const void *w, float eps, int
 
 __global__ void k_add_pos(DecState *s, int delta) { s->pos += delta; }
 
-// ---------------------------------------------------------------- hipBLASLt through dlopen
-namespace {
-struct LtApi {
-    void *lib = nullptr;
-    decltype(&hipblasLtCreate) Create = nullptr;
-    decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
-    decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
-    decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
-    decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
-    decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
-    decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
-    decltype(&hipblasLtMatmul) Matmul = nullptr;
-    hipblasLtHandle_t handle = nullptr;
-    hipblasLtMatmulPreference_t pref = nullptr;
-    void *workspace = nullptr;
-    size_t ws_bytes = 64u << 20;
-    struct Plan {
-        hipblasLtMatmulDesc_t desc;
-        hipblasLtMatrixLayout_t la, lb, lc;
-        hipblasLtMatmulAlgo_t algo;
-    };
-    std::map<std::tuple<int, int, int, int>, Plan> plans;  // (dtype, M, N, K)
-};
-LtApi g_lt;
-std::mutex g_lt_mutex;  // the handle, workspace and plan cache are process-wide; decoders on several host threads share them
-
-int lt_init() {
-    if (g_lt.handle) return PIE_OK;
-    const char *names[] = {"libhipblaslt.so.1", "libhipblaslt.so", "/opt/rocm/lib/libhipblaslt.so"};
-    for (const char *n : names)  // a copy the process already holds (torch's) wins over loading a second one
-        if ((g_lt.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-    for (const char *n : names)
-        if (!g_lt.lib) g_lt.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    const char *dl_msg = g_lt.lib ? nullptr : dlerror();  // dlerror() clears itself: read it once
-    PIE_REQUIRE(g_lt.lib, PIE_E_STATE,
-                std::string("prefill: cannot load hipBLASLt (") + (dl_msg ? dl_msg : "not found") +
-                    "); put libhipblaslt.so on the loader path, or pie_set_knob(PIE_KNOB_PREFILL_MIN, 1000000) to process prompts as iterated decode steps");
-#define LT_SYM(field, name)                                                        \
-    g_lt.field = reinterpret_cast<decltype(g_lt.field)>(dlsym(g_lt.lib, #name)); \
-    PIE_REQUIRE(g_lt.field, PIE_E_STATE, "prefill: hipBLASLt lacks " #name)
-    LT_SYM(Create, hipblasLtCreate);
-    LT_SYM(DescCreate, hipblasLtMatmulDescCreate);
-    LT_SYM(DescSet, hipblasLtMatmulDescSetAttribute);
-    LT_SYM(LayoutCreate, hipblasLtMatrixLayoutCreate);
-    LT_SYM(PrefCreate, hipblasLtMatmulPreferenceCreate);
-    LT_SYM(PrefSet, hipblasLtMatmulPreferenceSetAttribute);
-    LT_SYM(Heuristic, hipblasLtMatmulAlgoGetHeuristic);
-    LT_SYM(Matmul, hipblasLtMatmul);
-#undef LT_SYM
-    PIE_REQUIRE(g_lt.Create(&g_lt.handle) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtCreate failed");
-    PIE_REQUIRE(g_lt.PrefCreate(&g_lt.pref) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtMatmulPreferenceCreate failed");
-    PIE_HIP_TRY(hipMalloc(&g_lt.workspace, g_lt.ws_bytes));
-    g_lt.PrefSet(g_lt.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g_lt.ws_bytes, sizeof(g_lt.ws_bytes));
-    return PIE_OK;
-}
-
-// y[M, N] = x[M, K] . w[N, K]^T  (row-major T in, fp32 accumulate, T out).  Column-major view: Y'[N, M] = W'^T . X'.
-int gemm_xwt_impl(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
-    std::lock_guard<std::mutex> lock(g_lt_mutex);
-    int rc = lt_init();
-    if (rc) return rc;
-    const auto key = std::make_tuple(dtype, M, N, K);
-    auto it = g_lt.plans.find(key);
-    if (it == g_lt.plans.end()) {
-        LtApi::Plan p;
-        const hipDataType dt = dtype == PIE_BF16 ? HIP_R_16BF : HIP_R_16F;
-        PIE_REQUIRE(g_lt.DescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: matmul desc");
-        const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
-        g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
-        g_lt.DescSet(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
-        PIE_REQUIRE(g_lt.LayoutCreate(&p.la, dt, K, N, K) == HIPBLAS_STATUS_SUCCESS && g_lt.LayoutCreate(&p.lb, dt, K, M, K) == HIPBLAS_STATUS_SUCCESS &&
-                        g_lt.LayoutCreate(&p.lc, dt, N, M, N) == HIPBLAS_STATUS_SUCCESS,
-                    PIE_E_HIP, "prefill: matrix layouts");
-        constexpr int MAX_ALGOS = 8;
-        hipblasLtMatmulHeuristicResult_t res[MAX_ALGOS];
-        int n_res = 0;
-        const int want = M < 64 ? 1 : MAX_ALGOS;  // from 64 rows the heuristic's candidates are timed once per shape, below its first choice is taken
-        const hipblasStatus_t hs = g_lt.Heuristic(g_lt.handle, p.desc, p.la, p.lb, p.lc, p.lc, g_lt.pref, want, res, &n_res);
-        PIE_REQUIRE(hs == HIPBLAS_STATUS_SUCCESS && n_res > 0, PIE_E_HIP, "prefill: hipBLASLt has no kernel for this GEMM shape");
-        int best = 0;
-        if (n_res > 1) {  // first use of this shape: time the candidates on the real operands (the product is idempotent, beta = 0)
-            const float one = 1.0f, zero = 0.0f;
-            hipEvent_t e0, e1;
-            PIE_HIP_TRY(hipEventCreate(&e0));
-            PIE_HIP_TRY(hipEventCreate(&e1));
-            float best_ms = 1e30f;
-            for (int i = 0; i < n_res; ++i) {
-                bool ok = true;
-                for (int rep = 0; rep < 3 && ok; ++rep) {  // one warm-up, two timed
-                    if (rep == 1) (void)hipEventRecord(e0, st);
-                    ok = g_lt.Matmul(g_lt.handle, p.desc, &one, w, p.la, x, p.lb, &zero, y, p.lc, y, p.lc, &res[i].algo, g_lt.workspace, g_lt.ws_bytes,
-                                     st) == HIPBLAS_STATUS_SUCCESS;
-                }
-                (void)hipEventRecord(e1, st);
-                (void)hipEventSynchronize(e1);
-                float ms = 1e30f;
-                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) best_ms = ms, best = i;
-            }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-        }
-        p.algo = res[best].algo;
-        it = g_lt.plans.emplace(key, p).first;
-    }
-    const float alpha = 1.0f, beta = 0.0f;
-    const LtApi::Plan &p = it->second;
-    const hipblasStatus_t ms = g_lt.Matmul(g_lt.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, y, p.lc, y, p.lc, &p.algo, g_lt.workspace,
-                                           g_lt.ws_bytes, st);
-    PIE_REQUIRE(ms == HIPBLAS_STATUS_SUCCESS, PIE_E_HIP, "prefill: hipblasLtMatmul failed");
-    return PIE_OK;
-}
-}  // namespace
-
-// also used by vision.hip (pie_linear)
-int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st) {
-    return gemm_xwt_impl(dtype, x, w, y, M, N, K, st);
-}
-
 // ---------------------------------------------------------------- scratch
 struct PrefillScratch {
     int rows = 0;           // chunk capacity (rows)
     size_t w_elems = 0;     // capacity of the dequantised-weight buffer (elements)
-    u16 *wT = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
+    u16 *wT = nullptr, *wM = nullptr, *x = nullptr, *xn = nullptr, *qkv = nullptr, *q = nullptr, *attn = nullptr, *gu = nullptr, *act = nullptr, *r = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     u16 *kc = nullptr, *vc = nullptr;  // [n_kv_heads, rows, head_dim]: this pass's K / V rows, contiguous (several prompts in one pass)
     int part_splits = 0;
@@ -478,7 +355,7 @@ static int tail_stats_reserve(PrefillScratch *s, size_t entries) {
 }
 
 static void scratch_release(PrefillScratch *s) {  // the chunk buffers; resident weight copies survive a re-size
-    void *ptrs[] = {s->wT, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->kc, s->vc};
+    void *ptrs[] = {s->wT, s->wM, s->x, s->xn, s->qkv, s->q, s->attn, s->gu, s->act, s->r, s->part_acc, s->part_ml, s->rope_cs, s->kc, s->vc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     auto keep = std::move(s->resident);
@@ -545,12 +422,15 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
         PF_ALLOC(s->kc, 2 * R * c.n_kv_heads * c.head_dim);
         PF_ALLOC(s->vc, 2 * R * c.n_kv_heads * c.head_dim);
         PF_ALLOC(s->wT, 2 * we);
+        PF_ALLOC(s->wM, 2 * we);
         s->rows = rows, s->part_splits = splits, s->w_elems = we;
     }
     if (w_elems > s->w_elems) {
         if (s->wT) (void)hipFree(s->wT);
-        s->wT = nullptr;
+        if (s->wM) (void)hipFree(s->wM);
+        s->wT = nullptr, s->wM = nullptr;
         PF_ALLOC(s->wT, 2 * w_elems);
+        PF_ALLOC(s->wM, 2 * w_elems);
         s->w_elems = w_elems, ++s->alloc_gen;
     }
 #undef PF_ALLOC
@@ -558,7 +438,6 @@ static int scratch_reserve(pie_decoder *d, int rows, size_t w_elems, int splits)
 }
 
 // ---------------------------------------------------------------- the batched forward
-int unpack_w16s_launch(const void *packed, int N, int K, void *out, hipStream_t st);
 
 // Byte budget for resident T copies of layer matrices, fixed at the first batched prefill: half of the free device memory
 // (PIE_KNOB_PREFILL_RESIDENT: 0 disables, <GiB> sets it).  Matrices are admitted in first-use order while the budget lasts
@@ -575,22 +454,32 @@ static size_t resident_budget(pie_decoder *d) {
     return s->resident_left;
 }
 
+// w16_gemm.hpp / w4m_gemm.hip: the 16-bit many-row MFMA GEMM on W16M tiles (weights in MFMA A-fragment order)
+size_t w16m_size(int N, int K);
+int w16m_from_rows_launch(const void *w, int N, int K, void *w16m, hipStream_t st);
+int w16m_from_w16s_launch(const void *w16s, int N, int K, void *w16m, hipStream_t st);
+size_t w16l_workspace_bytes(int M, int N, int K);
+int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int ldx, int M, int N, int K, void *y, void *workspace, hipStream_t st, const void *bias,
+                     void *swiglu_act, bool *fused, int ldy);
+
+// The 16-bit operand of a many-row product, as W16M tiles: dense modules straight from their W16S units, int8 / group-32 modules
+// dequantised (mx.dequantize's arithmetic: the qmm regime multiplies T copies) into the row-major staging buffer and tiled from there.
 template <class T>
-static int expand_weights(pie_decoder *d, const void *packed, int N, int K, u16 *dst, hipStream_t st) {
+static int expand_weights(pie_decoder *d, const void *packed, int N, int K, void *w16m, u16 *staging, hipStream_t st) {
     const int wf = d->mat_fmt(packed);  // per-module quantisation: a checkpoint may mix formats (models/utils.py:99-109)
-    if (wf == PIE_W_DENSE) return unpack_w16s_launch(packed, N, K, dst, st);  // W16S units -> plain [N, K] (packed row order)
+    if (wf == PIE_W_DENSE) return w16m_from_w16s_launch(packed, N, K, w16m, st);
     if (wf == PIE_W_INT8_G64 || wf == PIE_W_INT8_G32) {
         const size_t w8 = (size_t)N * (K >> 2);
-        if (wf == PIE_W_INT8_G32) hipLaunchKernelGGL((k_dequant_w8s<T, true>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
-        else hipLaunchKernelGGL((k_dequant_w8s<T, false>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+        if (wf == PIE_W_INT8_G32) hipLaunchKernelGGL((k_dequant_w8s<T, true>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
+        else hipLaunchKernelGGL((k_dequant_w8s<T, false>), dim3((unsigned)((w8 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
         PIE_LAUNCH_CHECK();
-        return PIE_OK;
+        return w16m_from_rows_launch(staging, N, K, w16m, st);
     }
     const size_t words = (size_t)N * (K >> 3);
-    if (wf == PIE_W_INT4_G32) hipLaunchKernelGGL((k_dequant_w4s<T, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
-    else hipLaunchKernelGGL((k_dequant_w4s<T, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), dst);
+    if (wf == PIE_W_INT4_G32) hipLaunchKernelGGL((k_dequant_w4s<T, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
+    else hipLaunchKernelGGL((k_dequant_w4s<T, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
     PIE_LAUNCH_CHECK();
-    return PIE_OK;
+    return w16m_from_rows_launch(staging, N, K, w16m, st);
 }
 
 // y[M, N] = x[M, K] . W^T for one streaming-layout matrix.  keep: a layer matrix (eligible for the resident copy); the
@@ -762,24 +651,27 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
             return bias_rows<T>(y, bias, M, N, st);
         }
     }
-    u16 *wT = s->wT;
+    // Everything else -- dense modules, int8 and group-32 modules beyond the GEMV's rows -- multiplies a 16-bit copy of the matrix in W16M
+    // tiles with the hand-written MFMA GEMM (w16_gemm.hpp); resident copies are built on first use within the budget.
+    PIE_REQUIRE(K % 64 == 0, PIE_E_SHAPE, "prefill: a many-row Linear needs in_features % 64 == 0 (pie_set_knob(PIE_KNOB_PREFILL_MIN, 1000000) processes prompts as iterated decode steps)");
+    u16 *wM = s->wM;
     bool ready = false;
     if (keep) {
-        const size_t bytes = 2 * (size_t)N * K;
+        const size_t bytes = w16m_size(N, K);
         auto it = s->resident.find(packed);
-        if (it != s->resident.end()) wT = it->second, ready = true;
+        if (it != s->resident.end()) wM = it->second, ready = true;
         else if (resident_budget(d) >= bytes) {
-            if (hipMalloc((void **)&wT, bytes) == hipSuccess) s->resident[packed] = wT, s->resident_left -= bytes, ++s->alloc_gen;
-            else (void)hipGetLastError(), wT = s->wT, s->resident_left = 0;  // out of memory: scratch from here on
+            if (hipMalloc((void **)&wM, bytes) == hipSuccess) s->resident[packed] = wM, s->resident_left -= bytes, ++s->alloc_gen;
+            else (void)hipGetLastError(), wM = s->wM, s->resident_left = 0;  // out of memory: scratch from here on
         }
     }
-    if (!ready) {
-        const int rc = expand_weights<T>(d, packed, N, K, wT, st);
-        if (rc) return rc;
-    }
-    const int rc = gemm_xwt(d->cfg.dtype, x, wT, y, M, N, K, st);
-    if (rc || !bias) return rc;
-    return bias_rows<T>(y, bias, M, N, st);
+    int rc = PIE_OK;
+    if (!ready && (rc = expand_weights<T>(d, packed, N, K, wM, s->wT, st))) return rc;
+    if ((rc = w4l_reserve(w16l_workspace_bytes(M, N, K)))) return rc;  // fp32 slabs of a K-split shape (few rows, narrow matrices)
+    bool fused = false;  // gate|up: bias and SwiGLU in the GEMM's epilogue where the shape does not split K
+    rc = w16l_gemm_launch(d->cfg.dtype, wM, x, 0, M, N, K, y, s->w4l_ws, st, bias, (act && used_act) ? act : nullptr, &fused, 0);
+    if (fused) *used_act = true;
+    return rc;
 }
 
 template <class T>
@@ -787,9 +679,10 @@ static int prefill_t(pie_decoder *d, const int32_t *ids, const void *embeds, int
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
     const int chunk = prefill_chunk_rows() < L ? prefill_chunk_rows() : L;
-    size_t w_elems = (size_t)2 * I * H;
-    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
-    if (logits_all && (size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    size_t w_elems = w16m_size(2 * I, H) / 2;  // the 16-bit copies are W16M tiles (rows padded to 32, columns to 64)
+    if (w16m_size(NQKV, H) / 2 > w_elems) w_elems = w16m_size(NQKV, H) / 2;
+    if (w16m_size(H, I) / 2 > w_elems) w_elems = w16m_size(H, I) / 2;
+    if (logits_all && w16m_size(c.vocab, H) / 2 > w_elems) w_elems = w16m_size(c.vocab, H) / 2;
     int rc = scratch_reserve(d, chunk, w_elems, d->splits);
     if (rc) return rc;
     PrefillScratch *s = d->prefill;
@@ -924,9 +817,10 @@ static int decode_batch_t(pie_decoder *d, const int32_t *tokens, const int32_t *
                           const int32_t *block_tables, int max_blocks, int B, u16 *logits, float *logprobs, int32_t *next_tokens, hipStream_t st) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
-    size_t w_elems = (size_t)2 * I * H;
-    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
-    if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    size_t w_elems = w16m_size(2 * I, H) / 2;  // the 16-bit copies are W16M tiles (rows padded to 32, columns to 64)
+    if (w16m_size(NQKV, H) / 2 > w_elems) w_elems = w16m_size(NQKV, H) / 2;
+    if (w16m_size(H, I) / 2 > w_elems) w_elems = w16m_size(H, I) / 2;
+    if (w16m_size(c.vocab, H) / 2 > w_elems) w_elems = w16m_size(c.vocab, H) / 2;
     const int splits = batch_attn_splits(d, B, max_blocks);
     int rc = scratch_reserve(d, B, w_elems, splits > d->splits ? splits : d->splits);
     if (rc) return rc;
@@ -1058,9 +952,10 @@ static int prefill_varlen_t(pie_decoder *d, const int32_t *ids, const int32_t *r
                             int n_chunks = 0, const int32_t *chunks = nullptr) {
     const pie_decoder_config &c = d->cfg;
     const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D, KVD = c.n_kv_heads * D, NQKV = QD + 2 * KVD, I = c.inter;
-    size_t w_elems = (size_t)2 * I * H;
-    if ((size_t)NQKV * H > w_elems) w_elems = (size_t)NQKV * H;
-    if ((size_t)c.vocab * H > w_elems) w_elems = (size_t)c.vocab * H;
+    size_t w_elems = w16m_size(2 * I, H) / 2;  // the 16-bit copies are W16M tiles (rows padded to 32, columns to 64)
+    if (w16m_size(NQKV, H) / 2 > w_elems) w_elems = w16m_size(NQKV, H) / 2;
+    if (w16m_size(H, I) / 2 > w_elems) w_elems = w16m_size(H, I) / 2;
+    if (w16m_size(c.vocab, H) / 2 > w_elems) w_elems = w16m_size(c.vocab, H) / 2;
     const int dsplits = n_decode > 0 ? batch_attn_splits(d, n_decode, max_blocks) : 1;
     int rc = scratch_reserve(d, N > S ? N : S, w_elems, dsplits > d->splits ? dsplits : d->splits);
     if (rc) return rc;

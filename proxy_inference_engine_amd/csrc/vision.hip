@@ -1,13 +1,18 @@
 // vision.hip -- op-level kernels of the Qwen2.5-VL vision tower (reference models/intern/vision.py:87-442).
 //
-// The tower is dense 16-bit GEMMs (hipBLASLt, through prefill.hip's gemm_xwt: MFMA-bound, 1 k-4 k rows) plus four hand-written
-// pieces: the rotate-half rotary embedding with per-patch (row, column) angles fused with the q / k / v re-layout the attention
+// The tower is dense 16-bit GEMMs (the hand-written MFMA GEMM of w16_gemm.hpp on W16M-tiled weights: pie_linear_w16m, with the bias and
+// the MLP's SiLU * up in its epilogue) plus four hand-written pieces: the rotate-half rotary embedding with per-patch (row, column) angles fused with the q / k / v re-layout the attention
 // kernel wants, block-diagonal non-causal attention on the MFMA units (prefill_attn.hpp, SEG instantiation: full-image and
 // 64-patch-window layers are the same kernel with different segment tables), bias add for any column count, and erf-GELU.
 // RMSNorm, SiLU*up and residual adds are the ops the text tower already has (ops.hip).
 #include "prefill_attn.hpp"
 
-int gemm_xwt(int dtype, const void *x, const void *w, void *y, int M, int N, int K, hipStream_t st);  // prefill.hip
+// w4m_gemm.hip / w16_gemm.hpp
+size_t w16m_size(int N, int K);
+int w16m_from_rows_launch(const void *w, int N, int K, void *w16m, hipStream_t st);
+size_t w16l_workspace_bytes(int M, int N, int K);
+int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int ldx, int M, int N, int K, void *y, void *workspace, hipStream_t st, const void *bias,
+                     void *swiglu_act, bool *fused, int ldy);
 
 // y[m, n] = T(y[m, n] + b[n]), any N (two columns per thread; rows of odd length end in a single column)
 template <class T>
@@ -239,19 +244,29 @@ int bias_any_launch(int dtype, void *y, const void *bias, int M, int N, hipStrea
 
 extern "C" {
 
-int pie_linear(const void *x, const void *w, const void *bias, int M, int N, int K, int dtype, void *y, void *stream) {
-    PIE_REQUIRE(x && w && y, PIE_E_ARG, "pie_linear: null pointer");
-    PIE_REQUIRE(M > 0 && N > 0 && K > 0, PIE_E_SHAPE, "pie_linear: empty operand");
-    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_linear: dtype must be PIE_BF16 or PIE_F16");
-    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(w, 16) && pie_aligned(y, 16), PIE_E_ALIGN, "pie_linear: 16-byte alignment required");
-    hipStream_t st = (hipStream_t)stream;
-    int rc = gemm_xwt(dtype, x, w, y, M, N, K, st);
-    if (rc || !bias) return rc;
-    const size_t n = (size_t)M * ((N + 1) >> 1);
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    return by_dt(
-        dtype, [&] { hipLaunchKernelGGL(k_bias_any<F16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); },
-        [&] { hipLaunchKernelGGL(k_bias_any<BF16>, grid, block, 0, st, (u16 *)y, (const u16 *)bias, M, N); }, "pie_linear");
+size_t pie_w16m_bytes(int N, int K) { return N > 0 && K > 0 ? w16m_size(N, K) : 0; }
+
+int pie_repack_w16m(const void *w, int N, int K, int dtype, void *w16m, void *stream) {
+    PIE_REQUIRE(w && w16m, PIE_E_ARG, "pie_repack_w16m: null pointer");
+    PIE_REQUIRE(N > 0 && K > 0, PIE_E_SHAPE, "pie_repack_w16m: empty matrix");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_repack_w16m: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE(pie_aligned(w, 16) && pie_aligned(w16m, 256), PIE_E_ALIGN, "pie_repack_w16m: w needs 16-byte, w16m 256-byte alignment");
+    return w16m_from_rows_launch(w, N, K, w16m, (hipStream_t)stream);
+}
+
+size_t pie_linear_w16m_workspace(int M, int N, int K) { return M > 0 && N > 0 && K > 0 ? w16l_workspace_bytes(M, N, K) : 0; }
+
+int pie_linear_w16m(const void *x, int ldx, const void *w16m, const void *bias, int M, int N, int K, int dtype, void *y, int ldy, int swiglu,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    PIE_REQUIRE(x && w16m && y, PIE_E_ARG, "pie_linear_w16m: null pointer");
+    PIE_REQUIRE(M > 0 && N > 0 && K > 0, PIE_E_SHAPE, "pie_linear_w16m: empty operand");
+    PIE_REQUIRE(!swiglu || N % 8 == 0, PIE_E_SHAPE, "pie_linear_w16m: the fused SiLU * up needs N % 8 == 0");
+    PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "pie_linear_w16m: dtype must be PIE_BF16 or PIE_F16");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(w16m, 16) && pie_aligned(y, 16) && (!bias || pie_aligned(bias, (N & 3) ? 2 : 8)), PIE_E_ALIGN,
+                "pie_linear_w16m: 16-byte alignment required");
+    const size_t need = swiglu ? 0 : w16l_workspace_bytes(M, N, K);
+    PIE_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), PIE_E_ARG, "pie_linear_w16m: workspace smaller than pie_linear_w16m_workspace(M, N, K)");
+    return w16l_gemm_launch(dtype, w16m, x, ldx, M, N, K, swiglu ? nullptr : y, workspace, (hipStream_t)stream, bias, swiglu ? y : nullptr, nullptr, ldy);
 }
 
 int pie_gelu(const void *x, size_t n, int dtype, void *y, void *stream) {

@@ -11,8 +11,8 @@
 //
 // W16M layout (built once per matrix on the device: from row-major weights, from W16S units, or by the dequantisers): tiles of 32 output
 // rows x 64 columns, 4096 B, tile (nt, g) at ((nt * ceil(K / 64)) + g) * 4096; inside, k-step s (0..3) is 1 KiB: lane l = 32 kh + n holds
-// W[32 nt + n][64 g + 16 s + 8 kh .. + 8].  Rows past N and columns past K are zeros, so N and K of the Linear are free; x has to be
-// 64 ceil(K / 64) wide (zero columns: the caller pads it -- the tower's two odd widths, 1176 and 3420, are padded on the host).
+// W[32 nt + n][64 g + 16 s + 8 kh .. + 8].  Rows past N and columns past K are zeros, so N and K of the Linear are free; x rows have to
+// hold 64 ceil(K / 64) elements, zeros past K (any row stride: the host pads the tower's two odd widths, 1176 and 3420).
 //
 // K / 64 need not be a multiple of the 4-fold unrolled ring: the loop runs ceil4 steps, the first ones on a 4 KiB block of zeros.
 #pragma once
@@ -61,8 +61,10 @@ __global__ void __launch_bounds__(256) k_w16s_to_w16m(const uint4 *w16s, int N, 
 
 struct W16Args {
     const char *w16m;
-    const u16 *x;   // [M][K], K = 64 * groups
-    int M, N, K;    // N: the Linear's output features (stores are clipped to it; N % 4 == 0)
+    const u16 *x;   // [M] rows of ldx elements, the first K = 64 * groups of them used
+    int M, N, K;    // N: the Linear's output features (stores are clipped to it; any N -- 16-byte stores when N % 8 == 0)
+    int ldx;        // x row stride (elements, >= K, a multiple of 8)
+    int ldy;        // y row stride (elements, >= N or N / 2, a multiple of 4)
     u16 *y;         // [M][N], or the MLP activation [M][N / 2] (SWIGLU)
     float *part;    // gridDim.y > 1: fp32 slabs [z][M][N]
     const u16 *bias;
@@ -125,9 +127,9 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
         const int r = 8 * MB * wave + 8 * j + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int rr = r < rows ? r : rows - 1;  // ragged tile: rows past the end repeat the last one (never stored)
-        xoffs[j] = (u32)(((size_t)rr * a.K + (size_t)c * 8) * 2);
+        xoffs[j] = (u32)(((size_t)rr * a.ldx + (size_t)c * 8) * 2);
     }
-    const unsigned long long xbase = (unsigned long long)(uintptr_t)(a.x + (size_t)m0 * a.K + (size_t)g_lo * 64);
+    const unsigned long long xbase = (unsigned long long)(uintptr_t)(a.x + (size_t)m0 * a.ldx + (size_t)g_lo * 64);
     const unsigned lds0 = (unsigned)(size_t)(w4l_lds_void *)s_x;
     // (issued through asm: see k_w4l2_gemm; M0 = the wave's LDS destination)
     auto x_issue1 = [&](int v, int buf, int j) {  // tile v -> buffer buf (= v % 4, spelled statically by the callers)
@@ -290,7 +292,14 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
                 const int col = 32 * (nt0 + s) + 4 * kh + 8 * q;
                 u32 p01 = w4m_pack<T>(acc[s][mi][4 * q], acc[s][mi][4 * q + 1]), p23 = w4m_pack<T>(acc[s][mi][4 * q + 2], acc[s][mi][4 * q + 3]);  // the Linear's rounding to T
                 if (a.bias && col < a.N) {  // T(T(x W^T) + bias), like the text tower's Linear
-                    const uint2 bw = *reinterpret_cast<const uint2 *>(a.bias + col);
+                    uint2 bw;
+                    if (col + 4 <= a.N && !(a.N & 3)) bw = *reinterpret_cast<const uint2 *>(a.bias + col);
+                    else {  // any out_features: the last quad of a row may be partial, rows of the bias need not be 8-byte aligned
+                        u16 e[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) e[i] = col + i < a.N ? a.bias[col + i] : (u16)0;
+                        bw = make_uint2(e[0] | ((u32)e[1] << 16), e[2] | ((u32)e[3] << 16));
+                    }
                     p01 = w4m_pack<T>(lo_f32<T>(p01) + lo_f32<T>(bw.x), hi_f32<T>(p01) + hi_f32<T>(bw.x));
                     p23 = w4m_pack<T>(lo_f32<T>(p23) + lo_f32<T>(bw.y), hi_f32<T>(p23) + hi_f32<T>(bw.y));
                 }
@@ -307,7 +316,7 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
     }
     // (the same wave reads what it wrote: no barrier, the compiler's lgkmcnt wait orders the LDS accesses)
     constexpr int PR = OB / 16;               // 16-byte pieces per row
-    const int ldo = SWIGLU ? a.N >> 1 : a.N;  // output row length
+    const int ldo = SWIGLU ? a.N >> 1 : a.N;  // output row length (the row stride a.ldy may be longer: a zero-padded operand of the next GEMM)
     const int c0 = (SWIGLU ? 16 : 32) * nt0;  // the wave's first output column
 #pragma unroll
     for (int it = 0; it < MT * PR / 64; ++it) {
@@ -317,11 +326,16 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
         const uint2 hi = *reinterpret_cast<const uint2 *>(ot + r * OB + (((2 * j + 1) ^ rsv) << 3));
         const int col = c0 + 8 * j;
         if (r >= rows || col >= ldo || ((W16L_ABL & 64) && a.M > 1)) continue;
-        u16 *dst = a.y + (size_t)(m0 + r) * ldo + col;
-        if ((ldo & 7) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        else {  // (ldo % 4 == 0: rows are 8-byte aligned; the last piece of a row may be half)
+        u16 *dst = a.y + (size_t)(m0 + r) * a.ldy + col;
+        if (((ldo | a.ldy) & 7) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        else if (((ldo | a.ldy) & 3) == 0) {  // rows are 8-byte aligned; the last piece of a row may be half
             *reinterpret_cast<uint2 *>(dst) = lo;
             if (col + 4 < ldo) *reinterpret_cast<uint2 *>(dst + 4) = hi;
+        } else {  // any out_features: element by element
+            const u32 w[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col + e < ldo) dst[e] = (u16)(w[e >> 1] >> (16 * (e & 1)));
         }
     }
 }

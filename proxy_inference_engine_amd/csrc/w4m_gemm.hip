@@ -806,15 +806,15 @@ static int w16_even_splits(int groups, int S) {  // the largest split count <= S
         S = s2;
     }
 }
-static W16Plan w16_plan(int M, int N, int K) {
+static W16Plan w16_plan(int M, int N, int K, bool no_split = false) {
     const int groups = (K + 63) / 64;
     if (g_w16_plan_override[0]) return {g_w16_plan_override[0], g_w16_plan_override[1], w16_even_splits(groups, g_w16_plan_override[2])};
     const int mb_max = M <= 64 ? 2 : (M <= 128 ? 4 : 8);
     W16Plan best = {mb_max, 2, 1};
     double best_us = 1e30;
-    for (int S = 1; S <= 16 && (S == 1 || 8 * S <= groups); ++S)
+    for (int S = 1; S <= (no_split ? 1 : 16) && (S == 1 || 8 * S <= groups); ++S)
         for (int mb = mb_max; mb >= 2; mb >>= 1)
-            for (int sw = 2; sw >= 1; --sw) {
+            for (int sw = 2; sw >= (no_split ? 2 : 1); --sw) {
                 const double eff = (sw == 2 ? 0.85 : 0.70) * (mb == 8 ? 1.0 : (mb == 4 ? 0.92 : 0.80));
                 const int wgs = ((N + 128 * sw - 1) / (128 * sw)) * ((M + 32 * mb - 1) / (32 * mb)) * S;
                 const int steps = ((groups + S - 1) / S + 3) & ~3;
@@ -827,27 +827,40 @@ static W16Plan w16_plan(int M, int N, int K) {
 }
 int w16l_splits(int M, int N, int K) { return w16_plan(M, N, K).S; }
 size_t w16l_workspace_bytes(int M, int N, int K) {
+    if (N & 3) return 0;
     const int s = w16l_splits(M, N, K);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-// y [M, N] = x [M, Kx] . W^T (+ bias), W in W16M tiles of an [N, K] Linear; Kx = 64 ceil(K / 64) is x's row length (zero columns past K).
+// y [M, N] = x . W^T (+ bias), W in W16M tiles of an [N, K] Linear; x: M rows of ldx elements (0 = packed) holding 64 ceil(K / 64) used
+// columns, zeros past K.
 // swiglu_act (nullable): the packed gate|up matrix and the caller wants the MLP activation [M, N / 2] there; *fused says whether it got it.
 // workspace: w16l_workspace_bytes() of device scratch (may be null when that is 0).
-int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, int K, void *y, void *workspace, hipStream_t st, const void *bias,
-                     void *swiglu_act, bool *fused) {
+// ldy: row stride of the output that is written (y, or the activation; 0 = packed), a multiple of 4.
+int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int ldx, int M, int N, int K, void *y, void *workspace, hipStream_t st, const void *bias,
+                     void *swiglu_act, bool *fused, int ldy) {
     if (fused) *fused = false;
-    PIE_REQUIRE(M >= 1 && N > 0 && K > 0 && N % 4 == 0, PIE_E_SHAPE, "16-bit GEMM: N must be a multiple of 4");
-    PIE_REQUIRE(pie_aligned(w16m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8) && (!bias || pie_aligned(bias, 8)), PIE_E_ALIGN, "16-bit GEMM: 16-byte alignment required");
+    const int Kx = 64 * ((K + 63) / 64);
+    if (ldx == 0) ldx = Kx;
+    PIE_REQUIRE(ldx >= Kx && ldx % 8 == 0 && (size_t)256 * ldx * 2 < (1ull << 32), PIE_E_SHAPE,
+                "16-bit GEMM: x rows must hold 64 * ceil(K / 64) elements (zeros past K) at a stride that is a multiple of 8");
+    PIE_REQUIRE(M >= 1 && N > 0 && K > 0, PIE_E_SHAPE, "16-bit GEMM: empty operand");
+    PIE_REQUIRE(pie_aligned(w16m, 16) && pie_aligned(x, 16) && pie_aligned(y, 8) && (!bias || pie_aligned(bias, (N & 3) ? 2 : 8)), PIE_E_ALIGN, "16-bit GEMM: 16-byte alignment required");
     PIE_REQUIRE(dtype == PIE_BF16 || dtype == PIE_F16, PIE_E_ARG, "16-bit GEMM: dtype must be PIE_BF16 or PIE_F16");
-    W16Plan plan = w16_plan(M, N, K);
-    const bool sg = swiglu_act && fused && plan.S == 1;
+    // swiglu_act without `fused`: the caller has no fallback (the C ABI's fused MLP): plan without a K split, two strips per wave
+    W16Plan plan = w16_plan(M, N, K, (swiglu_act && !fused) || (N & 3));  // (the fp32 slabs of a K split are written 16 bytes at a time)
+    const bool sg = swiglu_act && plan.S == 1;
     if (sg) plan.sw = 2;  // (the fused activation is built for two strips per wave)
     PIE_REQUIRE(plan.S == 1 || workspace, PIE_E_ARG, "16-bit GEMM: this shape splits K and needs its workspace");
     W16Args a = {};
     int rc = w16_zero_block(&a.zero);
     if (rc) return rc;
-    a.w16m = (const char *)w16m, a.x = (const u16 *)x, a.M = M, a.N = N, a.K = 64 * ((K + 63) / 64);
+    PIE_REQUIRE(!sg || N % 8 == 0, PIE_E_SHAPE, "16-bit GEMM: a fused SwiGLU needs N % 8 == 0");
+    const int out_cols = sg ? N / 2 : N;
+    if (ldy == 0 || (swiglu_act && !sg)) ldy = out_cols;  // (a declined fusion writes the packed y)
+    PIE_REQUIRE(ldy >= out_cols, PIE_E_SHAPE, "16-bit GEMM: output row stride must cover the row");
+    PIE_REQUIRE(plan.S == 1 || ldy == N, PIE_E_SHAPE, "16-bit GEMM: a K-split shape writes packed rows");
+    a.w16m = (const char *)w16m, a.x = (const u16 *)x, a.M = M, a.N = N, a.K = Kx, a.ldx = ldx, a.ldy = ldy;
     a.y = (u16 *)(sg ? swiglu_act : y), a.part = plan.S > 1 ? (float *)workspace : nullptr;
     a.bias = plan.S > 1 ? nullptr : (const u16 *)bias;
     a.tm = (M + 32 * plan.mb - 1) / (32 * plan.mb), a.tn = (N + 128 * plan.sw - 1) / (128 * plan.sw);
@@ -870,7 +883,7 @@ int w16l_gemm_launch(int dtype, const void *w16m, const void *x, int M, int N, i
 #undef W16_SW
 #undef W16_GO
     PIE_LAUNCH_CHECK();
-    if (sg) *fused = true;
+    if (sg && fused) *fused = true;
     if (plan.S > 1) {
         const size_t MN = (size_t)M * N;
         const dim3 rg((unsigned)((MN / 4 + 255) / 256));

@@ -471,21 +471,64 @@ def gateup_row_map(inter: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------- vision tower ops
-def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """nn.Linear on a block of rows: x [M, K] @ weight [N, K].T (+ bias [N]) -> [M, N]; dense 16-bit weights, hipBLASLt GEMM
-    with fp32 accumulation (models/intern/vision.py:150-151,192-194,129-133; PatchEmbed's Conv3d with stride = kernel is the
-    same product over flattened patches, vision.py:97-121)."""
-    _dev(x), _dev(weight)
-    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1] or x.dtype != weight.dtype:
-        raise ValueError("linear_rows: x [M, K], weight [N, K] of one dtype")
-    if bias is not None and (bias.shape != (weight.shape[0],) or bias.dtype != x.dtype):
+class PackedLinear:
+    """An nn.Linear weight [N, K] (16-bit) as W16M tiles: 32 output rows x 64 columns in MFMA operand order, zero-padded
+    (csrc/w16_gemm.hpp) -- what the hand-written 16-bit GEMM streams straight into its fragment registers.  Built once per matrix."""
+
+    def __init__(self, weight: torch.Tensor):
+        _dev(weight)
+        if weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("PackedLinear: weight [N, K] in bfloat16 or float16")
+        weight = weight.contiguous()
+        self.N, self.K = (int(v) for v in weight.shape)
+        self.shape = (self.N, self.K)  # of the Linear's weight
+        self.dtype = weight.dtype
+        lib = _ffi.load()
+        self.tiles = torch.empty(int(lib.pie_w16m_bytes(self.N, self.K)), dtype=torch.uint8, device=weight.device)
+        _ffi.check(lib.pie_repack_w16m(_ffi.p(weight), self.N, self.K, _ffi.dtype_code(weight.dtype), _ffi.p(self.tiles), _ffi.stream()))
+
+
+def pack_linear(weight: torch.Tensor) -> PackedLinear:
+    return PackedLinear(weight)
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """Rows (or entries) of gate_proj and up_proj interleaved (gate_0, up_0, gate_1, ...): the order linear_rows(..., swiglu=True) wants."""
+    return torch.stack((gate, up), dim=1).reshape(2 * gate.shape[0], *gate.shape[1:]).contiguous()
+
+
+def linear_rows(x: torch.Tensor, weight, bias: torch.Tensor | None = None, *, swiglu: bool = False, pad_to: int = 0) -> torch.Tensor:
+    """nn.Linear on a block of rows: x [M, K] @ weight [N, K].T (+ bias [N]) -> [M, N]; dense 16-bit weights on the hand-written MFMA GEMM
+    (fp32 accumulation; models/intern/vision.py:150-151,192-194,129-133; PatchEmbed's Conv3d with stride = kernel is the same product
+    over flattened patches, vision.py:97-121).  weight: a PackedLinear (pack_linear: once per matrix), or the plain [N, K] tensor (packed
+    on the spot).  x may carry 64 * ceil(K / 64) columns, zeros past K; with just K columns and K % 64 != 0 it is padded here.
+    swiglu: weight rows (and bias) interleave gate and up (interleave_gate_up): returns silu(gate) * up [M, N / 2] (MLP, vision.py:196-197),
+    bias and activation in the GEMM's epilogue.  pad_to: the output rows are zero-padded to a multiple of it (the next GEMM's operand)."""
+    _dev(x)
+    pk = weight if isinstance(weight, PackedLinear) else PackedLinear(weight)
+    N, K = pk.N, pk.K
+    Kx = -(-K // 64) * 64
+    if x.dim() != 2 or x.shape[1] not in (K, Kx) or x.dtype != pk.dtype:
+        raise ValueError("linear_rows: x [M, K] (or zero-padded to a multiple of 64 columns), weight [N, K] of one dtype")
+    if bias is not None and (bias.shape != (N,) or bias.dtype != x.dtype):
         raise ValueError("linear_rows: bias must be [N] in the activation dtype")
-    x, weight = x.contiguous(), weight.contiguous()
-    M, K = x.shape
-    N = weight.shape[0]
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    _ffi.check(_ffi.load().pie_linear(_ffi.p(x), _ffi.p(weight), _ffi.p(bias.contiguous() if bias is not None else None), M, N, K,
-                                      _ffi.dtype_code(x.dtype), _ffi.p(y), _ffi.stream()))
+    if swiglu and N % 8:
+        raise ValueError("linear_rows: swiglu needs N % 8 == 0 (interleaved gate | up rows)")
+    if x.shape[1] != Kx:
+        x = torch.nn.functional.pad(x, (0, Kx - K))
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.stride(0) < Kx:
+        x = x.contiguous()
+    M = x.shape[0]
+    cols = N // 2 if swiglu else N
+    ldy = -(-cols // pad_to) * pad_to if pad_to else cols
+    y = (torch.zeros if ldy != cols else torch.empty)((M, ldy), dtype=x.dtype, device=x.device)
+    lib = _ffi.load()
+    wsb = 0 if swiglu else int(lib.pie_linear_w16m_workspace(M, N, K))
+    if wsb and ldy != cols:
+        raise ValueError("linear_rows: pad_to is not available for shapes that split K")
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    _ffi.check(lib.pie_linear_w16m(_ffi.p(x), x.stride(0), _ffi.p(pk.tiles), _ffi.p(bias.contiguous() if bias is not None else None), M, N, K,
+                                   _ffi.dtype_code(x.dtype), _ffi.p(y), ldy, int(swiglu), _ffi.p(ws), wsb, _ffi.stream()))
     return y
 
 

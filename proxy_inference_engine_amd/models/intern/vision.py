@@ -2,7 +2,7 @@
 
 Same structure and index logic as the reference -- PatchEmbed, `rot_pos_emb`, `get_window_index`, the window permutation,
 blocks of RMSNorm / attention / RMSNorm / SwiGLU MLP, PatchMerger, the inverse permutation -- with every tensor op on the
-device: dense GEMMs through pie_linear (hipBLASLt), rotary + q/k/v layout in one kernel, block-diagonal attention on the
+device: dense GEMMs on the hand-written 16-bit MFMA kernel (pie_linear_w16m), rotary + q/k/v layout in one kernel, block-diagonal attention on the
 MFMA units (full-image layers and 64-patch-window layers are the same kernel with different segment tables), pie_rms_norm,
 pie_silu_mul, pie_add, pie_gelu.  Index bookkeeping (positions, window order, cu_seqlens) is host numpy, as it is host
 Python in the reference; the row permutations are device gathers.
@@ -67,7 +67,9 @@ class VisionModel:
             raise ValueError("patch_embed.proj.weight must be a 5-D Conv3d weight")
         if check_array_shape(tuple(w.shape)):   # MLX order [out, kT, kH, kW, in] -> [out, in, kT, kH, kW] (sanitize, vision.py:444-459)
             w = w.permute(0, 4, 1, 2, 3)
-        self.patch_w = w.reshape(w.shape[0], -1).to(device=self.device, dtype=dtype).contiguous()   # [hidden, C*T*P*P]
+        # every Linear of the tower is a dense GEMM on the hand-written 16-bit MFMA kernel (ops.linear_rows -> pie_linear_w16m): the weights are
+        # tiled in MFMA operand order once, here (ops.pack_linear); rounds 1-4 called hipBLASLt
+        self.patch_w = ops.pack_linear(w.reshape(w.shape[0], -1).to(device=self.device, dtype=dtype).contiguous())   # [hidden, C*T*P*P]
         self.blocks = []
         H, D, DP = c.num_heads, self.head_dim, self.padded_head_dim
         for i in range(c.depth):
@@ -79,19 +81,18 @@ class VisionModel:
                 proj = wide.view(proj.shape[0], H * DP).contiguous()
             self.blocks.append({
                 "norm1": get(p + "norm1.weight"), "norm2": get(p + "norm2.weight"),
-                "qkv_w": get(p + "attn.qkv.weight"), "qkv_b": get(p + "attn.qkv.bias"),
-                "proj_w": proj, "proj_b": get(p + "attn.proj.bias"),
-                # gate_proj and up_proj as one GEMM: [2 * intermediate, hidden]
-                "gateup_w": torch.cat([get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")], dim=0).contiguous(),
-                "gate_b": get(p + "mlp.gate_proj.bias"), "up_b": get(p + "mlp.up_proj.bias"),
-                "down_w": get(p + "mlp.down_proj.weight"), "down_b": get(p + "mlp.down_proj.bias"),
+                "qkv_w": ops.pack_linear(get(p + "attn.qkv.weight")), "qkv_b": get(p + "attn.qkv.bias"),
+                "proj_w": ops.pack_linear(proj), "proj_b": get(p + "attn.proj.bias"),
+                # gate_proj and up_proj as ONE GEMM [2 * intermediate, hidden] with rows (gate_i, up_i) interleaved: the biases and
+                # silu(gate) * up ride in its epilogue (vision.py:196-197), the [N, 2 * intermediate] block is never written
+                "gateup_w": ops.pack_linear(ops.interleave_gate_up(get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight"))),
+                "gateup_b": ops.interleave_gate_up(get(p + "mlp.gate_proj.bias"), get(p + "mlp.up_proj.bias")),
+                "down_w": ops.pack_linear(get(p + "mlp.down_proj.weight")), "down_b": get(p + "mlp.down_proj.bias"),
             })
         self._table_cache: dict = {}
         self._graphs: dict = {}
-        self.merger = {"ln_q": get("merger.ln_q.weight"), "w0": get("merger.mlp.0.weight"), "b0": get("merger.mlp.0.bias"),
-                       "w2": get("merger.mlp.2.weight"), "b2": get("merger.mlp.2.bias")}
-        # every Linear of the tower is a plain dense GEMM: pie_linear -> hipBLASLt (the hand-written 16-bit kernel of rounds 2-3 was 15-38 % slower on
-        # these small shapes and was deleted in round 4: EXPERIMENTS.md)
+        self.merger = {"ln_q": get("merger.ln_q.weight"), "w0": ops.pack_linear(get("merger.mlp.0.weight")), "b0": get("merger.mlp.0.bias"),
+                       "w2": ops.pack_linear(get("merger.mlp.2.weight")), "b2": get("merger.mlp.2.bias")}
 
     # ------------------------------------------------------------------ vision.py:245-279
     def rot_pos_emb(self, grid_thw) -> np.ndarray:
@@ -167,7 +168,6 @@ class VisionModel:
         cos, sin = t["cos"], t["sin"]
         states = (x,) if output_hidden_states else ()
         scale = self.head_dim ** -0.5
-        I = c.intermediate_size
         fuse_norm = c.hidden_size % 8 == 0 and c.hidden_size <= 8192
         xn = ops.rms_norm(x, self.blocks[0]["norm1"], 1e-6) if self.blocks else None
         for i, b in enumerate(self.blocks):
@@ -183,8 +183,7 @@ class VisionModel:
                 x = ops.add_bias(x, r, b["proj_b"])
                 xn = ops.rms_norm(x, b["norm2"], 1e-6)
             # hidden_states + mlp(norm2(hidden_states))  (vision.py:218, :196-197)
-            gu = ops.linear_rows(xn, b["gateup_w"])
-            act = ops.bias_silu_mul(gu[:, :I], gu[:, I:], b["gate_b"], b["up_b"])
+            act = ops.linear_rows(xn, b["gateup_w"], b["gateup_b"], swiglu=True, pad_to=64)   # [N, I rounded up to 64 columns, zeros past I]
             r = ops.linear_rows(act, b["down_w"])
             nxt = self.blocks[i + 1]["norm1"] if i + 1 < len(self.blocks) else self.merger["ln_q"]   # the next consumer's norm
             if fuse_norm:
@@ -217,7 +216,7 @@ class VisionModel:
             return self._forward_device(x, t, bool(output_hidden_states))
         g = self._graphs.get(grid)
         if g is None:
-            out = self._forward_device(x, t)                 # first call: eager (also lets hipBLASLt pick its kernels)
+            out = self._forward_device(x, t)                 # first call: eager
             self._graphs[grid] = "warm"
             return out
         if g == "warm":

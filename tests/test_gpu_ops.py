@@ -463,7 +463,7 @@ def test_many_row_int4_gemm_vs_oracle_qmm(ops, dt, M, N, K):
 @pytest.mark.parametrize("M,N,K,bias", [(1, 32, 64, False), (33, 1280, 1176, True), (64, 96, 256, False), (130, 3840, 1280, False), (300, 1280, 3420, True),
                                         (513, 6840, 1280, False), (1000, 3584, 5120, True), (257, 100, 72, True)])
 def test_linear_rows_at_the_vision_tower_shapes_vs_oracle(ops, dt, M, N, K, bias):
-    """pie_linear (the library GEMM behind every dense many-row Linear): nn.Linear with 16-bit weights on a block of rows at the vision tower's
+    """pie_linear_w16m (the hand-written 16-bit MFMA GEMM behind every dense many-row Linear; weights tiled on the spot here): nn.Linear with 16-bit weights on a block of rows at the vision tower's
     shapes (PatchEmbed K = 1176, qkv 3840 x 1280, the MLP's K = 3420 whose rows are not 16-byte aligned, gate|up 6840 columns, the merger
     5120 -> 3584) and ragged N / K / M, with and without bias -- against the oracle's Linear (T x T products, fp32 accumulation, one
     rounding, then the bias)."""

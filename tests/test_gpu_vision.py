@@ -82,6 +82,30 @@ def test_bias_folded_elementwise_ops(ops, M, N):
         assert torch.equal(y2, y) and torch.equal(xn, ops.rms_norm(y, nw, 1e-6))
 
 
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,I,K", [(130, 212, 160), (300, 3420, 1280), (64, 64, 64), (1100, 1024, 512)])
+def test_fused_gate_up_linear_is_the_gemm_followed_by_bias_silu_mul(ops, dt, M, I, K):
+    """linear_rows(..., swiglu=True): gate_proj | up_proj as one GEMM on interleaved rows with the biases and silu(gate) * up in its epilogue
+    (MLP, vision.py:196-197) -- what the plain GEMM on the concatenated rows followed by bias_silu_mul gives (the same roundings; the plain
+    GEMM may split K, which moves an fp32 sum by an ulp here and there), and its zero-padded form feeds the next GEMM unchanged
+    (intermediate_size 3420 is not a multiple of 64)."""
+    rng = np.random.default_rng(M + I)
+    x = dev(po.round_T(rng.standard_normal((M, K)), dt), dt)
+    gw, uw = (dev(po.round_T(rng.standard_normal((I, K)) / np.sqrt(K), dt), dt) for _ in range(2))
+    gb, ub = (dev(po.round_T(rng.standard_normal(I) * 0.5, dt), dt) for _ in range(2))
+    gu = ops.linear_rows(x, torch.cat([gw, uw], dim=0))
+    want = ops.bias_silu_mul(gu[:, :I], gu[:, I:], gb, ub)
+    pk = ops.pack_linear(ops.interleave_gate_up(gw, uw))
+    got = ops.linear_rows(x, pk, ops.interleave_gate_up(gb, ub), swiglu=True)
+    assert got.shape == (M, I)
+    assert_bits_close(to_bits(got), to_bits(want), max_ulp=2, max_frac=0.01, what="fused gate|up")
+    padded = ops.linear_rows(x, pk, ops.interleave_gate_up(gb, ub), swiglu=True, pad_to=64)
+    Ip = -(-I // 64) * 64
+    assert padded.shape == (M, Ip) and torch.equal(padded[:, :I], got) and not padded[:, I:].any()
+    dw = dev(po.round_T(rng.standard_normal((96, I)) / np.sqrt(I), dt), dt)
+    assert torch.equal(ops.linear_rows(padded, ops.pack_linear(dw)), ops.linear_rows(got, dw))
+
+
 def _mask(cu, N, dt):
     m = np.full((N, N), vo.finfo_min(dt), np.float32)
     for i in range(1, len(cu)):
@@ -217,7 +241,7 @@ def test_vision_tower_mlx_ordered_conv_weight_and_errors():
     tw2 = dict(tw)
     tw2["vision_tower.patch_embed.proj.weight"] = tw["vision_tower.patch_embed.proj.weight"].permute(0, 2, 3, 4, 1).contiguous()   # MLX order
     b = VisionModel(VisionConfig(**CFG80), tw2)
-    pa, pb = a.patch_w, b.patch_w
+    pa, pb = a.patch_w.tiles, b.patch_w.tiles   # the W16M tiles of the flattened conv weight
     assert torch.equal(pa, pb)
     with pytest.raises(ValueError, match="grid_thw must be provided"):
         a(torch.zeros(4, 1176, device="cuda"))

@@ -81,9 +81,10 @@ static Problem make(int M, int N, int K, bool with_ref) {
     Problem p;
     p.M = M, p.N = N, p.K = K, p.Kx = 64 * ((K + 63) / 64);
     std::vector<u16> hw((size_t)N * K), hx((size_t)M * p.Kx, 0), hb(N);
-    for (auto &v : hw) v = f2bf(rnd() * 0.05f);
+    const bool zero = std::getenv("W16_ZERO") != nullptr;  // all-zero operands: the data-dependent share of the power
+    for (auto &v : hw) v = f2bf(zero ? 0.0f : rnd() * 0.05f);
     for (int m = 0; m < M; ++m)
-        for (int k = 0; k < K; ++k) hx[(size_t)m * p.Kx + k] = f2bf(rnd());
+        for (int k = 0; k < K; ++k) hx[(size_t)m * p.Kx + k] = f2bf(zero ? 0.0f : rnd());
     for (auto &v : hb) v = f2bf(rnd() * 0.5f);
     CK(hipMalloc((void **)&p.w, hw.size() * 2)), CK(hipMalloc((void **)&p.x, hx.size() * 2)), CK(hipMalloc((void **)&p.y, (size_t)M * N * 2));
     CK(hipMalloc((void **)&p.bias, N * 2)), CK(hipMalloc((void **)&p.act, (size_t)M * N));
@@ -111,7 +112,7 @@ static int check_one(int M, int N, int K, int mode, int mb, int sw, int S) {  //
     g_w16_plan_override[0] = mb, g_w16_plan_override[1] = sw, g_w16_plan_override[2] = S;
     CK(hipMemset(p.y, 0xFF, (size_t)M * N * 2)), CK(hipMemset(p.act, 0xFF, (size_t)M * N));
     bool fused = false;
-    const int rc = w16l_gemm_launch(PIE_BF16, p.w16m, p.x, M, N, K, p.y, p.ws, 0, mode == 1 ? p.bias : nullptr, mode == 2 ? p.act : nullptr, mode == 2 ? &fused : nullptr);
+    const int rc = w16l_gemm_launch(PIE_BF16, p.w16m, p.x, 0, M, N, K, p.y, p.ws, 0, mode == 1 ? p.bias : nullptr, mode == 2 ? p.act : nullptr, mode == 2 ? &fused : nullptr, 0);
     CK(hipDeviceSynchronize());
     if (rc) std::exit(2);
     std::vector<float> ref((size_t)M * N), sa((size_t)M * N);
@@ -199,11 +200,11 @@ static double time_lt(const Problem &p, int reps) {
 
 static double time_own(const Problem &p, int reps, bool swiglu) {
     bool fused = false;
-    for (int r = 0; r < 2; ++r) w16l_gemm_launch(PIE_BF16, p.w16m, p.x, p.M, p.N, p.K, p.y, p.ws, 0, nullptr, swiglu ? p.act : nullptr, swiglu ? &fused : nullptr);
+    for (int r = 0; r < 2; ++r) w16l_gemm_launch(PIE_BF16, p.w16m, p.x, 0, p.M, p.N, p.K, p.y, p.ws, 0, nullptr, swiglu ? p.act : nullptr, swiglu ? &fused : nullptr, 0);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)), CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < reps; ++r) w16l_gemm_launch(PIE_BF16, p.w16m, p.x, p.M, p.N, p.K, p.y, p.ws, 0, nullptr, swiglu ? p.act : nullptr, swiglu ? &fused : nullptr);
+    for (int r = 0; r < reps; ++r) w16l_gemm_launch(PIE_BF16, p.w16m, p.x, 0, p.M, p.N, p.K, p.y, p.ws, 0, nullptr, swiglu ? p.act : nullptr, swiglu ? &fused : nullptr, 0);
     CK(hipEventRecord(e1, 0)), CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -223,6 +224,9 @@ int main(int argc, char **argv) {
             bad += check_one(77, 1280, 3420, 1, pl[0], pl[1], pl[2]);   // the tower's odd width, with a bias
             if (pl[2] == 1) bad += check_one(130, 512, 512, 2, pl[0], pl[1], pl[2]);
         }
+        bad += check_one(64, 214, 1176, 1, 0, 0, 0);   // any out_features: element-wise stores
+        bad += check_one(5, 7, 64, 1, 0, 0, 0);
+        bad += check_one(257, 100, 72, 1, 0, 0, 0);
         bad += check_one(512, 4096, 4096, 0, 0, 0, 0);
         bad += check_one(1000, 6840, 1280, 1, 0, 0, 0);
         bad += check_one(33, 1024, 2048, 0, 0, 0, 0);
@@ -240,7 +244,7 @@ int main(int argc, char **argv) {
         CK(hipMalloc((void **)&g_w16_prof, (size_t)wgs * 32));
         for (int r = 0; r < 3; ++r) {
             CK(hipMemset(g_w16_prof, 0, (size_t)wgs * 32));
-            w16l_gemm_launch(PIE_BF16, p.w16m, p.x, M, N, K, p.y, p.ws, 0, nullptr, nullptr, nullptr);
+            w16l_gemm_launch(PIE_BF16, p.w16m, p.x, 0, M, N, K, p.y, p.ws, 0, nullptr, nullptr, nullptr, 0);
             CK(hipDeviceSynchronize());
         }
         std::vector<unsigned long long> h((size_t)wgs * 4);
