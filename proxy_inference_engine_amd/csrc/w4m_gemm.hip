@@ -788,9 +788,12 @@ int w16m_from_w16s_launch(const void *w16s, int N, int K, void *w16m, hipStream_
     return PIE_OK;
 }
 
-// Decomposition: row tile (64 / 128 / 256 rows), strips per wave (workgroup = 128 or 256 columns) and K split, by a small cost model:
-// a step is 4 MB SW MFMAs per wave (24.6 ns each at the ~1.3 GHz the chip holds under matrix load) at the tile's measured efficiency,
-// workgroups run in rounds of 256, a K split pays the fp32 slabs' write + read and the reduce launch.
+// Decomposition: row tile (64 / 128 / 256 rows), strips per wave (workgroup = 128 or 256 columns) and K split, by a small cost model
+// calibrated on tools/w16_bench sweep (8B and vision-tower shapes, 64 .. 4096 rows): a K step of a (32 mb) x (128 sw) tile costs
+// t(mb, sw) us -- larger tiles are cheaper per MFMA (0.125 us per 32 x 32 block pair for 64 x 128, 0.09 for 256 x 256) but quantise worse --
+// less when part of the chip idles (the large tiles are power-bound: the clock rises); workgroups run in rounds of 256; few rows
+// are bound by the weight stream (~5.5 TB/s); a launch costs ~4 us of ramp, prologue and epilogue; a K split writes and re-reads its fp32
+// slabs and launches the reduce.
 struct W16Plan {
     int mb, sw, S;
 };
@@ -812,14 +815,21 @@ static W16Plan w16_plan(int M, int N, int K, bool no_split = false) {
     const int mb_max = M <= 64 ? 2 : (M <= 128 ? 4 : 8);
     W16Plan best = {mb_max, 2, 1};
     double best_us = 1e30;
+    // t(mb, sw) = light + (full - light) * load: one partial round of workgroups runs at a higher clock than sustained full rounds
+    static const double t_light[4][3] = {{0, 0, 0}, {0, 0.25, 0.42}, {0, 0.31, 0.60}, {0, 0.50, 1.45}};  // [log2 mb][sw]
+    static const double t_full[4][3] = {{0, 0, 0}, {0, 0.25, 0.45}, {0, 0.48, 0.80}, {0, 0.83, 1.45}};
+    const double stream_us = 2.0 * N * (64.0 * groups) / 5.5e6;
     for (int S = 1; S <= (no_split ? 1 : 16) && (S == 1 || 8 * S <= groups); ++S)
         for (int mb = mb_max; mb >= 2; mb >>= 1)
             for (int sw = 2; sw >= (no_split ? 2 : 1); --sw) {
-                const double eff = (sw == 2 ? 0.85 : 0.70) * (mb == 8 ? 1.0 : (mb == 4 ? 0.92 : 0.80));
                 const int wgs = ((N + 128 * sw - 1) / (128 * sw)) * ((M + 32 * mb - 1) / (32 * mb)) * S;
                 const int steps = ((groups + S - 1) / S + 3) & ~3;
-                double us = (double)((wgs + 255) / 256) * steps * (4 * mb * sw * 0.0246 / eff) + 4.0;
-                if (S > 1) us += (double)M * N * 4.0 * (S + 1) / 2.0e6 + 4.0;
+                const int rounds = (wgs + 255) / 256;
+                const double load = rounds > 1 ? 1.0 : (double)wgs / 256.0;
+                const int mi = mb == 8 ? 3 : (mb == 4 ? 2 : 1);
+                double us = rounds * steps * (t_light[mi][sw] + (t_full[mi][sw] - t_light[mi][sw]) * load);
+                us = (us > stream_us ? us : stream_us) + 4.0;
+                if (S > 1) us += (double)M * N * 4.0 * (2 * S + 0.5) / 4.0e6 + 2.0;
                 if (us < best_us) best_us = us, best = {mb, sw, S};
             }
     best.S = w16_even_splits(groups, best.S);

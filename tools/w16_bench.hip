@@ -235,6 +235,27 @@ int main(int argc, char **argv) {
         std::printf(bad ? "check FAILED (%d)\n" : "check ok\n", bad);
         return bad ? 1 : 0;
     }
+    if (mode == "sweep") {  // every tile plan on one shape: tools/w16_bench sweep M N K
+        const int M = std::atoi(argv[2]), N = std::atoi(argv[3]), K = std::atoi(argv[4]);
+        Problem p = make(M, N, K, false);
+        CK(hipFree(p.ws));
+        CK(hipMalloc(&p.ws, (size_t)8 * M * N * 4));
+        const W16Plan def = w16_plan(M, N, K);
+        const double lt = time_lt(p, 30);
+        std::printf("M=%d N=%d K=%d: default plan mb=%d sw=%d S=%d; hipBLASLt %.2f us\n", M, N, K, def.mb, def.sw, def.S, lt);
+        for (int mb = 2; mb <= 8; mb *= 2)
+            for (int sw = 1; sw <= 2; ++sw)
+                for (int S = 1; S <= 8; ++S) {
+                    if (S > 1 && 4 * S > (K + 63) / 64) continue;
+                    if (32 * mb / 2 >= M + 32 * mb / 2 - 1 && mb > 2) continue;
+                    g_w16_plan_override[0] = mb, g_w16_plan_override[1] = sw, g_w16_plan_override[2] = S;
+                    if (w16_plan(M, N, K).S != S) continue;
+                    const double us = time_own(p, 30, false);
+                    std::printf("  mb=%d sw=%d S=%d: %8.2f us  x%.2f of hipBLASLt%s\n", mb, sw, S, us, lt / us, (mb == def.mb && sw == def.sw && S == def.S) ? "   <- default" : "");
+                    std::fflush(stdout);
+                }
+        return 0;
+    }
 #ifdef W16L_PROF
     if (mode == "prof") {  // core clock and cycles per K step inside the kernel: tools/w16_bench prof M N K
         const int M = std::atoi(argv[2]), N = std::atoi(argv[3]), K = std::atoi(argv[4]);
