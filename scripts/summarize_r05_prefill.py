@@ -15,10 +15,10 @@ PEAK = 2500.0  # TFLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def counters(d):
-    f = glob.glob(str(P / d / "*" / "*_counter_collection.csv"))
+    f = sorted(glob.glob(str(P / d / "*" / "*_counter_collection.csv")), key=lambda q: Path(q).stat().st_mtime)  # (gpurun merges runs: newest)
     if not f:
         return None
-    df = pd.read_csv(f[0])
+    df = pd.read_csv(f[-1])
     return df.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].agg(["mean", "count"]).reset_index()
 
 
@@ -27,11 +27,11 @@ def short(name):
 
 
 def one(tag, header):
-    stats = glob.glob(str(P / f"stats_{tag}" / "*" / "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(str(P / f"stats_{tag}" / "*" / "*_kernel_stats.csv")), key=lambda q: Path(q).stat().st_mtime)
     if not stats:
         return None
-    st = pd.read_csv(stats[0])
-    (OUT / f"r05_prefill{tag}_kernel_stats.csv").write_text(header + Path(stats[0]).read_text())
+    st = pd.read_csv(stats[-1])
+    (OUT / f"r05_prefill{tag}_kernel_stats.csv").write_text(header + Path(stats[-1]).read_text())
     m, b = counters(f"mfma_{tag}"), counters(f"busy_{tag}")
     out = {}
     if m is not None:
@@ -74,10 +74,10 @@ for tag in ("128", "512", "4096"):
 if int4:
     json.dump({"library": version, "workload": "tools/step_bench --model 8b --prefill N: one N-token prompt through pie_decoder_prefill (8B-shaped int4 g=64, bf16), after the one-off tile repack",
                "note": note, "prompts": int4}, open(OUT / "r05_prefill_mfma.json", "w"), indent=1)
-d = one("dense512", f"# library: {version}; rocprofv3 --kernel-trace --stats -- python3.10 scripts/bench_prefill.py --dense --prompts 512 --iterated-max 0 (Cijk_* = hipBLASLt; k_fill / at::native = the synthetic checkpoint)\n")
+d = one("dense512", f"# library: {version}; rocprofv3 --kernel-trace --stats -- python3.10 scripts/bench_prefill.py --dense --prompts 512 --iterated-max 0 (k_w16l_gemm = the hand-written 16-bit GEMM; k_fill / at::native = the synthetic checkpoint)\n")
 if d:
     json.dump({"library": version, "workload": "BASELINE.json configs[2] prefill half: Llama-3-8B-shaped dense bf16, one 512-token prompt (scripts/bench_prefill.py --dense --prompts 512)",
-               "gemm_library": "hipBLASLt (Cijk_* kernels): 16-bit many-row GEMMs are a library dependency (DESIGN.md 3)", "note": note, **d},
+               "gemm": "k_w16l_gemm (w16_gemm.hpp): hand-written; hipBLASLt was removed in round 5 (the round-4 library numbers: git history of this file, 11.67 ms)", "note": note, **d},
               open(OUT / "r05_dense_prefill512.json", "w"), indent=1)
 for tag, r in list(int4.items()) + ([("dense512", d)] if d else []):
     print(tag, r.get("unprofiled_run"), r.get("all_mfma_kernels"))

@@ -14,7 +14,7 @@ OUT = ROOT / "profiles"
 
 
 def counters(d):
-    df = pd.read_csv(glob.glob(str(P / d / "*" / "*_counter_collection.csv"))[0])
+    df = pd.read_csv(sorted(glob.glob(str(P / d / "*" / "*_counter_collection.csv")), key=lambda q: Path(q).stat().st_mtime)[-1])  # (gpurun merges runs: newest)
     return df.groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].agg(["mean", "count"]).reset_index()
 
 
@@ -25,7 +25,7 @@ def short(name):
 
 version = (P / "pie_version.txt").read_text().strip()
 for src, dst in (("step_stats", "r05_step_kernel_stats.csv"), ("bench_stats", "r05_bench_kernel_stats.csv")):
-    hit = glob.glob(str(P / src / "*" / "*_kernel_stats.csv"))
+    hit = sorted(glob.glob(str(P / src / "*" / "*_kernel_stats.csv")), key=lambda q: Path(q).stat().st_mtime)[-1:]
     if hit:
         (OUT / dst).write_text(f"# library: {version}; rocprofv3 --kernel-trace --stats, scripts/profile_r05.sh ({src})\n" + Path(hit[0]).read_text())
 

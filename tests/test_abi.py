@@ -61,3 +61,21 @@ def test_product_never_imports_the_oracle():
             if re.search(r"(import|from|include|CDLL).*oracle", f.read_text(errors="ignore")):
                 bad.append(str(f))
     assert not bad, bad
+
+
+def test_no_library_gemm_behind_the_c_abi():
+    """Every GEMM on the path is hand-written (round 5 removed the hipBLASLt dlopen of rounds 1-4): the built library neither names nor
+    links a BLAS, and the sources hold no include of one.  Size helpers of the 16-bit tile format answer without a GPU."""
+    import subprocess
+    from proxy_inference_engine_amd import _ffi, build
+    blob = build.build().read_bytes().lower()
+    for name in (b"hipblaslt", b"rocblas", b"hipblas"):
+        assert name not in blob, f"the library mentions {name!r}"
+    needed = subprocess.run(["readelf", "-d", str(build.build())], capture_output=True, text=True).stdout.lower()
+    assert "blas" not in needed
+    for f in (ROOT / "proxy_inference_engine_amd" / "csrc").iterdir():
+        assert not re.search(r"#include\s*<(hipblas|rocblas)", f.read_text(errors="ignore")), f
+    lib = _ffi.load()
+    assert lib.pie_w16m_bytes(1280, 3420) == 40 * 54 * 4096 and lib.pie_w16m_bytes(0, 64) == 0   # 32-row x 64-column tiles, zero-padded
+    assert lib.pie_linear_w16m_workspace(4096, 6144, 4096) == 0                                    # no K split where the tiles fill the chip
+    assert lib.pie_linear_w16m_workspace(64, 4096, 14336) % (64 * 4096 * 4) == 0 and lib.pie_linear_w16m_workspace(64, 4096, 14336) > 0
