@@ -253,11 +253,7 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
 #ifdef W16L_PROF
     if (threadIdx.x == 0 && a.prof) a.prof[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime(), a.prof[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
-    // accumulator register i of lane l <-> output column 32 nt + (i & 3) + 8 (i >> 2) + 4 kh, row m0 + 32 mi + (l & 31): a lane holds four
-    // consecutive columns of 32 DIFFERENT rows.  Stored from there (8 bytes per lane and row) the output cost 12-27 % of the kernel
-    // (t_qkv at 4096 rows 45.5 us, 33.0 without stores): every workgroup of a round finishes at the same time and the burst is made of
-    // 16-byte fragments.  So the rounded tile goes through LDS (free after the loop; each wave its own region, rows XOR-swizzled in 8-byte
-    // slots: conflict-free both ways) and leaves as whole 128-byte lines.
+    // epilogue: fp32 slabs of a K split straight from the accumulator layout; everything else rounded, through LDS, as whole lines (mfma_store.hpp)
     if (!SWIGLU && a.part) {  // K split: fp32 slabs, 16 bytes per lane and row (few rows by construction)
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
@@ -277,65 +273,7 @@ __global__ void __launch_bounds__(256) k_w16l_gemm(const W16Args a) {
         }
         return;
     }
-    constexpr int OB = (SWIGLU ? 32 : 64) * SW;  // output bytes per row of the wave's tile
-    constexpr int SL = OB / 8, RPB = 256 / OB;    // 8-byte slots per row; rows per 256-byte bank row
-    static_assert(4 * MT * OB <= XB * CHUNK, "the output tile fits the x buffers");
+    static_assert(4 * MT * ((SWIGLU ? 32 : 64) * SW) <= XB * CHUNK, "the output tile fits the x buffers");
     __syncthreads();  // everyone has read its last B fragments
-    char *ot = s_x + wave * (MT * OB);
-    const int sv = (n / RPB) & (SL - 1);  // the row's slot swizzle (rows 32 apart share it)
-#pragma unroll
-    for (int s = 0; s < SW; ++s) {
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = 32 * (nt0 + s) + 4 * kh + 8 * q;
-                u32 p01 = w4m_pack<T>(acc[s][mi][4 * q], acc[s][mi][4 * q + 1]), p23 = w4m_pack<T>(acc[s][mi][4 * q + 2], acc[s][mi][4 * q + 3]);  // the Linear's rounding to T
-                if (a.bias && col < a.N) {  // T(T(x W^T) + bias), like the text tower's Linear
-                    uint2 bw;
-                    if (col + 4 <= a.N && !(a.N & 3)) bw = *reinterpret_cast<const uint2 *>(a.bias + col);
-                    else {  // any out_features: the last quad of a row may be partial, rows of the bias need not be 8-byte aligned
-                        u16 e[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) e[i] = col + i < a.N ? a.bias[col + i] : (u16)0;
-                        bw = make_uint2(e[0] | ((u32)e[1] << 16), e[2] | ((u32)e[3] << 16));
-                    }
-                    p01 = w4m_pack<T>(lo_f32<T>(p01) + lo_f32<T>(bw.x), hi_f32<T>(p01) + hi_f32<T>(bw.x));
-                    p23 = w4m_pack<T>(lo_f32<T>(p23) + lo_f32<T>(bw.y), hi_f32<T>(p23) + hi_f32<T>(bw.y));
-                }
-                char *row = ot + (32 * mi + n) * OB;
-                if (SWIGLU) {  // columns (2 i, 2 i + 1) = (gate_i, up_i): two activations, 4 bytes at byte 32 s + 8 q + 4 kh of the row
-                    const float g0 = lo_f32<T>(p01), u0 = hi_f32<T>(p01), g1 = lo_f32<T>(p23), u1 = hi_f32<T>(p23);
-                    const u16 o0 = T::from_f32(round_T<T>(g0 / (1.0f + expf(-g0))) * u0), o1 = T::from_f32(round_T<T>(g1 / (1.0f + expf(-g1))) * u1);
-                    *reinterpret_cast<u32 *>(row + (((4 * s + q) ^ sv) << 3) + 4 * kh) = (u32)o0 | ((u32)o1 << 16);
-                } else {       // 8 bytes at byte 64 s + 16 q + 8 kh
-                    *reinterpret_cast<uint2 *>(row + (((8 * s + 2 * q + kh) ^ sv) << 3)) = make_uint2(p01, p23);
-                }
-            }
-        }
-    }
-    // (the same wave reads what it wrote: no barrier, the compiler's lgkmcnt wait orders the LDS accesses)
-    constexpr int PR = OB / 16;               // 16-byte pieces per row
-    const int ldo = SWIGLU ? a.N >> 1 : a.N;  // output row length (the row stride a.ldy may be longer: a zero-padded operand of the next GEMM)
-    const int c0 = (SWIGLU ? 16 : 32) * nt0;  // the wave's first output column
-#pragma unroll
-    for (int it = 0; it < MT * PR / 64; ++it) {
-        const int pc = it * 64 + lane, r = pc / PR, j = pc % PR;
-        const int rsv = ((r & 31) / RPB) & (SL - 1);
-        const uint2 lo = *reinterpret_cast<const uint2 *>(ot + r * OB + (((2 * j) ^ rsv) << 3));
-        const uint2 hi = *reinterpret_cast<const uint2 *>(ot + r * OB + (((2 * j + 1) ^ rsv) << 3));
-        const int col = c0 + 8 * j;
-        if (r >= rows || col >= ldo || ((W16L_ABL & 64) && a.M > 1)) continue;
-        u16 *dst = a.y + (size_t)(m0 + r) * a.ldy + col;
-        if (((ldo | a.ldy) & 7) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        else if (((ldo | a.ldy) & 3) == 0) {  // rows are 8-byte aligned; the last piece of a row may be half
-            *reinterpret_cast<uint2 *>(dst) = lo;
-            if (col + 4 < ldo) *reinterpret_cast<uint2 *>(dst + 4) = hi;
-        } else {  // any out_features: element by element
-            const u32 w[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (col + e < ldo) dst[e] = (u16)(w[e >> 1] >> (16 * (e & 1)));
-        }
-    }
+    mfma_tile_store<T, MB, SW, SWIGLU>(acc, s_x + wave * (MT * (SWIGLU ? 32 : 64) * SW), lane, nt0, m0, rows, a.N, a.ldy, a.y, a.bias, (W16L_ABL & 64) && a.M > 1);
 }

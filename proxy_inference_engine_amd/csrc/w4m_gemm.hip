@@ -71,6 +71,8 @@ __device__ __forceinline__ u32 w4m_pack<F16>(float lo, float hi) {
     return __builtin_bit_cast(u32, __builtin_convertvector((f2_t){lo, hi}, h2_t));
 }
 
+#include "mfma_store.hpp"  // the LDS-transposed output epilogue of the one-wave-per-SIMD GEMMs
+
 // 8 codes of one word -> 8 weights in T, the mx.dequantize arithmetic of k_dequant_w4s: T(fp32(s * q) + b), as the MFMA fragment
 template <class T>
 __device__ __forceinline__ uint4 w4m_dequant(u32 word, float s, float b) {
@@ -443,7 +445,8 @@ typedef __attribute__((address_space(1))) const void w4l_glb_void;
 template <class T, int MB, bool SWIGLU = false>
 __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x, int M, int N, int K, u16 *y, float *part) {
     constexpr int MT = 32 * MB, XJ = MB;  // rows per tile; DMA instructions per wave and tile (MT / 8 row groups over 4 waves)
-    __shared__ __attribute__((aligned(1024))) char s_x[2][MT * 128];
+    constexpr int OUT_BYTES = 4 * MT * (SWIGLU ? 64 : 128);  // the epilogue's output tile (mfma_store.hpp) reuses -- and outgrows -- the two x buffers
+    __shared__ __attribute__((aligned(1024))) char s_x[OUT_BYTES / (MT * 128) > 2 ? OUT_BYTES / (MT * 128) : 2][MT * 128];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, kh = lane >> 5, all_groups = K >> 6;
     const int per_z = (all_groups + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -578,42 +581,26 @@ __global__ void __launch_bounds__(256) k_w4l2_gemm(const char *w4m, const u16 *x
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // the clamped look-ahead loads of the last steps
-    // accumulator register i of lane l <-> output column 32 nt + (i & 3) + 8 (i >> 2) + 4 kh, row m0 + 32 mi + (l & 31)
+    if (!SWIGLU && part) {  // K split: fp32 partial tiles straight from the accumulator layout (register i of lane l <-> column 32 nt + (i & 3) + 8 (i >> 2) + 4 kh, row 32 mi + (l & 31))
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        if (!(s2 ? has1 : has0)) continue;
-        const int nt = nt0 + s2;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (!(s2 ? has1 : has0)) continue;
 #pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-            const int m = 32 * mi + n;
-            if (m < rows) {
-                const size_t o = (size_t)(m0 + m) * N + 32 * nt + 4 * kh;
-                if (SWIGLU) {
+            for (int mi = 0; mi < MB; ++mi) {
+                const int m = 32 * mi + n;
+                if (m >= rows) continue;
+                float *pr = part + (size_t)blockIdx.z * M * N + (size_t)(m0 + m) * N + 32 * (nt0 + s2) + 4 * kh;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u16 out2[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const u32 gu = w4m_pack<T>(acc[s2][mi][4 * q + 2 * e], acc[s2][mi][4 * q + 2 * e + 1]);  // the Linear's rounding to T
-                            const float g = lo_f32<T>(gu), u = hi_f32<T>(gu);
-                            out2[e] = T::from_f32(round_T<T>(g / (1.0f + expf(-g))) * u);
-                        }
-                        *reinterpret_cast<u32 *>(y + (size_t)(m0 + m) * (N >> 1) + ((32 * nt + 4 * kh + 8 * q) >> 1)) = (u32)out2[0] | ((u32)out2[1] << 16);
-                    }
-                } else if (part) {
-                    float *pr = part + (size_t)blockIdx.z * M * N + o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4 *>(pr + 8 * q) = make_float4(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1], acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<uint2 *>(y + o + 8 * q) =
-                            make_uint2(w4m_pack<T>(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1]), w4m_pack<T>(acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]));
-                }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(pr + 8 * q) = make_float4(acc[s2][mi][4 * q], acc[s2][mi][4 * q + 1], acc[s2][mi][4 * q + 2], acc[s2][mi][4 * q + 3]);
             }
         }
+        return;
     }
+    // everything else: rounded (SWIGLU: activated), through LDS, as whole lines (mfma_store.hpp; round 5: the 8-byte-per-row stores of the
+    // accumulator layout cost 8-27 % of these kernels).  Idle strips (N not a multiple of 256) fall outside N there.
+    __syncthreads();  // everyone has read its last B fragments
+    mfma_tile_store<T, MB, 2, SWIGLU>(acc, &s_x[0][0] + wave * (MT * (SWIGLU ? 64 : 128)), lane, nt0, m0, rows, N, SWIGLU ? N >> 1 : N, y, nullptr);
 }
 
 // y = T(sum over z, in z order, of the fp32 partial tiles)
