@@ -106,6 +106,33 @@ def test_fused_gate_up_linear_is_the_gemm_followed_by_bias_silu_mul(ops, dt, M, 
     assert torch.equal(ops.linear_rows(padded, ops.pack_linear(dw)), ops.linear_rows(got, dw))
 
 
+def test_linear_w16m_refuses_what_it_cannot_do(ops):
+    """pie_linear_w16m through the C ABI: a K-split shape without its workspace, a fused SiLU * up on an odd column count, an x row stride shorter
+    than the padded K, and a host tensor are errors (status + pie_last_error), not silent fallbacks."""
+    from proxy_inference_engine_amd import _ffi
+    lib = _ffi.load()
+    M, N, K = 64, 4096, 14336
+    need = int(lib.pie_linear_w16m_workspace(M, N, K))
+    assert need > 0 and need % (M * N * 4) == 0                      # whole fp32 slabs
+    x = torch.zeros((M, K), dtype=torch.bfloat16, device="cuda")
+    pk = ops.pack_linear(torch.zeros((N, K), dtype=torch.bfloat16, device="cuda"))
+    y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    args = (_ffi.p(x), K, _ffi.p(pk.tiles), None, M, N, K, _ffi.PIE_BF16, _ffi.p(y), 0, 0)
+    assert lib.pie_linear_w16m(*args, None, 0, _ffi.stream()) != 0 and b"workspace" in lib.pie_last_error()
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    assert lib.pie_linear_w16m(*args, _ffi.p(ws), need, _ffi.stream()) == 0
+    torch.cuda.synchronize()
+    assert not y.any()
+    small = ops.pack_linear(torch.zeros((36, 128), dtype=torch.bfloat16, device="cuda"))
+    xs = torch.zeros((8, 128), dtype=torch.bfloat16, device="cuda")
+    assert lib.pie_linear_w16m(_ffi.p(xs), 128, _ffi.p(small.tiles), None, 8, 36, 128, _ffi.PIE_BF16, _ffi.p(y), 0, 1, None, 0, _ffi.stream()) != 0
+    assert b"N % 8" in lib.pie_last_error()
+    assert lib.pie_linear_w16m(_ffi.p(xs), 64, _ffi.p(small.tiles), None, 8, 36, 128, _ffi.PIE_BF16, _ffi.p(y), 0, 0, None, 0, _ffi.stream()) != 0
+    assert b"x rows" in lib.pie_last_error()
+    with pytest.raises(ValueError, match="device"):
+        ops.linear_rows(torch.zeros((8, 128), dtype=torch.bfloat16), small)
+
+
 def _mask(cu, N, dt):
     m = np.full((N, N), vo.finfo_min(dt), np.float32)
     for i in range(1, len(cu)):
