@@ -55,7 +55,8 @@ enum {
     PIE_KNOB_ATTN_MERGE_MAX_CAP = 7, /* cache capacity up to which o_proj merges the split-KV partials (read at pie_decoder_create); default 1024 */
     PIE_KNOB_ATTN_WARM_MAX_MB = 8,   /* the attention launch's idle CUs warm the Infinity Cache with at most this many MB of o_proj's weights; 0 = off (read per step enqueue / graph capture) */
     PIE_KNOB_W4R = 9,                /* 0: int4 Linears of 6..256 rows on the round-2 kernels (k_w4m_gemm, k_w4l2_gemm) instead of the weight-streaming k_w4r_gemm (the tests' cross-check) */
-    PIE_KNOB_COUNT = 10
+    PIE_KNOB_FUSE_ATTN = 10,         /* 0: the step's attention as its own launch instead of behind the q|k|v launch's XCD-local seam (32 / 8 / 128 heads; bit-identical; read per step enqueue / graph capture) */
+    PIE_KNOB_COUNT = 11
 };
 #define PIE_KNOB_DEFAULT (-1)
 int pie_set_knob(int knob, int value);

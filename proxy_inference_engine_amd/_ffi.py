@@ -17,7 +17,7 @@ PIE_STEP_LOGITS, PIE_STEP_GRAPH = 1, 2
 PIE_OPT_KV_I8 = 2
 # test / tuning switches (include/pie_hip.h: pie_set_knob); -1 restores a default
 KNOBS = {"prefill_min": 0, "prefill_chunk": 1, "prefill_resident": 2, "small_m": 3, "w4l_slabs": 4, "prefill_attn_valu": 5,
-         "prefill_qt": 6, "attn_merge_max_cap": 7, "attn_warm_max_mb": 8, "w4r": 9}
+         "prefill_qt": 6, "attn_merge_max_cap": 7, "attn_warm_max_mb": 8, "w4r": 9, "fuse_attn": 10}
 PIE_I8 = 3  # KV page storage: int8 rows + per-head fp16 scales
 KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5, "lm_head": 6, "tail": 7}
 

@@ -9,6 +9,7 @@
 // k_attn_combine (op-level API) or by the o_proj GEMV's staging prologue (decoder), fp32 until the single
 // rounding at the end = MLX fused-kernel contract.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 constexpr int ATTN_MAX_SPLITS = 32;  // 8 kv-heads x 32 splits = one workgroup per CU
@@ -105,8 +106,17 @@ __device__ __forceinline__ uint4 attn_load_row(const u16 *p) {
 #define ATTN_STAMP(i)
 #endif
 
-template <class T, int D, int REP, bool PAGED = false, bool NTKV = false, int WAVES = ATTN_WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
+// The workgroup's work for (kv-head group g, split, query row): the body of k_attn_decode, also called by the q|k|v GEMV behind its XCD-local
+// seam (w4_gemv.hpp, FUSE: a workgroup of 8 waves of which the first WAVES run this -- the others only join the barrier).
+// SEAM: a callable run once, after the first K / V rows of the split are in flight and before anything this step's q|k|v launch wrote is read
+// (the fused caller waits for its kv-group there: the old rows' latency hides under the wait); nullptr_t = none.
+struct AttnNoSeam {
+    __device__ __forceinline__ void operator()() const {}
+};
+// q0: the first of the REP query heads scored here (the kernel: g * REP, all heads of the kv group; the fused caller: ONE head of group g per
+// workgroup -- a head's online softmax never looks at another head, so the grouping does not change a bit).
+template <class T, int D, int REP, bool PAGED, bool NTKV, int WAVES, class SEAM = AttnNoSeam>
+__device__ __forceinline__ void attn_decode_body(const AttnArgs &a, const int g, const int split, const int row, const int q0, const SEAM seam = SEAM()) {
     constexpr int LPT = D / 8;     // lanes per token row (16 B each)
     constexpr int TPW = 64 / LPT;  // token rows per wave-load
     constexpr int NSUB = WAVES;  // one merged online-softmax stream per wave reaches LDS
@@ -123,31 +133,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
     __shared__ float s_m[REP][NSTR], s_l[REP][NSTR];
     __shared__ float s_acc[REP][NSTR][D];
 
-    ATTN_STAMP(0);
-    const int g = blockIdx.x, split = blockIdx.y;
-    if (split >= a.splits) {  // warm-up role (uniform per workgroup)
-        const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
-        unsigned acc = 0;
-        const unsigned long long n16 = a.pf_bytes >> 4;  // 16-byte pieces
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr);
-        for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
-            const uint4 v = src[i];
-            acc ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-        if (acc == 0x9e3779b9u) a.pf_sink[0] = acc;  // keeps the loads alive; practically never taken
-        return;
-    }
+    const bool on = (int)threadIdx.x < NT;  // (a fused caller's extra waves: no loads, no streams, only the barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ts = lane / LPT, dc = lane % LPT;
     const float sl2 = a.scale * ATTN_LOG2E;
-    const int row = blockIdx.z;  // query row of a prefill chunk (0 at decode)
     const int Ttot = PAGED && a.ctx_len ? a.ctx_len[row] : (a.state ? a.state->pos + 1 : a.T) + row;
     const int cap = PAGED ? 64 : a.state ? a.state->cap : a.cap;
     const AttnSplit sp = attn_split(Ttot, a.splits);
     ATTN_STAMP(1);  // the position has arrived
     if constexpr (PAGED) {
         if (a.splits == 1 && a.ctx_len && sp.active == 0) {  // idle slot of a one-split batch: zeros, as k_attn_combine leaves it
-            for (int o = threadIdx.x; o < REP * D; o += NT) a.out[((size_t)row * a.Hq + g * REP) * D + o] = 0;
+            for (int o = threadIdx.x; o < REP * D; o += NT) a.out[((size_t)row * a.Hq + q0) * D + o] = 0;
             return;
         }
     }
@@ -158,7 +154,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
         if (!(PAGED && a.splits == 1))
             for (int o = threadIdx.x; o < REP * (D / 2); o += NT) {
                 const int h = o / (D / 2), d = (o % (D / 2)) * 2;
-                const size_t hq = (size_t)row * a.Hq + g * REP + h;
+                const size_t hq = (size_t)row * a.Hq + q0 + h;
                 *reinterpret_cast<float2 *>(a.part_acc + (hq * a.splits + split) * D + d) = make_float2(0.0f, 0.0f);
                 if (d == 0) a.part_ml[(hq * a.splits + split) * 2 + 0] = ATTN_NEG, a.part_ml[(hq * a.splits + split) * 2 + 1] = 0.0f;
             }
@@ -177,7 +173,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
 
     // row-blocks of this wave: block b covers tokens t_begin + (NSUB*b + wave)*TPW + [0, TPW)
     const int first = t_begin + wave * TPW;
-    const int n_blk = first < t_end ? (t_end - first + NSUB * TPW - 1) / (NSUB * TPW) : 0;
+    const int n_blk = on && first < t_end ? (t_end - first + NSUB * TPW - 1) / (NSUB * TPW) : 0;
     uint4 kq[DA], vq[DA];
     unsigned pgq[DA];  // PAGED: page id of the block ring slot d loads next, fetched one ring turn ahead of its use
     auto page_of = [&](int b) {
@@ -185,9 +181,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
         t = t < t_end ? t : t_end - 1;
         return min((unsigned)bt[t >> 6], last_page);  // a corrupt table must not become a wild address
     };
+    constexpr bool HAS_SEAM = !std::is_same<SEAM, AttnNoSeam>::value;
+    bool before_seam = HAS_SEAM;  // (compile-time false without a seam)
     auto issue = [&](int d, int b) {
         int t = first + b * NSUB * TPW + ts;
         t = t < t_end ? t : t_end - 1;  // clamp, never branch around a load
+        // Before the seam NO lane may touch the row this launch writes (position Ttot - 1) -- not even a clamped, discarded load: it would park a
+        // stale line of that row in this CU's L1, and the real load after the seam would hit it.  Such lanes read the row before it (an empty
+        // cache: the buffer's last row); the one valid lane is loaded again behind the seam.
+        if (HAS_SEAM && before_seam && t >= Ttot - 1) t = Ttot >= 2 ? Ttot - 2 : cap - 1;
         if constexpr (PAGED) {
             const size_t off = (size_t)pgq[d] * page_elems + (size_t)(t & 63) * D;
             kq[d] = attn_load_row<NTKV>(kbase + off);
@@ -204,11 +206,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
     }
 #pragma unroll
     for (int d = 0; d < DA; ++d) issue(d, d);
+    if constexpr (HAS_SEAM) {
+        static_assert(!PAGED, "the seam form is built for the contiguous cache");
+        // the rows cached by earlier steps are on their way; now wait for this step's q / k / v, then fetch the one row of the ring that was
+        // written in this launch (position Ttot - 1, if this split holds it and it sits in the first DA blocks)
+        seam();
+        before_seam = false;
+        ATTN_STAMP(7);  // released
+#pragma unroll
+        for (int d = 0; d < DA; ++d) {
+            const int t = first + d * NSUB * TPW + ts;
+            if (on && t == Ttot - 1 && t < t_end) {
+                if constexpr (PAGED) {
+                    const size_t off = (size_t)page_of(d) * page_elems + (size_t)(t & 63) * D;
+                    kq[d] = attn_load_row<NTKV>(kbase + off), vq[d] = attn_load_row<NTKV>(vbase + off);
+                } else {
+                    kq[d] = attn_load_row<NTKV>(kbase + (size_t)t * D), vq[d] = attn_load_row<NTKV>(vbase + (size_t)t * D);
+                }
+            }
+        }
+    }
 
     u32 qr[REP][4];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
-        uint4 qv = *reinterpret_cast<const uint4 *>(a.q + ((size_t)row * a.Hq + g * REP + h) * D + dc * 8);
+        uint4 qv = *reinterpret_cast<const uint4 *>(a.q + ((size_t)row * a.Hq + q0 + h) * D + dc * 8);
         qr[h][0] = qv.x, qr[h][1] = qv.y, qr[h][2] = qv.z, qr[h][3] = qv.w;
     }
     float m[REP], l[REP], acc[REP][8];
@@ -296,7 +318,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
         // lane (ts, dc): stream wave * TPW + ts, dims dc * 8 .. + 7 of every head
         const int str = wave * TPW + ts;
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
+        for (int h = 0; h < REP && on; ++h) {
             if (dc == 0) s_m[h][str] = m[h], s_l[h][str] = l[h];
             *reinterpret_cast<float4 *>(&s_acc[h][str][dc * 8]) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
             *reinterpret_cast<float4 *>(&s_acc[h][str][dc * 8 + 4]) = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
@@ -321,7 +343,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
             acc[h][j] = xor32_sum(xor16_sum(acc[h][j]));
         }
     }
-    if (ts == 0) {
+    if (ts == 0 && on) {
 #pragma unroll
         for (int h = 0; h < REP; ++h) {
             if (dc == 0) s_m[h][wave] = m[h], s_l[h][wave] = l[h];
@@ -348,7 +370,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
             Lsum = fmaf(w, s_l[h][i], Lsum);
             A0 = fmaf(w, av.x, A0), A1 = fmaf(w, av.y, A1);
         }
-        const size_t hq = (size_t)row * a.Hq + g * REP + h;
+        const size_t hq = (size_t)row * a.Hq + q0 + h;
         if constexpr (PAGED) {
             if (a.splits == 1 && a.ctx_len) {  // a batch of short sequences, one split each: the partial IS the result (k_attn_combine would
                 // compute fma(1, acc, 0) / fma(1, l, 0) -- the same bits) and the launcher skips the combine launch
@@ -363,6 +385,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
         }
     }
     ATTN_STAMP(6);
+}
+
+template <class T, int D, int REP, bool PAGED = false, bool NTKV = false, int WAVES = ATTN_WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_attn_decode(const AttnArgs a) {
+    constexpr int NT = WAVES * 64;
+    const int g = blockIdx.x, split = blockIdx.y;
+    if (split >= a.splits) {  // warm-up role (uniform per workgroup)
+        const unsigned nblk = (unsigned)a.pf_rows * gridDim.x, bid = (unsigned)(split - a.splits) * gridDim.x + g;
+        unsigned acc = 0;
+        const unsigned long long n16 = a.pf_bytes >> 4;  // 16-byte pieces
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.pf_ptr);
+        for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
+            const uint4 v = src[i];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+        if (acc == 0x9e3779b9u) a.pf_sink[0] = acc;  // keeps the loads alive; practically never taken
+        return;
+    }
+    attn_decode_body<T, D, REP, PAGED, NTKV, WAVES>(a, g, split, (int)blockIdx.z, g * REP);
 }
 
 // Merge of the active splits for 8 consecutive dims [d0, d0+8) of q-head h (fp32):

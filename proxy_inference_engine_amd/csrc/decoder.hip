@@ -26,7 +26,7 @@ constexpr int PROF_QKV = 16, PROF_O = 20, PROF_GU = 24, PROF_DOWN = 28;
 #endif
 }
 namespace {
-int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int g_knobs[PIE_KNOB_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 }
 int pie_knob(int knob) { return knob >= 0 && knob < PIE_KNOB_COUNT ? g_knobs[knob] : PIE_KNOB_DEFAULT; }
 namespace pie {
@@ -82,6 +82,64 @@ static void drop_graphs(pie_decoder *d) {
 // can carry; uncapped, the 33.5 MB of the dense 8B o_proj stretched the launch itself: dense 2.81 -> 3.00 ms per step, int8 (17.8 MB) 1.74 -> 1.81
 // (cap 10: 2.81 / 1.75; off: 2.81 / 1.74; int4: 1.186-1.191 with, 1.190 without)
 constexpr int ATTN_WARM_DEFAULT_MB = 10;
+// Workgroups with equal blockIdx.x % 8 share an XCD (tools/pilot_probe, every grid size and history): what the fused q|k|v + attention launch
+// relies on, so it is checked once per process on the real dispatcher (a partitioned device with one XCD passes trivially).
+__global__ void k_xcc_probe(unsigned *out) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc;
+}
+static bool xcd_classes_hold() {
+    static int cached = -1;  // (one device per process)
+    if (cached >= 0) return cached == 1;
+    unsigned *dev = nullptr, host[256];
+    bool ok = hipMalloc((void **)&dev, sizeof(host)) == hipSuccess;
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+        hipLaunchKernelGGL(k_xcc_probe, dim3(256), dim3(512), 0, 0, dev);
+        ok = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int b = 0; b < 256 && ok; ++b) ok = host[b] == host[b & 7];
+    }
+    if (dev) (void)hipFree(dev);
+    (void)hipGetLastError();
+    cached = ok ? 1 : 0;
+    return ok;
+}
+
+// The step's attention inside the q|k|v launch (w4_gemv.hpp, FUSE): the 32 / 8 / 128 head geometry (kv-group = XCD class), int4 g=64 q|k|v,
+// the short-cache plan on a contiguous cache, one GPU.  Knob PIE_KNOB_FUSE_ATTN = 0 keeps the two launches (bit-identical; the tests' cross-check).
+static bool fuse_attn(const pie_decoder *d, int li) {
+    const pie_decoder_config &c = d->cfg;
+    if (pie_knob(PIE_KNOB_FUSE_ATTN) == 0 || !d->xcd_ok || !d->seam) return false;
+    return !d->tp() && !d->combine && !d->block_table && !d->kv_i8 && c.n_heads == 32 && c.n_kv_heads == 8 && c.head_dim == 128 && c.hidden <= 4096 &&
+           d->mat_fmt(d->layers[li].wqkv) == PIE_W_INT4_G64 && d->splits >= 1 && d->splits <= 4;
+}
+
+// What the step's attention launch is given (contiguous or T-page cache, not the int8 pages)
+static AttnArgs attn_args(pie_decoder *d, int li) {
+    const pie_decoder_config &c = d->cfg;
+    const int H = c.hidden, D = c.head_dim, QD = c.n_heads * D;
+    const pie_layer_weights &w = d->layers[li];
+    AttnArgs a = {};
+    a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
+    a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
+    a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
+    a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
+    a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
+    a.prof = d->pf_sink;
+    // the CUs this launch leaves idle warm the Infinity Cache with o_proj's weights (attention.hpp: +1.3 % on the step)
+    if (!d->combine) {
+        const int f = d->mat_fmt(w.wo);
+        a.pf_rows = (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;
+        if (a.pf_rows < 0) a.pf_rows = 0;
+        a.pf_ptr = (const char *)w.wo, a.pf_sink = d->pf_sink;
+        a.pf_bytes = f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : (f == PIE_W_INT4_G32 ? pie_w4s32_bytes(H, QD) : (f == PIE_W_INT8_G32 ? pie_w8s32_bytes(H, QD) : pie_w4s_bytes(H, QD))));
+        const int cap_mb = pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) >= 0 ? pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) : ATTN_WARM_DEFAULT_MB;
+        if (a.pf_bytes > (unsigned long long)cap_mb << 20) a.pf_bytes = (unsigned long long)cap_mb << 20;
+        if (!a.pf_bytes) a.pf_rows = 0;
+    }
+    return a;
+}
+
 // One launch of the step's sequence (PIE_K_* of include/pie_hip.h); `li` is the layer for per-layer kernels.
 int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 *logits_dst, hipStream_t st, bool embed_here) {
     const pie_decoder_config &c = d->cfg;
@@ -114,6 +172,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
                 a.emb_codes = (const u32 *)d->glob.embed_codes, a.emb_scales = (const u16 *)d->glob.embed_scales, a.emb_biases = (const u16 *)d->glob.embed_biases;
                 a.emb_vocab = d->embed_vocab();
             }
+            if (fuse_attn(d, li)) a.fuse = 1, a.attn = attn_args(d, li), a.seam = d->seam;  // the step's attention behind an XCD-local seam of this launch
             const int rc = w4s_gemv_launch(c.dtype, embed_here ? PRO_EMBED : PRO_RMSNORM, EPI_ROPE_KV, a, 1, st);
             if (rc || !i8) return rc;
             const size_t blk = (size_t)c.n_kv_heads * PIE_PAGE_TOKENS * D;
@@ -130,24 +189,8 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
                 a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
                 return paged_attn_i8_launch(c.dtype, D, a, st);  // merges its splits itself (k_attn_combine): o_proj reads d->attn
             }
-            AttnArgs a = {};
-            a.q = d->qbuf, a.kv_table = d->kv_table, a.layer = li, a.n_layers = c.n_layers, a.state = d->state;
-            a.Hq = c.n_heads, a.Hkv = c.n_kv_heads, a.splits = d->splits, a.scale = 1.0f / sqrtf((float)D);
-            a.part_acc = d->part_acc, a.part_ml = d->part_ml, a.out = d->attn;
-            a.block_table = d->block_table, a.n_pages = d->n_pages, a.bt_stride = 0;
-            a.nt_kv = d->combine;  // long-context plan (capacity > 1024): the cache no longer survives in the Infinity Cache between steps
-            a.prof = d->pf_sink;
-            // the CUs this launch leaves idle warm the Infinity Cache with o_proj's weights (attention.hpp: +1.3 % on the step)
-            if (!d->combine) {
-                const int f = d->mat_fmt(w.wo);
-                a.pf_rows = (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;
-                if (a.pf_rows < 0) a.pf_rows = 0;
-                a.pf_ptr = (const char *)w.wo, a.pf_sink = d->pf_sink;
-                a.pf_bytes = f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : (f == PIE_W_INT4_G32 ? pie_w4s32_bytes(H, QD) : (f == PIE_W_INT8_G32 ? pie_w8s32_bytes(H, QD) : pie_w4s_bytes(H, QD))));
-                const int cap_mb = pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) >= 0 ? pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) : ATTN_WARM_DEFAULT_MB;
-                if (a.pf_bytes > (unsigned long long)cap_mb << 20) a.pf_bytes = (unsigned long long)cap_mb << 20;
-                if (!a.pf_bytes) a.pf_rows = 0;
-            }
+            if (fuse_attn(d, li)) return PIE_OK;  // ran behind the q|k|v launch's seam
+            AttnArgs a = attn_args(d, li);
             return attn_decode_launch(c.dtype, D, a, d->combine, st);  // short caches: partials are merged by the o_proj prologue
         }
         case PIE_K_OPROJ: {  // h = x + o_proj(attn)  (language.py:108,151)
@@ -280,6 +323,8 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->stats, sizeof(LogitStat) * (size_t)d->n_stats);
     PIE_ALLOC(d->rope_cs, sizeof(float) * (size_t)c.head_dim);
     PIE_ALLOC(d->pf_sink, 8192);  // the developer builds' stamps (-DPIE_ATTN_PROF: words 2..9; -DPIE_GEMV_PROF: 16 + 4 kind ..)
+    PIE_ALLOC(d->seam, 2048);     // 8 x {counter, generation} 64 bytes apart, [256] the give-up flag
+    d->xcd_ok = xcd_classes_hold();
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));  // RCCL backend: the fp32 partial; [hidden]: the step's log-sum-exp
 #undef PIE_ALLOC
     plan_attention(d);
@@ -291,7 +336,7 @@ int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
     drop_graphs(d);
     prefill_free(d);
-    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->tp_part, d->kv_stage, d->kv_table_stage,
+    void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->seam, d->tp_part, d->kv_stage, d->kv_table_stage,
                     d->zero_table};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -23,6 +23,8 @@ struct pie_decoder {
     u16 *qbuf = nullptr, *attn = nullptr, *act = nullptr;
     float *part_acc = nullptr, *part_ml = nullptr, *rope_cs = nullptr;
     unsigned *pf_sink = nullptr;  // scratch for the developer builds' in-kernel stamps
+    unsigned *seam = nullptr;     // the fused q|k|v + attention launch's per-XCD arrival counters / generations (w4_gemv.hpp, FUSE); zeroed once
+    bool xcd_ok = false;          // the dispatcher places workgroups with equal blockIdx.x % 8 on one XCD (checked at creation)
     // caller-owned outputs (pie_decoder_bind_outputs)
     u16 *h = nullptr, *logits = nullptr;
     float *logprobs = nullptr;

@@ -96,6 +96,10 @@ struct GemvArgs {
     const unsigned *tp_epoch;
     int tp_rank, tp_world;
     unsigned tp_stride;
+    // FUSE (EPI_ROPE_KV, the 32 / 8 / 128 head geometry): the step's attention runs behind an XCD-local seam of this launch
+    int fuse;             // launcher: take the FUSE instantiation
+    AttnArgs attn;        // what k_attn_decode would be launched with
+    unsigned *seam;       // per XCD class c: arrival counter at [32 c], generation at [32 c + 16]; [256]: a spin gave up (never, unless CUs are masked)
 };
 
 // out[0..8) = T(scale * q + bias) of one code word: separate multiply and add roundings, like the oracle (mx.dequantize)
@@ -256,7 +260,15 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 #define GEMV_STAMP(i)
 #endif
 
-template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S>
+// FUSE (round 5; q|k|v of a model with 32 query heads, 8 kv heads of 128: Llama-3-8B, Mistral-7B): the rows of kv-group g -- its 4 q heads, its
+// k and its v head -- are computed by the 32 workgroups with blockIdx.x % 8 == g, which the dispatcher places on ONE XCD (tools/pilot_probe,
+// checked again at decoder creation), and the step's attention for that group runs in the same launch: stores are write-through to the XCD's
+// L2, every workgroup adds 1 to its XCD's counter (an atomic performed AT that L2: no release fence), the last arriver bumps a generation
+// word, and the group's `splits` attention workgroups poll it with sc1 loads and then run k_attn_decode's body (no acquire fence: the CU's L1
+// was invalidated at launch and has not seen these lines).  tools/seam_probe: 0.12 us from the last arrival to the release, 0.96 us until 32 KB
+// of the group's fresh data are read -- against 3.9 us for a dependent launch.  The other 28 workgroups of the XCD warm the Infinity Cache
+// with o_proj's weights (what the attention launch's idle workgroups did).  Same rows, same units, same order: bit-identical to two launches.
+template <class T, int PRO, int EPI, int NPT, int ABL = 0, int FMT = FMT_W4S, int FUSE = 0>
 __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs a) {
 #if defined(PIE_GEMV_PROF) && PIE_GEMV_PROF == 3
     // fine stamps of the prologue (workgroup 0, thread 0; stored at the very end at prof[8..12]): kernel entry | first kernel argument usable |
@@ -288,13 +300,21 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     // this wave's row pairs: gw, gw + W, gw + 2W, ...  Interleaving keeps the set of units in flight across the chip
     // a compact window that sweeps through the matrix (like a non-persistent grid would), instead of 4096 distant
     // streams -- measured faster on HBM (tools/w4s_bench).
-    const int gw = blockIdx.x * GEMV_WAVES + wave;
+    // FUSE: physical workgroup 8 j + g works as logical workgroup 32 g + j, so group g's q pairs (logical workgroups 32 g .. 32 g + 31) stay on XCD class g
+    const int bx = FUSE ? (int)((blockIdx.x & 7) * 32 + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int gw = bx * GEMV_WAVES + wave;
     const int W = a.n_waves;
+    unsigned seam_gen0 = 0;
+    if (FUSE && threadIdx.x == 0) seam_gen0 = __hip_atomic_load(a.seam + 32 * (blockIdx.x & 7) + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // before this workgroup arrives
     // The pairs that do not fill a whole round of W waves are dealt over the WORKGROUPS, not over the first waves: q|k|v of the 8B
     // model is 3072 pairs on 2048 waves, and with the leftover 1024 on waves 0..1023 half of the CUs streamed twice what the other half
     // did (a launch lasts as long as its busiest CU's ingest).  Leftover pair r goes to wave r / n_blocks of workgroup r % n_blocks.
     const int kf = a.full_rounds;
-    const int rem_r = a.n_blocks > 0 ? wave * a.n_blocks + (int)blockIdx.x : gw;  // this wave's leftover pair, if r < rem_pairs (n_blocks 0: dealt over the first waves)
+    int rem_r = a.n_blocks > 0 ? wave * a.n_blocks + (int)blockIdx.x : gw;  // this wave's leftover pair, if r < rem_pairs (n_blocks 0: dealt over the first waves)
+    if (FUSE) {  // the 1024 leftover pairs are the k rows (0 .. 511) and the v rows (512 ..): group g's 64 + 64 go to its own 32 workgroups, waves 0 .. 3
+        const int u = wave * 32 + (int)(blockIdx.x >> 3), g8 = (int)(blockIdx.x & 7);
+        rem_r = wave < 4 ? (u < 64 ? 64 * g8 + u : 512 + 64 * g8 + (u - 64)) : a.rem_pairs;
+    }
     const bool has_rem = rem_r < a.rem_pairs;
     const int run = (gw < W ? kf : 0) + (has_rem ? 1 : 0);       // <= GEMV_MAX_RUN (host-checked)
     const int last_pair = kf * W + rem_r;                        // local pair kf, when has_rem
@@ -694,6 +714,51 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         a.prof[8] = ts_entry, a.prof[9] = ts_args, a.prof[10] = ts_x, a.prof[11] = ts_b1, a.prof[12] = ts_staged, a.prof[13] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (FUSE) {
+        static_assert(EPI == EPI_ROPE_KV && FMT == FMT_W4S, "the seam follows the q|k|v epilogue");
+        const int c = blockIdx.x & 7, j = blockIdx.x >> 3;
+        unsigned *cnt = a.seam + 32 * c, *gen = cnt + 16;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's q / k / v stores are in the XCD's L2
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // performed at the L2
+            if (old == 31u) {  // the group's last arrival: re-arm the counter for the next launch, then release
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        const int n_attn = 4 * a.attn.splits;  // attention workgroups of the group: one per (query head, split)
+        if (j < n_attn) {  // query head 4 c + (j & 3), split j >> 2 of kv-group c
+            auto seam_wait = [&]() {  // called by the attention body once its old K / V rows are in flight
+                if (threadIdx.x == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seam_gen0) {  // sc1: from the L2
+                        __builtin_amdgcn_s_sleep(0);
+                        if (++spins > (1u << 24)) {  // ~ seconds: the group is not co-resident (masked CUs?) -- say so and go on rather than hang the device
+                            a.seam[256] = 1u;
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+            };
+            // one head per workgroup (the launch form scores the group's four heads in one): 16 instead of 4 of the group's 32 workgroups share the
+            // post-seam work -- scoring 1.1 -> ~0.5 us on the critical path; a head's arithmetic does not depend on the grouping.
+            // (The K / V prefetch goes out before the wait; issued ahead of the weight stream it delayed the GEMV: 1.174 -> 1.195 ms.)
+            attn_decode_body<T, 128, 1, false, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);
+        } else if (a.attn.pf_rows > 0) {  // Infinity-Cache warm-up of o_proj (attention.hpp: AttnArgs::pf_ptr)
+            const unsigned nblk = 8u * (32u - (unsigned)n_attn), bid = (unsigned)c * (32u - (unsigned)n_attn) + (unsigned)(j - n_attn);
+            unsigned acc = 0;
+            const unsigned long long n16 = a.attn.pf_bytes >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.attn.pf_ptr);
+            for (unsigned long long i = (unsigned long long)bid * NT + threadIdx.x; i < n16; i += (unsigned long long)nblk * NT) {
+                const uint4 v = src[i];
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+            if (acc == 0x9e3779b9u) a.attn.pf_sink[0] = acc;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- a few activation rows against ONE pass over the weights

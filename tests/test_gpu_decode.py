@@ -209,6 +209,36 @@ def test_llama8b_shaped_layers_vs_oracle(dtype):
         + 2 * (2 * 4096 * 2 + 2 * 1024 * 2 * 128 + 2 * 1024 * 2) + (8192 * 4096 // 2 + 2 * (8192 * 4096 // 64) * 2) + 4096 * 2 + 8192 * 4
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dtype, knobs):
+    """32 / 8 / 128 heads (Llama-3-8B, Mistral-7B): the step's attention runs inside the q|k|v launch, behind an XCD-local seam (the rows of a
+    kv-group are computed by the 32 workgroups of one XCD, which hand q / k / v to the group's attention workgroups through that XCD's L2:
+    w4_gemv.hpp FUSE).  Same rows, same units, same order: knob fuse_attn = 0 (two launches) gives identical logits, caches and tokens, eagerly and
+    through the replayed graph, across a cache growth, and the graph holds one launch per layer less."""
+    cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 3, "intermediate_size": 14336,
+           "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
+           "quantization": {"group_size": 64, "bits": 4}}
+    w = po.synth_checkpoint(cfg, seed=3, dtype=dtype, lm_head_gain=4.0)
+    prompt = torch.from_numpy(np.random.default_rng(5).integers(0, cfg["vocab_size"], 250)).cuda()
+    runs = {}
+    for mode in (0, None):
+        knobs("fuse_attn", mode)
+        model = build(cfg, w, dtype)
+        cache = model.make_cache()
+        tok, _, logits = model.step(prompt, cache)
+        rows = [logits.clone()]
+        toks = [int(tok.item())]
+        for _ in range(12):          # 250 + 12 tokens: the cache grows from 256 to 512 rows on the way
+            tok, _, logits = model.step(tok, cache)
+            rows.append(logits.clone()), toks.append(int(tok.item()))
+        launches = model.graph_launches(True)
+        runs[mode] = (torch.stack(rows), toks, cache[0].keys.clone(), cache[2].values.clone(), launches)
+    a, b = runs[0], runs[None]
+    assert a[1] == b[1] and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert a[4] - b[4] == cfg["num_hidden_layers"], (a[4], b[4])
+
+
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
 def test_tinyllama_shaped_layers_vs_oracle(dtype):
     """BASELINE.json configs[0] geometry (TinyLlama-1.1B: H=2048, I=5632 = 2.75 K-slices, 32/4 heads -> 8 q-heads per

@@ -344,6 +344,13 @@ int main(int argc, char **argv) {
             }
         }
         const unsigned long long *q = t + 2;
+        if (!q[0] && q[1] && t[16]) {  // the attention ran behind the q|k|v launch's seam: one timeline, from that launch's start (workgroup 0 = kv-group 0, split 0)
+            const unsigned long long s0 = t[16];
+            printf("fused q|k|v + attention, workgroup 0, us after its start: x staged %.2f | stream done %.2f | epilogue done %.2f | position read %.2f | released %.2f | "
+                   "K/V rows + q landed %.2f | scoring done %.2f | streams in LDS %.2f | barrier %.2f | partials stored %.2f\n",
+                   (t[17] - s0) * 0.01, (t[18] - s0) * 0.01, (t[19] - s0) * 0.01, (q[1] - s0) * 0.01, (q[7] - s0) * 0.01, (q[2] - s0) * 0.01, (q[3] - s0) * 0.01, (q[4] - s0) * 0.01,
+                   (q[5] - s0) * 0.01, (q[6] - s0) * 0.01);
+        }
         if (q[0] && q[6] > q[0])
             printf("attention launch, workgroup (0,0,0), us after its start: position arrived %.2f | first K/V rows %.2f | scoring done %.2f | wave merge %.2f | "
                    "barrier %.2f | partials stored %.2f\n", (q[1] - q[0]) * 0.01, (q[2] - q[0]) * 0.01, (q[3] - q[0]) * 0.01, (q[4] - q[0]) * 0.01, (q[5] - q[0]) * 0.01,
