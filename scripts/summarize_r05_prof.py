@@ -37,13 +37,15 @@ def lin(n, k):
     return n * k // 2 + 2 * (n * k // 64) * 2
 
 
-alg = {"k_w4s_gemv<BF16, 1, 2, 1, 0, 0>": ("qkv: rmsnorm + GEMV + RoPE + cache append", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, L - 1),
-       "k_w4s_gemv<BF16, 3, 2, 1, 0, 0>": ("layer 0's qkv with the embedding row dequantised in its prologue", lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2, 1),
-       "k_attn_decode<BF16, 128, 4, false, false, 4>": ("split-KV attention (cache capacity 512: partials merged by o_proj) + the Infinity-Cache warm-up of o_proj on its idle CUs", 2 * KVD * 2 * T, L),
-       "k_w4s_gemv<BF16, 2, 1, 1, 0, 0>": ("o_proj: split merge + GEMV + residual", lin(H, QD), L),
-       "k_w4s_gemv<BF16, 1, 3, 1, 0, 0>": ("gate/up: rmsnorm + GEMV + SwiGLU", lin(2 * I, H) + H * 2, L),
-       "k_w4s_gemv<BF16, 0, 1, 4, 0, 0>": ("down: GEMV + residual", lin(H, I), L),
-       "k_w4s_gemv<BF16, 1, 4, 1, 0, 0>": ("lm_head: rmsnorm + GEMV + log-softmax partials", lin(V, H) + H * 2, 1),
+QKV = lin(QD + 2 * KVD, H) + H * 2 + 2 * KVD * 2
+ATT = 2 * KVD * 2 * T  # the K and V rows of the context
+alg = {"k_w4s_gemv<BF16, 1, 2, 1, 0, 0, 1>": ("qkv: rmsnorm + GEMV + RoPE + cache append, then -- behind the XCD-local seam of the same launch -- the split-KV attention (partials merged by o_proj) "
+                                               "and the Infinity-Cache warm-up of o_proj on the workgroups that do neither", QKV + ATT, L - 1),
+       "k_w4s_gemv<BF16, 3, 2, 1, 0, 0, 1>": ("layer 0's qkv + attention with the embedding row dequantised in its prologue", QKV + ATT, 1),
+       "k_w4s_gemv<BF16, 2, 1, 1, 0, 0, 0>": ("o_proj: split merge + GEMV + residual", lin(H, QD), L),
+       "k_w4s_gemv<BF16, 1, 3, 1, 0, 0, 0>": ("gate/up: rmsnorm + GEMV + SwiGLU", lin(2 * I, H) + H * 2, L),
+       "k_w4s_gemv<BF16, 0, 1, 4, 0, 0, 0>": ("down: GEMV + residual", lin(H, I), L),
+       "k_w4s_gemv<BF16, 1, 4, 1, 0, 0, 0>": ("lm_head: rmsnorm + GEMV + log-softmax partials", lin(V, H) + H * 2, 1),
        "k_logits_finish<BF16>": ("tail: log-softmax + argmax", V * 4, 1)}
 f, w = counters("step_fetch"), counters("step_write")
 
@@ -66,7 +68,7 @@ for key, (what, a, per_step) in alg.items():
                  "FETCH_SIZE_KB": round(fk / 2048, 2), "WRITE_SIZE_KB": round(wk / 1024, 2), "ratio": round((fk + wk) / a, 4)}
     step_meas += (fk + wk) * per_step
     step_alg += a * per_step
-gu = rows["k_w4s_gemv<BF16, 1, 3, 1, 0, 0>"]
+gu = rows["k_w4s_gemv<BF16, 1, 3, 1, 0, 0, 0>"]
 out = {"library": version, "kernel": "k_w4s_gemv<BF16, rmsnorm, swiglu> (gate/up, N=28672 K=4096)", "hbm_bytes_per_launch": gu["hbm_bytes_per_launch"],
        "algorithmic_bytes_per_launch": gu["algorithmic_bytes"], "FETCH_SIZE_KB": gu["FETCH_SIZE_KB"], "WRITE_SIZE_KB": gu["WRITE_SIZE_KB"],
        "step": {"hbm_bytes": int(step_meas), "algorithmic_bytes": int(step_alg), "ratio": round(step_meas / step_alg, 4), "context": T},
