@@ -357,7 +357,9 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
 /* Decoder options.  PIE_OPT_KV_I8 = 1: the slabs handed to pie_decoder_step_batch / pie_decoder_prefill_batch hold int8 pages (PIE_I8 pools,
  * pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back.  Changing an option drops the
  * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of a bounded wait of the tensor-parallel collectives in
- * *error (0 = none; sticky; that step's token is -1). */
+ * *error (0 = none; sticky; that step's token is -1); bit 31: the fused q|k|v + attention launch (32 / 8 / 128 head geometry, PIE_KNOB_FUSE_ATTN) gave up
+ * waiting for its kv-group -- its 256 workgroups have to be co-resident, which holds for up to two such launches at a time on a full device; a process
+ * that overlaps three or more decode streams on one GPU, or masks CUs, sets PIE_KNOB_FUSE_ATTN = 0 (results after a give-up are not valid). */
 enum { PIE_OPT_KV_I8 = 2 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);

@@ -189,6 +189,7 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs &a, const int g,
         // Before the seam NO lane may touch the row this launch writes (position Ttot - 1) -- not even a clamped, discarded load: it would park a
         // stale line of that row in this CU's L1, and the real load after the seam would hit it.  Such lanes read the row before it (an empty
         // cache: the buffer's last row); the one valid lane is loaded again behind the seam.
+        // (PAGED: the page id stays the clamped row's -- any row of any of the sequence's pages will do, as long as it is not row (Ttot - 1) % 64 of its page)
         if (HAS_SEAM && before_seam && t >= Ttot - 1) t = Ttot >= 2 ? Ttot - 2 : cap - 1;
         if constexpr (PAGED) {
             const size_t off = (size_t)pgq[d] * page_elems + (size_t)(t & 63) * D;
@@ -207,7 +208,6 @@ __device__ __forceinline__ void attn_decode_body(const AttnArgs &a, const int g,
 #pragma unroll
     for (int d = 0; d < DA; ++d) issue(d, d);
     if constexpr (HAS_SEAM) {
-        static_assert(!PAGED, "the seam form is built for the contiguous cache");
         // the rows cached by earlier steps are on their way; now wait for this step's q / k / v, then fetch the one row of the ring that was
         // written in this launch (position Ttot - 1, if this split holds it and it sits in the first DA blocks)
         seam();

@@ -106,11 +106,11 @@ static bool xcd_classes_hold() {
 }
 
 // The step's attention inside the q|k|v launch (w4_gemv.hpp, FUSE): the 32 / 8 / 128 head geometry (kv-group = XCD class), int4 g=64 q|k|v,
-// the short-cache plan on a contiguous cache, one GPU.  Knob PIE_KNOB_FUSE_ATTN = 0 keeps the two launches (bit-identical; the tests' cross-check).
+// the short-cache plan on a contiguous or T-page cache (not int8 pages), one GPU.  Knob PIE_KNOB_FUSE_ATTN = 0 keeps the two launches (bit-identical; the tests' cross-check).
 static bool fuse_attn(const pie_decoder *d, int li) {
     const pie_decoder_config &c = d->cfg;
     if (pie_knob(PIE_KNOB_FUSE_ATTN) == 0 || !d->xcd_ok || !d->seam) return false;
-    return !d->tp() && !d->combine && !d->block_table && !d->kv_i8 && c.n_heads == 32 && c.n_kv_heads == 8 && c.head_dim == 128 && c.hidden <= 4096 &&
+    return !d->tp() && !d->combine && !(d->kv_i8 && d->block_table) && c.n_heads == 32 && c.n_kv_heads == 8 && c.head_dim == 128 && c.hidden <= 4096 &&
            d->mat_fmt(d->layers[li].wqkv) == PIE_W_INT4_G64 && d->splits >= 1 && d->splits <= 4;
 }
 
@@ -647,7 +647,13 @@ int pie_decoder_status(pie_decoder *d, unsigned *error) {
     PIE_REQUIRE(d && error, PIE_E_ARG, "pie_decoder_status: null pointer");
     PIE_HIP_TRY(hipDeviceSynchronize());
     *error = 0;
-    return d->comm ? pie_comm_status(d->comm, error) : PIE_OK;
+    const int rc = d->comm ? pie_comm_status(d->comm, error) : PIE_OK;
+    if (!rc && d->seam) {  // the fused q|k|v + attention launch: a kv-group's workgroups were not co-resident within its bounded wait (w4_gemv.hpp, FUSE)
+        unsigned gave_up = 0;
+        PIE_HIP_TRY(hipMemcpy(&gave_up, d->seam + 256, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (gave_up) *error |= 0x80000000u;
+    }
+    return rc;
 }
 
 static size_t lin_bytes(const pie_decoder *d, const void *m, size_t n, size_t k) {  // algorithmic bytes of one Linear's weights

@@ -746,7 +746,8 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             // one head per workgroup (the launch form scores the group's four heads in one): 16 instead of 4 of the group's 32 workgroups share the
             // post-seam work -- scoring 1.1 -> ~0.5 us on the critical path; a head's arithmetic does not depend on the grouping.
             // (The K / V prefetch goes out before the wait; issued ahead of the weight stream it delayed the GEMV: 1.174 -> 1.195 ms.)
-            attn_decode_body<T, 128, 1, false, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);
+            if (a.attn.block_table) attn_decode_body<T, 128, 1, true, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);  // T pages (uniform)
+            else attn_decode_body<T, 128, 1, false, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);
         } else if (a.attn.pf_rows > 0) {  // Infinity-Cache warm-up of o_proj (attention.hpp: AttnArgs::pf_ptr)
             const unsigned nblk = 8u * (32u - (unsigned)n_attn), bid = (unsigned)c * (32u - (unsigned)n_attn) + (unsigned)(j - n_attn);
             unsigned acc = 0;

@@ -215,6 +215,8 @@ def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dt
     kv-group are computed by the 32 workgroups of one XCD, which hand q / k / v to the group's attention workgroups through that XCD's L2:
     w4_gemv.hpp FUSE).  Same rows, same units, same order: knob fuse_attn = 0 (two launches) gives identical logits, caches and tokens, eagerly and
     through the replayed graph, across a cache growth, and the graph holds one launch per layer less."""
+    import ctypes as C
+    from proxy_inference_engine_amd import _ffi
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 3, "intermediate_size": 14336,
            "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
            "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
@@ -234,9 +236,29 @@ def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dt
             rows.append(logits.clone()), toks.append(int(tok.item()))
         launches = model.graph_launches(True)
         runs[mode] = (torch.stack(rows), toks, cache[0].keys.clone(), cache[2].values.clone(), launches)
+        err = C.c_uint(1)
+        _ffi.check(_ffi.load().pie_decoder_status(model._dec, C.byref(err)))
+        assert err.value == 0                                            # no bounded wait of the seam ever gave up
     a, b = runs[0], runs[None]
     assert a[1] == b[1] and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     assert a[4] - b[4] == cfg["num_hidden_layers"], (a[4], b[4])
+    # ... and on scattered 64-token T pages (the seam form of the paged attention body): across page boundaries, same logits as the contiguous cache
+    paged = {}
+    for mode in (0, None):
+        knobs("fuse_attn", mode)
+        model = build(cfg, w, dtype)
+        pool = model.enable_paged_kv(num_pages=16, max_blocks=8)
+        for _ in range(3):
+            pool.allocate_page()
+        pool.free_page(1)
+        cache = model.make_cache()
+        tok, _, logits = model.step(prompt[:120], cache)
+        rows = [logits.clone()]
+        for _ in range(12):          # positions 120 .. 131: the step at 128 opens a new page
+            tok, _, logits = model.step(tok, cache)
+            rows.append(logits.clone())
+        paged[mode] = (torch.stack(rows), model.graph_launches(True))
+    assert torch.equal(paged[0][0], paged[None][0]) and paged[0][1] - paged[None][1] == cfg["num_hidden_layers"]
 
 
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
