@@ -358,8 +358,9 @@ size_t pie_decoder_step_bytes(const pie_decoder *d, int T, int with_logits);
  * pie_paged_*_i8 below): new rows are quantised with their page's scales, the step's attention reads them back.  Changing an option drops the
  * captured graphs.  pie_decoder_status: synchronises the device and reports a give-up of a bounded wait of the tensor-parallel collectives in
  * *error (0 = none; sticky; that step's token is -1); bit 31: the fused q|k|v + attention launch (32 / 8 / 128 head geometry, PIE_KNOB_FUSE_ATTN) gave up
- * waiting for its kv-group -- its 256 workgroups have to be co-resident, which holds for up to two such launches at a time on a full device; a process
- * that overlaps three or more decode streams on one GPU, or masks CUs, sets PIE_KNOB_FUSE_ATTN = 0 (results after a give-up are not valid). */
+ * waiting for its kv-group (the producers of a group must get dispatched while its <= 128 attention workgroups spin: guaranteed for up to five such
+ * launches in flight on a full device; the library fuses only while a process holds at most four decoders; a process that masks CUs sets
+ * PIE_KNOB_FUSE_ATTN = 0).  Results after a give-up are not valid. */
 enum { PIE_OPT_KV_I8 = 2 };
 int pie_decoder_configure(pie_decoder *d, int option, int value);
 int pie_decoder_status(pie_decoder *d, unsigned *error);

@@ -5,6 +5,7 @@
 //
 // Launches per step: embed | per layer { rmsnorm+qkv+rope+append, split-KV attention, [combine: caches beyond 1024
 // positions only], merge+o_proj+residual, rmsnorm+gate/up+swiglu, down+residual } | rmsnorm+lm_head(+wave stats) | finish.
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -107,9 +108,13 @@ static bool xcd_classes_hold() {
 
 // The step's attention inside the q|k|v launch (w4_gemv.hpp, FUSE): the 32 / 8 / 128 head geometry (kv-group = XCD class), int4 g=64 q|k|v,
 // the short-cache plan on a contiguous or T-page cache (not int8 pages), one GPU.  Knob PIE_KNOB_FUSE_ATTN = 0 keeps the two launches (bit-identical; the tests' cross-check).
+// The fused launch's attention workgroups spin until their kv-group has arrived.  They are the last-dispatched half of the grid, the other half leaves
+// after arriving, so a launch holds at most 128 workgroup slots while it waits and the chip has 768 for this kernel: up to five such launches in flight
+// cannot starve each other's producers.  A process that holds more than four live decoders gets the two-launch form (captured graphs follow at their next step).
+static std::atomic<int> g_live_decoders{0};
 static bool fuse_attn(const pie_decoder *d, int li) {
     const pie_decoder_config &c = d->cfg;
-    if (pie_knob(PIE_KNOB_FUSE_ATTN) == 0 || !d->xcd_ok || !d->seam) return false;
+    if (pie_knob(PIE_KNOB_FUSE_ATTN) == 0 || !d->xcd_ok || !d->seam || g_live_decoders.load() > 4) return false;
     return !d->tp() && !d->combine && !(d->kv_i8 && d->block_table) && c.n_heads == 32 && c.n_kv_heads == 8 && c.head_dim == 128 && c.hidden <= 4096 &&
            d->mat_fmt(d->layers[li].wqkv) == PIE_W_INT4_G64 && d->splits >= 1 && d->splits <= 4;
 }
@@ -325,6 +330,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_ALLOC(d->pf_sink, 8192);  // the developer builds' stamps (-DPIE_ATTN_PROF: words 2..9; -DPIE_GEMV_PROF: 16 + 4 kind ..)
     PIE_ALLOC(d->seam, 2048);     // 8 x {counter, generation} 64 bytes apart, [256] the give-up flag
     d->xcd_ok = xcd_classes_hold();
+    ++g_live_decoders;
     if (d->tp()) PIE_ALLOC(d->tp_part, sizeof(float) * ((size_t)c.hidden + 4));  // RCCL backend: the fp32 partial; [hidden]: the step's log-sum-exp
 #undef PIE_ALLOC
     plan_attention(d);
@@ -334,6 +340,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
 
 int pie_decoder_destroy(pie_decoder *d) {
     if (!d) return PIE_OK;
+    if (d->seam) --g_live_decoders;  // (counted once the seam buffer exists: a create that failed earlier never was)
     drop_graphs(d);
     prefill_free(d);
     void *ptrs[] = {d->state, d->kv_table, d->qbuf, d->attn, d->act, d->part_acc, d->part_ml, d->stats, d->rope_cs, d->pf_sink, d->seam, d->tp_part, d->kv_stage, d->kv_table_stage,
@@ -488,7 +495,9 @@ int pie_decoder_step(pie_decoder *d, int flags, void *stream) {
     const bool with_logits = (flags & PIE_STEP_LOGITS) != 0;
     if (!(flags & PIE_STEP_GRAPH)) return enqueue_step(d, &d->state->token, with_logits, d->logits, st);
     const int gi = with_logits ? 1 : 0;
+    if (d->graph[gi] && d->graph_fused[gi] && !fuse_attn(d, 0)) drop_graphs(d);  // fusion was withdrawn (knob, a third live decoder): capture the two-launch form
     if (!d->graph[gi]) {
+        d->graph_fused[gi] = fuse_attn(d, 0);
         if (d->graph[gi]) {
             (void)hipGraphExecDestroy(d->graph[gi]);
             d->graph[gi] = nullptr;

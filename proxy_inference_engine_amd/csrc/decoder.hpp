@@ -49,6 +49,7 @@ struct pie_decoder {
     std::vector<const void *> slab_host;           // the layers' slab bases (host copy of kv_table's first half)
     hipGraphExec_t graph[2] = {nullptr, nullptr};  // [with_logits]
     int graph_kernels[2] = {-1, -1};                // kernel nodes of each captured graph (hipGraphGetNodes)
+    bool graph_fused[2] = {false, false};           // the captured graph holds the fused q|k|v + attention launch (re-captured when fusion is withdrawn)
     struct PrefillScratch *prefill = nullptr;       // batched prompt processing (prefill.hip), allocated on first use
     // tensor parallelism (cfg.tp_world > 1): this decoder is one rank's shard; comm is caller-owned (pie_decoder_set_comm)
     pie_comm *comm = nullptr;

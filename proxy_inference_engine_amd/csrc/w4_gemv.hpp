@@ -728,8 +728,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        const int n_attn = 4 * a.attn.splits;  // attention workgroups of the group: one per (query head, split)
-        if (j < n_attn) {  // query head 4 c + (j & 3), split j >> 2 of kv-group c
+        // attention workgroups of the group: one per (query head, split) -- the LAST ones of the class: workgroups are dispatched in index order, so when
+        // one of them spins every lower-indexed workgroup of the launch is already running (and will arrive and leave); the slots a launch can hold while
+        // it waits are its <= 128 attention workgroups, and five such launches still leave the dispatcher room (3 workgroups of this kernel per CU)
+        const int n_attn = 4 * a.attn.splits, ja = j - (32 - n_attn);
+        if (ja >= 0) {  // query head 4 c + (ja & 3), split ja >> 2 of kv-group c
             auto seam_wait = [&]() {  // called by the attention body once its old K / V rows are in flight
                 if (threadIdx.x == 0) {
                     unsigned spins = 0;
@@ -746,10 +749,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             // one head per workgroup (the launch form scores the group's four heads in one): 16 instead of 4 of the group's 32 workgroups share the
             // post-seam work -- scoring 1.1 -> ~0.5 us on the critical path; a head's arithmetic does not depend on the grouping.
             // (The K / V prefetch goes out before the wait; issued ahead of the weight stream it delayed the GEMV: 1.174 -> 1.195 ms.)
-            if (a.attn.block_table) attn_decode_body<T, 128, 1, true, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);  // T pages (uniform)
-            else attn_decode_body<T, 128, 1, false, false, 4>(a.attn, c, j >> 2, 0, 4 * c + (j & 3), seam_wait);
+            if (a.attn.block_table) attn_decode_body<T, 128, 1, true, false, 4>(a.attn, c, ja >> 2, 0, 4 * c + (ja & 3), seam_wait);  // T pages (uniform)
+            else attn_decode_body<T, 128, 1, false, false, 4>(a.attn, c, ja >> 2, 0, 4 * c + (ja & 3), seam_wait);
         } else if (a.attn.pf_rows > 0) {  // Infinity-Cache warm-up of o_proj (attention.hpp: AttnArgs::pf_ptr)
-            const unsigned nblk = 8u * (32u - (unsigned)n_attn), bid = (unsigned)c * (32u - (unsigned)n_attn) + (unsigned)(j - n_attn);
+            const unsigned nblk = 8u * (32u - (unsigned)n_attn), bid = (unsigned)c * (32u - (unsigned)n_attn) + (unsigned)j;
             unsigned acc = 0;
             const unsigned long long n16 = a.attn.pf_bytes >> 4;
             const uint4 *src = reinterpret_cast<const uint4 *>(a.attn.pf_ptr);
