@@ -259,6 +259,26 @@ def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dt
             rows.append(logits.clone())
         paged[mode] = (torch.stack(rows), model.graph_launches(True))
     assert torch.equal(paged[0][0], paged[None][0]) and paged[0][1] - paged[None][1] == cfg["num_hidden_layers"]
+    # ... and the library withdraws the fusion (and re-captures the graph) while the process holds more than four decoders: a waiting launch must
+    # never starve another launch's producers
+    knobs("fuse_attn", None)
+    import gc
+    gc.collect()
+    model = build(cfg, w, dtype)
+    cache = model.make_cache()
+    tok, _, _ = model.step(prompt[:40], cache)
+    for _ in range(3):
+        tok, _, _ = model.step(tok, cache)
+    fused_launches = model.graph_launches(True)
+    small = dict(cfg, hidden_size=256, intermediate_size=512, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=1, vocab_size=512)
+    ws = po.synth_checkpoint(small, seed=1, dtype=dtype)
+    crowd = [build(small, ws, dtype) for _ in range(5)]
+    tok, _, la = model.step(tok, cache)
+    crowded_launches = model.graph_launches(True)
+    del crowd
+    gc.collect()
+    assert crowded_launches - fused_launches in (0, cfg["num_hidden_layers"])   # (0: other tests' models already crowded the process)
+    assert crowded_launches == a[4]                                                # the two-launch graph
 
 
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
