@@ -205,6 +205,8 @@ int pie_sample(const float *logprobs, int rows, int V, int mode, double temp, do
  * (engine/inference_engine.py:252-271) with the greedy sampler, as 5 launches per layer (6 beyond 1024 positions):
  *   rmsnorm+qkv GEMV+RoPE+cache append | split-KV attention | [combine] | split merge+o_proj+residual |
  *   rmsnorm+gate/up GEMV+SwiGLU | down_proj+residual ; then rmsnorm+lm_head ; log-softmax+argmax.
+ * 4 per layer for models with 32 query / 8 kv heads of 128 and hidden <= 4096 (Llama-3-8B, Mistral-7B; any weight format) on a contiguous or T-page cache up to 1024 positions: the
+ * attention then runs inside the q|k|v launch, behind an XCD-local seam (PIE_KNOB_FUSE_ATTN; bit-identical).
  * Position and token live in device memory so the captured hipGraph is replayable. */
 typedef struct pie_decoder pie_decoder;
 

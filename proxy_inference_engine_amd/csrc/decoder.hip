@@ -5,6 +5,8 @@
 //
 // Launches per step: embed | per layer { rmsnorm+qkv+rope+append, split-KV attention, [combine: caches beyond 1024
 // positions only], merge+o_proj+residual, rmsnorm+gate/up+swiglu, down+residual } | rmsnorm+lm_head(+wave stats) | finish.
+// (The embedding rides in layer 0's q|k|v launch for int4 models; for the 32 / 8 / 128 head geometry the attention rides in every q|k|v launch,
+// behind an XCD-local seam: fuse_attn() below.)
 #include <atomic>
 #include <cstring>
 #include <new>
@@ -106,7 +108,7 @@ static bool xcd_classes_hold() {
     return ok;
 }
 
-// The step's attention inside the q|k|v launch (w4_gemv.hpp, FUSE): the 32 / 8 / 128 head geometry (kv-group = XCD class), int4 g=64 q|k|v,
+// The step's attention inside the q|k|v launch (w4_gemv.hpp, FUSE): the 32 / 8 / 128 head geometry (kv-group = XCD class), any weight format,
 // the short-cache plan on a contiguous or T-page cache (not int8 pages), one GPU.  Knob PIE_KNOB_FUSE_ATTN = 0 keeps the two launches (bit-identical; the tests' cross-check).
 // The fused launch's attention workgroups spin until their kv-group has arrived.  They are the last-dispatched half of the grid, the other half leaves
 // after arriving, so a launch holds at most 128 workgroup slots while it waits and the chip has 768 for this kernel: up to five such launches in flight
@@ -115,8 +117,9 @@ static std::atomic<int> g_live_decoders{0};
 static bool fuse_attn(const pie_decoder *d, int li) {
     const pie_decoder_config &c = d->cfg;
     if (pie_knob(PIE_KNOB_FUSE_ATTN) == 0 || !d->xcd_ok || !d->seam || g_live_decoders.load() > 4) return false;
+    (void)li;  // (any weight format of the q|k|v matrix)
     return !d->tp() && !d->combine && !(d->kv_i8 && d->block_table) && c.n_heads == 32 && c.n_kv_heads == 8 && c.head_dim == 128 && c.hidden <= 4096 &&
-           d->mat_fmt(d->layers[li].wqkv) == PIE_W_INT4_G64 && d->splits >= 1 && d->splits <= 4;
+           d->splits >= 1 && d->splits <= 4;
 }
 
 // What the step's attention launch is given (contiguous or T-page cache, not the int8 pages)

@@ -356,20 +356,24 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs - a.full_rounds * a.n_waves;
     a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (int)grid.x : 0;  // whole workgroups only: every wave that gets a leftover pair also has a slot in stats[]
     if (a.fuse) {  // the q|k|v launch with the step's attention behind an XCD-local seam (w4_gemv.hpp, FUSE)
-        PIE_REQUIRE(epi == EPI_ROPE_KV && (pro == PRO_RMSNORM || pro == PRO_EMBED) && a.fmt == FMT_W4S && M == 1 && a.seam && a.block_table == a.attn.block_table, PIE_E_ARG,
-                    "w4s_gemv: the fused attention follows an int4 q|k|v launch on the same (contiguous or T-page) cache");
+        PIE_REQUIRE(epi == EPI_ROPE_KV && (pro == PRO_RMSNORM || (pro == PRO_EMBED && a.fmt == FMT_W4S)) && M == 1 && a.seam && a.block_table == a.attn.block_table, PIE_E_ARG,
+                    "w4s_gemv: the fused attention follows a q|k|v launch on the same (contiguous or T-page) cache");
         PIE_REQUIRE(a.n_heads == 32 && a.n_kv_heads == 8 && a.head_dim == 128 && grid.x == 256 && a.n_waves == 2048 && a.full_rounds == 1 && a.rem_pairs == 1024 &&
                         a.attn.splits >= 1 && a.attn.splits <= 4 && a.attn.Hq == 32 && a.attn.Hkv == 8 && a.attn.part_acc && a.attn.part_ml && a.attn.q,
                     PIE_E_SHAPE, "w4s_gemv: the fused attention is built for 32 query heads and 8 kv heads of 128 (kv-group = XCD)");
         PIE_REQUIRE(a.K <= 8 * GEMV_WAVES * 64, PIE_E_SHAPE, "w4s_gemv: the fused attention takes hidden sizes up to 4096");
-#define PIE_FUSE_GO(TT, PRO_) hipLaunchKernelGGL((k_w4s_gemv<TT, PRO_, EPI_ROPE_KV, 1, 0, FMT_W4S, 1>), grid, dim3(GEMV_WAVES * 64), lds, stream, a)
-        if (dtype == PIE_BF16) {
-            if (pro == PRO_EMBED) PIE_FUSE_GO(BF16, PRO_EMBED);
-            else PIE_FUSE_GO(BF16, PRO_RMSNORM);
-        } else if (dtype == PIE_F16) {
-            if (pro == PRO_EMBED) PIE_FUSE_GO(F16, PRO_EMBED);
-            else PIE_FUSE_GO(F16, PRO_RMSNORM);
-        } else return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
+#define PIE_FUSE_GO(TT, PRO_, FMT_) hipLaunchKernelGGL((k_w4s_gemv<TT, PRO_, EPI_ROPE_KV, 1, 0, FMT_, 1>), grid, dim3(GEMV_WAVES * 64), lds, stream, a)
+#define PIE_FUSE_FMT(TT)                                                  \
+    if (pro == PRO_EMBED) PIE_FUSE_GO(TT, PRO_EMBED, FMT_W4S);            \
+    else if (a.fmt == FMT_W16S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W16S);   \
+    else if (a.fmt == FMT_W8S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W8S);     \
+    else if (a.fmt == FMT_W4S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S32); \
+    else if (a.fmt == FMT_W8S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W8S32); \
+    else PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S)
+        if (dtype == PIE_BF16) { PIE_FUSE_FMT(BF16); }
+        else if (dtype == PIE_F16) { PIE_FUSE_FMT(F16); }
+        else return pie::fail(PIE_E_ARG, "w4s_gemv: dtype must be PIE_BF16 or PIE_F16");
+#undef PIE_FUSE_FMT
 #undef PIE_FUSE_GO
         PIE_LAUNCH_CHECK();
         return PIE_OK;

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         a.prof[8] = ts_entry, a.prof[9] = ts_args, a.prof[10] = ts_x, a.prof[11] = ts_b1, a.prof[12] = ts_staged, a.prof[13] = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (FUSE) {
-        static_assert(EPI == EPI_ROPE_KV && FMT == FMT_W4S, "the seam follows the q|k|v epilogue");
+        static_assert(EPI == EPI_ROPE_KV, "the seam follows the q|k|v epilogue");
         const int c = blockIdx.x & 7, j = blockIdx.x >> 3;
         unsigned *cnt = a.seam + 32 * c, *gen = cnt + 16;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's q / k / v stores are in the XCD's L2

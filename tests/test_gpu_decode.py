@@ -209,8 +209,9 @@ def test_llama8b_shaped_layers_vs_oracle(dtype):
         + 2 * (2 * 4096 * 2 + 2 * 1024 * 2 * 128 + 2 * 1024 * 2) + (8192 * 4096 // 2 + 2 * (8192 * 4096 // 64) * 2) + 4096 * 2 + 8192 * 4
 
 
-@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dtype, knobs):
+@pytest.mark.parametrize("dtype,quant", [("bfloat16", {"group_size": 64, "bits": 4}), ("float16", {"group_size": 64, "bits": 4}), ("bfloat16", None),
+                                         ("bfloat16", {"group_size": 64, "bits": 8}), ("float16", {"group_size": 32, "bits": 4})])
+def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dtype, quant, knobs):
     """32 / 8 / 128 heads (Llama-3-8B, Mistral-7B): the step's attention runs inside the q|k|v launch, behind an XCD-local seam (the rows of a
     kv-group are computed by the 32 workgroups of one XCD, which hand q / k / v to the group's attention workgroups through that XCD's L2:
     w4_gemv.hpp FUSE).  Same rows, same units, same order: knob fuse_attn = 0 (two launches) gives identical logits, caches and tokens, eagerly and
@@ -219,8 +220,9 @@ def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dt
     from proxy_inference_engine_amd import _ffi
     cfg = {"model_type": "llama", "hidden_size": 4096, "num_hidden_layers": 3, "intermediate_size": 14336,
            "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "vocab_size": 8192,
-           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False,
-           "quantization": {"group_size": 64, "bits": 4}}
+           "rope_theta": 500000.0, "max_position_embeddings": 8192, "tie_word_embeddings": False}
+    if quant:                        # int4 g=64 (the metric's format), dense 16-bit, int8, int4 g=32: every streaming format of the q|k|v matrix
+        cfg["quantization"] = quant
     w = po.synth_checkpoint(cfg, seed=3, dtype=dtype, lm_head_gain=4.0)
     prompt = torch.from_numpy(np.random.default_rng(5).integers(0, cfg["vocab_size"], 250)).cuda()
     runs = {}
