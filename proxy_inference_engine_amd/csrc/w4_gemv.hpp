@@ -99,7 +99,7 @@ struct GemvArgs {
     // FUSE (EPI_ROPE_KV, the 32 / 8 / 128 head geometry): the step's attention runs behind an XCD-local seam of this launch
     int fuse;             // launcher: take the FUSE instantiation
     AttnArgs attn;        // what k_attn_decode would be launched with
-    unsigned *seam;       // per XCD class c: arrival counter at [32 c], generation at [32 c + 16]; [256]: a spin gave up (never, unless CUs are masked)
+    unsigned *seam;       // per XCD class c: a monotonic arrival counter at [32 c] (+32 per launch); [256]: a spin gave up (never, unless CUs are masked)
 };
 
 // out[0..8) = T(scale * q + bias) of one code word: separate multiply and add roundings, like the oracle (mx.dequantize)
@@ -263,8 +263,8 @@ __device__ __forceinline__ float lane_value(float v, int lane) {  // wave-unifor
 // FUSE (round 5; q|k|v of a model with 32 query heads, 8 kv heads of 128: Llama-3-8B, Mistral-7B): the rows of kv-group g -- its 4 q heads, its
 // k and its v head -- are computed by the 32 workgroups with blockIdx.x % 8 == g, which the dispatcher places on ONE XCD (tools/pilot_probe,
 // checked again at decoder creation), and the step's attention for that group runs in the same launch: stores are write-through to the XCD's
-// L2, every workgroup adds 1 to its XCD's counter (an atomic performed AT that L2: no release fence), the last arriver bumps a generation
-// word, and the group's `splits` attention workgroups poll it with sc1 loads and then run k_attn_decode's body (no acquire fence: the CU's L1
+// L2, every workgroup adds 1 to its XCD's counter (an atomic performed AT that L2: no release fence; the counter only grows, 32 per
+// launch), and the group's attention workgroups poll it with sc1 loads and then run k_attn_decode's body (no acquire fence: the CU's L1
 // was invalidated at launch and has not seen these lines).  tools/seam_probe: 0.12 us from the last arrival to the release, 0.96 us until 32 KB
 // of the group's fresh data are read -- against 3.9 us for a dependent launch.  The other 28 workgroups of the XCD warm the Infinity Cache
 // with o_proj's weights (what the attention launch's idle workgroups did).  Same rows, same units, same order: bit-identical to two launches.
@@ -304,8 +304,10 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     const int bx = FUSE ? (int)((blockIdx.x & 7) * 32 + (blockIdx.x >> 3)) : (int)blockIdx.x;
     const int gw = bx * GEMV_WAVES + wave;
     const int W = a.n_waves;
-    unsigned seam_gen0 = 0;
-    if (FUSE && threadIdx.x == 0) seam_gen0 = __hip_atomic_load(a.seam + 32 * (blockIdx.x & 7) + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // before this workgroup arrives
+    // the XCD's arrival counter only ever grows, by 32 per launch: whatever this workgroup reads here (before it arrives) lies in [32 k, 32 k + 31], and the
+    // launch is complete at 32 (k + 1)
+    unsigned seam_target = 0;
+    if (FUSE && threadIdx.x == 0) seam_target = (__hip_atomic_load(a.seam + 32 * (blockIdx.x & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~31u) + 32u;
     // The pairs that do not fill a whole round of W waves are dealt over the WORKGROUPS, not over the first waves: q|k|v of the 8B
     // model is 3072 pairs on 2048 waves, and with the leftover 1024 on waves 0..1023 half of the CUs streamed twice what the other half
     // did (a launch lasts as long as its busiest CU's ingest).  Leftover pair r goes to wave r / n_blocks of workgroup r % n_blocks.
@@ -717,17 +719,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     if constexpr (FUSE) {
         static_assert(EPI == EPI_ROPE_KV, "the seam follows the q|k|v epilogue");
         const int c = blockIdx.x & 7, j = blockIdx.x >> 3;
-        unsigned *cnt = a.seam + 32 * c, *gen = cnt + 16;
+        unsigned *cnt = a.seam + 32 * c;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's q / k / v stores are in the XCD's L2
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // performed at the L2
-            if (old == 31u) {  // the group's last arrival: re-arm the counter for the next launch, then release
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        // the arrival: an atomic performed AT the L2, nothing returned, nothing re-armed -- the release is the 32nd add itself
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // attention workgroups of the group: one per (query head, split) -- the LAST ones of the class: workgroups are dispatched in index order, so when
         // one of them spins every lower-indexed workgroup of the launch is already running (and will arrive and leave); the slots a launch can hold while
         // it waits are its <= 128 attention workgroups, and five such launches still leave the dispatcher room (3 workgroups of this kernel per CU)
@@ -736,7 +732,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             auto seam_wait = [&]() {  // called by the attention body once its old K / V rows are in flight
                 if (threadIdx.x == 0) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seam_gen0) {  // sc1: from the L2
+                    while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seam_target) < 0) {  // sc1: from the L2
                         __builtin_amdgcn_s_sleep(0);
                         if (++spins > (1u << 24)) {  // ~ seconds: the group is not co-resident (masked CUs?) -- say so and go on rather than hang the device
                             a.seam[256] = 1u;
