@@ -261,6 +261,21 @@ def test_attention_behind_the_qkv_launch_seam_is_the_two_launches_bit_for_bit(dt
             rows.append(logits.clone())
         paged[mode] = (torch.stack(rows), model.graph_launches(True))
     assert torch.equal(paged[0][0], paged[None][0]) and paged[0][1] - paged[None][1] == cfg["num_hidden_layers"]
+    # ... with a pinned split count (1 / 2: four / eight attention workgroups per kv-group instead of sixteen)
+    if quant == {"group_size": 64, "bits": 4} and dtype == "bfloat16":
+        for splits in (1, 2):
+            pinned = {}
+            for mode in (0, None):
+                knobs("fuse_attn", mode)
+                model = build(cfg, w, dtype, kv_splits=splits)
+                cache = model.make_cache()
+                tok, _, logits = model.step(prompt[:70], cache)
+                rows = [logits.clone()]
+                for _ in range(6):
+                    tok, _, logits = model.step(tok, cache)
+                    rows.append(logits.clone())
+                pinned[mode] = (torch.stack(rows), model.graph_launches(True))
+            assert torch.equal(pinned[0][0], pinned[None][0]) and pinned[0][1] - pinned[None][1] == cfg["num_hidden_layers"], splits
     # ... and the library withdraws the fusion (and re-captures the graph) while the process holds more than four decoders: a waiting launch must
     # never starve another launch's producers
     knobs("fuse_attn", None)
