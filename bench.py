@@ -377,12 +377,14 @@ def main():
     # (publish the output) + 1.15 (the consumer's first touch of it) = 3.93 us before any weight is streamed, and 1.150 ms with the 8B model's
     # 4.24 GB behind it (tools/pipeline_probe.cpp; profiles/r04_pipeline_probe.txt, "serial: barrier bit, agent fences").  The serial sum below
     # assumes no overlap between those per-launch costs and the stream; the probe's chain overlaps the stream's head with the staging.
+    # (The probe chain is the FIVE-launches-per-layer structure, 162 launches.  Since round 5 the 32 / 8 / 128 head geometry runs four per layer -- the
+    # attention behind an XCD-local seam of the q|k|v launch -- so `launches` is 130 there and the step may come out below the 162-launch chain.)
     per_launch_us = {"dispatch": 1.59, "workgroup_start": 0.56, "publish": 0.63, "first_touch": 1.15}
     n_launch = launches_per_step if launches_per_step and launches_per_step > 0 else 5 * n_l + 2
     stream_ms = step_bytes / (stream_gbps * 1e9) * 1e3
     launch_ms = n_launch * sum(per_launch_us.values()) * 1e-3
     floor = {"launches": n_launch, "per_launch_us": per_launch_us, "launch_ms": launch_ms, "stream_ms": stream_ms, "serial_sum_ms": launch_ms + stream_ms,
-             "probe_chain_ms_8b": 1.150, "source": "tools/pipeline_probe.cpp, profiles/r04_pipeline_probe.txt (raw-AQL chain of the step's shape); stream term = step bytes / stream_peak of this run",
+             "probe_chain_ms_8b": 1.150, "probe_chain_launches": 162, "source": "tools/pipeline_probe.cpp, profiles/r04_pipeline_probe.txt (raw-AQL chain of the step's shape); stream term = step bytes / stream_peak of this run",
              "ms_per_step_over_serial_sum": (1e3 * elapsed / args.steps) / (launch_ms + stream_ms)}
     if args.model == "8b" and args.bits == 4 and not args.dense and not args.layers:
         floor["ms_per_step_over_probe_chain"] = (1e3 * elapsed / args.steps) / 1.150
