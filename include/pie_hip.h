@@ -105,6 +105,16 @@ int pie_dequantize_g64(const uint32_t *codes, const void *scales, const void *bi
 int pie_embedding_g64(const int32_t *ids, int L, const uint32_t *codes, const void *scales, const void *biases, int V, int H,
                       int bits, int dtype, void *out, void *stream);
 
+/* ---------------------------------------------------------------- MLX int2 group-64 checkpoints (config "quantization": {"group_size": 64 | 128,
+ * "bits": 2}; models/utils.py:96-111 forwards any bits nn.quantize takes): weight uint32 [N, K/16] (code k of a word at bits [2k, 2k+2)),
+ * scales / biases T [N, K/64].  Same call sites and streaming kernel on "W2S" units of 1280 B (row pair x 2048-wide K slice, ONE 16-byte code
+ * piece per lane + its {scale | bias << 16}): 0.3125 B per weight in HBM, the checkpoint's own figure (round 4 streamed these as 4-bit codes,
+ * 0.5625 B).  The embedding TABLE of such a checkpoint is handed to the decoder as 4-bit codes (one row per step); W2S is a Linear format. */
+size_t pie_w2s_bytes(int N_out, int K);
+int pie_repack_w2g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream);
+int pie_qgemv_w2g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
+
 /* ---------------------------------------------------------------- MLX group-32 checkpoints (config "quantization": {"group_size": 32,
  * "bits": 4 | 8}; nn.quantize takes any group_size in {32, 64, 128}, models/utils.py:96-111): weight uint32 [N, K*bits/32], scales / biases
  * T [N, K/32].  Same call sites and streaming kernel as the group-64 paths on "W4S32" units of 2560 B / "W8S32" units of 4608 B: the W4S / W8S
@@ -227,7 +237,8 @@ typedef struct {
                              pie_decoder_set_comm's communicator adds over the ranks before the one rounding + residual add. */
 } pie_decoder_config;
 enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1, PIE_W_INT8_G64 = 2 /* W8S units, embed_codes uint32 [vocab, hidden/4] */,
-       PIE_W_INT4_G32 = 3 /* W4S32 units, embed scales / biases [vocab, hidden/32] */, PIE_W_INT8_G32 = 4 /* W8S32 units */ };
+       PIE_W_INT4_G32 = 3 /* W4S32 units, embed scales / biases [vocab, hidden/32] */, PIE_W_INT8_G32 = 4 /* W8S32 units */,
+       PIE_W_INT2_G64 = 5 /* W2S units (Linear matrices only: per-matrix fmt_* or the default with fmt_embed = PIE_W_INT4_G64 + 1) */ };
 
 typedef struct {
     const void *attn_norm, *mlp_norm;   /* T [hidden] */

@@ -52,6 +52,8 @@ struct BF16 {
     // per word instead of three.
     static constexpr float ODD_SCALE = 0.0625f;
     static __device__ __forceinline__ void dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]);
+    static constexpr float W2_S1 = 0.25f, W2_S2 = 0.0625f, W2_S3 = 0.015625f;  // W2S: what chains 1, 2, 3 are divided by (dot_word2 below)
+    static __device__ __forceinline__ void dot_word2(u32 w, const u32 *x, float (&d)[4]);
     // the same in two steps, for kernels that multiply one code word with several activation rows: the four dot2 operands of a word
     // (the masking, 5 of the 9 instructions per word) are formed once and reused per row
     static __device__ __forceinline__ void word_ops(u32 w, u32 (&e)[4]) {
@@ -65,6 +67,20 @@ struct BF16 {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
     }
 };
+// W2S: sixteen 2-bit codes of one word against eight activation pairs.  The masks stay in place (no shift): the pair at bit 2j of both halves is
+// the bf16 number q * 4^j * 2^-133 (gradual underflow is continuous up to 0x00FF, common.hpp W8S), so chain j & 3 carries the factor 4^(j & 3) and the caller
+// folds 1, 1/4, 1/16, 1/64 into the four chain sums: 8 v_and + 8 v_dot2c + 1 shift per 16 weights, the W4S loop's instruction count per weight.
+__device__ __forceinline__ void BF16::dot_word2(u32 w, const u32 *x, float (&d)[4]) {
+    const u32 w8 = w >> 8;
+    d[0] = dot2(w & 0x00030003u, x[0], d[0]);
+    d[1] = dot2(w & 0x000C000Cu, x[1], d[1]);
+    d[2] = dot2(w & 0x00300030u, x[2], d[2]);
+    d[3] = dot2(w & 0x00C000C0u, x[3], d[3]);
+    d[0] = dot2(w8 & 0x00030003u, x[4], d[0]);
+    d[1] = dot2(w8 & 0x000C000Cu, x[5], d[1]);
+    d[2] = dot2(w8 & 0x00300030u, x[6], d[2]);
+    d[3] = dot2(w8 & 0x00C000C0u, x[7], d[3]);
+}
 __device__ __forceinline__ void BF16::dot_word(u32 w, u32 x0, u32 x1, u32 x2, u32 x3, float (&d)[4]) {
     const u32 w8 = w >> 8;
     d[0] = dot2(w & 0x000F000Fu, x0, d[0]);
@@ -91,6 +107,11 @@ struct F16 {
         d[1] = dot2(codes2((w >> 4) & 0x000F000Fu), x1, d[1]);
         d[2] = dot2(codes2((w >> 8) & 0x000F000Fu), x2, d[2]);
         d[3] = dot2(codes2((w >> 12) & 0x000F000Fu), x3, d[3]);
+    }
+    static constexpr float W2_S1 = 1.0f, W2_S2 = 1.0f, W2_S3 = 1.0f;  // W2S chain factors: every pair is shifted down, all chains at scale 1
+    static __device__ __forceinline__ void dot_word2(u32 w, const u32 *x, float (&d)[4]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j & 3] = dot2(codes2((w >> (2 * j)) & 0x00030003u), x[j], d[j & 3]);
     }
     static __device__ __forceinline__ float to_f32(u16 b) { return (float)__builtin_bit_cast(_Float16, b); }
     static __device__ __forceinline__ u16 from_f32(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
@@ -188,8 +209,14 @@ constexpr int W8S_UNIT_BYTES = 4352;
 constexpr int W4S32_UNIT_BYTES = 2560;
 // W8S32 (MLX int8 group-32 triplets): likewise the W8S unit with two {scale | bias << 16} words per lane (code pieces 0-1 / 2-3) = 4608 B.
 constexpr int W8S32_UNIT_BYTES = 4608;
-enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3, FMT_W8S32 = 4 };
+enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3, FMT_W8S32 = 4, FMT_W2S = 5 };
 static inline __host__ __device__ constexpr int fmt_unit_bytes(int fmt) {
+    if (fmt == FMT_W2S) return 1280;
     return fmt == FMT_W16S ? W16S_UNIT_BYTES : (fmt == FMT_W8S ? W8S_UNIT_BYTES : (fmt == FMT_W4S32 ? W4S32_UNIT_BYTES : (fmt == FMT_W8S32 ? W8S32_UNIT_BYTES : W4S_UNIT_BYTES)));
 }
+// W2S (MLX int2 group-64 triplets, round 5): the same unit shape with ONE 16-byte code piece per lane (its group's 64 two-bit codes) --
+// [64 lanes x 16 B] codes + [64 x 4 B] {scale | bias << 16} = 1280 B per row pair x 2048-wide K slice: 0.3125 B per weight, the checkpoint's own figure.
+// Word t of a lane's piece holds codes 16 t .. 16 t + 15 of the group: the even ones in the low 16-bit half, the odd ones in the high half, pair j
+// (codes 16 t + 2 j, + 1) at bits 2 j of both halves, so that (w >> 2 j) & 0x00030003 is one activation pair's two codes.
+constexpr int W2S_UNIT_BYTES = 1280;
 constexpr int PIE_EMBED_W4G32 = 36, PIE_EMBED_W8G32 = 40;  // embedding_launch's `bits` for 4- / 8-bit codes in 32-wide groups (4 and 8 = the 64-wide group forms)

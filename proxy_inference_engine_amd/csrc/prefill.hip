@@ -45,6 +45,28 @@ __global__ void k_dequant_w4s(const u32 *packed, int N, int K, int ns, u16 *out)
     *reinterpret_cast<uint4 *>(out + (size_t)r * K + (size_t)wk * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// W2S -> T row-major [N, K]; one thread per code word (16 weights, 32 B out).
+template <class T>
+__global__ void k_dequant_w2s(const u32 *packed, int N, int K, int ns, u16 *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = K >> 4;  // words per row
+    if (idx >= (size_t)N * wpr) return;
+    const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
+    const int g = wk >> 2, lane = (r & 1) * 32 + (g & 31), t = wk & 3;
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W2S_UNIT_BYTES / 4);
+    const u32 word = unit[lane * 4 + t], sb = unit[256 + lane];
+    const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
+    u32 o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // codes (2j, 2j+1) of the word sit at bits 2j of the low / high half (the W2S order)
+        const float lo = __fadd_rn(__fmul_rn(s, (float)((word >> (2 * j)) & 0x3u)), b);
+        const float hi = __fadd_rn(__fmul_rn(s, (float)((word >> (16 + 2 * j)) & 0x3u)), b);
+        o[j] = pack2<T>(lo, hi);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)r * K + (size_t)wk * 16);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]), dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // W8S -> T row-major [N, K]; one thread per code word (4 weights, 8 B out).
 template <class T, bool G32 = false>  // G32: W8S32 units (code pieces 0-1 / 2-3 are two 32-wide groups)
 __global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out) {
@@ -475,6 +497,12 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, void
         PIE_LAUNCH_CHECK();
         return w16m_from_rows_launch(staging, N, K, w16m, st);
     }
+    if (wf == PIE_W_INT2_G64) {
+        const size_t w2 = (size_t)N * (K >> 4);
+        hipLaunchKernelGGL((k_dequant_w2s<T>), dim3((unsigned)((w2 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
+        PIE_LAUNCH_CHECK();
+        return w16m_from_rows_launch(staging, N, K, w16m, st);
+    }
     const size_t words = (size_t)N * (K >> 3);
     if (wf == PIE_W_INT4_G32) hipLaunchKernelGGL((k_dequant_w4s<T, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
     else hipLaunchKernelGGL((k_dequant_w4s<T, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
@@ -547,9 +575,9 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; that split applies to the RoPE consumer, not to the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
-    if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 codes, qmv regime: the streaming GEMV, one pass per row
+    if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32 || d->mat_fmt(packed) == PIE_W_INT2_G64) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 / two-bit codes, qmv regime: the streaming GEMV, one pass per row
         GemvArgs a = {};
-        a.fmt = d->mat_fmt(packed) == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
+        a.fmt = d->mat_fmt(packed) == PIE_W_INT2_G64 ? FMT_W2S : d->mat_fmt(packed) == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
         return w4s_gemv_launch(d->cfg.dtype, PRO_NONE, EPI_STORE, a, M, st);
     }
     // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the

@@ -205,6 +205,38 @@ __global__ void k_repack_w8s(const u32 *codes, const u16 *scales, const u16 *bia
     packed[idx] = out;
 }
 
+// MLX int2 g=64 triplet -> W2S (common.hpp).  One thread per output dword: dwords [0,256) = the code piece (lane l -> dwords 4 l .. 4 l + 3),
+// [256,320) = {scale | bias << 16} per lane.  Dword t of lane l = source word 4*group + t (MLX: code k of a word at bits [2k, 2k+2)) with its
+// even codes gathered in the low half and its odd codes in the high half.
+__global__ void k_repack_w2s(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs, int ns,
+                             u32 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 320;
+    if (idx >= total) return;
+    const size_t unit = idx / 320;
+    const int dw = (int)(idx % 320);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    const bool is_sb = dw >= 256;
+    const int lane = is_sb ? dw - 256 : dw >> 2, t = dw & 3;
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int g = 32 * s + (lane & 31), G = K >> 6;
+    u32 out = 0;
+    if (g < G && row >= 0 && row < N_src) {
+        if (is_sb) {
+            out = (u32)scales[(size_t)row * G + g] | ((u32)biases[(size_t)row * G + g] << 16);
+        } else {
+            const u32 src = codes[(size_t)row * (K >> 4) + 4 * g + t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                out |= ((src >> (4 * j)) & 0x3u) << (2 * j);
+                out |= ((src >> (4 * j + 2)) & 0x3u) << (16 + 2 * j);
+            }
+        }
+    }
+    packed[idx] = out;
+}
+
 // MLX int8 g=32 triplet -> W8S32 (common.hpp): the W8S unit with two {scale | bias << 16} words per lane -- dwords [1024, 1152): lane l ->
 // 1024 + 2l (group 2g: code pieces 0, 1) and 1024 + 2l + 1 (group 2g + 1: pieces 2, 3).
 __global__ void k_repack_w8s32(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs, int ns,
@@ -307,6 +339,7 @@ static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     if (a.fmt == FMT_W8S) return launch_f<T, FMT_W8S>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W4S32) return launch_f<T, FMT_W4S32>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W8S32) return launch_f<T, FMT_W8S32>(pro, epi, a, grid, lds, st);
+    if (a.fmt == FMT_W2S) return launch_f<T, FMT_W2S>(pro, epi, a, grid, lds, st);
     return launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
 }
 
@@ -324,7 +357,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
     PIE_REQUIRE(a.K <= 32768, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
-    PIE_REQUIRE(a.fmt >= FMT_W4S && a.fmt <= FMT_W8S32, PIE_E_ARG, "w4s_gemv: unknown weight format");
+    PIE_REQUIRE(a.fmt >= FMT_W4S && a.fmt <= FMT_W2S, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
     // Every pointer the chosen prologue / epilogue dereferences, checked HERE so that a null can never reach a kernel (a dense
@@ -369,6 +402,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     else if (a.fmt == FMT_W8S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W8S);     \
     else if (a.fmt == FMT_W4S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S32); \
     else if (a.fmt == FMT_W8S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W8S32); \
+    else if (a.fmt == FMT_W2S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W2S);     \
     else PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S)
         if (dtype == PIE_BF16) { PIE_FUSE_FMT(BF16); }
         else if (dtype == PIE_F16) { PIE_FUSE_FMT(F16); }
@@ -569,6 +603,39 @@ int pie_qgemv_w8g64(const void *x, int M, const void *packed, int N, int K, cons
     PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w8g64: misaligned pointer");
     GemvArgs a = {};
     a.fmt = FMT_W8S;
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
+}
+
+size_t pie_w2s_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w4s_slices(K) * W2S_UNIT_BYTES;
+}
+
+int pie_repack_w2g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream) {
+    PIE_REQUIRE(codes && scales && biases && packed, PIE_E_ARG, "pie_repack_w2g64: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_w2g64: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0 && K <= 32768, PIE_E_SHAPE, "pie_repack_w2g64: K must be a multiple of 64, at most 32768");
+    PIE_REQUIRE(pie_aligned(packed, 256), PIE_E_ALIGN, "pie_repack_w2g64: packed must be 256-byte aligned");
+    const int n_pairs = N_out / 2, ns = w4s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 320;
+    hipLaunchKernelGGL(k_repack_w2s, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes, (const u16 *)scales,
+                       (const u16 *)biases, N_src, K, row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qgemv_w2g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w2g64: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w2g64: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w2g64: misaligned pointer");
+    GemvArgs a = {};
+    a.fmt = FMT_W2S;
     a.w = (const char *)packed;
     a.K = K, a.N = N;
     a.x = (const u16 *)x;

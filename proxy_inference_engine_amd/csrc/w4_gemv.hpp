@@ -140,6 +140,16 @@ __device__ __forceinline__ float w4s_unit_dot(const uint4 &c0, const uint4 &c1, 
     return (d[0] + d[2]) + (d[1] + d[3]) * T::ODD_SCALE;
 }
 
+// W2S: one 16-byte piece = the lane's 64 two-bit codes; word t covers activation pairs 8 t .. 8 t + 7 (common.hpp: dot_word2).
+template <class T>
+__device__ __forceinline__ float w2s_unit_dot(const uint4 &c0, const u32 (&xr)[32]) {
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const u32 w[4] = {c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) T::dot_word2(w[t], &xr[8 * t], d);
+    return (d[0] + d[2] * T::W2_S2) + (d[1] * T::W2_S1 + d[3] * T::W2_S3);
+}
+
 // W4S32: the two code pieces of a lane are two 32-wide groups -- the same chains, summed per piece.
 template <class T>
 __device__ __forceinline__ void w4s_unit_dot2(const uint4 &c0, const uint4 &c1, const u32 (&xr)[32], float &da, float &db) {
@@ -398,7 +408,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             else sincosf((float)pos * (1.0f / a.freqs[ii]), &pre_sn, &pre_cs);
         }
     }
-    uint4 c0[D], c1[D];
+    uint4 c0[D], c1[D];  // W2S: one code piece per lane (c1 stays unused)
     uint4 c2[W8 ? D : 1], c3[W8 ? D : 1];  // W8S: a lane's 64 codes are four pieces
     u32 sb[D];
     u32 sb2[G32 ? D : 1];  // W4S32 / W8S32: the second 32-wide group's {scale | bias << 16}
@@ -431,9 +441,13 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
             // re-read, nt on every stream measured 761 -> 780 tok/s (two A/B rounds in one session), gate/up 13.1 -> 12.7 us
             constexpr int AUX = (EPI == EPI_LOGITS || PIE_GEMV_NT) ? 2 : 0;
             const u32x4_t v0 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, AUX);
-            const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, AUX);
             c0[d] = make_uint4(v0.x, v0.y, v0.z, v0.w);
-            c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+            if constexpr (FMT == FMT_W2S) {  // one code piece per lane, then the lane's {scale | bias << 16}
+                sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 1024 - lane * 12, 0, AUX);
+            } else {
+                const u32x4_t v1 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 1024, 0, AUX);
+                c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+            }
             if (FMT == FMT_W4S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
             if (FMT == FMT_W4S32) {
                 typedef __attribute__((ext_vector_type(2))) u32 u32x2_t;
@@ -612,6 +626,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const float sx = (ABL & 4) ? 64.0f : sxs[gc];
                 float dd;
                 if (FMT == FMT_W8S) dd = w8s_unit_dot<T>(c0[d], c1[d], c2[d], c3[d], xr);
+                else if (FMT == FMT_W2S) dd = w2s_unit_dot<T>(c0[d], xr);
                 else dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
                                     : w4s_unit_dot<T>(c0[d], c1[d], xr);
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);

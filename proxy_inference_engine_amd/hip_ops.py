@@ -84,6 +84,20 @@ class W8SWeight:
 
 
 @dataclass
+class W2SWeight:
+    """One MLX int2 g=64 Linear in the W2S streaming layout (include/pie_hip.h)."""
+    packed: torch.Tensor          # uint8 [pie_w2s_bytes(N, K)]
+    N: int
+    K: int
+    dtype: torch.dtype
+    lin_bias: torch.Tensor | None = None
+
+    @property
+    def nbytes(self) -> int:
+        return self.packed.numel()
+
+
+@dataclass
 class W4S32Weight:
     """One MLX int4 group-32 Linear in the W4S32 streaming layout (include/pie_hip.h)."""
     packed: torch.Tensor          # uint8 [pie_w4s32_bytes(N, K)]
@@ -125,6 +139,25 @@ def repack_w4s32(codes, scales, biases, row_map: torch.Tensor | None = None, lin
 
 def repack_w8s32(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8S32Weight:
     return repack_w4s32(codes, scales, biases, row_map=row_map, lin_bias=lin_bias, bits=8)
+
+
+def repack_w2s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W2SWeight:
+    """Load-time repack of an MLX 2-bit group-64 triplet (weight [N_src, K/16], scales / biases [N_src, K/64]) into W2S; row_map as for repack_w4s."""
+    for t in (codes, scales, biases):
+        _dev(t)
+    N_src, K = codes.shape[0], codes.shape[1] * 16
+    if tuple(scales.shape) != (N_src, K // 64) or tuple(biases.shape) != (N_src, K // 64):
+        raise ValueError(f"group-64 scales / biases must be [{N_src}, {K // 64}], got {tuple(scales.shape)} / {tuple(biases.shape)}")
+    N_out = N_src if row_map is None else int(row_map.numel())
+    nbytes = _ffi.load().pie_w2s_bytes(N_out, K)
+    if nbytes == 0:
+        raise ValueError(f"unsupported shape for W2S: N={N_out} (must be even), K={K} (multiple of 64)")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+    if row_map is not None:
+        row_map = row_map.to(device=codes.device, dtype=torch.int32).contiguous()
+    _ffi.check(_ffi.load().pie_repack_w2g64(_ffi.p(codes.contiguous()), _ffi.p(scales.contiguous()), _ffi.p(biases.contiguous()), N_src, K, _ffi.p(row_map), N_out,
+                                            _ffi.p(packed), _ffi.stream()))
+    return W2SWeight(packed, N_out, K, scales.dtype, lin_bias)
 
 
 def repack_w8s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8SWeight:
@@ -223,7 +256,7 @@ def embedding_dense(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", transpose: bool = True, group_size: int | None = None, bits: int | None = None):
     """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64|32, bits=4|8) on a W4S / W8S / W4S32 weight:
     x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""
-    w_bits = 8 if isinstance(w, (W8SWeight, W8S32Weight)) else 4
+    w_bits = 8 if isinstance(w, (W8SWeight, W8S32Weight)) else (2 if isinstance(w, W2SWeight) else 4)
     w_group = 32 if isinstance(w, W4S32Weight) else 64
     if not transpose or (group_size is not None and group_size != w_group) or (bits is not None and bits != w_bits):
         raise ValueError("only transpose=True with the weight's own group size and bit width is implemented (the nn.QuantizedLinear form)")
@@ -233,7 +266,7 @@ def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", 
     M = x.numel() // w.K
     y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
     lib = _ffi.load()
-    fn = (lib.pie_qgemv_w8g32 if w_bits == 8 else lib.pie_qgemv_w4g32) if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
+    fn = lib.pie_qgemv_w2g64 if w_bits == 2 else (lib.pie_qgemv_w8g32 if w_bits == 8 else lib.pie_qgemv_w4g32) if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
     _ffi.check(fn(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y), _ffi.dtype_code(x.dtype), _ffi.stream()))
     return y
 

@@ -246,6 +246,45 @@ def test_int8_g64_quantize_gemv_embedding_vs_oracle(ops, dt):
             assert np.array_equal(to_bits(rows), to_bits(deq[[1, N - 1, 7]]))
 
 
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_int2_g64_gemv_vs_oracle(ops, dt):
+    """MLX 2-bit group-64 triplets (config "quantization": {"bits": 2}; models/utils.py:96-111 forwards any bits) on native W2S units: one 16-byte
+    code piece per lane, 1280 B per row pair x 2048-wide K slice = the checkpoint's own 0.3125 B per weight.  The code pairs are masked IN PLACE and
+    fed to v_dot2c as bf16 numbers q * 4^j * 2^-133 (f16: shifted down, 1024 + q), so the GEMV must agree with orc_quantized_matmul_t on the 2-bit
+    codes -- few and many row pairs, ragged last K slices (704, 3072), 1-3 rows, a Linear bias and a row map."""
+    rng = np.random.default_rng(202)
+    for N, K, M in ((96, 256, 2), (4096, 4096, 1), (130, 704, 3), (1024, 3072, 1), (64, 14336, 2)):
+        w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+        x = po.round_T(rng.standard_normal((M, K)), dt)
+        wq, sc, bi = po.quantize(w, 64, 2, dt)
+        assert wq.shape == (N, K // 16) and sc.shape == (N, K // 64)
+        codes, scales, biases = codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt)
+        lin_bias = po.round_T(rng.standard_normal(N) * 0.1, dt) if N == 130 else None
+        want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=2, dtype=dt, lin_bias=None if lin_bias is None else po.to_bits(lin_bias, dt))
+        wt = ops.repack_w2s(codes, scales, biases, lin_bias=None if lin_bias is None else to_dev(po.to_bits(lin_bias, dt), dt))
+        assert wt.nbytes == (N // 2) * ((K + 2047) // 2048) * 1280
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt, group_size=64, bits=2)
+        # with a Linear bias the product is rounded to T before the add: a one-ulp landing there is carried into the sum (assert_dot_close: mag)
+        assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"int2 gemv {N}x{K} M={M} {dt}", mag=None if lin_bias is None else want - lin_bias[None, :])
+        if N == 96:
+            perm = torch.from_numpy(rng.permutation(N).astype(np.int32))
+            got_p = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), ops.repack_w2s(codes, scales, biases, row_map=perm))
+            assert torch.equal(got_p, got[:, perm.long().cuda()])
+    # every code value at every position of a word: x = one-hot rows pick single weights, which must be scale * q + bias exactly (up to T rounding)
+    N, K = 64, 128
+    q = rng.integers(0, 4, (N, K)).astype(np.uint32)
+    wq = np.zeros((N, K // 16), np.uint32)
+    for k in range(K):
+        wq[:, k // 16] |= q[:, k] << np.uint32(2 * (k % 16))
+    sc, bi = po.to_bits(np.full((N, K // 64), 0.5), dt), po.to_bits(np.full((N, K // 64), -0.75), dt)
+    wt = ops.repack_w2s(codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt))
+    for k in (0, 1, 2, 15, 16, 31, 63, 64, 77, 127):
+        x = np.zeros((1, K), np.float32)
+        x[0, k] = 1.0
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt).float().cpu().numpy()[0]
+        assert np.array_equal(got, 0.5 * q[:, k].astype(np.float32) - 0.75), f"W2S code position {k} {dt}"
+
+
 @pytest.mark.parametrize("bits", [4, 8])
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
 def test_g32_gemv_embedding_vs_oracle(ops, dt, bits):
