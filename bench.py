@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--tp-backend", choices=["ipc", "rccl"], default="ipc", help="--tp: the communicator behind the fused step's collectives: the one-shot all-reduce over "
                     "IPC-mapped peer memory (default) or RCCL (ncclAllReduce on the launch stream): the comparator for the first run on a real node")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="developer: one of the library's test / tuning switches (_ffi.KNOBS) for this run")
-    ap.add_argument("--bits", type=int, choices=[4, 8], default=4, help="8: MLX int8 g=64 weights (a different workload than the metric's)")
+    ap.add_argument("--bits", type=int, choices=[2, 4, 6, 8], default=4, help="8 / 6 / 2: MLX int8 / int6 / int2 g=64 weights (W8S / W6S / W2S units; a different workload than the metric's)")
     ap.add_argument("--dense", action="store_true", help="BASELINE.json configs[2]: unquantised bf16 weights (a different workload than the metric's)")
     return ap.parse_args()
 

@@ -93,7 +93,7 @@ int pie_qgemv_w4g64(const void *x, int M, const void *packed, int N, int K, cons
 /* ---------------------------------------------------------------- MLX int8 group-64 checkpoints (config "quantization":
  * {"group_size": 64, "bits": 8}): weight uint32 [N, K/4] (byte i of word w = code 4w+i), scales/biases T [N, K/64].
  * Same call sites and kernel as the int4 path on "W8S" units of 4352 B (row pair x 2048-wide K slice, four 16-byte code
- * pieces per lane).  pie_quantize_g64 / pie_dequantize_g64 / pie_embedding_g64 are the bits-generic forms (bits = 4 | 8)
+ * pieces per lane).  pie_quantize_g64 (bits = 2 | 4 | 6 | 8) / pie_dequantize_g64 / pie_embedding_g64 (bits = 4 | 8) are the bits-generic forms
  * of the w4g64 entry points above. */
 size_t pie_w8s_bytes(int N_out, int K);
 int pie_repack_w8g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map,
@@ -114,6 +114,16 @@ size_t pie_w2s_bytes(int N_out, int K);
 int pie_repack_w2g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
                      void *packed, void *stream);
 int pie_qgemv_w2g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- MLX int6 group-64 checkpoints (config "quantization": {"group_size": 64 | 128,
+ * "bits": 6}): weight uint32 [N, 3K/16] -- MLX's little-endian bit stream, code k of a row at bits [6k, 6k+6) -- scales / biases T [N, K/64].
+ * "W6S" units of 3328 B (row pair x 2048-wide K slice): the low nibbles as the W4S unit's two code pieces, the high two bits as the W2S unit's one
+ * piece, then {scale | bias << 16} per lane: 0.8125 B per weight in HBM, the checkpoint's own figure (round 4 streamed these as bytes, 1.0625 B).
+ * A group's dot product = the W4S dot of the low plane + 16 x the W2S dot of the high plane.  The embedding table is handed over as 8-bit codes. */
+size_t pie_w6s_bytes(int N_out, int K);
+int pie_repack_w6g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream);
+int pie_qgemv_w6g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream);
 
 /* ---------------------------------------------------------------- MLX group-32 checkpoints (config "quantization": {"group_size": 32,
  * "bits": 4 | 8}; nn.quantize takes any group_size in {32, 64, 128}, models/utils.py:96-111): weight uint32 [N, K*bits/32], scales / biases
@@ -238,7 +248,8 @@ typedef struct {
 } pie_decoder_config;
 enum { PIE_W_INT4_G64 = 0, PIE_W_DENSE = 1, PIE_W_INT8_G64 = 2 /* W8S units, embed_codes uint32 [vocab, hidden/4] */,
        PIE_W_INT4_G32 = 3 /* W4S32 units, embed scales / biases [vocab, hidden/32] */, PIE_W_INT8_G32 = 4 /* W8S32 units */,
-       PIE_W_INT2_G64 = 5 /* W2S units (Linear matrices only: per-matrix fmt_* or the default with fmt_embed = PIE_W_INT4_G64 + 1) */ };
+       PIE_W_INT2_G64 = 5 /* W2S units (Linear matrices only: per-matrix fmt_* or the default with fmt_embed = PIE_W_INT4_G64 + 1) */,
+       PIE_W_INT6_G64 = 6 /* W6S units (Linear matrices only; the embedding table as 8-bit codes, fmt_embed = PIE_W_INT8_G64 + 1) */ };
 
 typedef struct {
     const void *attn_norm, *mlp_norm;   /* T [hidden] */

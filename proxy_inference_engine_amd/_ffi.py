@@ -24,7 +24,7 @@ KERNELS = {"embed": 0, "qkv": 1, "attn": 2, "o_proj": 3, "gate_up": 4, "down": 5
 EXPORTS = [
     "pie_hello", "pie_version", "pie_last_error", "pie_device_info", "pie_set_knob", "pie_get_knob",
     "pie_quantize_w4g64", "pie_dequantize_w4g64", "pie_w4s_bytes", "pie_repack_w4g64", "pie_w8s_bytes", "pie_repack_w8g64", "pie_qgemv_w8g64", "pie_quantize_g64", "pie_dequantize_g64", "pie_embedding_g64", "pie_w4s32_bytes", "pie_repack_w4g32", "pie_qgemv_w4g32", "pie_w8s32_bytes", "pie_repack_w8g32", "pie_qgemv_w8g32", "pie_embedding_g32",
-    "pie_w2s_bytes", "pie_repack_w2g64", "pie_qgemv_w2g64",
+    "pie_w2s_bytes", "pie_repack_w2g64", "pie_qgemv_w2g64", "pie_w6s_bytes", "pie_repack_w6g64", "pie_qgemv_w6g64",
     "pie_w16s_bytes", "pie_repack_dense", "pie_gemv_dense", "pie_embedding_dense", "pie_qgemv_w4g64", "pie_qgemv_w4g64_f32",
     "pie_embedding_w4g64", "pie_rms_norm", "pie_rope", "pie_rope_ex", "pie_sdpa_decode_workspace_bytes", "pie_sdpa_decode", "pie_sdpa_prefill",
     "pie_silu_mul", "pie_add", "pie_logprobs_argmax", "pie_stream_read", "pie_decoder_graph_launches", "pie_qkv_row_map", "pie_gateup_row_map",
@@ -91,7 +91,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{path} does not export {name}")
     for name in ("pie_hello", "pie_version", "pie_last_error"):
         getattr(lib, name).restype = C.c_char_p
-    for name in ("pie_w4s_bytes", "pie_w16s_bytes", "pie_w8s_bytes", "pie_w4s32_bytes", "pie_w8s32_bytes", "pie_w2s_bytes", "pie_sdpa_decode_workspace_bytes", "pie_decoder_step_bytes", "pie_decoder_kernel_bytes"):
+    for name in ("pie_w4s_bytes", "pie_w16s_bytes", "pie_w8s_bytes", "pie_w4s32_bytes", "pie_w8s32_bytes", "pie_w2s_bytes", "pie_w6s_bytes", "pie_sdpa_decode_workspace_bytes", "pie_decoder_step_bytes", "pie_decoder_kernel_bytes"):
         getattr(lib, name).restype = C.c_size_t
     lib.pie_sdpa_decode.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pie_sdpa_prefill.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]

@@ -209,9 +209,10 @@ constexpr int W8S_UNIT_BYTES = 4352;
 constexpr int W4S32_UNIT_BYTES = 2560;
 // W8S32 (MLX int8 group-32 triplets): likewise the W8S unit with two {scale | bias << 16} words per lane (code pieces 0-1 / 2-3) = 4608 B.
 constexpr int W8S32_UNIT_BYTES = 4608;
-enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3, FMT_W8S32 = 4, FMT_W2S = 5 };
+enum { FMT_W4S = 0, FMT_W16S = 1, FMT_W8S = 2, FMT_W4S32 = 3, FMT_W8S32 = 4, FMT_W2S = 5, FMT_W6S = 6 };
 static inline __host__ __device__ constexpr int fmt_unit_bytes(int fmt) {
     if (fmt == FMT_W2S) return 1280;
+    if (fmt == FMT_W6S) return 3328;
     return fmt == FMT_W16S ? W16S_UNIT_BYTES : (fmt == FMT_W8S ? W8S_UNIT_BYTES : (fmt == FMT_W4S32 ? W4S32_UNIT_BYTES : (fmt == FMT_W8S32 ? W8S32_UNIT_BYTES : W4S_UNIT_BYTES)));
 }
 // W2S (MLX int2 group-64 triplets, round 5): the same unit shape with ONE 16-byte code piece per lane (its group's 64 two-bit codes) --
@@ -219,4 +220,9 @@ static inline __host__ __device__ constexpr int fmt_unit_bytes(int fmt) {
 // Word t of a lane's piece holds codes 16 t .. 16 t + 15 of the group: the even ones in the low 16-bit half, the odd ones in the high half, pair j
 // (codes 16 t + 2 j, + 1) at bits 2 j of both halves, so that (w >> 2 j) & 0x00030003 is one activation pair's two codes.
 constexpr int W2S_UNIT_BYTES = 1280;
+// W6S (MLX int6 group-64 triplets, round 5): a lane's 64 six-bit codes as TWO PLANES -- the low nibbles as the W4S unit's two code pieces, the high
+// two bits as the W2S unit's one piece: [2 x 64 x 16 B] + [64 x 16 B] + [64 x 4 B] {scale | bias << 16} = 3328 B per row pair x 2048-wide K slice =
+// 0.8125 B per weight, the checkpoint's own figure (MLX stores the codes as a byte-straddling bit stream, four to three bytes).  q = lo + 16 hi, so a
+// group's dot product is the W4S dot of the low plane plus 16 times the W2S dot of the high plane: both loops unchanged, no straddling read in the stream.
+constexpr int W6S_UNIT_BYTES = 3328;
 constexpr int PIE_EMBED_W4G32 = 36, PIE_EMBED_W8G32 = 40;  // embedding_launch's `bits` for 4- / 8-bit codes in 32-wide groups (4 and 8 = the 64-wide group forms)

@@ -140,7 +140,7 @@ static AttnArgs attn_args(pie_decoder *d, int li) {
         a.pf_rows = (256 - c.n_kv_heads * d->splits) / c.n_kv_heads;
         if (a.pf_rows < 0) a.pf_rows = 0;
         a.pf_ptr = (const char *)w.wo, a.pf_sink = d->pf_sink;
-        a.pf_bytes = f == PIE_W_INT2_G64 ? pie_w2s_bytes(H, QD) : f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : (f == PIE_W_INT4_G32 ? pie_w4s32_bytes(H, QD) : (f == PIE_W_INT8_G32 ? pie_w8s32_bytes(H, QD) : pie_w4s_bytes(H, QD))));
+        a.pf_bytes = f == PIE_W_INT2_G64 ? pie_w2s_bytes(H, QD) : f == PIE_W_INT6_G64 ? pie_w6s_bytes(H, QD) : f == PIE_W_DENSE ? pie_w16s_bytes(H, QD) : (f == PIE_W_INT8_G64 ? pie_w8s_bytes(H, QD) : (f == PIE_W_INT4_G32 ? pie_w4s32_bytes(H, QD) : (f == PIE_W_INT8_G32 ? pie_w8s32_bytes(H, QD) : pie_w4s_bytes(H, QD))));
         const int cap_mb = pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) >= 0 ? pie_knob(PIE_KNOB_ATTN_WARM_MAX_MB) : ATTN_WARM_DEFAULT_MB;
         if (a.pf_bytes > (unsigned long long)cap_mb << 20) a.pf_bytes = (unsigned long long)cap_mb << 20;
         if (!a.pf_bytes) a.pf_rows = 0;
@@ -156,6 +156,7 @@ int enqueue_kernel(pie_decoder *d, int which, int li, const int *token_ptr, u16 
     auto gfmt = [d](const void *m) {  // streaming format of one matrix (per-module quantisation: models/utils.py:99-109)
         const int f = d->mat_fmt(m);
         if (f == PIE_W_INT2_G64) return (int)FMT_W2S;
+        if (f == PIE_W_INT6_G64) return (int)FMT_W6S;
         return f == PIE_W_DENSE ? (int)FMT_W16S : (f == PIE_W_INT8_G64 ? FMT_W8S : (f == PIE_W_INT4_G32 ? FMT_W4S32 : (f == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S)));
     };
     const int efmt = d->mat_fmt(d->glob.embed_codes);
@@ -308,7 +309,7 @@ int pie_decoder_create(const pie_decoder_config *cfg, pie_decoder **out) {
     PIE_REQUIRE(c.n_layers > 0 && c.n_heads > 0 && c.n_kv_heads > 0 && c.n_heads % c.n_kv_heads == 0, PIE_E_SHAPE, "pie_decoder_create: bad head counts");
     PIE_REQUIRE(c.vocab > 0 && c.vocab % 2 == 0, PIE_E_SHAPE, "pie_decoder_create: vocab must be even");
     PIE_REQUIRE(c.hidden <= 32768 && c.inter <= 32768 && c.n_heads * c.head_dim <= 32768, PIE_E_SHAPE, "pie_decoder_create: K > 32768 not supported");
-    PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE || c.weight_format == PIE_W_INT8_G64 || c.weight_format == PIE_W_INT4_G32 || c.weight_format == PIE_W_INT8_G32 || c.weight_format == PIE_W_INT2_G64, PIE_E_ARG,
+    PIE_REQUIRE(c.weight_format == PIE_W_INT4_G64 || c.weight_format == PIE_W_DENSE || c.weight_format == PIE_W_INT8_G64 || c.weight_format == PIE_W_INT4_G32 || c.weight_format == PIE_W_INT8_G32 || c.weight_format == PIE_W_INT2_G64 || c.weight_format == PIE_W_INT6_G64, PIE_E_ARG,
                 "pie_decoder_create: unknown weight_format");
     PIE_REQUIRE(c.tp_world >= 0 && c.tp_world <= 8 && c.tp_rank >= 0 && c.tp_rank < (c.tp_world > 0 ? c.tp_world : 1), PIE_E_ARG,
                 "pie_decoder_create: 0 <= tp_rank < tp_world <= 8");
@@ -368,7 +369,7 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
         const int f[4] = {w->fmt_qkv, w->fmt_o, w->fmt_gateup, w->fmt_down};
         const void *m[4] = {w->wqkv, w->wo, w->wgateup, w->wdown};
         for (int i = 0; i < 4; ++i) {
-            PIE_REQUIRE(f[i] >= 0 && f[i] <= PIE_W_INT2_G64 + 1, PIE_E_ARG, "pie_decoder_set_layer: unknown per-matrix weight format");
+            PIE_REQUIRE(f[i] >= 0 && f[i] <= PIE_W_INT6_G64 + 1, PIE_E_ARG, "pie_decoder_set_layer: unknown per-matrix weight format");
             if (f[i]) d->fmt_map[m[i]] = f[i] - 1;
             else d->fmt_map.erase(m[i]);
         }
@@ -383,12 +384,12 @@ int pie_decoder_set_layer(pie_decoder *d, int layer, const pie_layer_weights *w)
 int pie_decoder_set_globals(pie_decoder *d, const pie_global_weights *w) {
     PIE_REQUIRE(d && w, PIE_E_ARG, "pie_decoder_set_globals: null pointer");
     PIE_REQUIRE(w->embed_codes && w->final_norm && w->lm_head && w->rope_freqs, PIE_E_ARG, "pie_decoder_set_globals: null weight");
-    PIE_REQUIRE(w->fmt_embed >= 0 && w->fmt_embed <= PIE_W_INT8_G32 + 1 && w->fmt_lm_head >= 0 && w->fmt_lm_head <= PIE_W_INT2_G64 + 1, PIE_E_ARG,
+    PIE_REQUIRE(w->fmt_embed >= 0 && w->fmt_embed <= PIE_W_INT8_G32 + 1 && w->fmt_lm_head >= 0 && w->fmt_lm_head <= PIE_W_INT6_G64 + 1, PIE_E_ARG,
                 "pie_decoder_set_globals: unknown per-matrix weight format");
     PIE_REQUIRE((w->fmt_embed ? w->fmt_embed - 1 : d->cfg.weight_format) == PIE_W_DENSE || (w->embed_scales && w->embed_biases), PIE_E_ARG,
                 "pie_decoder_set_globals: a quantised embedding needs scales and biases");
-    PIE_REQUIRE((w->fmt_embed ? w->fmt_embed - 1 : d->cfg.weight_format) != PIE_W_INT2_G64, PIE_E_ARG,
-                "pie_decoder_set_globals: the embedding table of a 2-bit checkpoint is handed over as 4-bit codes (fmt_embed = PIE_W_INT4_G64 + 1); W2S is a Linear format");
+    PIE_REQUIRE((w->fmt_embed ? w->fmt_embed - 1 : d->cfg.weight_format) != PIE_W_INT2_G64 && (w->fmt_embed ? w->fmt_embed - 1 : d->cfg.weight_format) != PIE_W_INT6_G64, PIE_E_ARG,
+                "pie_decoder_set_globals: the embedding table of a 2- / 6-bit checkpoint is handed over as 4- / 8-bit codes (fmt_embed = PIE_W_INT4_G64 + 1 / PIE_W_INT8_G64 + 1); W2S and W6S are Linear formats");
     if (w->fmt_embed) d->fmt_map[w->embed_codes] = w->fmt_embed - 1;
     else d->fmt_map.erase(w->embed_codes);
     if (w->fmt_lm_head) d->fmt_map[w->lm_head] = w->fmt_lm_head - 1;
@@ -675,6 +676,7 @@ static size_t lin_bytes(const pie_decoder *d, const void *m, size_t n, size_t k)
     const int f = d->mat_fmt(m);
     if (f == PIE_W_DENSE) return n * k * 2;
     if (f == PIE_W_INT2_G64) return n * k / 4 + 2 * (n * k / 64) * 2;  // two-bit codes + the group's 16-bit scale and bias
+    if (f == PIE_W_INT6_G64) return n * k * 3 / 4 + 2 * (n * k / 64) * 2;  // six-bit codes likewise
     return n * k / (f == PIE_W_INT8_G64 || f == PIE_W_INT8_G32 ? 1 : 2) + 2 * (n * k / (f == PIE_W_INT4_G32 || f == PIE_W_INT8_G32 ? 32 : 64)) * 2;  // codes + 16-bit scale and bias per group of 64 (32)
 }
 

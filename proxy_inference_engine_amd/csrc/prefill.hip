@@ -67,6 +67,27 @@ __global__ void k_dequant_w2s(const u32 *packed, int N, int K, int ns, u16 *out)
     dst[0] = make_uint4(o[0], o[1], o[2], o[3]), dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// W6S -> T row-major [N, K]; one thread per low-plane code word (8 weights, 16 B out): q = low nibble + 16 x the high plane's two bits.
+template <class T>
+__global__ void k_dequant_w6s(const u32 *packed, int N, int K, int ns, u16 *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int wpr = K >> 3;
+    if (idx >= (size_t)N * wpr) return;
+    const int r = (int)(idx / wpr), wk = (int)(idx % wpr);
+    const int g = wk >> 3, lane = (r & 1) * 32 + (g & 31), w4 = wk & 7, j = w4 >> 2, t = w4 & 3;
+    const u32 *unit = packed + ((size_t)(r >> 1) * ns + (g >> 5)) * (W6S_UNIT_BYTES / 4);
+    const u32 word = unit[j * 256 + lane * 4 + t], sb = unit[768 + lane];
+    const u32 hiw = unit[512 + lane * 4 + (w4 >> 1)] >> (8 * (w4 & 1));  // codes 8 w4 .. + 7 = pairs 4 (w4 & 1) .. + 3 of high word w4 >> 1
+    const float s = lo_f32<T>(sb), b = hi_f32<T>(sb);
+    u32 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 qa = ((word >> (4 * i)) & 0xFu) | (((hiw >> (2 * i)) & 0x3u) << 4), qb = ((word >> (16 + 4 * i)) & 0xFu) | (((hiw >> (16 + 2 * i)) & 0x3u) << 4);
+        o[i] = pack2<T>(__fadd_rn(__fmul_rn(s, (float)qa), b), __fadd_rn(__fmul_rn(s, (float)qb), b));
+    }
+    *reinterpret_cast<uint4 *>(out + (size_t)r * K + (size_t)wk * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // W8S -> T row-major [N, K]; one thread per code word (4 weights, 8 B out).
 template <class T, bool G32 = false>  // G32: W8S32 units (code pieces 0-1 / 2-3 are two 32-wide groups)
 __global__ void k_dequant_w8s(const u32 *packed, int N, int K, int ns, u16 *out) {
@@ -503,6 +524,12 @@ static int expand_weights(pie_decoder *d, const void *packed, int N, int K, void
         PIE_LAUNCH_CHECK();
         return w16m_from_rows_launch(staging, N, K, w16m, st);
     }
+    if (wf == PIE_W_INT6_G64) {
+        const size_t w6 = (size_t)N * (K >> 3);
+        hipLaunchKernelGGL((k_dequant_w6s<T>), dim3((unsigned)((w6 + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
+        PIE_LAUNCH_CHECK();
+        return w16m_from_rows_launch(staging, N, K, w16m, st);
+    }
     const size_t words = (size_t)N * (K >> 3);
     if (wf == PIE_W_INT4_G32) hipLaunchKernelGGL((k_dequant_w4s<T, true>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
     else hipLaunchKernelGGL((k_dequant_w4s<T, false>), dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const u32 *)packed, N, K, w4s_slices(K), staging);
@@ -575,9 +602,9 @@ static int linear_rows(pie_decoder *d, const void *packed, int N, int K, const u
     // below ~200 rows -- 4.21 ms at 64 tokens -- so few rows get four workgroups each there; that split applies to the RoPE consumer, not to the
     // add + RMSNorm consumers, whose row-wide reduction keeps them at one workgroup per row.)
     const bool is_int4 = d->mat_fmt(packed) == PIE_W_INT4_G64;
-    if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32 || d->mat_fmt(packed) == PIE_W_INT2_G64) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 / two-bit codes, qmv regime: the streaming GEMV, one pass per row
+    if ((d->mat_fmt(packed) == PIE_W_INT4_G32 || d->mat_fmt(packed) == PIE_W_INT8_G32 || d->mat_fmt(packed) == PIE_W_INT2_G64 || d->mat_fmt(packed) == PIE_W_INT6_G64) && M <= GEMV_ROWS_MAX && K <= 32768 && N % 2 == 0) {  // group-32 / two-bit codes, qmv regime: the streaming GEMV, one pass per row
         GemvArgs a = {};
-        a.fmt = d->mat_fmt(packed) == PIE_W_INT2_G64 ? FMT_W2S : d->mat_fmt(packed) == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
+        a.fmt = d->mat_fmt(packed) == PIE_W_INT2_G64 ? FMT_W2S : d->mat_fmt(packed) == PIE_W_INT6_G64 ? FMT_W6S : d->mat_fmt(packed) == PIE_W_INT8_G32 ? FMT_W8S32 : FMT_W4S32, a.w = (const char *)packed, a.K = K, a.N = N, a.x = x, a.y = y, a.lin_bias = (const u16 *)bias;
         return w4s_gemv_launch(d->cfg.dtype, PRO_NONE, EPI_STORE, a, M, st);
     }
     // Below 6 rows MLX multiplies row by row (qmv: exact fp32 per row, mx.quantized_matmul as reached from nn.QuantizedLinear): the

@@ -11,7 +11,7 @@
 template <class T, int BITS>
 __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *scales, u16 *biases) {
     constexpr float LEVELS = (float)((1 << BITS) - 1);
-    constexpr int PER_WORD = 32 / BITS, WORDS = 64 / PER_WORD;
+    constexpr int PER_WORD = BITS == 6 ? 5 : 32 / BITS, WORDS = BITS == 6 ? 12 : 64 / PER_WORD;  // 6 bits: MLX's bit stream, 64 codes in 12 words (below)
     const int G = K >> 6;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)N * G) return;
@@ -44,6 +44,20 @@ __global__ void k_quantize_w4g64(const u16 *w, int N, int K, u32 *codes, u16 *sc
     scales[gid] = T::from_f32(scale);
     biases[gid] = T::from_f32(bias);
     u32 *dst = codes + gid * WORDS;
+    if constexpr (BITS == 6) {  // code k of the row at bits [6k, 6k+6): a group of 64 fills 12 words exactly
+        u32 words[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            float c = rintf(__fdiv_rn(__fsub_rn(v[i], bias), scale));
+            c = c < 0.0f ? 0.0f : (c > LEVELS ? LEVELS : c);
+            const u32 q = (u32)c;
+            words[(6 * i) >> 5] |= q << ((6 * i) & 31);
+            if (((6 * i) & 31) > 26) words[((6 * i) >> 5) + 1] |= q >> (32 - ((6 * i) & 31));
+        }
+#pragma unroll
+        for (int wd = 0; wd < 12; ++wd) dst[wd] = words[wd];
+        return;
+    }
 #pragma unroll
     for (int wd = 0; wd < WORDS; ++wd) {
         u32 word = 0;
@@ -237,6 +251,46 @@ __global__ void k_repack_w2s(const u32 *codes, const u16 *scales, const u16 *bia
     packed[idx] = out;
 }
 
+// MLX int6 g=64 triplet -> W6S (common.hpp).  One thread per output dword: dwords [0,512) = the low-nibble plane in the W4S order (piece j: lane l ->
+// dwords 256 j + 4 l .. + 3), [512,768) = the high-two-bit plane in the W2S order (lane l -> dwords 512 + 4 l .. + 3), [768,832) = {scale | bias << 16}.
+// MLX packs 6-bit codes as a little-endian bit stream (code k of a row at bits [6k, 6k+6)): read through a two-word window.
+__device__ __forceinline__ u32 mlx_code6(const u32 *row, int k) {
+    const int bit = 6 * k, wd = bit >> 5, sh = bit & 31;
+    u32 v = row[wd] >> sh;
+    if (sh > 26) v |= row[wd + 1] << (32 - sh);
+    return v & 63u;
+}
+__global__ void k_repack_w6s(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs, int ns,
+                             u32 *packed) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_pairs * ns * 832;
+    if (idx >= total) return;
+    const size_t unit = idx / 832;
+    const int dw = (int)(idx % 832);
+    const int pair = (int)(unit / ns), s = (int)(unit % ns);
+    const bool is_sb = dw >= 768, is_hi = dw >= 512 && !is_sb;
+    const int lane = is_sb ? dw - 768 : (dw & 255) >> 2, t = dw & 3, j = dw >> 8;
+    const int prow = 2 * pair + (lane >> 5);
+    const int row = row_map ? row_map[prow] : prow;
+    const int g = 32 * s + (lane & 31), G = K >> 6;
+    u32 out = 0;
+    if (g < G && row >= 0 && row < N_src) {
+        if (is_sb) {
+            out = (u32)scales[(size_t)row * G + g] | ((u32)biases[(size_t)row * G + g] << 16);
+        } else {
+            const u32 *src = codes + (size_t)row * (3 * (K >> 4));
+            if (is_hi) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) out |= (mlx_code6(src, 64 * g + 16 * t + c) >> 4) << (2 * (c >> 1) + 16 * (c & 1));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) out |= (mlx_code6(src, 64 * g + 8 * (4 * j + t) + c) & 15u) << (4 * (c >> 1) + 16 * (c & 1));
+            }
+        }
+    }
+    packed[idx] = out;
+}
+
 // MLX int8 g=32 triplet -> W8S32 (common.hpp): the W8S unit with two {scale | bias << 16} words per lane -- dwords [1024, 1152): lane l ->
 // 1024 + 2l (group 2g: code pieces 0, 1) and 1024 + 2l + 1 (group 2g + 1: pieces 2, 3).
 __global__ void k_repack_w8s32(const u32 *codes, const u16 *scales, const u16 *biases, int N_src, int K, const int *row_map, int n_pairs, int ns,
@@ -340,6 +394,7 @@ static int launch_t(int pro, int epi, const GemvArgs &a, dim3 grid, unsigned lds
     if (a.fmt == FMT_W4S32) return launch_f<T, FMT_W4S32>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W8S32) return launch_f<T, FMT_W8S32>(pro, epi, a, grid, lds, st);
     if (a.fmt == FMT_W2S) return launch_f<T, FMT_W2S>(pro, epi, a, grid, lds, st);
+    if (a.fmt == FMT_W6S) return launch_f<T, FMT_W6S>(pro, epi, a, grid, lds, st);
     return launch_f<T, FMT_W4S>(pro, epi, a, grid, lds, st);
 }
 
@@ -357,7 +412,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     PIE_REQUIRE(a.K % 64 == 0 && a.K > 0, PIE_E_SHAPE, "w4s_gemv: K must be a positive multiple of 64");
     PIE_REQUIRE(a.N % 2 == 0 && a.N > 0, PIE_E_SHAPE, "w4s_gemv: N must be even");
     PIE_REQUIRE(a.K <= 32768, PIE_E_SHAPE, "w4s_gemv: K > 32768 not supported");
-    PIE_REQUIRE(a.fmt >= FMT_W4S && a.fmt <= FMT_W2S, PIE_E_ARG, "w4s_gemv: unknown weight format");
+    PIE_REQUIRE(a.fmt >= FMT_W4S && a.fmt <= FMT_W6S, PIE_E_ARG, "w4s_gemv: unknown weight format");
     PIE_REQUIRE(pro != PRO_ATTN || (a.splits >= 1 && a.splits <= GEMV_ATTN_SPLITS && a.K <= 2 * 8 * GEMV_WAVES * 64 && a.head_dim % 8 == 0), PIE_E_SHAPE,
                 "w4s_gemv: attention-merge prologue supports <= 4 splits and n_heads*head_dim <= 8192");
     // Every pointer the chosen prologue / epilogue dereferences, checked HERE so that a null can never reach a kernel (a dense
@@ -403,6 +458,7 @@ int w4s_gemv_launch(int dtype, int pro, int epi, GemvArgs &a, int M, hipStream_t
     else if (a.fmt == FMT_W4S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S32); \
     else if (a.fmt == FMT_W8S32) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W8S32); \
     else if (a.fmt == FMT_W2S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W2S);     \
+    else if (a.fmt == FMT_W6S) PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W6S);     \
     else PIE_FUSE_GO(TT, PRO_RMSNORM, FMT_W4S)
         if (dtype == PIE_BF16) { PIE_FUSE_FMT(BF16); }
         else if (dtype == PIE_F16) { PIE_FUSE_FMT(F16); }
@@ -502,13 +558,21 @@ int pie_quantize_w4g64(const void *w, int N, int K, int dtype, uint32_t *codes, 
 
 int pie_quantize_g64(const void *w, int N, int K, int bits, int dtype, uint32_t *codes, void *scales, void *biases, void *stream) {
     PIE_REQUIRE(w && codes && scales && biases, PIE_E_ARG, "pie_quantize_w4g64: null pointer");
-    PIE_REQUIRE(bits == 4 || bits == 8, PIE_E_ARG, "pie_quantize_g64: bits must be 4 or 8");
+    PIE_REQUIRE(bits == 2 || bits == 4 || bits == 6 || bits == 8, PIE_E_ARG, "pie_quantize_g64: bits must be 2, 4, 6 or 8");
     PIE_REQUIRE(N > 0 && K > 0 && K % 64 == 0, PIE_E_SHAPE, "pie_quantize_w4g64: K must be a multiple of 64");
     PIE_REQUIRE(pie_aligned(w, 16) && pie_aligned(codes, 16), PIE_E_ALIGN, "pie_quantize_w4g64: 16-byte alignment required");
     const size_t groups = (size_t)N * (K / 64);
     dim3 grid((unsigned)((groups + 127) / 128)), block(128);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PIE_BF16 && bits == 4)
+    if (dtype == PIE_BF16 && bits == 6)
+        hipLaunchKernelGGL((k_quantize_w4g64<BF16, 6>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_F16 && bits == 6)
+        hipLaunchKernelGGL((k_quantize_w4g64<F16, 6>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_BF16 && bits == 2)
+        hipLaunchKernelGGL((k_quantize_w4g64<BF16, 2>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_F16 && bits == 2)
+        hipLaunchKernelGGL((k_quantize_w4g64<F16, 2>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
+    else if (dtype == PIE_BF16 && bits == 4)
         hipLaunchKernelGGL((k_quantize_w4g64<BF16, 4>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
     else if (dtype == PIE_F16 && bits == 4)
         hipLaunchKernelGGL((k_quantize_w4g64<F16, 4>), grid, block, 0, st, (const u16 *)w, N, K, codes, (u16 *)scales, (u16 *)biases);
@@ -636,6 +700,39 @@ int pie_qgemv_w2g64(const void *x, int M, const void *packed, int N, int K, cons
     PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w2g64: misaligned pointer");
     GemvArgs a = {};
     a.fmt = FMT_W2S;
+    a.w = (const char *)packed;
+    a.K = K, a.N = N;
+    a.x = (const u16 *)x;
+    a.y = (u16 *)y;
+    a.lin_bias = (const u16 *)lin_bias;
+    return w4s_gemv_launch(dtype, PRO_NONE, EPI_STORE, a, M, (hipStream_t)stream);
+}
+
+size_t pie_w6s_bytes(int N_out, int K) {
+    if (N_out <= 0 || K <= 0 || (N_out & 1) || (K & 63)) return 0;
+    return (size_t)(N_out / 2) * w4s_slices(K) * W6S_UNIT_BYTES;
+}
+
+int pie_repack_w6g64(const uint32_t *codes, const void *scales, const void *biases, int N_src, int K, const int32_t *row_map, int N_out,
+                     void *packed, void *stream) {
+    PIE_REQUIRE(codes && scales && biases && packed, PIE_E_ARG, "pie_repack_w6g64: null pointer");
+    PIE_REQUIRE(N_src > 0 && N_out > 0 && (N_out % 2) == 0, PIE_E_SHAPE, "pie_repack_w6g64: N_out must be even");
+    PIE_REQUIRE(K > 0 && K % 64 == 0 && K <= 32768, PIE_E_SHAPE, "pie_repack_w6g64: K must be a multiple of 64, at most 32768");
+    PIE_REQUIRE(pie_aligned(packed, 256), PIE_E_ALIGN, "pie_repack_w6g64: packed must be 256-byte aligned");
+    const int n_pairs = N_out / 2, ns = w4s_slices(K);
+    const size_t total = (size_t)n_pairs * ns * 832;
+    hipLaunchKernelGGL(k_repack_w6s, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, codes, (const u16 *)scales,
+                       (const u16 *)biases, N_src, K, row_map, n_pairs, ns, (u32 *)packed);
+    PIE_LAUNCH_CHECK();
+    return PIE_OK;
+}
+
+int pie_qgemv_w6g64(const void *x, int M, const void *packed, int N, int K, const void *lin_bias, void *y, int dtype, void *stream) {
+    PIE_REQUIRE(x && packed && y, PIE_E_ARG, "pie_qgemv_w6g64: null pointer");
+    PIE_REQUIRE(M > 0 && M <= 65535, PIE_E_SHAPE, "pie_qgemv_w6g64: M out of range");
+    PIE_REQUIRE(pie_aligned(x, 16) && pie_aligned(packed, 16) && pie_aligned(y, 4), PIE_E_ALIGN, "pie_qgemv_w6g64: misaligned pointer");
+    GemvArgs a = {};
+    a.fmt = FMT_W6S;
     a.w = (const char *)packed;
     a.K = K, a.N = N;
     a.x = (const u16 *)x;

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
     unsigned long long ts_x = 0, ts_b1 = 0, ts_staged = 0;
 #endif
     GEMV_STAMP(0);
-    constexpr int D = GEMV_DEPTH;
+    constexpr int D = GEMV_DEPTH;  // also for the 1280-byte W2S units: twice the depth (the W4S bytes in flight) measured 1.007 vs 0.993 ms per 2-bit 8B step
     constexpr int UB = fmt_unit_bytes(FMT);
     constexpr bool G32 = FMT == FMT_W4S32 || FMT == FMT_W8S32;  // two 32-wide groups per lane
     constexpr bool W8 = FMT == FMT_W8S || FMT == FMT_W8S32;      // byte codes: four pieces per lane
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
         }
     }
     uint4 c0[D], c1[D];  // W2S: one code piece per lane (c1 stays unused)
-    uint4 c2[W8 ? D : 1], c3[W8 ? D : 1];  // W8S: a lane's 64 codes are four pieces
+    uint4 c2[(W8 || FMT == FMT_W6S) ? D : 1], c3[W8 ? D : 1];  // W6S: c2 = the high-bit plane  // W8S: a lane's 64 codes are four pieces
     u32 sb[D];
     u32 sb2[G32 ? D : 1];  // W4S32 / W8S32: the second 32-wide group's {scale | bias << 16}
     // Weight loads go through a buffer descriptor over the whole matrix: a ring slot that has no unit left to fetch is
@@ -449,6 +449,11 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 c1[d] = make_uint4(v1.x, v1.y, v1.z, v1.w);
             }
             if (FMT == FMT_W4S) sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 2048 - lane * 12, 0, AUX);
+            if constexpr (FMT == FMT_W6S) {  // the high two bits of the lane's 64 codes (W2S word order), then {scale | bias << 16}
+                const u32x4_t v2 = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off + 2048, 0, AUX);
+                c2[d] = make_uint4(v2.x, v2.y, v2.z, v2.w);
+                sb[d] = __builtin_amdgcn_raw_buffer_load_b32(wrsrc, off + 3072 - lane * 12, 0, AUX);
+            }
             if (FMT == FMT_W4S32) {
                 typedef __attribute__((ext_vector_type(2))) u32 u32x2_t;
                 const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrsrc, off + 2048 - lane * 8, 0, AUX);
@@ -627,6 +632,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 float dd;
                 if (FMT == FMT_W8S) dd = w8s_unit_dot<T>(c0[d], c1[d], c2[d], c3[d], xr);
                 else if (FMT == FMT_W2S) dd = w2s_unit_dot<T>(c0[d], xr);
+                else if (FMT == FMT_W6S) dd = w4s_unit_dot<T>(c0[d], c1[d], xr) + 16.0f * w2s_unit_dot<T>(c2[d], xr);  // q = lo + 16 hi
                 else dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
                                     : w4s_unit_dot<T>(c0[d], c1[d], xr);
                 const float scale = lo_f32<T>(sb[d]), bias = hi_f32<T>(sb[d]);

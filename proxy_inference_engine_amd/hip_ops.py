@@ -28,9 +28,9 @@ def _dev(t: torch.Tensor) -> None:
 
 
 def quantize(w: torch.Tensor, group_size: int = 64, bits: int = 4):
-    """mx.quantize(w, group_size=64, bits=4|8): w [N,K] -> (codes [N,K*bits/32] uint32-in-int32, scales, biases [N,K/64])."""
-    if group_size != 64 or bits not in (4, 8):
-        raise ValueError("only group_size=64 with bits=4 or 8 is implemented")
+    """mx.quantize(w, group_size=64, bits=2|4|6|8): w [N,K] -> (codes [N,K*bits/32] uint32-in-int32, scales, biases [N,K/64])."""
+    if group_size != 64 or bits not in (2, 4, 6, 8):
+        raise ValueError("only group_size=64 with bits=2, 4, 6 or 8 is implemented")
     _dev(w)
     N, K = w.shape
     if K % 64:
@@ -98,6 +98,11 @@ class W2SWeight:
 
 
 @dataclass
+class W6SWeight(W2SWeight):
+    """One MLX int6 g=64 Linear in the W6S streaming layout (low-nibble plane + high-two-bit plane; include/pie_hip.h)."""
+
+
+@dataclass
 class W4S32Weight:
     """One MLX int4 group-32 Linear in the W4S32 streaming layout (include/pie_hip.h)."""
     packed: torch.Tensor          # uint8 [pie_w4s32_bytes(N, K)]
@@ -158,6 +163,25 @@ def repack_w2s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_b
     _ffi.check(_ffi.load().pie_repack_w2g64(_ffi.p(codes.contiguous()), _ffi.p(scales.contiguous()), _ffi.p(biases.contiguous()), N_src, K, _ffi.p(row_map), N_out,
                                             _ffi.p(packed), _ffi.stream()))
     return W2SWeight(packed, N_out, K, scales.dtype, lin_bias)
+
+
+def repack_w6s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W6SWeight:
+    """Load-time repack of an MLX 6-bit group-64 triplet (weight [N_src, 3K/16]: MLX's bit stream; scales / biases [N_src, K/64]) into W6S."""
+    for t in (codes, scales, biases):
+        _dev(t)
+    N_src, K = codes.shape[0], codes.shape[1] * 16 // 3
+    if codes.shape[1] % 12 or tuple(scales.shape) != (N_src, K // 64) or tuple(biases.shape) != (N_src, K // 64):
+        raise ValueError(f"6-bit rows hold 12 words per group of 64; scales / biases must be [{N_src}, {K // 64}], got {tuple(codes.shape)} / {tuple(scales.shape)} / {tuple(biases.shape)}")
+    N_out = N_src if row_map is None else int(row_map.numel())
+    nbytes = _ffi.load().pie_w6s_bytes(N_out, K)
+    if nbytes == 0:
+        raise ValueError(f"unsupported shape for W6S: N={N_out} (must be even), K={K} (multiple of 64)")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=codes.device)
+    if row_map is not None:
+        row_map = row_map.to(device=codes.device, dtype=torch.int32).contiguous()
+    _ffi.check(_ffi.load().pie_repack_w6g64(_ffi.p(codes.contiguous()), _ffi.p(scales.contiguous()), _ffi.p(biases.contiguous()), N_src, K, _ffi.p(row_map), N_out,
+                                            _ffi.p(packed), _ffi.stream()))
+    return W6SWeight(packed, N_out, K, scales.dtype, lin_bias)
 
 
 def repack_w8s(codes, scales, biases, row_map: torch.Tensor | None = None, lin_bias=None) -> W8SWeight:
@@ -256,7 +280,7 @@ def embedding_dense(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", transpose: bool = True, group_size: int | None = None, bits: int | None = None):
     """mx.quantized_matmul(x, w, scales, biases, transpose=True, group_size=64|32, bits=4|8) on a W4S / W8S / W4S32 weight:
     x [..., K] -> [..., N]; fp32 accumulate, result in x.dtype (+ nn.QuantizedLinear's bias when present)."""
-    w_bits = 8 if isinstance(w, (W8SWeight, W8S32Weight)) else (2 if isinstance(w, W2SWeight) else 4)
+    w_bits = 8 if isinstance(w, (W8SWeight, W8S32Weight)) else (6 if isinstance(w, W6SWeight) else (2 if isinstance(w, W2SWeight) else 4))
     w_group = 32 if isinstance(w, W4S32Weight) else 64
     if not transpose or (group_size is not None and group_size != w_group) or (bits is not None and bits != w_bits):
         raise ValueError("only transpose=True with the weight's own group size and bit width is implemented (the nn.QuantizedLinear form)")
@@ -266,7 +290,7 @@ def quantized_matmul(x: torch.Tensor, w: "W4SWeight | W8SWeight | W4S32Weight", 
     M = x.numel() // w.K
     y = torch.empty((*x.shape[:-1], w.N), dtype=x.dtype, device=x.device)
     lib = _ffi.load()
-    fn = lib.pie_qgemv_w2g64 if w_bits == 2 else (lib.pie_qgemv_w8g32 if w_bits == 8 else lib.pie_qgemv_w4g32) if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
+    fn = lib.pie_qgemv_w2g64 if w_bits == 2 else lib.pie_qgemv_w6g64 if w_bits == 6 else (lib.pie_qgemv_w8g32 if w_bits == 8 else lib.pie_qgemv_w4g32) if w_group == 32 else (lib.pie_qgemv_w8g64 if w_bits == 8 else lib.pie_qgemv_w4g64)
     _ffi.check(fn(_ffi.p(x), M, _ffi.p(w.packed), w.N, w.K, _ffi.p(w.lin_bias), _ffi.p(y), _ffi.dtype_code(x.dtype), _ffi.stream()))
     return y
 

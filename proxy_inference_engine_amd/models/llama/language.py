@@ -136,24 +136,25 @@ class Model:
             raise ValueError(f"config['quantization'] = {dict(q)}: mx.quantize knows group_size 32, 64, 128 and bits 2, 3, 4, 6, 8 "
                              f"(got group_size={q.get('group_size')}, bits={q.get('bits')})")
         self.checkpoint_bits = int(q["bits"]) if q else 16
-        # 2-bit codes in 64- / 128-wide groups stream as W2S units, 0.3125 B per weight -- the checkpoint's own bytes (round 5).  Only the embedding
-        # TABLE (one row per step) is re-packed as 4-bit codes; a tied lm_head is packed from the original 2-bit codes.
-        self.native_w2 = bool(q) and self.checkpoint_bits == 2 and q.get("group_size") in (64, 128)
-        embed_codes2 = None
+        # 2- and 6-bit codes in 64- / 128-wide groups stream as W2S / W6S units, 0.3125 / 0.8125 B per weight -- the checkpoint's own bytes (round 5).
+        # Only the embedding TABLE (one row per step) is re-packed as 4- / 8-bit codes; a tied lm_head is packed from the original codes.
+        self.native_narrow = self.checkpoint_bits if bool(q) and self.checkpoint_bits in (2, 6) and q.get("group_size") in (64, 128) else 0
+        self.native_w2 = self.native_narrow == 2
+        embed_codes_narrow = None
         if q and self.checkpoint_bits in (2, 3, 6):
-            # Same weights, wider container: 3-bit codes (and 2-bit codes in 32-wide groups) are stored as 4-bit codes, 6-bit codes as bytes, scales
-            # and biases unchanged -- every product is what the narrow code gives (same q, same affine pair, same fp32 sums); HBM holds 0.5625 /
-            # 1.0625 B per weight instead of the checkpoint's 0.4375 / 0.8125.
+            # Same weights, wider container: 3-bit codes (and 2- / 6-bit codes in 32-wide groups) are stored as 4-bit codes / bytes, scales and biases
+            # unchanged -- every product is what the narrow code gives (same q, same affine pair, same fp32 sums); HBM holds 0.5625 / 1.0625 B per
+            # weight instead of the checkpoint's 0.4375 (3-bit: a native unit would need two planes at ~2.1 VALU instructions per weight and lose).
             to_bits = 8 if self.checkpoint_bits == 6 else 4
             weights = dict(weights)
             for k in [k for k in weights if k.endswith(".scales")]:
                 wk = k[:-len(".scales")] + ".weight"
                 if weights[wk].shape[-1] * 32 % self.checkpoint_bits or (weights[wk].shape[-1] * 32 // self.checkpoint_bits) % 64:
                     raise ValueError(f"{wk}: {self.checkpoint_bits}-bit rows must hold a multiple of 64 codes")
-                if self.native_w2:
+                if self.native_narrow:
                     if wk == "model.embed_tokens.weight":
-                        embed_codes2 = weights[wk]
-                        weights[wk] = _recode_mlx_codes(weights[wk], 2, 4)
+                        embed_codes_narrow = weights[wk]
+                        weights[wk] = _recode_mlx_codes(weights[wk], self.checkpoint_bits, to_bits)
                     continue
                 weights[wk] = _recode_mlx_codes(weights[wk], self.checkpoint_bits, to_bits)
             q = dict(q, bits=to_bits)
@@ -164,7 +165,9 @@ class Model:
             # affine sums up to fp32 association (qmv regime) -- for 0.5625 instead of the checkpoint's 0.53125 B per weight in HBM.
             weights = dict(weights)
             for k in [k for k in weights if k.endswith(".scales") or k.endswith(".biases")]:
-                if weights[k[:k.rindex(".")] + ".weight"].shape[-1] * (32 // int(q["bits"])) % 128:
+                wk = k[:k.rindex(".")] + ".weight"
+                code_bits = self.checkpoint_bits if self.native_narrow and wk != "model.embed_tokens.weight" else int(q["bits"])  # native narrow Linears keep their codes
+                if (weights[wk].shape[-1] * 32 // code_bits) % 128:
                     raise ValueError(f"{k}: group_size 128 needs a multiple of 128 input features")
                 weights[k] = weights[k].repeat_interleave(2, dim=-1).contiguous()
         self.bits = int(q["bits"]) if q else 16
@@ -194,7 +197,7 @@ class Model:
         g32 = self.group_size == 32
         wfmt = (4 if self.bits == 8 else 3) if g32 else (2 if self.bits == 8 else 0)  # PIE_W_INT8_G32 / INT4_G32 / INT8_G64 / INT4_G64
         fmt_code = {False: 2, True: wfmt + 1}  # pie_layer_weights.fmt_*: PIE_W_* + 1 (0 = the decoder's default format)
-        PIE_W_INT2_G64 = 5  # W2S units: every Linear of a native 2-bit checkpoint (the embedding table stays wfmt = 4-bit codes)
+        PIE_W_INT2_G64, PIE_W_INT6_G64 = 5, 6  # W2S / W6S units: every Linear of a native 2- / 6-bit checkpoint (the embedding table stays wfmt = 4- / 8-bit codes)
         self.mixed = False  # some module is dense although config["quantization"] is set (per-module predicate, models/utils.py:99-109)
 
         def quantized(names: list[str]) -> bool:
@@ -210,9 +213,11 @@ class Model:
                 ws = [_dense(weights, n, self.dtype) for n in names]
                 return hip_ops.repack_dense(torch.cat(ws, dim=0) if len(ws) > 1 else ws[0], row_map=row_map), fmt_code[False]
             trip = [torch.cat(t, dim=0) for t in zip(*(_triplet(weights, n) for n in names))]
-            if self.native_w2:
-                if names == ["model.embed_tokens"]:  # tied lm_head: the table's own 2-bit codes, not the gather's 4-bit copy
-                    trip[0] = embed_codes2
+            if self.native_narrow:
+                if names == ["model.embed_tokens"]:  # tied lm_head: the table's own narrow codes, not the gather's 4- / 8-bit copy
+                    trip[0] = embed_codes_narrow
+                if self.native_narrow == 6:
+                    return hip_ops.repack_w6s(*trip, row_map=row_map), PIE_W_INT6_G64 + 1
                 return hip_ops.repack_w2s(*trip, row_map=row_map), PIE_W_INT2_G64 + 1
             if g32:
                 return hip_ops.repack_w4s32(*trip, row_map=row_map, bits=self.bits), fmt_code[True]

@@ -1068,24 +1068,26 @@ def test_narrow_code_and_group_32_checkpoints_vs_oracle(bits, group):
         tok = int(np.argmax(w1))
 
 
-@pytest.mark.parametrize("group,tied,dtype", [(64, True, "bfloat16"), (128, False, "bfloat16"), (64, False, "float16")])
-def test_two_bit_checkpoint_streams_native_units(group, tied, dtype):
-    """A 2-bit checkpoint in 64- / 128-wide groups runs on W2S units: every Linear -- a tied lm_head included -- is packed from the
-    2-bit codes themselves at the checkpoint's 0.3125 B per weight, pie_decoder_step_bytes counts exactly that, and a 5-row prompt (row-by-row
-    streaming GEMV), a 40-token prompt (dequantise-to-T, 16-bit GEMM) and decode steps are what the oracle computes from the narrow codes."""
+@pytest.mark.parametrize("bits,group,tied,dtype", [(2, 64, True, "bfloat16"), (2, 128, False, "bfloat16"), (2, 64, False, "float16"),
+                                                   (6, 64, True, "bfloat16"), (6, 128, False, "bfloat16"), (6, 64, False, "float16")])
+def test_narrow_checkpoints_stream_native_units(bits, group, tied, dtype):
+    """2- and 6-bit checkpoints in 64- / 128-wide groups run on W2S / W6S units: every Linear -- a tied lm_head included -- is packed
+    from the narrow codes themselves at the checkpoint's 0.3125 / 0.8125 B per weight, pie_decoder_step_bytes counts exactly that, and a 5-row prompt
+    (row-by-row streaming GEMV), a 40-token prompt (dequantise-to-T, 16-bit GEMM) and decode steps are what the oracle computes from the narrow codes."""
     cfg = {"model_type": "llama", "hidden_size": 256, "num_hidden_layers": 2, "intermediate_size": 768, "num_attention_heads": 4,
            "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "vocab_size": 512, "rope_theta": 10000.0, "max_position_embeddings": 2048,
-           "tie_word_embeddings": tied, "quantization": {"group_size": group, "bits": 2}}
-    w = po.synth_checkpoint(cfg, seed=72, dtype=dtype, lm_head_gain=4.0)
+           "tie_word_embeddings": tied, "quantization": {"group_size": group, "bits": bits}}
+    w = po.synth_checkpoint(cfg, seed=70 + bits, dtype=dtype, lm_head_gain=4.0)
     model = build(cfg, w, dtype)
-    assert model.native_w2 and model.checkpoint_bits == 2
+    assert model.native_narrow == bits and model.checkpoint_bits == bits and model.native_w2 == (bits == 2)
     H, I, V, QKV = 256, 768, 512, 256 + 2 * 128
     n_lin = 2 * (QKV * H + H * H + 2 * I * H + H * I) + V * H          # weights of every Linear the step streams
+    unit = 1280 if bits == 2 else 3328
     for m in (model.layers[0].wqkv, model.layers[0].wdown, model.lm_head):
-        assert type(m).__name__ == "W2SWeight" and m.nbytes == (m.N // 2) * ((m.K + 2047) // 2048) * 1280
-    want_bytes = n_lin * 5 // 16                                            # 2 bits + a 16-bit (scale, bias) pair per 64 weights
+        assert type(m).__name__ == ("W2SWeight" if bits == 2 else "W6SWeight") and m.nbytes == (m.N // 2) * ((m.K + 2047) // 2048) * unit
+    want_bytes = n_lin * (4 * bits + 2) // 32                              # `bits` per weight + a 16-bit (scale, bias) pair per 64 weights
     got_bytes = model.step_bytes(64)
-    assert want_bytes <= got_bytes <= want_bytes + 200_000, (got_bytes, want_bytes)   # + norms, the embedding row, 64 positions of K / V, the tail
+    assert want_bytes <= got_bytes <= want_bytes + 200_000, (got_bytes, want_bytes)   # + norms, 64 positions of K / V, the tail
     orc = po.OracleLlama(cfg, w, dtype)
     rng = np.random.default_rng(group)
     for L in (5, 40):
@@ -1095,12 +1097,12 @@ def test_two_bit_checkpoint_streams_native_units(group, tied, dtype):
         cache = model.make_cache()
         got = model(torch.from_numpy(prompt)[None].cuda(), cache=cache)[0].float().cpu().numpy()
         for l in range(L):
-            assert_vec_close(got[l], want[l], dtype, what=f"2-bit g={group} L={L} position {l}")
+            assert_vec_close(got[l], want[l], dtype, what=f"{bits}-bit g={group} L={L} position {l}")
         tok = int(np.argmax(want[-1]))
         for i in range(3):
             w1 = orc.forward(np.array([tok]), ocache)[0]
             _, _, g1 = model.step(torch.tensor([tok], dtype=torch.int32, device="cuda"), cache)
-            assert_vec_close(g1.float().cpu().numpy(), w1, dtype, what=f"2-bit g={group} decode step {i} after L={L}")
+            assert_vec_close(g1.float().cpu().numpy(), w1, dtype, what=f"{bits}-bit g={group} decode step {i} after L={L}")
             tok = int(np.argmax(w1))
 
 

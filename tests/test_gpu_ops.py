@@ -258,7 +258,8 @@ def test_int2_g64_gemv_vs_oracle(ops, dt):
         x = po.round_T(rng.standard_normal((M, K)), dt)
         wq, sc, bi = po.quantize(w, 64, 2, dt)
         assert wq.shape == (N, K // 16) and sc.shape == (N, K // 64)
-        codes, scales, biases = codes_dev(wq), to_dev(sc, dt), to_dev(bi, dt)
+        codes, scales, biases = ops.quantize(to_dev(po.to_bits(w, dt), dt), bits=2)  # the HIP quantiser at 2 bits: bit-identical to the oracle's mx.quantize
+        assert np.array_equal(codes.cpu().numpy().view(np.uint32), wq) and np.array_equal(to_bits(scales), sc) and np.array_equal(to_bits(biases), bi)
         lin_bias = po.round_T(rng.standard_normal(N) * 0.1, dt) if N == 130 else None
         want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=2, dtype=dt, lin_bias=None if lin_bias is None else po.to_bits(lin_bias, dt))
         wt = ops.repack_w2s(codes, scales, biases, lin_bias=None if lin_bias is None else to_dev(po.to_bits(lin_bias, dt), dt))
@@ -283,6 +284,49 @@ def test_int2_g64_gemv_vs_oracle(ops, dt):
         x[0, k] = 1.0
         got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt).float().cpu().numpy()[0]
         assert np.array_equal(got, 0.5 * q[:, k].astype(np.float32) - 0.75), f"W2S code position {k} {dt}"
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_int6_g64_gemv_vs_oracle(ops, dt):
+    """MLX 6-bit group-64 triplets on native W6S units: the byte-straddling bit stream (four codes to three bytes) is split at load into a low-nibble
+    plane (W4S order) and a high-two-bit plane (W2S order), 3328 B per row pair x 2048-wide K slice = the checkpoint's own 0.8125 B per weight; a
+    group's dot product is the W4S dot of the low plane + 16 x the W2S dot of the high plane.  Against orc_quantized_matmul_t on the 6-bit codes."""
+    rng = np.random.default_rng(606)
+    for N, K, M in ((96, 256, 2), (4096, 4096, 1), (130, 704, 3), (1024, 3072, 1), (64, 14336, 2)):
+        w = po.round_T(rng.standard_normal((N, K)) * 0.05, dt)
+        x = po.round_T(rng.standard_normal((M, K)), dt)
+        wq, sc, bi = po.quantize(w, 64, 6, dt)
+        assert wq.shape == (N, 3 * K // 16) and sc.shape == (N, K // 64)
+        codes, scales, biases = ops.quantize(to_dev(po.to_bits(w, dt), dt), bits=6)  # the HIP quantiser's 6-bit stream: bit-identical to the oracle's mx.quantize
+        assert np.array_equal(codes.cpu().numpy().view(np.uint32), wq) and np.array_equal(to_bits(scales), sc) and np.array_equal(to_bits(biases), bi)
+        lin_bias = po.round_T(rng.standard_normal(N) * 0.1, dt) if N == 130 else None
+        want = po.quantized_matmul(x, wq, sc, bi, group_size=64, bits=6, dtype=dt, lin_bias=None if lin_bias is None else po.to_bits(lin_bias, dt))
+        wt = ops.repack_w6s(codes, scales, biases, lin_bias=None if lin_bias is None else to_dev(po.to_bits(lin_bias, dt), dt))
+        assert wt.nbytes == (N // 2) * ((K + 2047) // 2048) * 3328
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt, group_size=64, bits=6)
+        assert_dot_close(got.float().cpu().numpy(), want, dt, what=f"int6 gemv {N}x{K} M={M} {dt}", mag=None if lin_bias is None else want - lin_bias[None, :])
+        if N == 96:
+            perm = torch.from_numpy(rng.permutation(N).astype(np.int32))
+            got_p = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), ops.repack_w6s(codes, scales, biases, row_map=perm))
+            assert torch.equal(got_p, got[:, perm.long().cuda()])
+    # every code position of a group with every plane exercised: one-hot activations pick single weights = scale * q + bias exactly
+    N, K = 64, 128
+    q = rng.integers(0, 64, (N, K)).astype(np.uint64)
+    q[:, :4] = np.array([63, 48, 15, 16])
+    bits_row = np.zeros((N, K * 6 // 32), np.uint32)
+    for k in range(K):
+        pos = 6 * k
+        v = q[:, k] << np.uint64(pos % 32)
+        bits_row[:, pos // 32] |= (v & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        if pos % 32 > 26:
+            bits_row[:, pos // 32 + 1] |= (v >> np.uint64(32)).astype(np.uint32)
+    sc, bi = po.to_bits(np.full((N, K // 64), 0.25), dt), po.to_bits(np.full((N, K // 64), -2.0), dt)
+    wt = ops.repack_w6s(codes_dev(bits_row), to_dev(sc, dt), to_dev(bi, dt))
+    for k in (0, 1, 2, 3, 5, 15, 16, 31, 63, 64, 77, 127):
+        x = np.zeros((1, K), np.float32)
+        x[0, k] = 1.0
+        got = ops.quantized_matmul(to_dev(po.to_bits(x, dt), dt), wt).float().cpu().numpy()[0]
+        assert np.array_equal(got, 0.25 * q[:, k].astype(np.float32) - 2.0), f"W6S code position {k} {dt}"
 
 
 @pytest.mark.parametrize("bits", [4, 8])

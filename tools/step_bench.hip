@@ -78,11 +78,18 @@ struct Quant {
         if (n_elems <= cap) return;
         if (w) { CK(hipFree(w)); CK(hipFree(codes)); CK(hipFree(scales)); CK(hipFree(biases)); }
         cap = n_elems;
-        w = (u16 *)dmalloc(cap * 2), codes = (uint32_t *)dmalloc(cap / 2), scales = (u16 *)dmalloc(cap / 32), biases = (u16 *)dmalloc(cap / 32);
+        w = (u16 *)dmalloc(cap * 2), codes = (uint32_t *)dmalloc(cap), scales = (u16 *)dmalloc(cap / 32), biases = (u16 *)dmalloc(cap / 32);
     }
+    int bits = 4;  // --bits 2: MLX int2 g=64 triplets on W2S units (every Linear; the embedding table stays 4-bit codes)
     void *pack(int N, int K, unsigned seed, float amp, const int32_t *row_map_dev) {
         reserve((size_t)N * K);
         fill(w, (size_t)N * K, seed, amp);
+        if (bits == 2 || bits == 6) {
+            PK(pie_quantize_g64(w, N, K, bits, PIE_BF16, codes, scales, biases, nullptr));
+            void *packed2 = dmalloc(bits == 2 ? pie_w2s_bytes(N, K) : pie_w6s_bytes(N, K));
+            PK((bits == 2 ? pie_repack_w2g64 : pie_repack_w6g64)(codes, scales, biases, N, K, row_map_dev, N, packed2, nullptr));
+            return packed2;
+        }
         PK(pie_quantize_w4g64(w, N, K, PIE_BF16, codes, scales, biases, nullptr));
         void *packed = dmalloc(pie_w4s_bytes(N, K));
         PK(pie_repack_w4g64(codes, scales, biases, N, K, row_map_dev, N, packed, nullptr));
@@ -92,7 +99,7 @@ struct Quant {
 
 int main(int argc, char **argv) {
     Geo g = {4096, 14336, 32, 8, 128, 128256, 32};
-    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1, kv_splits = 0, prefill = 0, prefill_reps = 3, no_mega = 0, sync_every = 0, heads = -1;
+    int steps = 50, warmup = 10, ctx = 128, cap = 512, check = 0, graph = 1, kv_splits = 0, prefill = 0, prefill_reps = 3, no_mega = 0, sync_every = 0, heads = -1, bits = 4;
     std::string mode = "both";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -104,6 +111,7 @@ int main(int argc, char **argv) {
             else if (m == "3b") g = {3072, 8192, 24, 8, 128, 128256, 28};
         } else if (a == "--layers") g.L = atoi(next());
         else if (a == "--steps") steps = atoi(next());
+        else if (a == "--bits") bits = atoi(next());                    // 2 / 6: W2S / W6S units (int2 / int6 g=64), 4: W4S
         else if (a == "--warmup") warmup = atoi(next());
         else if (a == "--ctx") ctx = atoi(next());
         else if (a == "--cap") cap = atoi(next());
@@ -148,6 +156,8 @@ int main(int argc, char **argv) {
     PK(pie_decoder_create(&cfg, &dec));
 
     Quant q;
+    q.bits = bits == 2 || bits == 6 ? bits : 4;
+    const int lin_fmt = bits == 2 ? PIE_W_INT2_G64 + 1 : (bits == 6 ? PIE_W_INT6_G64 + 1 : 0);  // per-matrix format code (0: the decoder's default, int4 g=64)
     const float amp = 1.7f / sqrtf((float)g.H);  // uniform(-a, a): std a / sqrt(3) ~ 1 / sqrt(H)
     for (int l = 0; l < g.L; ++l) {
         pie_layer_weights lw = {};
@@ -158,6 +168,7 @@ int main(int argc, char **argv) {
         lw.wo = q.pack(g.H, QD, 10 * l + 2, amp, nullptr);
         lw.wgateup = q.pack(2 * g.I, g.H, 10 * l + 3, amp, gmap_d);
         lw.wdown = q.pack(g.H, g.I, 10 * l + 4, 1.7f / sqrtf((float)g.I), nullptr);
+        lw.fmt_qkv = lw.fmt_o = lw.fmt_gateup = lw.fmt_down = lin_fmt;
         PK(pie_decoder_set_layer(dec, l, &lw));
     }
     pie_global_weights gw = {};
@@ -178,6 +189,7 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(fd, fr.data(), g.D * 2, hipMemcpyHostToDevice));
         gw.rope_freqs = fd;
     }
+    gw.fmt_lm_head = lin_fmt;
     PK(pie_decoder_set_globals(dec, &gw));
 
     const size_t kv_bytes = (size_t)g.kv * cap * g.D * 2;
