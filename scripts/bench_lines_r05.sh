@@ -11,3 +11,9 @@ python bench.py --model 70b --steps 32 --no-cpu-baseline > $O/r05_bench_line_70b
 for f in $O/r05_bench_line_*.json; do python -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1], round(d['value'],1), round(d['repetitions']['median_ms_per_step'],4), round(d['roofline']['step']['frac'],4), 'traffic' if d['roofline']['traffic'] is not None else 'no-traffic', d.get('parity',{}).get('ok'), d.get('parity',{}).get('ids_checked'))" $f; done
+# second session of round 5: the native narrow units
+python bench.py --bits 2 > $O/r05_bench_line_bits2.json 2> $O/bits2.err
+python bench.py --bits 6 > $O/r05_bench_line_bits6.json 2> $O/bits6.err
+for f in $O/r05_bench_line_bits2.json $O/r05_bench_line_bits6.json; do python -c "
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1], round(d['value'],1), round(d['repetitions']['median_ms_per_step'],4), round(d['roofline']['step']['frac'],4), d.get('parity',{}).get('ok'), d.get('parity',{}).get('ids_checked'))" $f; done
