@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(GEMV_WAVES * 64, 4) k_w4s_gemv(const GemvArgs 
                 const float sx = (ABL & 4) ? 64.0f : sxs[gc];
                 float dd;
                 if (FMT == FMT_W8S) dd = w8s_unit_dot<T>(c0[d], c1[d], c2[d], c3[d], xr);
-                else if (FMT == FMT_W2S) dd = w2s_unit_dot<T>(c0[d], xr);
+                else if (FMT == FMT_W2S) dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ xr[d] ^ xr[8 + d] ^ xr[16 + d] ^ xr[24 + d]) : w2s_unit_dot<T>(c0[d], xr);
                 else if (FMT == FMT_W6S) dd = w4s_unit_dot<T>(c0[d], c1[d], xr) + 16.0f * w2s_unit_dot<T>(c2[d], xr);  // q = lo + 16 hi
                 else dd = (ABL & 2) ? __builtin_bit_cast(float, c0[d].x ^ c0[d].y ^ c0[d].z ^ c0[d].w ^ c1[d].x ^ c1[d].y ^ c1[d].z ^ c1[d].w ^ xr[d])
                                     : w4s_unit_dot<T>(c0[d], c1[d], xr);

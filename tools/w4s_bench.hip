@@ -179,6 +179,37 @@ int main(int argc, char **argv) {
         RUN_ABL(PRO_NONE, EPI_STORE, 0, "abl store full")
         RUN_ABL(PRO_NONE, EPI_STORE, 4, "abl store no-x-staging")
     }
+    // ablations of the W2S stream (2-bit units, round 5) on the lm_head shape (N=128256, K=4096) and on gate/up: what bounds it?
+    for (int shape = 0; shape < 2; ++shape) {
+        const int N = shape ? 28672 : 128256, K = 4096;
+        size_t b = (size_t)(N / 2) * w4s_slices(K) * W2S_UNIT_BYTES;
+        int sl = (int)(W_BYTES / b);
+        auto mk = [&](int i) {
+            GemvArgs a = {};
+            a.fmt = FMT_W2S;
+            a.w = w + (size_t)(i % sl) * b, a.K = K, a.N = N, a.x = xin, a.norm_w = normw, a.eps = 1e-5f, a.y = y, a.resid = resid;
+            a.n_slices = w4s_slices(K), a.n_pairs = N / 2, a.n_waves = w4s_gemv_waves(N, K);
+            a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs % a.n_waves, a.n_blocks = a.n_waves % GEMV_WAVES == 0 ? (a.n_waves / GEMV_WAVES) : 0;
+            return a;
+        };
+        const unsigned lds = (unsigned)gemv_lds(K).total;
+#define RUN_ABL2(ABL, label)                                                                                              \
+        {                                                                                                                  \
+            dim3 grid((w4s_gemv_waves(N, K) + GEMV_WAVES - 1) / GEMV_WAVES), block(64 * GEMV_WAVES);                        \
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO_NONE, EPI_STORE, 1, ABL, FMT_W2S>), grid, block, lds, 0, mk(i)); \
+            CK(hipDeviceSynchronize()); t.start();                                                                         \
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO_NONE, EPI_STORE, 1, ABL, FMT_W2S>), grid, block, lds, 0, mk(i)); \
+            char nm[64]; snprintf(nm, 64, "w2s N=%d %s", N, label); report(nm, b, reps, t.stop());                                      \
+        }
+        RUN_ABL2(0, "full")
+        RUN_ABL2(1, "no-weight-loads")
+        RUN_ABL2(2, "no-dot")
+        RUN_ABL2(4, "no-x-reads")
+        RUN_ABL2(6, "loads only")
+        RUN_ABL2(5, "dot only")
+        RUN_ABL2(7, "nothing")
+#undef RUN_ABL2
+    }
     // ablations of the product kernel on the qkv shape (N=6144, K=4096)
     {
         const int N = 6144, K = 4096;
