@@ -202,6 +202,19 @@ int main(int argc, char **argv) {
             char nm[64]; snprintf(nm, 64, "w2s N=%d %s", N, label); report(nm, b, reps, t.stop());                                      \
         }
         RUN_ABL2(0, "full")
+        {   // the same launch with TWO 8-wave workgroups per CU (4096 waves): does a second pair of waves per SIMD hide the per-unit serial chain?
+            auto mk2 = [&](int i) {
+                GemvArgs a = mk(i);
+                a.n_waves = 4096;
+                a.full_rounds = a.n_pairs / a.n_waves, a.rem_pairs = a.n_pairs % a.n_waves, a.n_blocks = a.n_waves / GEMV_WAVES;
+                return a;
+            };
+            dim3 grid(4096 / GEMV_WAVES), block(64 * GEMV_WAVES);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO_NONE, EPI_STORE, 1, 0, FMT_W2S>), grid, block, lds, 0, mk2(i));
+            CK(hipDeviceSynchronize()); t.start();
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_w4s_gemv<BF16, PRO_NONE, EPI_STORE, 1, 0, FMT_W2S>), grid, block, lds, 0, mk2(i));
+            char nm2[64]; snprintf(nm2, 64, "w2s N=%d full, 4096 waves", N); report(nm2, b, reps, t.stop());
+        }
         RUN_ABL2(1, "no-weight-loads")
         RUN_ABL2(2, "no-dot")
         RUN_ABL2(4, "no-x-reads")
